@@ -1,0 +1,45 @@
+"""Golden-vector case list shared by make_golden.py (build container) and the parity tests.
+
+Field meanings follow the reference CLI (src/sdrterm.py:54-107): ``code`` is the --encoding name
+(misc/file_util.py:44-56), ``q`` is --decimation, ``center`` is --center-frequency, ``vfos`` is the
+--vfos csv (rows = csv entries + center, then center last, vfo_processor.py:43-47), ``omega_out`` is
+--omega-out, ``normalize`` / ``correct_iq`` are --normalize-input / --correct-iq.
+"""
+READ_SIZE = 131072  # bytes per chunk, misc/read_file.py:38
+
+_VFOS8 = '-200000,-150000,-100000,-50000,50000,100000,150000,200000'
+
+
+def _c(name, code, q, mode, center=0, vfos=None, omega_out=5000, fs=1024000, n_chunks=2, seed=1, amp=3000,
+       **kw):
+    d = dict(name=name, code=code, q=q, mode=mode, center=center, vfos=vfos, omega_out=omega_out, fs=fs,
+             n_chunks=n_chunks, seed=seed, amp=amp)
+    d.update(kw)
+    return d
+
+
+CASES = [
+    _c('h_q64_fm_c0', 'h', 64, 'fm', seed=11),
+    _c('h_q64_fm_c', 'h', 64, 'fm', center=15700, seed=12),
+    _c('h_q64_am_norm_c', 'h', 64, 'am', center=-15700, normalize=True, seed=13),
+    _c('h_q64_am_raw', 'h', 64, 'am', center=15700, seed=14),
+    _c('h_q32_fm_c', 'h', 32, 'fm', center=20300, seed=15),
+    _c('h_q32_am_norm_c0', 'h', 32, 'am', normalize=True, seed=16),
+    _c('f_q64_fm_c', 'f', 64, 'fm', center=15700, seed=17),
+    _c('f_q32_am_c0', 'f', 32, 'am', seed=18),
+    _c('h_q64_fm_vfo9', 'h', 64, 'fm', center=15700, vfos=_VFOS8, seed=19),
+    _c('h_q32_am_norm_vfo9_iq', 'h', 32, 'am', center=15700, vfos=_VFOS8, normalize=True, correct_iq=True,
+       n_chunks=3, dc=(500, -300), seed=20),
+    _c('h_q32_fm_vfo9_iq', 'h', 32, 'fm', center=0, vfos=_VFOS8, correct_iq=True, n_chunks=3, dc=(500, -300),
+       seed=21),
+    _c('h_q64_fm_iq', 'h', 64, 'fm', center=15700, correct_iq=True, n_chunks=3, dc=(500, -300), seed=22),
+    _c('B_q64_fm_c', 'B', 64, 'fm', center=15700, amp=100, seed=23),
+    _c('h_be_q64_fm_c', 'h', 64, 'fm', center=15700, big_endian=True, seed=24),
+    _c('d_q64_fm_c', 'd', 64, 'fm', center=15700, seed=25),
+    _c('i_q16_fm_c', 'i', 16, 'fm', center=15700, amp=100000, seed=26),
+    _c('b_q128_fm_c0', 'b', 128, 'fm', omega_out=2500, amp=100, seed=27),
+    _c('H_q64_am_norm_c', 'H', 64, 'am', center=15700, normalize=True, seed=28),
+    _c('h_q256_fm_c', 'h', 256, 'fm', center=15700, omega_out=1500, seed=29),
+]
+
+BY_NAME = {c['name']: c for c in CASES}

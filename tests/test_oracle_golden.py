@@ -1,0 +1,99 @@
+"""Pins the oracle (oracle/ref_chain.py and oracle/chain.c) to vectors produced by the real reference."""
+import numpy as np
+import pytest
+
+from oracle import c_chain, ref_chain
+from tests.util import CASES, case_raw, ref_tol, samples_per_chunk, tol_for
+
+
+def _chain(case):
+    return ref_chain.Chain(case['fs'], case['q'], case['mode'], case['code'], center=case['center'],
+                           vfos=case.get('vfos'), omega_out=case['omega_out'],
+                           normalize=bool(case.get('normalize')), correct_iq=bool(case.get('correct_iq')),
+                           big_endian=bool(case.get('big_endian')))
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
+def test_numpy_oracle_matches_reference(case, golden):
+    z, _ = golden
+    name = case['name']
+    raw = case_raw(case)
+    n = samples_per_chunk(case['code'])
+    item = len(raw) // (2 * n * case['n_chunks'])
+    ch = _chain(case)
+    exp = z[f'{name}/z']
+    for c in range(case['n_chunks']):
+        rawc = raw[c * 2 * n * item:(c + 1) * 2 * n * item]
+        zin = ch.read(rawc)
+        np.testing.assert_allclose(zin[::case.get('zsub', 251)], z[f'{name}/reader_sub'][c], rtol=1e-12, atol=1e-9)
+        assert abs(zin[-1] - z[f'{name}/reader_last'][c]) <= 1e-9 * max(1.0, abs(zin[-1]))
+        out, y = ref_chain.process_chunk(zin, case['q'], case['mode'], ch.shift, ch.out_sos, True)
+        assert np.abs(out - exp[c]).max() <= tol_for(exp[c]) * 1e-3   # same scipy -> essentially exact
+        if c == 0:
+            y0 = z[f'{name}/y0']
+            assert np.abs(y - y0).max() <= (1e-6 if case['code'] == 'f' else 1e-9) * np.abs(y0).max()
+    np.testing.assert_array_equal(ref_chain.cheby_sos(case['q']), z[f'{name}/cheby_sos'])
+    np.testing.assert_allclose(ch.out_sos, z[f'{name}/ellip_sos'], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
+def test_c_oracle_matches_reference(case, golden):
+    z, _ = golden
+    name = case['name']
+    raw = case_raw(case)
+    n = samples_per_chunk(case['code'])
+    rows = ref_chain.vfo_rows(case['center'], case.get('vfos'))
+    shift = None
+    if case.get('vfos') or case['center']:
+        shift = c_chain.shift_table(rows, case['fs'], n)
+    norm = ref_chain.generate_domain(case['code']) if case.get('normalize') else None
+    L = 50 / case['fs'] if case.get('correct_iq') else None
+    out, off = c_chain.process_stream(raw, case['code'], n, case['q'], case['mode'], shift,
+                                      z[f'{name}/cheby_sos'], z[f'{name}/ellip_sos'],
+                                      big_endian=bool(case.get('big_endian')), norm=norm, iq_inductance=L,
+                                      threads=2)
+    exp = z[f'{name}/z']
+    assert out.shape == exp.shape
+    assert np.abs(out - exp).max() <= ref_tol(case, exp)
+
+
+def test_known_answer_vectors(golden):
+    """test/dsp/demodulation_test.py:19-50 (8-sample KATs), oracle vs the reference's own outputs."""
+    z, _ = golden
+    inp = z['kat_in'][0]
+    np.testing.assert_allclose(c_chain.fm(inp), z['kat_fm'][0], atol=1e-12, rtol=0)
+    np.testing.assert_allclose(ref_chain.fm_demod(inp[None, :])[0], z['kat_fm'][0], atol=1e-12, rtol=0)
+    np.testing.assert_allclose(c_chain.am(inp), z['kat_am'][0], atol=1e-12, rtol=0)
+    np.testing.assert_allclose(ref_chain.am_demod(inp), z['kat_am'][0], atol=1e-12, rtol=0)
+    # the reference test's own expectation: atan2 of the pair products, FFT-resampled 4 -> 8
+    import math
+    from scipy.signal import resample
+    pairs = [inp[i] * inp[i + 1].conjugate() for i in range(0, 8, 2)]
+    expect = resample([math.atan2(p.imag, p.real) for p in pairs], 8)
+    np.testing.assert_allclose(c_chain.fm(inp), expect, atol=1e-12, rtol=0)
+    np.testing.assert_allclose(z['kat_re'][0], inp.real)
+    np.testing.assert_allclose(z['kat_im'][0], inp.imag)
+
+
+def test_c_oracle_zi_and_edge(golden):
+    z, _ = golden
+    import ctypes as C
+    lib = c_chain.lib()
+    for q in (4, 8, 16, 32, 64, 128, 256):
+        sos = np.ascontiguousarray(z[f'coef/cheby1_q{q}'])
+        zi = np.empty((4, 2))
+        lib.orc_sosfilt_zi(sos.ctypes.data_as(C.c_void_p), C.c_int(4), zi.ctypes.data_as(C.c_void_p))
+        np.testing.assert_allclose(zi, z[f'coef/cheby1_zi_q{q}'], rtol=1e-9)
+        lib.orc_sosfiltfilt_edge.restype = C.c_int
+        assert lib.orc_sosfiltfilt_edge(sos.ctypes.data_as(C.c_void_p), C.c_int(4)) == 27
+
+
+def test_generate_domain_table():
+    """test/misc/read_file_test.py:12-22."""
+    chars = ('B', 'b', 'H', 'h', 'I', 'i', 'L', 'l')
+    vals = (0, 255, -128, 127, 0, 65536, -32768, 32767, 0, 4294967295, -2147483648, 2147483647,
+            0, 18446744073709551615, -9223372036854775808, 9223372036854775807)
+    for c, (a, b) in zip(chars, [(vals[i], vals[i + 1]) for i in range(0, len(vals), 2)]):
+        xmin, diff = ref_chain.generate_domain(c)
+        assert xmin == a and diff == 1 / (b - a)
+    assert ref_chain.generate_domain('f') is None
