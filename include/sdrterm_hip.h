@@ -1,0 +1,139 @@
+/*
+ * sdrterm_hip.h -- C ABI of the MI355X-native sdrterm DSP hot path (libsdrterm_hip.so).
+ *
+ * This is the drop-in boundary for peads/sdrterm's src/dsp streaming chain.  Every entry point uses
+ * plain C types and caller-owned buffers; nothing throws across it.  Each function cites the
+ * reference interface it replaces (paths relative to the reference repository root).
+ *
+ * One context == one reference processor instance:
+ *     DspProcessor(fs, center, omegaOut, dec, ...)            src/dsp/dsp_processor.py:48-77
+ *     VfoProcessor(fs, vfoHost, vfos, ...)                    src/dsp/vfo_processor.py:36-57
+ * plus the reader's per-sample steps that precede it in the stream
+ *     unpack / _normalize / _correctIq                        src/misc/read_file.py:55-103
+ *
+ * A "chunk" is what the reference's reader enqueues per read: readSize = 131072 bytes of interleaved
+ * (re, im) records (src/misc/read_file.py:38,51,119-124).  Every chunk is filtered independently, as
+ * the reference does (dsp_processor.py:140-149); the only cross-chunk state is the IQ-correction
+ * offset (read_file.py:53,103), which the context carries.
+ */
+#ifndef SDRTERM_HIP_H
+#define SDRTERM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDRT_ABI_VERSION 1
+
+/* Input encodings: src/misc/file_util.py:44-56 (DataType b,B,h,H,i,I,f,d). */
+enum sdrt_dtype {
+    SDRT_S8 = 0, SDRT_U8 = 1, SDRT_S16 = 2, SDRT_U16 = 3, SDRT_S32 = 4, SDRT_U32 = 5, SDRT_F32 = 6, SDRT_F64 = 7
+};
+
+/* Demodulation: DspProcessor.selectOutputFm / selectOutputAm (dsp_processor.py:116-128). */
+enum sdrt_mode { SDRT_FM = 0, SDRT_AM = 1 };
+
+enum sdrt_status {
+    SDRT_OK = 0,
+    SDRT_EINVAL = 1,      /* bad argument / unsupported configuration (message in sdrt_last_error) */
+    SDRT_EHIP = 2,        /* a HIP runtime call failed */
+    SDRT_ENOMEM = 3,
+    SDRT_ENODEVICE = 4    /* no usable GPU: the library never falls back to the CPU */
+};
+
+typedef struct sdrt_ctx sdrt_ctx;
+
+typedef struct sdrt_config {
+    uint32_t struct_size;     /* sizeof(sdrt_config), for ABI evolution */
+    int32_t device;           /* HIP device ordinal */
+    double fs;                /* input sample rate, Hz (DspProcessor.fs) */
+    int32_t decimation;       /* DspProcessor.decimation, >= 2 (dsp_processor.py:92-97) */
+    int32_t mode;             /* enum sdrt_mode */
+    int32_t dtype;            /* enum sdrt_dtype of each of re and im */
+    int32_t swap_endianness;  /* records are opposite to host byte order (read_file.py:48-49) */
+    int32_t n_samples;        /* complex samples per chunk (131072 / record size in the reference) */
+    int32_t n_rows;           /* 1 for DspProcessor; len(vfos)+1 for VfoProcessor (vfo_processor.py:45-47) */
+    const double *row_freqs;  /* Hz per row, as VfoProcessor builds them (csv+center ..., center LAST);
+                                 for DspProcessor: {center}.  May be NULL when apply_shift == 0 */
+    int32_t apply_shift;      /* 0 == the reference's _shift is None (center == 0, no --simo) */
+    int32_t normalize;        /* --normalize-input (read_file.py:82-96) */
+    double norm_xmin;         /* generateDomain(): xmin      (read_file.py:177-196) */
+    double norm_inv_range;    /* generateDomain(): 1/(xmax - xmin) */
+    int32_t correct_iq;       /* --correct-iq (read_file.py:57-77) */
+    int32_t reserved0;
+    double iq_inductance;     /* impedance / fs (read_file.py:65) */
+    const double *dec_sos;    /* decimator SOS [dec_sections][6]: scipy cheby1(8, 0.05, 0.8/q, 'sos'),
+                                 what scipy.signal.decimate builds at dsp_processor.py:147 */
+    int32_t dec_sections;
+    int32_t out_sections;
+    const double *out_sos;    /* output lowpass SOS [out_sections][6]: generateEllipFilter, dsp_processor.py:39-45 */
+} sdrt_config;
+
+/* Library / device discovery. */
+int sdrt_abi_version(void);
+int sdrt_device_count(int *count);
+const char *sdrt_last_error(void);   /* thread-local, valid until the next call on the same thread */
+
+/*
+ * Construct / destroy: replaces DspProcessor.__init__ + selectOutput*() (dsp_processor.py:51-128) or
+ * VfoProcessor.__init__ (vfo_processor.py:38-57) together with the lazy buffer/shift allocation of
+ * _processData/_generateShift (dsp_processor.py:164-187, vfo_processor.py:71-78).
+ */
+int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out);
+void sdrt_destroy(sdrt_ctx *ctx);
+
+/* Output samples per chunk per row: n_samples / decimation (dsp_processor.py:173). */
+int sdrt_out_per_chunk(const sdrt_ctx *ctx);
+int sdrt_rows(const sdrt_ctx *ctx);
+
+/*
+ * Process n_chunks consecutive chunks: the body of DspProcessor._processData/_processChunk
+ * (dsp_processor.py:140-149,164-183) preceded by feedBuffers' per-sample steps (read_file.py:100-103).
+ *   raw : n_chunks * n_samples interleaved (re, im) records of cfg.dtype
+ *   out : rows * n_chunks * m float64, row-major [row][chunk][m] -- row r is exactly the byte stream the
+ *         reference writes for that row (file for DspProcessor, client socket r for VfoProcessor).
+ * The *_device form is asynchronous on `stream` (a hipStream_t, NULL = default stream) and takes
+ * device pointers; the *_host form copies in, runs, copies out and synchronises.
+ */
+int sdrt_process_device(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, double *out_dev, void *stream);
+int sdrt_process_host(sdrt_ctx *ctx, const void *raw_host, size_t n_chunks, double *out_host);
+
+/* Same as sdrt_process_device, additionally storing the decimated complex samples (the value of `y` after
+ * dsp_processor.py:147) as interleaved float64 (re, im), layout [row][chunk][m][2].  For parity tests. */
+int sdrt_process_device_debug(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, double *out_dev,
+                              double *ydec_dev, void *stream);
+
+/* The carried IQ-correction offset (read_file.py:53): get/set as (re, im). */
+int sdrt_get_iq_offset(sdrt_ctx *ctx, double *re, double *im);
+int sdrt_set_iq_offset(sdrt_ctx *ctx, double re, double im);
+
+/*
+ * Per-kernel device timing with HIP events recorded on the launch stream (for bench.py's roofline line).
+ * enable != 0 makes every sdrt_process_* call bracket each kernel with events; sdrt_kernel_time returns the
+ * accumulated milliseconds and launch count for kernel `which` (0 = decimate+demod, 1 = post/output filter,
+ * 2 = IQ-correction prefix kernels) and resets nothing; sdrt_profile_reset clears the accumulators.
+ */
+int sdrt_profile_enable(sdrt_ctx *ctx, int enable);
+int sdrt_kernel_time(sdrt_ctx *ctx, int which, double *total_ms, int64_t *launches);
+int sdrt_profile_reset(sdrt_ctx *ctx);
+const char *sdrt_kernel_name(int which);
+
+/* Thin device-memory helpers so a ctypes host needs no other GPU runtime binding. */
+int sdrt_malloc(void **dev_ptr, size_t bytes);
+int sdrt_free(void *dev_ptr);
+int sdrt_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int sdrt_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int sdrt_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes);
+int sdrt_device_synchronize(void);
+int sdrt_set_device(int device);
+
+/* Self-test of the f64 MFMA operand layout the decimator relies on (runs a 16x16x4 product on the GPU). */
+int sdrt_selftest_mfma(double *max_abs_err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRTERM_HIP_H */

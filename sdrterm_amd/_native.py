@@ -1,0 +1,141 @@
+"""ctypes binding of libsdrterm_hip.so -- the only way this package computes anything.
+
+Loading fails loudly (``NativeLibraryError``) when the shared library has not been built; there is no
+fallback.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C sdrterm_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsdrterm_hip.so')
+
+# enum sdrt_dtype, keyed by the reference's DataType names (src/misc/file_util.py:44-56)
+DTYPES = {'b': 0, 'B': 1, 'h': 2, 'H': 3, 'i': 4, 'I': 5, 'f': 6, 'd': 7}
+ITEM_SIZE = {'b': 1, 'B': 1, 'h': 2, 'H': 2, 'i': 4, 'I': 4, 'f': 4, 'd': 8}
+MODES = {'fm': 0, 'am': 1}
+OK, EINVAL, EHIP, ENOMEM, ENODEVICE = 0, 1, 2, 3, 4
+
+EXPORTS = (
+    'sdrt_abi_version', 'sdrt_device_count', 'sdrt_last_error', 'sdrt_create', 'sdrt_destroy',
+    'sdrt_out_per_chunk', 'sdrt_rows', 'sdrt_process_device', 'sdrt_process_host',
+    'sdrt_process_device_debug', 'sdrt_get_iq_offset', 'sdrt_set_iq_offset', 'sdrt_profile_enable',
+    'sdrt_kernel_time', 'sdrt_profile_reset', 'sdrt_kernel_name', 'sdrt_malloc', 'sdrt_free',
+    'sdrt_memcpy_h2d', 'sdrt_memcpy_d2h', 'sdrt_memcpy_d2d', 'sdrt_device_synchronize', 'sdrt_set_device',
+    'sdrt_selftest_mfma',
+)
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class SdrtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f'[sdrt {code}] {message}')
+        self.code = code
+
+
+class Config(C.Structure):
+    """struct sdrt_config (include/sdrterm_hip.h)."""
+    _fields_ = [
+        ('struct_size', C.c_uint32), ('device', C.c_int32), ('fs', C.c_double),
+        ('decimation', C.c_int32), ('mode', C.c_int32), ('dtype', C.c_int32), ('swap_endianness', C.c_int32),
+        ('n_samples', C.c_int32), ('n_rows', C.c_int32), ('row_freqs', C.POINTER(C.c_double)),
+        ('apply_shift', C.c_int32), ('normalize', C.c_int32), ('norm_xmin', C.c_double),
+        ('norm_inv_range', C.c_double), ('correct_iq', C.c_int32), ('reserved0', C.c_int32),
+        ('iq_inductance', C.c_double), ('dec_sos', C.POINTER(C.c_double)), ('dec_sections', C.c_int32),
+        ('out_sections', C.c_int32), ('out_sos', C.POINTER(C.c_double)),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f'{LIB_PATH} is missing: the HIP extension has not been built and there is no CPU path. '
+            'Run `make -C sdrterm_amd/csrc` (needs hipcc, targets gfx950).')
+    try:
+        l = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 not found
+        raise NativeLibraryError(f'cannot load {LIB_PATH}: {e}') from e
+    for name in EXPORTS:
+        if not hasattr(l, name):
+            raise NativeLibraryError(f'{LIB_PATH} does not export {name}')
+    l.sdrt_last_error.restype = C.c_char_p
+    l.sdrt_kernel_name.restype = C.c_char_p
+    l.sdrt_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    l.sdrt_destroy.argtypes = [C.c_void_p]
+    l.sdrt_destroy.restype = None
+    l.sdrt_out_per_chunk.argtypes = [C.c_void_p]
+    l.sdrt_rows.argtypes = [C.c_void_p]
+    l.sdrt_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    l.sdrt_process_device_debug.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    l.sdrt_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    l.sdrt_get_iq_offset.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    l.sdrt_set_iq_offset.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    l.sdrt_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    l.sdrt_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    l.sdrt_profile_reset.argtypes = [C.c_void_p]
+    l.sdrt_kernel_name.argtypes = [C.c_int]
+    l.sdrt_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    l.sdrt_free.argtypes = [C.c_void_p]
+    l.sdrt_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    l.sdrt_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    l.sdrt_memcpy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    l.sdrt_set_device.argtypes = [C.c_int]
+    l.sdrt_device_count.argtypes = [C.POINTER(C.c_int)]
+    l.sdrt_selftest_mfma.argtypes = [C.POINTER(C.c_double)]
+    if l.sdrt_abi_version() != 1:
+        raise NativeLibraryError('libsdrterm_hip.so ABI version mismatch')
+    _lib = l
+    return l
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise SdrtError(rc, lib().sdrt_last_error().decode(errors='replace'))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().sdrt_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+class DeviceBuffer:
+    """A raw device allocation (sdrt_malloc / sdrt_free) for hosts that have no other GPU runtime binding."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().sdrt_malloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def upload(self, data) -> 'DeviceBuffer':
+        import numpy as np
+        a = np.ascontiguousarray(data)
+        assert a.nbytes <= self.nbytes
+        check(lib().sdrt_memcpy_h2d(self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self, out):
+        assert out.flags['C_CONTIGUOUS'] and out.nbytes <= self.nbytes
+        check(lib().sdrt_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().sdrt_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,428 @@
+// C ABI of libsdrterm_hip.so (see include/sdrterm_hip.h).  Host side only: context management, table
+// construction/upload, launches.  There is deliberately no CPU compute path here: every processing entry point
+// needs a working HIP device and fails with SDRT_ENODEVICE / SDRT_EHIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(SDRT_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+const int kItemSize[8] = {1, 1, 2, 2, 4, 4, 4, 8};
+
+struct Pending {
+    int which;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct sdrt_ctx {
+    sdrt_config cfg;
+    int L = 0, m = 0, n_tiles = 0, rows = 1, mid_per_chunk = 0;
+    bool nco = false;
+    double norm_scale = 1.0, norm_bias = 0.0;
+    DecimTables *d_tab = nullptr;
+    double *d_nco_tile = nullptr, *d_nco_phase = nullptr, *d_resample = nullptr, *d_out_sos = nullptr;
+    double *d_mid = nullptr;
+    size_t mid_cap_chunks = 0;
+    void *d_raw = nullptr;
+    double *d_out = nullptr;
+    size_t stage_cap_chunks = 0;
+    double iq_re = 0.0, iq_im = 0.0;
+    bool profile = false;
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> free_events;
+    double ms[3] = {0, 0, 0};
+    int64_t launches[3] = {0, 0, 0};
+};
+
+namespace {
+
+hipEvent_t get_event(sdrt_ctx *c) {
+    if (!c->free_events.empty()) {
+        hipEvent_t e = c->free_events.back();
+        c->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+int resolve_pending(sdrt_ctx *c) {
+    for (auto &p : c->pending) {
+        HIP_TRY(hipEventSynchronize(p.b));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, p.a, p.b));
+        c->ms[p.which] += (double) t;
+        c->launches[p.which] += 1;
+        c->free_events.push_back(p.a);
+        c->free_events.push_back(p.b);
+    }
+    c->pending.clear();
+    return SDRT_OK;
+}
+
+struct Timed {
+    sdrt_ctx *c;
+    hipStream_t s;
+    int which;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(sdrt_ctx *c_, hipStream_t s_, int w) : c(c_), s(s_), which(w) {
+        if (c->profile) {
+            a = get_event(c);
+            b = get_event(c);
+            if (a && b) (void) hipEventRecord(a, s);
+        }
+    }
+    ~Timed() {
+        if (c->profile && a && b) {
+            (void) hipEventRecord(b, s);
+            c->pending.push_back({which, a, b});
+        }
+    }
+};
+
+template <class T>
+int upload(T **dst, const void *src, size_t bytes) {
+    HIP_TRY(hipMalloc((void **) dst, bytes));
+    HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return SDRT_OK;
+}
+
+int ensure_mid(sdrt_ctx *c, size_t n_chunks) {
+    if (n_chunks <= c->mid_cap_chunks) return SDRT_OK;
+    if (c->d_mid) HIP_TRY(hipFree(c->d_mid));
+    c->d_mid = nullptr;
+    c->mid_cap_chunks = 0;
+    HIP_TRY(hipMalloc((void **) &c->d_mid, n_chunks * (size_t) c->rows * c->mid_per_chunk * sizeof(double)));
+    c->mid_cap_chunks = n_chunks;
+    return SDRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdrt_abi_version(void) { return SDRT_ABI_VERSION; }
+
+const char *sdrt_last_error(void) { return g_err; }
+
+int sdrt_device_count(int *count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        if (count) *count = 0;
+        return fail(SDRT_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    if (count) *count = n;
+    return SDRT_OK;
+}
+
+int sdrt_set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return SDRT_OK;
+}
+
+int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
+    if (!cfg || !out) return fail(SDRT_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(sdrt_config))
+        return fail(SDRT_EINVAL, "sdrt_config size mismatch (got %u, built with %zu)", cfg->struct_size, sizeof(sdrt_config));
+    if (cfg->decimation < 2) return fail(SDRT_EINVAL, "Decimation must be at least 2.");  // dsp_processor.py:94-95
+    if (cfg->dtype < 0 || cfg->dtype > 7) return fail(SDRT_EINVAL, "unknown dtype %d", cfg->dtype);
+    if (cfg->mode != SDRT_FM && cfg->mode != SDRT_AM) return fail(SDRT_EINVAL, "unknown mode %d", cfg->mode);
+    if (!cfg->dec_sos || !cfg->out_sos) return fail(SDRT_EINVAL, "dec_sos and out_sos are required");
+    if (cfg->out_sections < 1 || cfg->out_sections > SDRT_MAX_OUT_SECTIONS)
+        return fail(SDRT_EINVAL, "out_sections must be 1..%d", SDRT_MAX_OUT_SECTIONS);
+    if (cfg->n_rows < 1) return fail(SDRT_EINVAL, "n_rows must be >= 1");
+    if (cfg->apply_shift && !cfg->row_freqs) return fail(SDRT_EINVAL, "row_freqs required when apply_shift is set");
+    if (!(cfg->fs > 0)) return fail(SDRT_EINVAL, "fs must be positive");
+    const int q = cfg->decimation, n = cfg->n_samples;
+    if (q < 8 || (q & (q - 1)))
+        return fail(SDRT_EINVAL, "this build supports decimation factors that are powers of two >= 8 (got %d)", q);
+    if (n <= SDRT_EDGE) return fail(SDRT_EINVAL, "n_samples must exceed the filter pad length %d", SDRT_EDGE);
+    const int L = q < SDRT_MAXL ? q : SDRT_MAXL;
+    if (n % (SDRT_TB * L)) return fail(SDRT_EINVAL, "n_samples (%d) must be a multiple of %d", n, SDRT_TB * L);
+    if (n % q) return fail(SDRT_EINVAL, "decimation must divide n_samples");   // dsp_processor.py:147,173
+    const int m = n / q;
+    if (cfg->mode == SDRT_FM && (m < 2 || (m & 1))) return fail(SDRT_EINVAL, "FM needs an even number of outputs per chunk");
+    if (cfg->correct_iq) return fail(SDRT_EINVAL, "correct_iq is not implemented in this build");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(SDRT_ENODEVICE, "no HIP device available (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(SDRT_EINVAL, "device %d out of range (%d found)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    sdrt_ctx *c = new (std::nothrow) sdrt_ctx();
+    if (!c) return fail(SDRT_ENOMEM, "out of host memory");
+    c->cfg = *cfg;
+    c->cfg.row_freqs = nullptr;
+    c->cfg.dec_sos = nullptr;
+    c->cfg.out_sos = nullptr;
+    c->L = L;
+    c->m = m;
+    c->n_tiles = n / (SDRT_TB * L);
+    c->rows = cfg->n_rows;
+    c->nco = cfg->apply_shift != 0;
+    c->mid_per_chunk = cfg->mode == SDRT_FM ? m / 2 : m;
+    if (cfg->normalize) {
+        // read_file.py:96: 1.6*(z - xmin)*d - 0.8 with complex z: only Re is offset.
+        c->norm_scale = 1.6 * cfg->norm_inv_range;
+        c->norm_bias = -1.6 * cfg->norm_xmin * cfg->norm_inv_range - 0.8;
+    }
+    const size_t lds = decim_lds_bytes(n, L, m, c->nco);
+    if (lds > 160 * 1024) {
+        delete c;
+        return fail(SDRT_EINVAL, "chunk needs %zu bytes of LDS (> 160 KiB): n_samples/decimation combination unsupported", lds);
+    }
+
+    int rc = SDRT_OK;
+    DecimTables tab;
+    const char *msg = nullptr;
+    if (sdrt_build_decim_tables(cfg->dec_sos, cfg->dec_sections, q, &tab, &msg) != 0) {
+        delete c;
+        return fail(SDRT_EINVAL, "decimator tables: %s", msg ? msg : "failed");
+    }
+    rc = upload(&c->d_tab, &tab, sizeof(tab));
+    if (rc == SDRT_OK) rc = upload(&c->d_out_sos, cfg->out_sos, sizeof(double) * 6 * cfg->out_sections);
+    if (rc == SDRT_OK && c->nco) {
+        const int tile_len = SDRT_TB * L;
+        std::vector<double> tile((size_t) c->rows * tile_len * 2), phase((size_t) c->rows * c->n_tiles * 2);
+        for (int r = 0; r < c->rows; ++r)
+            sdrt_build_nco(cfg->row_freqs[r], cfg->fs, tile_len, c->n_tiles, &tile[(size_t) r * tile_len * 2],
+                           &phase[(size_t) r * c->n_tiles * 2]);
+        rc = upload(&c->d_nco_tile, tile.data(), tile.size() * sizeof(double));
+        if (rc == SDRT_OK) rc = upload(&c->d_nco_phase, phase.data(), phase.size() * sizeof(double));
+    }
+    if (rc == SDRT_OK && cfg->mode == SDRT_FM) {
+        std::vector<double> h((size_t) m / 2);
+        sdrt_build_resample_odd(m / 2, h.data());
+        rc = upload(&c->d_resample, h.data(), h.size() * sizeof(double));
+    }
+    if (rc != SDRT_OK) {
+        sdrt_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return SDRT_OK;
+}
+
+void sdrt_destroy(sdrt_ctx *c) {
+    if (!c) return;
+    (void) hipSetDevice(c->cfg.device);
+    (void) hipDeviceSynchronize();
+    for (auto &p : c->pending) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
+    for (auto &e : c->free_events) (void) hipEventDestroy(e);
+    (void) hipFree(c->d_tab);
+    (void) hipFree(c->d_nco_tile);
+    (void) hipFree(c->d_nco_phase);
+    (void) hipFree(c->d_resample);
+    (void) hipFree(c->d_out_sos);
+    (void) hipFree(c->d_mid);
+    (void) hipFree(c->d_raw);
+    (void) hipFree(c->d_out);
+    delete c;
+}
+
+int sdrt_out_per_chunk(const sdrt_ctx *c) { return c ? c->m : -1; }
+int sdrt_rows(const sdrt_ctx *c) { return c ? c->rows : -1; }
+
+int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *out_dev, double *ydec_dev,
+                              void *stream) {
+    if (!c) return fail(SDRT_EINVAL, "null context");
+    if (n_chunks == 0) return SDRT_OK;
+    if (!raw_dev || !out_dev) return fail(SDRT_EINVAL, "null buffer");
+    if (((uintptr_t) raw_dev & 15) != 0) return fail(SDRT_EINVAL, "raw_dev must be 16-byte aligned");
+    if (n_chunks * (size_t) c->rows > 0x7fffffffull) return fail(SDRT_EINVAL, "too many chunks in one call");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    int rc = ensure_mid(c, n_chunks);
+    if (rc != SDRT_OK) return rc;
+    hipStream_t s = (hipStream_t) stream;
+
+    DecimArgs da;
+    da.raw = raw_dev;
+    da.tab = c->d_tab;
+    da.nco_tile = c->d_nco_tile;
+    da.nco_phase = c->d_nco_phase;
+    da.mid = c->d_mid;
+    da.ydec = ydec_dev;
+    da.n_chunks = n_chunks;
+    da.n = c->cfg.n_samples;
+    da.m = c->m;
+    da.n_tiles = c->n_tiles;
+    da.rows = c->rows;
+    da.mode = c->cfg.mode;
+    da.swap = c->cfg.swap_endianness && kItemSize[c->cfg.dtype] > 1;
+    da.norm_scale = c->norm_scale;
+    da.norm_bias = c->norm_bias;
+    {
+        Timed t(c, s, 0);
+        HIP_TRY(launch_decim(da, c->L, c->cfg.dtype, c->nco, n_chunks, s));
+    }
+    PostArgs pa;
+    pa.mid = c->d_mid;
+    pa.resample_odd = c->d_resample;
+    pa.out_sos = c->d_out_sos;
+    pa.out = out_dev;
+    pa.m = c->m;
+    pa.mode = c->cfg.mode;
+    pa.out_sections = c->cfg.out_sections;
+    {
+        Timed t(c, s, 1);
+        HIP_TRY(launch_post(pa, n_chunks * (size_t) c->rows, s));
+    }
+    return SDRT_OK;
+}
+
+int sdrt_process_device(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *out_dev, void *stream) {
+    return sdrt_process_device_debug(c, raw_dev, n_chunks, out_dev, nullptr, stream);
+}
+
+int sdrt_process_host(sdrt_ctx *c, const void *raw_host, size_t n_chunks, double *out_host) {
+    if (!c) return fail(SDRT_EINVAL, "null context");
+    if (n_chunks == 0) return SDRT_OK;
+    if (!raw_host || !out_host) return fail(SDRT_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const size_t in_bytes = (size_t) c->cfg.n_samples * 2 * kItemSize[c->cfg.dtype];
+    const size_t out_elems = (size_t) c->rows * c->m;
+    if (n_chunks > c->stage_cap_chunks) {
+        if (c->d_raw) HIP_TRY(hipFree(c->d_raw));
+        if (c->d_out) HIP_TRY(hipFree(c->d_out));
+        c->d_raw = nullptr;
+        c->d_out = nullptr;
+        c->stage_cap_chunks = 0;
+        HIP_TRY(hipMalloc(&c->d_raw, n_chunks * in_bytes));
+        HIP_TRY(hipMalloc((void **) &c->d_out, n_chunks * out_elems * sizeof(double)));
+        c->stage_cap_chunks = n_chunks;
+    }
+    HIP_TRY(hipMemcpy(c->d_raw, raw_host, n_chunks * in_bytes, hipMemcpyHostToDevice));
+    int rc = sdrt_process_device(c, c->d_raw, n_chunks, c->d_out, nullptr);
+    if (rc != SDRT_OK) return rc;
+    HIP_TRY(hipMemcpy(out_host, c->d_out, n_chunks * out_elems * sizeof(double), hipMemcpyDeviceToHost));
+    return SDRT_OK;
+}
+
+int sdrt_get_iq_offset(sdrt_ctx *c, double *re, double *im) {
+    if (!c) return fail(SDRT_EINVAL, "null context");
+    if (re) *re = c->iq_re;
+    if (im) *im = c->iq_im;
+    return SDRT_OK;
+}
+
+int sdrt_set_iq_offset(sdrt_ctx *c, double re, double im) {
+    if (!c) return fail(SDRT_EINVAL, "null context");
+    c->iq_re = re;
+    c->iq_im = im;
+    return SDRT_OK;
+}
+
+int sdrt_profile_enable(sdrt_ctx *c, int enable) {
+    if (!c) return fail(SDRT_EINVAL, "null context");
+    c->profile = enable != 0;
+    return SDRT_OK;
+}
+
+int sdrt_kernel_time(sdrt_ctx *c, int which, double *total_ms, int64_t *launches) {
+    if (!c || which < 0 || which > 2) return fail(SDRT_EINVAL, "bad argument");
+    int rc = resolve_pending(c);
+    if (rc != SDRT_OK) return rc;
+    if (total_ms) *total_ms = c->ms[which];
+    if (launches) *launches = c->launches[which];
+    return SDRT_OK;
+}
+
+int sdrt_profile_reset(sdrt_ctx *c) {
+    if (!c) return fail(SDRT_EINVAL, "null context");
+    int rc = resolve_pending(c);
+    for (int i = 0; i < 3; ++i) { c->ms[i] = 0; c->launches[i] = 0; }
+    return rc;
+}
+
+const char *sdrt_kernel_name(int which) {
+    switch (which) {
+        case 0: return "decim_demod_kernel";
+        case 1: return "post_kernel";
+        case 2: return "iq_prefix_kernels";
+    }
+    return "";
+}
+
+int sdrt_malloc(void **p, size_t bytes) {
+    if (!p) return fail(SDRT_EINVAL, "null argument");
+    HIP_TRY(hipMalloc(p, bytes ? bytes : 1));
+    return SDRT_OK;
+}
+int sdrt_free(void *p) {
+    HIP_TRY(hipFree(p));
+    return SDRT_OK;
+}
+int sdrt_memcpy_h2d(void *d, const void *s, size_t b) {
+    HIP_TRY(hipMemcpy(d, s, b, hipMemcpyHostToDevice));
+    return SDRT_OK;
+}
+int sdrt_memcpy_d2h(void *d, const void *s, size_t b) {
+    HIP_TRY(hipMemcpy(d, s, b, hipMemcpyDeviceToHost));
+    return SDRT_OK;
+}
+int sdrt_memcpy_d2d(void *d, const void *s, size_t b) {
+    HIP_TRY(hipMemcpy(d, s, b, hipMemcpyDeviceToDevice));
+    return SDRT_OK;
+}
+int sdrt_device_synchronize(void) {
+    HIP_TRY(hipDeviceSynchronize());
+    return SDRT_OK;
+}
+
+int sdrt_selftest_mfma(double *max_abs_err) {
+    double A[64], B[64], D[256], *dA = nullptr, *dB = nullptr, *dD = nullptr;
+    for (int i = 0; i < 16; ++i)
+        for (int k = 0; k < 4; ++k) A[i * 4 + k] = (double) (1 + i * 5 + k * 3);     // asymmetric integer data
+    for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 16; ++j) B[k * 16 + j] = (double) (2 + k * 7 - j * 2);
+    HIP_TRY(hipMalloc((void **) &dA, sizeof(A)));
+    HIP_TRY(hipMalloc((void **) &dB, sizeof(B)));
+    HIP_TRY(hipMalloc((void **) &dD, sizeof(D)));
+    HIP_TRY(hipMemcpy(dA, A, sizeof(A), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dB, B, sizeof(B), hipMemcpyHostToDevice));
+    HIP_TRY(launch_mfma_selftest(dA, dB, dD, nullptr));
+    HIP_TRY(hipMemcpy(D, dD, sizeof(D), hipMemcpyDeviceToHost));
+    (void) hipFree(dA);
+    (void) hipFree(dB);
+    (void) hipFree(dD);
+    double worst = 0.0;
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            double ref = 0.0;
+            for (int k = 0; k < 4; ++k) ref += A[i * 4 + k] * B[k * 16 + j];
+            worst = std::fmax(worst, std::fabs(ref - D[i * 16 + j]));
+        }
+    if (max_abs_err) *max_abs_err = worst;
+    return worst == 0.0 ? SDRT_OK : fail(SDRT_EHIP, "MFMA f64 16x16x4 operand layout mismatch (max err %g)", worst);
+}
+
+}  // extern "C"

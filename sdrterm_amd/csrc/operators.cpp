@@ -1,0 +1,249 @@
+// Host-side construction of the operator tables (tables.h) in 113-bit arithmetic (__float128).
+//
+// What is restated here is the operator scipy applies when the reference calls
+//     y[:] = decimate(x, self._decimationFactor)            src/dsp/dsp_processor.py:147
+// i.e. sosfiltfilt(cheby1(8, 0.05, 0.8/q, 'sos'), x)[::q] with its defaults: odd extension by 27 samples,
+// sosfilt_zi initial conditions scaled by the first sample, forward pass, backward pass, strip, stride.
+// Instead of running the recursion sample by sample, the forward-backward filter is expanded in partial
+// fractions over its 8 poles p_i (4 conjugate pairs):
+//     H(z) H(1/z)  =  d0 + sum_i alpha_i [ z^-1/(1 - p_i z^-1) + z/(1 - p_i z) ]
+// so every output is   d0 u[t] + sum_i alpha_i ( phi_i(t) + Z_i(t) )   with a causal first-order state
+// phi_i and an anticausal first-order state Z_i per pole.  The edge handling (odd extension and zi) turns
+// into the initial values of phi_i at the left edge and of Z_i at the right edge, both linear in a few
+// edge samples; those linear maps are obtained below by evaluating the literal definition on unit inputs.
+// Everything is built in __float128 and rounded once to double, so table error is ~1e-16 relative.
+#include "tables.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+typedef __float128 R;
+
+struct C {
+    R re, im;
+    C() : re(0), im(0) {}
+    C(R r) : re(r), im(0) {}
+    C(R r, R i) : re(r), im(i) {}
+};
+inline C operator+(C a, C b) { return C(a.re + b.re, a.im + b.im); }
+inline C operator-(C a, C b) { return C(a.re - b.re, a.im - b.im); }
+inline C operator*(C a, C b) { return C(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+inline C operator/(C a, C b) {
+    R d = b.re * b.re + b.im * b.im;
+    return C((a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d);
+}
+inline C conj(C a) { return C(a.re, -a.im); }
+inline C cpow(C a, int n) {
+    C r(1);
+    C b = a;
+    while (n > 0) {
+        if (n & 1) r = r * b;
+        b = b * b;
+        n >>= 1;
+    }
+    return r;
+}
+inline R rsqrt128(R x) {  // sqrt by Newton from a double seed
+    if (x <= 0) return 0;
+    R y = (R) std::sqrt((double) x);
+    for (int i = 0; i < 4; ++i) y = (y + x / y) / 2;
+    return y;
+}
+inline void put(double *dst, C v) {
+    dst[0] = (double) v.re;
+    dst[1] = (double) v.im;
+}
+
+struct Modal {
+    C p[8], r[8], alpha[8], X[8][8];
+    R D, d0;
+};
+
+// Poles, residues of the cascade H(z) = prod (b0 + b1 z^-1 + b2 z^-2)/(1 + a1 z^-1 + a2 z^-2) = D + sum r_i/(z - p_i),
+// and the partial-fraction data of H(z)H(1/z).  Index 2i / 2i+1 = pole with Im > 0 / its conjugate.
+bool build_modal(const double *sos, int nsec, Modal &m, const char **err) {
+    if (nsec != 4) { if (err) *err = "decimator must have 4 second-order sections (order 8)"; return false; }
+    R b[4][3], a[4][3];
+    for (int s = 0; s < 4; ++s) {
+        R a0 = sos[6 * s + 3];
+        if (a0 == 0) { if (err) *err = "a0 == 0 in decimator SOS"; return false; }
+        for (int k = 0; k < 3; ++k) { b[s][k] = (R) sos[6 * s + k] / a0; a[s][k] = (R) sos[6 * s + 3 + k] / a0; }
+        R disc = a[s][1] * a[s][1] - 4 * a[s][2];
+        if (!(disc < 0)) { if (err) *err = "decimator section has real poles (unsupported)"; return false; }
+        R sq = rsqrt128(-disc);
+        m.p[2 * s] = C(-a[s][1] / 2, sq / 2);
+        m.p[2 * s + 1] = C(-a[s][1] / 2, -sq / 2);
+    }
+    m.D = 1;
+    for (int s = 0; s < 4; ++s) m.D = m.D * b[s][0];
+    for (int i = 0; i < 8; ++i) {
+        C num(1), den(1), p = m.p[i];
+        for (int s = 0; s < 4; ++s) num = num * (C(b[s][0]) * p * p + C(b[s][1]) * p + C(b[s][2]));
+        for (int j = 0; j < 8; ++j) if (j != i) den = den * (p - m.p[j]);
+        m.r[i] = num / den;
+    }
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) m.X[i][j] = m.r[j] / (C(1) - m.p[i] * m.p[j]);
+    C sumrho(0);
+    for (int j = 0; j < 8; ++j) {
+        C s(0);
+        for (int i = 0; i < 8; ++i) s = s + m.r[i] / (C(1) - m.p[i] * m.p[j]);
+        C rho = m.r[j] * s;
+        m.alpha[j] = C(m.D) * m.r[j] + m.p[j] * rho;
+        sumrho = sumrho + rho;
+    }
+    m.d0 = m.D * m.D + sumrho.re;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int sdrt_build_decim_tables(const double *sos, int sections, int q, DecimTables *out, const char **err) {
+    static const char *kBadQ = "decimation must be a power of two >= 4 for the MFMA path";
+    if (q < 4 || (q & (q - 1))) { if (err) *err = kBadQ; return -1; }
+    Modal m;
+    if (!build_modal(sos, sections, m, err)) return -2;
+    std::memset(out, 0, sizeof(*out));
+    const int L = q < SDRT_MAXL ? q : SDRT_MAXL;
+    out->L = L;
+    out->ksteps = L / 4;
+    out->out_stride = q / L;
+    out->edge = SDRT_EDGE;
+
+    C P[4], ac[4], aa[4], mu[4];
+    C sum_a_over_p(0);
+    for (int i = 0; i < 8; ++i) sum_a_over_p = sum_a_over_p + m.alpha[i] / m.p[i];
+    out->d0p = (double) (m.d0 - sum_a_over_p.re);
+    for (int i = 0; i < 4; ++i) {
+        P[i] = m.p[2 * i];
+        ac[i] = m.alpha[2 * i];
+        aa[i] = m.alpha[2 * i] / P[i];
+        mu[i] = cpow(P[i], L);
+    }
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < L; ++j) {
+            C wc = ac[i] * cpow(P[i], L - 1 - j);
+            C wa = aa[i] * cpow(P[i], j);
+            out->W[i][j] = (double) wc.re;
+            out->W[4 + i][j] = (double) wc.im;
+            out->W[8 + i][j] = (double) wa.re;
+            out->W[12 + i][j] = (double) wa.im;
+        }
+        const int pw[5] = {1, 2, 4, 8, 16};
+        for (int k = 0; k < 5; ++k) put(out->mu_pow[k][i], cpow(mu[i], pw[k]));
+        for (int nb = 0; nb < SDRT_TB; ++nb) {
+            put(out->cF[nb][i], cpow(mu[i], nb));
+            put(out->cG[nb][i], cpow(mu[i], SDRT_TB - nb));
+        }
+    }
+
+    // Left edge: phi_i just before the first real sample, for a real stream u[0..27] (literal evaluation:
+    // e[t] = 2u[0] - u[27-t], t < 27; phi(0) = e[0]/(1-p); phi(t+1) = p phi(t) + e[t]).  Scaled by alpha_i.
+    const int E = SDRT_EDGE;
+    for (int l = 0; l <= E; ++l) {
+        R u[E + 1];
+        for (int k = 0; k <= E; ++k) u[k] = (k == l) ? 1 : 0;
+        for (int i = 0; i < 4; ++i) {
+            C phi = C(2 * u[0] - u[E]) / (C(1) - P[i]);
+            for (int t = 0; t < E; ++t) phi = P[i] * phi + C(2 * u[0] - u[E - t]);
+            put(out->head[i][l], ac[i] * phi);
+        }
+    }
+
+    // Right edge: anticausal state (after consuming the first extension sample) as a real-linear function of the
+    // causal states F_j at the end of the data (scaled coordinates) and of the last 28 samples of the stream.
+    // Literal evaluation over all 8 poles of: forward through the 27 extension samples, y_f[N-1], the backward
+    // initial state zi*y_f[N-1] in modal form, the decoupling term, then back through the extension.
+    auto tail_eval = [&](const C Fs[4], const R ut[E + 1], C G[4]) {
+        C phi[8], prev[8];
+        for (int i = 0; i < 4; ++i) {
+            C ph = Fs[i] / ac[i];
+            phi[2 * i] = ph;
+            phi[2 * i + 1] = conj(ph);
+        }
+        R et[E];
+        for (int t = 0; t < E; ++t) et[t] = 2 * ut[E] - ut[E - 1 - t];   // 2u[n-1] - u[n-2-t]
+        for (int t = 0; t < E; ++t) {
+            for (int i = 0; i < 8; ++i) { prev[i] = phi[i]; phi[i] = m.p[i] * phi[i] + C(et[t]); }
+        }
+        C yf(m.D * et[E - 1]);
+        for (int i = 0; i < 8; ++i) yf = yf + m.r[i] * prev[i];
+        C Zp[8];
+        for (int i = 0; i < 8; ++i) {
+            C gam = yf / (C(1) - m.p[i]);
+            for (int j = 0; j < 8; ++j) gam = gam - m.X[i][j] * phi[j];
+            Zp[i] = m.r[i] * gam / m.alpha[i];
+        }
+        for (int t = E - 1; t >= 1; --t)
+            for (int i = 0; i < 8; ++i) Zp[i] = m.p[i] * Zp[i] + C(et[t]);
+        for (int i = 0; i < 4; ++i) G[i] = aa[i] * (m.p[2 * i] * Zp[2 * i] + C(et[0]));
+    };
+    {
+        R zero_u[E + 1];
+        for (int k = 0; k <= E; ++k) zero_u[k] = 0;
+        for (int j = 0; j < 4; ++j) {
+            C F1[4], Fi[4], G1[4], Gi[4];
+            F1[j] = C(1);
+            Fi[j] = C(0, 1);
+            tail_eval(F1, zero_u, G1);
+            tail_eval(Fi, zero_u, Gi);
+            for (int i = 0; i < 4; ++i) {
+                // G1 = a + b, Gi = i(a - b)  ->  a = (G1 - i Gi)/2, b = (G1 + i Gi)/2
+                C iGi = C(0, 1) * Gi[i];
+                put(out->tailF[i][j], (G1[i] - iGi) / C(2));
+                put(out->tailFc[i][j], (G1[i] + iGi) / C(2));
+            }
+        }
+        C F0[4];
+        for (int l = 0; l <= E; ++l) {
+            R u[E + 1];
+            for (int k = 0; k <= E; ++k) u[k] = (k == l) ? 1 : 0;
+            C G[4];
+            tail_eval(F0, u, G);
+            for (int i = 0; i < 4; ++i) put(out->tailU[i][l], G[i]);
+        }
+    }
+    return 0;
+}
+
+extern "C" void sdrt_build_nco(double f, double fs, int tile_len, int n_tiles, double *tile, double *tilephase) {
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    auto phasor = [&](long double t, double *dst) {
+        // exp(-2 pi i (f/fs) t): reduce f*t modulo fs before scaling so the angle stays in (-2pi, 2pi)
+        long double cyc = fmodl((long double) f * t, (long double) fs) / (long double) fs;
+        long double ang = -two_pi * cyc;
+        dst[0] = (double) cosl(ang);
+        dst[1] = (double) sinl(ang);
+    };
+    for (int t = 0; t < tile_len; ++t) phasor((long double) t, tile + 2 * t);
+    for (int T = 0; T < n_tiles; ++T) phasor((long double) T * (long double) tile_len, tilephase + 2 * T);
+}
+
+extern "C" void sdrt_build_resample_odd(int N, double *h) {
+    // scipy.signal.resample(a, 2N), real a (demodulation.py:35-38): X = rfft(a); Y[:N/2+1] = X; if N even the bin
+    // N/2 is halved; y = irfft(Y, 2N) * 2.  For a unit impulse at 0 the odd outputs are
+    //   h[d] = y[2d+1] = (1/N) [ 1 + 2 sum_{f=1}^{F} cos(pi f (2d+1)/N) ],  F = N/2-1 (N even; the halved bin
+    //   contributes cos(pi(2d+1)/2) = 0) or (N-1)/2 (N odd).
+    const long double pi = 3.141592653589793238462643383279502884L;
+    const int F = (N % 2 == 0) ? N / 2 - 1 : (N - 1) / 2;
+    for (int d = 0; d < N; ++d) {
+        long double s = 1.0L;
+        for (int f = 1; f <= F; ++f) {
+            // reduce f*(2d+1) modulo 2N exactly in integers before calling cosl
+            long long k = ((long long) f * (2LL * d + 1)) % (2LL * N);
+            s += 2.0L * cosl(pi * (long double) k / (long double) N);
+        }
+        h[d] = (double) (s / (long double) N);
+    }
+}
+
+extern "C" void sdrt_build_iq_pow(double lambda, int count, double *pw) {
+    R a = (R) 1 - (R) lambda;
+    R v = 1;
+    for (int j = 0; j <= count; ++j) {
+        pw[j] = (double) v;
+        v = v * a;
+    }
+}

@@ -1,0 +1,48 @@
+// Host-built operator tables shared between operators.cpp (extended-precision construction, host only)
+// and the HIP translation unit (device kernels + C ABI).  Plain-old-data, copied to the device verbatim.
+#pragma once
+#include <stdint.h>
+
+#define SDRT_MAXL 64        // samples per block (K dimension of the stage-A MFMA contraction)
+#define SDRT_TB 16          // blocks per tile == MFMA N dimension
+#define SDRT_EDGE 27        // sosfiltfilt odd-extension length for the order-8 decimator (3 * (2*4+1))
+#define SDRT_NMODE 4        // conjugate pole pairs of the order-8 decimator
+
+// Zero-phase decimator in modal block form (see DESIGN.md "Decimator").  All complex numbers are {re, im}.
+struct DecimTables {
+    int32_t L;              // block length in samples: min(q, 64)
+    int32_t ksteps;         // L / 4 MFMA k-steps per block
+    int32_t out_stride;     // one output every out_stride blocks: q / L
+    int32_t edge;           // == SDRT_EDGE
+    // Stage-A weights, row r = mode (r & 3), kind (r >> 2): 0 Re causal, 1 Im causal, 2 Re anticausal, 3 Im anticausal.
+    // causal row i:  alpha_i * p_i^(L-1-j);  anticausal row i: (alpha_i / p_i) * p_i^j.
+    double W[16][SDRT_MAXL];
+    double mu_pow[5][SDRT_NMODE][2];    // mu_i^(1,2,4,8,16), mu_i = p_i^L
+    double cF[SDRT_TB][SDRT_NMODE][2];  // mu_i^nb        (carry-in of the causal state to block nb of a tile)
+    double cG[SDRT_TB][SDRT_NMODE][2];  // mu_i^(16-nb)   (carry-in of the anticausal state)
+    double d0p;                          // direct term
+    double head[SDRT_NMODE][SDRT_EDGE + 1][2];   // F_0,i = sum_l head[i][l] * u[l]            (per real stream)
+    double tailF[SDRT_NMODE][SDRT_NMODE][2];     // G_end,i = sum_j tailF[i][j] F_j + tailFc[i][j] conj(F_j)
+    double tailFc[SDRT_NMODE][SDRT_NMODE][2];    //          + sum_l tailU[i][l] * u[n-28+l]
+    double tailU[SDRT_NMODE][SDRT_EDGE + 1][2];
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// Builds the tables from the decimator SOS (scipy layout [sections][6]).  Returns 0 or a negative code;
+// on failure *err (if non-null) points to a static message.
+int sdrt_build_decim_tables(const double *sos, int sections, int q, struct DecimTables *out, const char **err);
+
+// NCO tables for one row: tile[t] = exp(-2*pi*i*(f/fs)*t), t < tile_len; tilephase[T] = exp(-2*pi*i*(f/fs)*tile_len*T).
+void sdrt_build_nco(double f, double fs, int tile_len, int n_tiles, double *tile /*[tile_len][2]*/,
+                    double *tilephase /*[n_tiles][2]*/);
+
+// Odd-sample kernel of scipy.signal.resample(a, 2N) for real a of length N: y[2j+1] = sum_k a[k] h[(j-k) mod N].
+void sdrt_build_resample_odd(int N, double *h /*[N]*/);
+
+// IQ-correction geometric weights: pw[j] = (1-lambda)^j, j <= count.
+void sdrt_build_iq_pow(double lambda, int count, double *pw);
+#ifdef __cplusplus
+}
+#endif

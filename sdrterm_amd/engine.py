@@ -1,0 +1,161 @@
+"""Host-side wrapper around one ``sdrt_ctx`` (include/sdrterm_hip.h): coefficient design + configuration.
+
+Filter coefficients are designed on the host exactly where the reference designs them, with the same
+scipy calls, and handed to the library as plain SOS tables:
+  * decimator  -- scipy.signal.decimate's default IIR, ``cheby1(8, 0.05, 0.8/q, output='sos')``
+                  (what the reference invokes at src/dsp/dsp_processor.py:147)
+  * output     -- ``ellip(3, 1, 30, omegaOut, 'lowpass', output='sos', fs=decimatedFs)``
+                  (generateEllipFilter, src/dsp/dsp_processor.py:39-45)
+All per-sample work runs on the GPU; nothing here touches sample data except to copy it.
+"""
+import ctypes as C
+import sys
+
+import numpy as np
+from scipy.signal import cheby1, ellip
+
+from . import _native as nat
+
+READ_SIZE = 131072  # bytes per chunk the reference's reader produces (src/misc/read_file.py:38)
+
+
+def generate_domain(code: str):
+    """Value range table of src/misc/read_file.py:177-196 (generateDomain)."""
+    table = {'B': (0, 255), 'h': (-32768, 32767), 'b': (-128, 127), 'i': (-2147483648, 2147483647),
+             'H': (0, 65536), 'I': (0, 4294967295)}
+    if code not in table:
+        return None
+    xmin, xmax = table[code]
+    return xmin, 1 / (-xmin + xmax)
+
+
+def decimator_sos(q: int) -> np.ndarray:
+    return np.ascontiguousarray(cheby1(8, 0.05, 0.8 / q, output='sos'), dtype=np.float64)
+
+
+def output_sos(fs_dec: int, omega_out, degree: int = 3) -> np.ndarray:
+    return np.ascontiguousarray(
+        ellip(degree, 1, 30, omega_out, btype='lowpass', analog=False, output='sos', fs=fs_dec), dtype=np.float64)
+
+
+class Engine:
+    """One GPU context == one reference processor (rows = VFO channels)."""
+
+    def __init__(self, fs, decimation, mode, code='h', n_samples=None, row_freqs=None, apply_shift=None,
+                 out_sos=None, omega_out=12500, normalize=False, correct_iq=False, impedance=50,
+                 big_endian=False, device=0):
+        if mode not in nat.MODES:
+            raise ValueError(f'unsupported demodulation mode {mode!r}')
+        if code not in nat.DTYPES:
+            raise ValueError(f'unsupported encoding {code!r}')
+        self.fs = fs
+        self.q = int(decimation)
+        self.mode = mode
+        self.code = code
+        self.n = int(n_samples) if n_samples else READ_SIZE // (2 * nat.ITEM_SIZE[code])
+        freqs = [0.0] if row_freqs is None else [float(f) for f in row_freqs]
+        self.rows = len(freqs)
+        if apply_shift is None:
+            apply_shift = self.rows > 1 or any(f != 0 for f in freqs)
+        self._freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+        self._dec_sos = decimator_sos(self.q)
+        self._out_sos = np.ascontiguousarray(
+            out_sos if out_sos is not None else output_sos(int(fs) // self.q, omega_out), dtype=np.float64)
+        dom = generate_domain(code) if normalize else None
+        swap = bool(big_endian) != (sys.byteorder == 'big') and nat.ITEM_SIZE[code] > 1
+
+        cfg = nat.Config()
+        cfg.struct_size = C.sizeof(nat.Config)
+        cfg.device = device
+        cfg.fs = float(fs)
+        cfg.decimation = self.q
+        cfg.mode = nat.MODES[mode]
+        cfg.dtype = nat.DTYPES[code]
+        cfg.swap_endianness = int(swap)
+        cfg.n_samples = self.n
+        cfg.n_rows = self.rows
+        cfg.row_freqs = self._freqs.ctypes.data_as(C.POINTER(C.c_double))
+        cfg.apply_shift = int(bool(apply_shift))
+        cfg.normalize = int(dom is not None)
+        cfg.norm_xmin = float(dom[0]) if dom else 0.0
+        cfg.norm_inv_range = float(dom[1]) if dom else 0.0
+        cfg.correct_iq = int(bool(correct_iq))
+        cfg.iq_inductance = impedance / fs
+        cfg.dec_sos = self._dec_sos.ctypes.data_as(C.POINTER(C.c_double))
+        cfg.dec_sections = self._dec_sos.shape[0]
+        cfg.out_sos = self._out_sos.ctypes.data_as(C.POINTER(C.c_double))
+        cfg.out_sections = self._out_sos.shape[0]
+        self._ctx = C.c_void_p()
+        nat.check(nat.lib().sdrt_create(C.byref(cfg), C.byref(self._ctx)))
+        self.m = nat.lib().sdrt_out_per_chunk(self._ctx)
+        self.chunk_bytes = self.n * 2 * nat.ITEM_SIZE[code]
+
+    # -- processing ---------------------------------------------------------------------------------
+    def process(self, raw, n_chunks=None) -> np.ndarray:
+        """Host buffers in, host array out: (rows, n_chunks*m) float64 (row r == stream of VFO r)."""
+        buf = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else \
+            np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+        if n_chunks is None:
+            if buf.size % self.chunk_bytes:
+                raise ValueError(f'input is not a whole number of {self.chunk_bytes}-byte chunks')
+            n_chunks = buf.size // self.chunk_bytes
+        out = np.empty((self.rows, n_chunks * self.m), dtype=np.float64)
+        nat.check(nat.lib().sdrt_process_host(self._ctx, buf.ctypes.data, n_chunks, out.ctypes.data))
+        return out
+
+    def process_device(self, raw_ptr: int, n_chunks: int, out_ptr: int, stream: int = 0, ydec_ptr: int = 0):
+        """Device pointers in/out, asynchronous on ``stream`` (hipStream_t handle, 0 = default)."""
+        if ydec_ptr:
+            nat.check(nat.lib().sdrt_process_device_debug(self._ctx, raw_ptr, n_chunks, out_ptr, ydec_ptr, stream or None))
+        else:
+            nat.check(nat.lib().sdrt_process_device(self._ctx, raw_ptr, n_chunks, out_ptr, stream or None))
+
+    def process_debug(self, raw, n_chunks=None):
+        """(out, ydec): as process(), plus the decimated complex samples (rows, n_chunks*m) complex128."""
+        buf = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else \
+            np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+        if n_chunks is None:
+            n_chunks = buf.size // self.chunk_bytes
+        d_raw = nat.DeviceBuffer(n_chunks * self.chunk_bytes).upload(buf[:n_chunks * self.chunk_bytes])
+        d_out = nat.DeviceBuffer(self.rows * n_chunks * self.m * 8)
+        d_y = nat.DeviceBuffer(self.rows * n_chunks * self.m * 16)
+        self.process_device(d_raw.ptr, n_chunks, d_out.ptr, 0, d_y.ptr)
+        nat.check(nat.lib().sdrt_device_synchronize())
+        out = d_out.download(np.empty((self.rows, n_chunks * self.m), dtype=np.float64))
+        y = d_y.download(np.empty((self.rows, n_chunks * self.m), dtype=np.complex128))
+        for b in (d_raw, d_out, d_y):
+            b.free()
+        return out, y
+
+    # -- state / profiling --------------------------------------------------------------------------
+    @property
+    def iq_offset(self) -> complex:
+        re, im = C.c_double(), C.c_double()
+        nat.check(nat.lib().sdrt_get_iq_offset(self._ctx, C.byref(re), C.byref(im)))
+        return complex(re.value, im.value)
+
+    @iq_offset.setter
+    def iq_offset(self, v: complex):
+        nat.check(nat.lib().sdrt_set_iq_offset(self._ctx, float(v.real), float(v.imag)))
+
+    def profile(self, enable: bool = True):
+        nat.check(nat.lib().sdrt_profile_enable(self._ctx, int(enable)))
+
+    def profile_reset(self):
+        nat.check(nat.lib().sdrt_profile_reset(self._ctx))
+
+    def kernel_time(self, which: int):
+        ms, cnt = C.c_double(), C.c_int64()
+        nat.check(nat.lib().sdrt_kernel_time(self._ctx, which, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def close(self):
+        if getattr(self, '_ctx', None) is not None and self._ctx.value:
+            nat.lib().sdrt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

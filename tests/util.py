@@ -18,7 +18,10 @@ _ITEM = {'b': 1, 'B': 1, 'h': 2, 'H': 2, 'i': 4, 'I': 4, 'f': 4, 'd': 8}
 ABS_TOL = 1e-6
 
 
-def tol_for(expected: np.ndarray) -> float:
+def tol_for(expected: np.ndarray, mode: str = 'am') -> float:
+    """FM outputs are angles: the north-star 1e-6 max-abs applies as is.  AM scales with |x|^2."""
+    if mode == 'fm':
+        return ABS_TOL
     return ABS_TOL * max(1.0, float(np.abs(expected).max()))
 
 
@@ -48,4 +51,4 @@ F32_REF_RTOL = 5e-3
 def ref_tol(case: dict, expected: np.ndarray) -> float:
     if case['code'] == 'f':
         return F32_REF_RTOL * max(1.0, float(np.abs(expected).max()))
-    return tol_for(expected)
+    return tol_for(expected, case['mode'])
