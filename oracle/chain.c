@@ -142,15 +142,15 @@ int orc_sosfiltfilt_edge(const double *sos, int nsec) {
     return 3 * ntaps;
 }
 
-/* y must hold n values; returns 0 or -1 if n <= edge (scipy raises ValueError there). */
-int orc_sosfiltfilt(const double *sos, int nsec, const cplx *x, size_t n, cplx *y) {
+/* Workspace variant: ext must hold n + 2*edge values.  y must hold n values.
+ * Returns 0, or -1 if n <= edge (scipy raises ValueError there). */
+static int sosfiltfilt_ws(const double *sos, int nsec, const cplx *x, size_t n, cplx *y, cplx *ext) {
     int edge = orc_sosfiltfilt_edge(sos, nsec);
     if (n <= (size_t) edge) return -1;
     size_t N = n + 2 * (size_t) edge;
-    cplx *ext = (cplx *) malloc(N * sizeof(cplx));
     double zi[32];
     cplx st[32];
-    if (!ext || nsec > 16) { free(ext); return -2; }
+    if (nsec > 16) return -2;
     /* odd_ext (scipy/signal/_arraytools.py): 2*x[0] - x[edge:0:-1] | x | 2*x[-1] - x[-2:-(edge+2):-1] */
     for (int i = 0; i < edge; ++i) ext[i] = 2.0 * x[0] - x[edge - i];
     memcpy(ext + edge, x, n * sizeof(cplx));
@@ -163,8 +163,15 @@ int orc_sosfiltfilt(const double *sos, int nsec, const cplx *x, size_t n, cplx *
     for (int k = 0; k < 2 * nsec; ++k) st[k] = zi[k] * ext[0];
     orc_sosfilt_c(sos, nsec, ext, N, st);
     for (size_t i = 0; i < n; ++i) y[i] = ext[N - 1 - edge - i];
-    free(ext);
     return 0;
+}
+
+int orc_sosfiltfilt(const double *sos, int nsec, const cplx *x, size_t n, cplx *y) {
+    cplx *ext = (cplx *) malloc((n + 2 * 3 * (2 * (size_t) nsec + 1)) * sizeof(cplx));
+    if (!ext) return -2;
+    int rc = sosfiltfilt_ws(sos, nsec, x, n, y, ext);
+    free(ext);
+    return rc;
 }
 
 /* scipy.signal.decimate(x, q) defaults (dsp_processor.py:147): sosfiltfilt(cheby1 sos) then y[::q]. */
@@ -268,30 +275,47 @@ void orc_am(const cplx *y, size_t m, double *out) {
  *   y = decimate(x, q);  demod;  sosfilt(out_sos) with zero state.
  * out: rows*m doubles (row-major).  ydec (optional): rows*m complex.
  */
-int orc_process_chunk(const cplx *z, size_t n, int q, int mode, const cplx *shift, int rows,
-                      const double *dec_sos, int dec_nsec, const double *out_sos, int out_nsec,
-                      double *out, cplx *ydec) {
+/* scratch for one chunk: x[n], full[n], ext[n + 2*edge], y[m+1] */
+static size_t chunk_ws_elems(size_t n, int q, int dec_nsec) {
+    return 3 * n + 6 * (2 * (size_t) dec_nsec + 1) + n / (size_t) q + 2;
+}
+
+static int process_chunk_ws(const cplx *z, size_t n, int q, int mode, const cplx *shift, int rows,
+                            const double *dec_sos, int dec_nsec, const double *out_sos, int out_nsec,
+                            double *out, cplx *ydec, cplx *ws) {
     size_t m = n / (size_t) q;
-    cplx *x = (cplx *) malloc(n * sizeof(cplx));
-    cplx *y = (cplx *) malloc((m + 1) * sizeof(cplx));
+    cplx *x = ws, *full = ws + n, *y = full + n, *ext = y + m + 2;
     int rc = 0;
-    if (!x || !y) { free(x); free(y); return -2; }
     for (int r = 0; r < rows && rc == 0; ++r) {
         if (shift) {
-            for (size_t i = 0; i < n; ++i) x[i] = z[i] * shift[(size_t) r * n + i];
+            /* plain complex product (no C99 Annex G inf/nan recovery: inputs are finite) */
+            const cplx *sh = shift + (size_t) r * n;
+            for (size_t i = 0; i < n; ++i) {
+                double a = creal(z[i]), b = cimag(z[i]), c = creal(sh[i]), d = cimag(sh[i]);
+                x[i] = (a * c - b * d) + (a * d + b * c) * I;
+            }
         } else {
             memcpy(x, z, n * sizeof(cplx));
         }
-        rc = orc_decimate(dec_sos, dec_nsec, x, n, q, y);
+        rc = sosfiltfilt_ws(dec_sos, dec_nsec, x, n, full, ext);
         if (rc) break;
+        { size_t k = 0; for (size_t i = 0; i < n; i += (size_t) q) y[k++] = full[i]; }
         if (ydec) memcpy(ydec + (size_t) r * m, y, m * sizeof(cplx));
         double *o = out + (size_t) r * m;
         if (mode == ORC_FM) rc = orc_fm(y, m, o); else orc_am(y, m, o);
         double st[32] = {0};
         orc_sosfilt_r(out_sos, out_nsec, o, m, st);
     }
-    free(x);
-    free(y);
+    return rc;
+}
+
+int orc_process_chunk(const cplx *z, size_t n, int q, int mode, const cplx *shift, int rows,
+                      const double *dec_sos, int dec_nsec, const double *out_sos, int out_nsec,
+                      double *out, cplx *ydec) {
+    cplx *ws = (cplx *) malloc(chunk_ws_elems(n, q, dec_nsec) * sizeof(cplx));
+    if (!ws) return -2;
+    int rc = process_chunk_ws(z, n, q, mode, shift, rows, dec_sos, dec_nsec, out_sos, out_nsec, out, ydec, ws);
+    free(ws);
     return rc;
 }
 
@@ -321,26 +345,37 @@ int orc_process_stream(const void *raw, int code, int swap, size_t n, size_t n_c
     }
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel
 #endif
-    for (long c = 0; c < (long) n_chunks; ++c) {
-        cplx *z;
-        if (zall) {
-            z = zall + (size_t) c * n;
-        } else {
-            z = (cplx *) malloc(n * sizeof(cplx));
-            orc_unpack((const unsigned char *) raw + (size_t) c * n * 2 * (size_t) sz, code, swap, n, z);
-            if (do_norm) orc_normalize(z, n, xmin, inv_range);
-        }
-        int rc = orc_process_chunk(z, n, q, mode, shift, rows, dec_sos, dec_nsec, out_sos, out_nsec,
-                                   out + (size_t) c * (size_t) rows * m, NULL);
-        if (rc) {
+    {
+        /* one scratch block per thread, allocated once (per-chunk malloc of MiB-sized blocks serialises on mmap) */
+        cplx *ws = (cplx *) malloc((chunk_ws_elems(n, q, dec_nsec) + n) * sizeof(cplx));
+        cplx *zbuf = ws ? ws + chunk_ws_elems(n, q, dec_nsec) : NULL;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (long c = 0; c < (long) n_chunks; ++c) {
+            int rc = -2;
+            if (ws) {
+                const cplx *z;
+                if (zall) {
+                    z = zall + (size_t) c * n;
+                } else {
+                    orc_unpack((const unsigned char *) raw + (size_t) c * n * 2 * (size_t) sz, code, swap, n, zbuf);
+                    if (do_norm) orc_normalize(zbuf, n, xmin, inv_range);
+                    z = zbuf;
+                }
+                rc = process_chunk_ws(z, n, q, mode, shift, rows, dec_sos, dec_nsec, out_sos, out_nsec,
+                                      out + (size_t) c * (size_t) rows * m, NULL, ws);
+            }
+            if (rc) {
 #ifdef _OPENMP
 #pragma omp critical
 #endif
-            rc_all = rc;
+                rc_all = rc;
+            }
         }
-        if (!zall) free(z);
+        free(ws);
     }
     free(zall);
     return rc_all;
