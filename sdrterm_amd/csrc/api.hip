@@ -41,13 +41,12 @@ struct Pending {
 
 struct sdrt_ctx {
     sdrt_config cfg;
-    int L = 0, m = 0, n_tiles = 0, rows = 1, mid_per_chunk = 0;
+    int L = 0, m = 0, n_tiles = 0, rows = 1;
     bool nco = false;
     double norm_scale = 1.0, norm_bias = 0.0;
     DecimTables *d_tab = nullptr;
+    OutTables *d_otab = nullptr;
     double *d_nco_tile = nullptr, *d_nco_phase = nullptr, *d_resample = nullptr, *d_out_sos = nullptr;
-    double *d_mid = nullptr;
-    size_t mid_cap_chunks = 0;
     void *d_raw = nullptr;
     double *d_out = nullptr;
     size_t stage_cap_chunks = 0;
@@ -110,16 +109,6 @@ template <class T>
 int upload(T **dst, const void *src, size_t bytes) {
     HIP_TRY(hipMalloc((void **) dst, bytes));
     HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
-    return SDRT_OK;
-}
-
-int ensure_mid(sdrt_ctx *c, size_t n_chunks) {
-    if (n_chunks <= c->mid_cap_chunks) return SDRT_OK;
-    if (c->d_mid) HIP_TRY(hipFree(c->d_mid));
-    c->d_mid = nullptr;
-    c->mid_cap_chunks = 0;
-    HIP_TRY(hipMalloc((void **) &c->d_mid, n_chunks * (size_t) c->rows * c->mid_per_chunk * sizeof(double)));
-    c->mid_cap_chunks = n_chunks;
     return SDRT_OK;
 }
 
@@ -189,13 +178,12 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     c->n_tiles = n / (SDRT_TB * L);
     c->rows = cfg->n_rows;
     c->nco = cfg->apply_shift != 0;
-    c->mid_per_chunk = cfg->mode == SDRT_FM ? m / 2 : m;
     if (cfg->normalize) {
         // read_file.py:96: 1.6*(z - xmin)*d - 0.8 with complex z: only Re is offset.
         c->norm_scale = 1.6 * cfg->norm_inv_range;
         c->norm_bias = -1.6 * cfg->norm_xmin * cfg->norm_inv_range - 0.8;
     }
-    const size_t lds = decim_lds_bytes(n, L, m, c->nco);
+    const size_t lds = chain_lds_bytes(n, L, m, c->nco, cfg->mode == SDRT_FM);
     if (lds > 160 * 1024) {
         delete c;
         return fail(SDRT_EINVAL, "chunk needs %zu bytes of LDS (> 160 KiB): n_samples/decimation combination unsupported", lds);
@@ -210,12 +198,18 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     }
     rc = upload(&c->d_tab, &tab, sizeof(tab));
     if (rc == SDRT_OK) rc = upload(&c->d_out_sos, cfg->out_sos, sizeof(double) * 6 * cfg->out_sections);
+    if (rc == SDRT_OK) {
+        OutTables otab;
+        sdrt_build_out_tables(cfg->out_sos, cfg->out_sections, m, &otab);
+        rc = upload(&c->d_otab, &otab, sizeof(otab));
+    }
     if (rc == SDRT_OK && c->nco) {
-        const int tile_len = SDRT_TB * L;
-        std::vector<double> tile((size_t) c->rows * tile_len * 2), phase((size_t) c->rows * c->n_tiles * 2);
+        // exp(i theta t) is factored as (sample within block) x (block within chunk): L + n/L table entries per row
+        const int nblk = n / L;
+        std::vector<double> tile((size_t) c->rows * L * 2), phase((size_t) c->rows * nblk * 2);
         for (int r = 0; r < c->rows; ++r)
-            sdrt_build_nco(cfg->row_freqs[r], cfg->fs, tile_len, c->n_tiles, &tile[(size_t) r * tile_len * 2],
-                           &phase[(size_t) r * c->n_tiles * 2]);
+            sdrt_build_nco(cfg->row_freqs[r], cfg->fs, L, nblk, &tile[(size_t) r * L * 2],
+                           &phase[(size_t) r * nblk * 2]);
         rc = upload(&c->d_nco_tile, tile.data(), tile.size() * sizeof(double));
         if (rc == SDRT_OK) rc = upload(&c->d_nco_phase, phase.data(), phase.size() * sizeof(double));
     }
@@ -243,7 +237,7 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_nco_phase);
     (void) hipFree(c->d_resample);
     (void) hipFree(c->d_out_sos);
-    (void) hipFree(c->d_mid);
+    (void) hipFree(c->d_otab);
     (void) hipFree(c->d_raw);
     (void) hipFree(c->d_out);
     delete c;
@@ -260,16 +254,18 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     if (((uintptr_t) raw_dev & 15) != 0) return fail(SDRT_EINVAL, "raw_dev must be 16-byte aligned");
     if (n_chunks * (size_t) c->rows > 0x7fffffffull) return fail(SDRT_EINVAL, "too many chunks in one call");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    int rc = ensure_mid(c, n_chunks);
-    if (rc != SDRT_OK) return rc;
     hipStream_t s = (hipStream_t) stream;
 
     DecimArgs da;
     da.raw = raw_dev;
     da.tab = c->d_tab;
+    da.otab = c->d_otab;
     da.nco_tile = c->d_nco_tile;
     da.nco_phase = c->d_nco_phase;
-    da.mid = c->d_mid;
+    da.resample_odd = c->d_resample;
+    da.out_sos = c->d_out_sos;
+    da.out_sections = c->cfg.out_sections;
+    da.out = out_dev;
     da.ydec = ydec_dev;
     da.n_chunks = n_chunks;
     da.n = c->cfg.n_samples;
@@ -282,19 +278,7 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     da.norm_bias = c->norm_bias;
     {
         Timed t(c, s, 0);
-        HIP_TRY(launch_decim(da, c->L, c->cfg.dtype, c->nco, n_chunks, s));
-    }
-    PostArgs pa;
-    pa.mid = c->d_mid;
-    pa.resample_odd = c->d_resample;
-    pa.out_sos = c->d_out_sos;
-    pa.out = out_dev;
-    pa.m = c->m;
-    pa.mode = c->cfg.mode;
-    pa.out_sections = c->cfg.out_sections;
-    {
-        Timed t(c, s, 1);
-        HIP_TRY(launch_post(pa, n_chunks * (size_t) c->rows, s));
+        HIP_TRY(launch_chain(da, c->L, c->cfg.dtype, c->nco, n_chunks, s));
     }
     return SDRT_OK;
 }
@@ -365,8 +349,8 @@ int sdrt_profile_reset(sdrt_ctx *c) {
 
 const char *sdrt_kernel_name(int which) {
     switch (which) {
-        case 0: return "decim_demod_kernel";
-        case 1: return "post_kernel";
+        case 0: return "chain_kernel";
+        case 1: return "(unused)";
         case 2: return "iq_prefix_kernels";
     }
     return "";

@@ -1,9 +1,9 @@
 // Device kernels of the MI355X-native sdrterm DSP hot path (gfx950 only).
 //
-// K1  decim_demod_kernel   one workgroup per (chunk, row): unpack -> normalise -> [IQ correction] -> NCO ->
-//                          zero-phase order-8 decimator in modal block form (stage A on the f64 matrix cores,
-//                          in-tile scans with DPP row shifts, tile carries through LDS) -> FM pair-angle / AM.
-// K2  post_kernel          one workgroup per (chunk, row): FM resample m/2 -> m, output lowpass sosfilt.
+// chain_kernel   one workgroup per (chunk, row), everything fused:
+//                 unpack -> normalise -> [IQ correction] -> NCO -> zero-phase order-8 decimator in modal block form
+//                 (stage A on the f64 matrix cores, in-tile scans with DPP row shifts, tile carries through LDS)
+//                 -> FM pair-angle + resample m/2 -> m, or AM -> output lowpass as a 256-thread modal scan -> store.
 //
 // Reference steps replaced (peads/sdrterm, paths relative to its root):
 //   read_file.py:100-103 (unpack/_normalize/_correctIq), demodulation.py:71-79 (shiftFreq),
@@ -81,80 +81,148 @@ __device__ __forceinline__ void load_bytes(const unsigned char *p, void *dst) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
-// K1: decimate + demodulate.
+// Fused chain kernel.
 // Workgroup = 256 threads (4 waves) per (chunk, row).  A tile is 16 consecutive blocks of L samples; wave w takes
 // tiles w, w+4, ...  Lane l = (g = l>>4, nb = l&15) loads the L/4 consecutive samples [nb*L + g*L/4, +L/4) of its
 // tile: they are the k-slices {4s+g} of the MFMA B operand for block nb (column nb).
 // ---------------------------------------------------------------------------------------------------------------
+struct LdsLayout {
+    int o, y, carF, carG, edge, cF, cG, tailF, tailFc, f0, gu, nco, hr, wtot, total;   // offsets in 16-byte units
+};
+__host__ __device__ inline LdsLayout lds_layout(int n, int L, int m, bool nco, bool fm) {
+    const int nblk = n / L, nt = nblk / SDRT_TB;
+    LdsLayout l;
+    int p = 0;
+    l.o = p; p += nblk;                      // local output parts; reused as the real work area (2*nblk doubles)
+    l.y = p; p += m;                         // decimated complex samples
+    l.carF = p; p += (nt + 1) * 8;           // [t][mode][stream]
+    l.carG = p; p += (nt + 1) * 8;
+    l.edge = p; p += 2 * (SDRT_EDGE + 1);
+    l.cF = p; p += SDRT_TB * 4;
+    l.cG = p; p += SDRT_TB * 4;
+    l.tailF = p; p += 16;
+    l.tailFc = p; p += 16;
+    l.f0 = p; p += 8;
+    l.gu = p; p += 8;
+    l.wtot = p; p += SDRT_OUT_MAXMODES * 4;
+    l.nco = p; p += nco ? L : 0;
+    l.hr = p; p += fm ? (m / 2 + 1) / 2 : 0; // m/2 doubles
+    l.total = p;
+    return l;
+}
+
 template <int L, int DT, bool NCO>
-__global__ __launch_bounds__(256) void decim_demod_kernel(DecimArgs a) {
+__global__ __launch_bounds__(256) void chain_kernel(DecimArgs a) {
     constexpr int KS = L / 4;                       // k-steps == samples per lane per tile
     constexpr int ITEM = Enc<DT>::size;
     constexpr int BYTES = KS * 2 * ITEM;            // per lane per tile
     constexpr int TILE = SDRT_TB * L;               // samples per tile
+    constexpr int NBUF = BYTES < 16 ? 16 : BYTES;
     typedef typename Enc<DT>::raw raw_t;
 
     extern __shared__ __align__(16) unsigned char smem[];
     const DecimTables *__restrict__ tab = a.tab;
-    const int n = a.n, m = a.m, nt = a.n_tiles, nblk = n / L;
-    const int row = blockIdx.x % a.rows;
-    const long chunk = blockIdx.x / a.rows;
+    const OutTables *__restrict__ ot = a.otab;
+    const int n = a.n, m = a.m, nt = a.n_tiles;
+    const bool fm = a.mode == SDRT_FM;
+    // (chunk, row) from the block id: all rows of a chunk get ids that share an XCD (ids are dealt round-robin
+    // over 8 XCDs), so the chunk is pulled through one L2 only.  Placement changes speed only, never results.
+    const unsigned bid = blockIdx.x;
+    const unsigned xcd = bid & 7u, slot = bid >> 3;
+    const long chunk = (long) (slot / (unsigned) a.rows) * 8 + xcd;
+    const int row = (int) (slot % (unsigned) a.rows);
+    if (chunk >= (long) a.n_chunks) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, nb = lane & 15;
     const bool swap = a.swap != 0;
 
-    // LDS carve-up (all 16-byte aligned)
-    cd *o_lds = (cd *) smem;                         // [nblk]      local output part per block
-    cd *y_lds = o_lds + nblk;                        // [m]         decimated samples
-    cd *aggF = y_lds + m;                            // [nt][4][2]  causal tile aggregates (mode, stream)
-    cd *aggG = aggF + nt * 8;                        // [nt][4][2]
-    cd *carF = aggG + nt * 8;                        // [nt+1][4][2]
-    cd *carG = carF + (nt + 1) * 8;                  // [nt+1][4][2]
-    cd *edge_u = carG + (nt + 1) * 8;                // [2][28] head / tail samples after normalise/NCO
-    cd *nco_lds = edge_u + 2 * (SDRT_EDGE + 1);      // [TILE]      only if NCO
+    const LdsLayout lo = lds_layout(n, L, m, NCO, fm);
+    cd *base = (cd *) smem;
+    cd *o_lds = base + lo.o, *y_lds = base + lo.y, *carF = base + lo.carF, *carG = base + lo.carG;
+    cd *edge_u = base + lo.edge, *cF = base + lo.cF, *cG = base + lo.cG, *tailF = base + lo.tailF;
+    cd *tailFc = base + lo.tailFc, *F0 = base + lo.f0, *Gu = base + lo.gu, *wtot = base + lo.wtot;
+    cd *nco_lds = base + lo.nco;
+    double *hr = (double *) (base + lo.hr);
+    double *work = (double *) o_lds;                 // after phase 3: a[] at work[0..m/2), z[] at work[m..2m)
 
     const unsigned char *chunk_raw = (const unsigned char *) a.raw + (size_t) chunk * (size_t) n * 2 * ITEM;
     const double nsc = a.norm_scale, nbias = a.norm_bias;
-    const cd *nco_tile_g = (const cd *) a.nco_tile + (size_t) row * TILE;
-    const cd *nco_phase_g = (const cd *) a.nco_phase + (size_t) row * nt;
+    const cd *nco_samp_g = (const cd *) a.nco_tile + (size_t) row * L;              // exp(i theta j), j < L
+    const cd *nco_blk_g = (const cd *) a.nco_phase + (size_t) row * (size_t) (n / L);   // exp(i theta L B), B < n/L
 
+    // ---- prologue: tables to LDS, edge samples --------------------------------------------------------------------
     if constexpr (NCO) {
-        for (int i = tid; i < TILE; i += 256) nco_lds[i] = nco_tile_g[i];
+        for (int i = tid; i < L; i += 256) nco_lds[i] = nco_samp_g[i];
     }
-    // Edge samples (first and last 28 of the chunk), after normalise and NCO.
-    if (tid < 2 * (SDRT_EDGE + 1)) {
-        const int which = tid / (SDRT_EDGE + 1), l = tid % (SDRT_EDGE + 1);
+    if (tid < 64) {
+        cF[tid] = mk(tab->cF[tid >> 2][tid & 3][0], tab->cF[tid >> 2][tid & 3][1]);
+        cG[tid] = mk(tab->cG[tid >> 2][tid & 3][0], tab->cG[tid >> 2][tid & 3][1]);
+    } else if (tid < 80) {
+        const int i = tid - 64;
+        tailF[i] = mk(tab->tailF[i >> 2][i & 3][0], tab->tailF[i >> 2][i & 3][1]);
+        tailFc[i] = mk(tab->tailFc[i >> 2][i & 3][0], tab->tailFc[i >> 2][i & 3][1]);
+    }
+    if (fm) {
+        const int N = m >> 1;
+        for (int i = tid; i < N; i += 256) hr[i] = a.resample_odd[i == 0 ? 0 : N - i];   // hr[i] = h[(-i) mod N]
+    }
+    if (tid >= 128 && tid < 128 + 2 * (SDRT_EDGE + 1)) {
+        const int e = tid - 128;
+        const int which = e / (SDRT_EDGE + 1), l = e % (SDRT_EDGE + 1);
         const long idx = which ? (long) n - (SDRT_EDGE + 1) + l : l;
         const raw_t *rp = (const raw_t *) chunk_raw + 2 * idx;
         double xr = fma(decode<DT>(rp[0], swap), nsc, nbias);
         double xi = decode<DT>(rp[1], swap) * nsc;
         if constexpr (NCO) {
-            const int tl = (int) (idx % TILE);
-            cd c = cmul(nco_tile_g[tl], nco_phase_g[idx / TILE]);
-            cd u = cmul(mk(xr, xi), c);
+            const cd c = cmul(nco_samp_g[idx % L], nco_blk_g[idx / L]);
+            const cd u = cmul(mk(xr, xi), c);
             xr = u.re;
             xi = u.im;
         }
-        edge_u[tid] = mk(xr, xi);
+        edge_u[e] = mk(xr, xi);
     }
 
     // Stage-A weights for this lane: A operand of v_mfma_f64_16x16x4: lane holds A[row = l&15][k = l>>4].
     double w[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) w[s] = tab->W[lane & 15][g * KS + s];
-    // scan multipliers of this lane's mode g
     cd mup[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) mup[k] = mk(tab->mu_pow[k][g][0], tab->mu_pow[k][g][1]);
     const double d0p = tab->d0p;
 
-    if constexpr (NCO) __syncthreads();
+    alignas(16) unsigned char cur[NBUF], nxt[NBUF];
+    const size_t lane_off = ((size_t) nb * L + (size_t) g * KS) * 2 * ITEM;
+    if (wave < nt) load_bytes<BYTES>(chunk_raw + (size_t) wave * TILE * 2 * ITEM + lane_off, cur);
 
+    __syncthreads();
+
+    // Edge operators (they only need the 56 edge samples): F0 = head . u_head, Gu = tailU . u_tail, per (mode, stream).
+    {
+        const int o = tid >> 5, l = tid & 31, mode = o >> 1, st = o & 1;
+        cd f = mk(0.0, 0.0), gq = mk(0.0, 0.0);
+        if (l <= SDRT_EDGE) {
+            const cd eh = edge_u[l], et = edge_u[(SDRT_EDGE + 1) + l];
+            const double uh = st ? eh.im : eh.re, ut = st ? et.im : et.re;
+            f = mk(tab->head[mode][l][0] * uh, tab->head[mode][l][1] * uh);
+            gq = mk(tab->tailU[mode][l][0] * ut, tab->tailU[mode][l][1] * ut);
+        }
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) {
+            f.re += __shfl_xor(f.re, d);
+            f.im += __shfl_xor(f.im, d);
+            gq.re += __shfl_xor(gq.re, d);
+            gq.im += __shfl_xor(gq.im, d);
+        }
+        if (l == 0) { F0[o] = f; Gu[o] = gq; }
+    }
+
+    // ---- main loop over this wave's tiles, next tile's bytes prefetched ----------------------------------------------
     for (int tile = wave; tile < nt; tile += 4) {
-        alignas(16) unsigned char buf[BYTES < 16 ? 16 : BYTES];
-        const size_t soff = (size_t) tile * TILE + (size_t) nb * L + (size_t) g * KS;  // first sample of this lane
-        load_bytes<BYTES>(chunk_raw + soff * 2 * ITEM, buf);
-        const raw_t *rb = (const raw_t *) buf;
+        if (tile + 4 < nt) load_bytes<BYTES>(chunk_raw + (size_t) (tile + 4) * TILE * 2 * ITEM + lane_off, nxt);
+        const raw_t *rb = (const raw_t *) cur;
+        cd psi = mk(1.0, 0.0);
+        if constexpr (NCO) psi = nco_blk_g[tile * SDRT_TB + nb];   // phasor common to this lane's block
 
         v4d acc_r = {0.0, 0.0, 0.0, 0.0}, acc_i = {0.0, 0.0, 0.0, 0.0};
         double u0r = 0.0, u0i = 0.0;
@@ -163,7 +231,7 @@ __global__ __launch_bounds__(256) void decim_demod_kernel(DecimArgs a) {
             double xr = fma(decode<DT>(rb[2 * s], swap), nsc, nbias);
             double xi = decode<DT>(rb[2 * s + 1], swap) * nsc;
             if constexpr (NCO) {
-                const cd c = nco_lds[nb * L + g * KS + s];
+                const cd c = nco_lds[g * KS + s];
                 const double tr = xr * c.re - xi * c.im;
                 xi = xr * c.im + xi * c.re;
                 xr = tr;
@@ -177,8 +245,7 @@ __global__ __launch_bounds__(256) void decim_demod_kernel(DecimArgs a) {
         cd Cr = mk(acc_r[0], acc_r[1]), Ar = mk(acc_r[2], acc_r[3]);
         cd Ci = mk(acc_i[0], acc_i[1]), Ai = mk(acc_i[2], acc_i[3]);
         if constexpr (NCO) {
-            // the tile's common phasor psi multiplies the complex DATA: re' = pr*re - pi*im, im' = pi*re + pr*im
-            const cd psi = nco_phase_g[tile];
+            // the block's common phasor multiplies the complex DATA: re' = pr*re - pi*im, im' = pi*re + pr*im
             cd t;
             t = mk(psi.re * Cr.re - psi.im * Ci.re, psi.re * Cr.im - psi.im * Ci.im);
             Ci = mk(psi.im * Cr.re + psi.re * Ci.re, psi.im * Cr.im + psi.re * Ci.im);
@@ -207,9 +274,10 @@ __global__ __launch_bounds__(256) void decim_demod_kernel(DecimArgs a) {
         Ci = cfma(mup[3], dpp_row<0x118>(Ci), Ci);
         Ar = cfma(mup[3], dpp_row<0x108>(Ar), Ar);
         Ai = cfma(mup[3], dpp_row<0x108>(Ai), Ai);
-        // tile aggregates: causal inclusive at the last block, anticausal inclusive at the first block
-        if (nb == 15) { aggF[(tile * 4 + g) * 2 + 0] = Cr; aggF[(tile * 4 + g) * 2 + 1] = Ci; }
-        if (nb == 0) { aggG[(tile * 4 + g) * 2 + 0] = Ar; aggG[(tile * 4 + g) * 2 + 1] = Ai; }
+        // tile aggregates go straight into the carry arrays: causal inclusive at the last block -> slot t+1,
+        // anticausal inclusive at the first block -> slot t.  Index = slot*8 + mode*2 + stream.
+        if (nb == 15) { carF[(tile + 1) * 8 + g * 2 + 0] = Cr; carF[(tile + 1) * 8 + g * 2 + 1] = Ci; }
+        if (nb == 0) { carG[tile * 8 + g * 2 + 0] = Ar; carG[tile * 8 + g * 2 + 1] = Ai; }
         // local output part: direct term + 2 Re(exclusive causal + inclusive anticausal), summed over the 4 modes
         const double cexr = dpp_row<0x111>(Cr.re), cexi = dpp_row<0x111>(Ci.re);
         double pr = 2.0 * (cexr + Ar.re), pi = 2.0 * (cexi + Ai.re);
@@ -219,62 +287,53 @@ __global__ __launch_bounds__(256) void decim_demod_kernel(DecimArgs a) {
         pr += __shfl_xor(pr, 32);
         pi += __shfl_xor(pi, 32);
         if (g == 0) o_lds[tile * SDRT_TB + nb] = mk(pr, pi);
+#pragma unroll
+        for (int i = 0; i < NBUF / 4; ++i) ((uint32_t *) cur)[i] = ((const uint32_t *) nxt)[i];
     }
     __syncthreads();
 
-    // Phase 2: carries across tiles.  Threads 0..7 = (mode, stream).
+    // ---- phase 2: carries across tiles.  Threads 0..7 = (mode, stream), o = mode*2 + stream ------------------------------
     if (tid < 8) {
-        const int mode = tid & 3, st = tid >> 2;
+        const int mode = tid >> 1;
         const cd mu16 = mk(tab->mu_pow[4][mode][0], tab->mu_pow[4][mode][1]);
-        cd F = mk(0.0, 0.0);
-        for (int l = 0; l <= SDRT_EDGE; ++l) {
-            const double u = st ? edge_u[l].im : edge_u[l].re;
-            F.re = fma(tab->head[mode][l][0], u, F.re);
-            F.im = fma(tab->head[mode][l][1], u, F.im);
-        }
-        carF[mode * 2 + st] = F;
+        cd F = F0[tid];
+        carF[tid] = F;
         for (int t = 0; t < nt; ++t) {
-            F = cfma(mu16, F, aggF[(t * 4 + mode) * 2 + st]);
-            carF[((t + 1) * 4 + mode) * 2 + st] = F;
+            F = cfma(mu16, F, carF[(t + 1) * 8 + tid]);
+            carF[(t + 1) * 8 + tid] = F;
         }
     }
     __syncthreads();
     if (tid < 8) {
-        const int mode = tid & 3, st = tid >> 2;
+        const int mode = tid >> 1, st = tid & 1;
         const cd mu16 = mk(tab->mu_pow[4][mode][0], tab->mu_pow[4][mode][1]);
-        cd G = mk(0.0, 0.0);
+        cd G = Gu[tid];
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const cd Fj = carF[(nt * 4 + j) * 2 + st];
-            G = cfma(mk(tab->tailF[mode][j][0], tab->tailF[mode][j][1]), Fj, G);
-            G = cfma(mk(tab->tailFc[mode][j][0], tab->tailFc[mode][j][1]), mk(Fj.re, -Fj.im), G);
+            const cd Fj = carF[nt * 8 + j * 2 + st];
+            G = cfma(tailF[mode * 4 + j], Fj, G);
+            G = cfma(tailFc[mode * 4 + j], mk(Fj.re, -Fj.im), G);
         }
-        for (int l = 0; l <= SDRT_EDGE; ++l) {
-            const cd e = edge_u[(SDRT_EDGE + 1) + l];
-            const double u = st ? e.im : e.re;
-            G.re = fma(tab->tailU[mode][l][0], u, G.re);
-            G.im = fma(tab->tailU[mode][l][1], u, G.im);
-        }
-        carG[(nt * 4 + mode) * 2 + st] = G;
+        carG[nt * 8 + tid] = G;
         for (int t = nt - 1; t >= 0; --t) {
-            G = cfma(mu16, G, aggG[(t * 4 + mode) * 2 + st]);
-            carG[(t * 4 + mode) * 2 + st] = G;
+            G = cfma(mu16, G, carG[t * 8 + tid]);
+            carG[t * 8 + tid] = G;
         }
     }
     __syncthreads();
 
-    // Phase 3: add the carried parts at the output blocks.
+    // ---- phase 3: add the carried parts at the output blocks -> decimated samples y ----------------------------------
     const int stride = tab->out_stride;
     for (int k = tid; k < m; k += 256) {
         const int kb = k * stride, tile = kb >> 4, nbk = kb & 15;
         cd v = o_lds[kb];
 #pragma unroll
         for (int mode = 0; mode < 4; ++mode) {
-            const double fr = tab->cF[nbk][mode][0], fi = tab->cF[nbk][mode][1];
-            const double gr = tab->cG[nbk][mode][0], gi = tab->cG[nbk][mode][1];
-            const cd F0 = carF[(tile * 4 + mode) * 2 + 0], F1 = carF[(tile * 4 + mode) * 2 + 1];
-            const cd G0 = carG[((tile + 1) * 4 + mode) * 2 + 0], G1 = carG[((tile + 1) * 4 + mode) * 2 + 1];
-            v.re += 2.0 * (fr * F0.re - fi * F0.im + gr * G0.re - gi * G0.im);
-            v.im += 2.0 * (fr * F1.re - fi * F1.im + gr * G1.re - gi * G1.im);
+            const cd f = cF[nbk * 4 + mode], gq = cG[nbk * 4 + mode];
+            const cd Fa = carF[tile * 8 + mode * 2 + 0], Fb = carF[tile * 8 + mode * 2 + 1];
+            const cd Ga = carG[(tile + 1) * 8 + mode * 2 + 0], Gb = carG[(tile + 1) * 8 + mode * 2 + 1];
+            v.re += 2.0 * (f.re * Fa.re - f.im * Fa.im + gq.re * Ga.re - gq.im * Ga.im);
+            v.im += 2.0 * (f.re * Fb.re - f.im * Fb.im + gq.re * Gb.re - gq.im * Gb.im);
         }
         y_lds[k] = v;
         if (a.ydec) {
@@ -285,67 +344,118 @@ __global__ __launch_bounds__(256) void decim_demod_kernel(DecimArgs a) {
     }
     __syncthreads();
 
-    // Phase 4: demodulate (demodulation.py:25-32 pair angle; :41-48 |d^2|).  FM resampling happens in K2.
-    if (a.mode == SDRT_FM) {
-        const int h = m >> 1;
-        double *mid = a.mid + ((size_t) row * a.n_chunks + chunk) * h;
-        for (int j = tid; j < h; j += 256) {
+    // ---- phase 4: demodulate (demodulation.py:25-32 pair angle; :41-48 |d^2|) into work[] ------------------------------
+    double *zb = work + m;          // [m] demodulated samples at the decimated rate
+    if (fm) {
+        const int N = m >> 1;
+        for (int j = tid; j < N; j += 256) {
             const cd p = y_lds[2 * j], c = y_lds[2 * j + 1];
             const double re = p.re * c.re + p.im * c.im;   // d[i] * conj(d[i+1])
             const double im = p.im * c.re - p.re * c.im;
-            mid[j] = atan2(im, re);
+            work[j] = atan2(im, re);
+        }
+        __syncthreads();
+        // phase 5: scipy.signal.resample N -> 2N (demodulation.py:35-38): even samples are the input, odd samples
+        // a circulant product with the half-sample Dirichlet kernel: z[2j+1] = sum_k a[k] hr[(k - j) mod N].
+        for (int j = tid; j < N; j += 256) {
+            double s0 = 0.0, s1 = 0.0;
+            int k = 0;
+            for (; k + 1 < j; k += 2) {
+                s0 = fma(work[k], hr[k - j + N], s0);
+                s1 = fma(work[k + 1], hr[k + 1 - j + N], s1);
+            }
+            for (; k < j; ++k) s0 = fma(work[k], hr[k - j + N], s0);
+            for (; k + 1 < N; k += 2) {
+                s0 = fma(work[k], hr[k - j], s0);
+                s1 = fma(work[k + 1], hr[k + 1 - j], s1);
+            }
+            for (; k < N; ++k) s0 = fma(work[k], hr[k - j], s0);
+            zb[2 * j] = work[j];
+            zb[2 * j + 1] = s0 + s1;
         }
     } else {
-        double *mid = a.mid + ((size_t) row * a.n_chunks + chunk) * m;
         for (int k = tid; k < m; k += 256) {
             const cd v = y_lds[k];
-            mid[k] = v.re * v.re + v.im * v.im;
+            zb[k] = v.re * v.re + v.im * v.im;
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// K2: FM resample (scipy.signal.resample m/2 -> m as a circulant product on the odd samples) and output lowpass.
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int m = a.m, tid = threadIdx.x;
-    const size_t item = blockIdx.x;   // row * n_chunks + chunk
-    double *z = (double *) smem;      // [m]
-    if (a.mode == SDRT_FM) {
-        const int N = m >> 1;
-        double *av = z + m;           // [N]
-        double *h = av + N;           // [N]
-        const double *mid = a.mid + item * N;
-        for (int i = tid; i < N; i += 256) { av[i] = mid[i]; h[i] = a.resample_odd[i]; }
-        __syncthreads();
-        for (int j = tid; j < N; j += 256) {
-            double s = 0.0;
-            for (int k = 0; k <= j; ++k) s = fma(av[k], h[j - k], s);
-            for (int k = j + 1; k < N; ++k) s = fma(av[k], h[j - k + N], s);
-            z[2 * j] = av[j];
-            z[2 * j + 1] = s;
-        }
-    } else {
-        const double *mid = a.mid + item * m;
-        for (int i = tid; i < m; i += 256) z[i] = mid[i];
     }
     __syncthreads();
-    // scipy.signal.sosfilt, zero initial state per chunk (dsp_processor.py:32-36,149): transposed direct form II.
-    if (tid == 0) {
-        double st[2 * SDRT_MAX_OUT_SECTIONS];
-        for (int s = 0; s < 2 * SDRT_MAX_OUT_SECTIONS; ++s) st[s] = 0.0;
-        double *out = a.out + item * m;
-        for (int i = 0; i < m; ++i) {
-            double xc = z[i];
-            for (int s = 0; s < a.out_sections; ++s) {
-                const double *c = a.out_sos + 6 * s;
-                const double xn = fma(c[0], xc, st[2 * s]);
-                st[2 * s] = fma(c[1], xc, fma(-c[4], xn, st[2 * s + 1]));
-                st[2 * s + 1] = fma(c[2], xc, -c[5] * xn);
-                xc = xn;
+
+    // ---- phase 6: output lowpass (dsp_processor.py:32-36,149: sosfilt, zero state per chunk) --------------------------------
+    double *out = a.out + ((size_t) row * a.n_chunks + chunk) * m;
+    const int nmodes = ot->nmodes;
+    if (nmodes < 0) {
+        // sequential transposed-direct-form-II cascade (any SOS); used only when the modal form is not available
+        if (tid == 0) {
+            double st[2 * SDRT_MAX_OUT_SECTIONS];
+            for (int s = 0; s < 2 * SDRT_MAX_OUT_SECTIONS; ++s) st[s] = 0.0;
+            for (int i = 0; i < m; ++i) {
+                double xc = zb[i];
+                for (int s = 0; s < a.out_sections; ++s) {
+                    const double *c = a.out_sos + 6 * s;
+                    const double xn = fma(c[0], xc, st[2 * s]);
+                    st[2 * s] = fma(c[1], xc, fma(-c[4], xn, st[2 * s + 1]));
+                    st[2 * s + 1] = fma(c[2], xc, -c[5] * xn);
+                    xc = xn;
+                }
+                out[i] = xc;
             }
-            out[i] = xc;
+        }
+        return;
+    }
+    // modal form: y[t] = D x[t] + sum_k Re(r_k s_k(t)), s_k(t+1) = p_k s_k(t) + x[t].  Thread tid owns samples
+    // [tid*E, tid*E+E).  Per mode: local end state -> inclusive scan over the wave (shuffles) -> wave totals via LDS.
+    const int E = ot->E, t0 = tid * E;
+    cd sinc[SDRT_OUT_MAXMODES];
+#pragma unroll
+    for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
+        sinc[k] = mk(0.0, 0.0);
+        if (k < nmodes) {
+            const cd p = mk(ot->p[k][0], ot->p[k][1]);
+            cd s = mk(0.0, 0.0);
+            for (int e = 0; e < E; ++e) {
+                const double x = (t0 + e < m) ? zb[t0 + e] : 0.0;
+                s = cfma(p, s, mk(x, 0.0));
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int d = 1 << i;
+                cd t = mk(__shfl_up(s.re, d), __shfl_up(s.im, d));
+                if (lane < d) t = mk(0.0, 0.0);
+                s = cfma(mk(ot->pstep[k][i][0], ot->pstep[k][i][1]), t, s);
+            }
+            sinc[k] = s;
+            if (lane == 63) wtot[k * 4 + wave] = s;
+        }
+    }
+    __syncthreads();
+    cd sst[SDRT_OUT_MAXMODES];
+#pragma unroll
+    for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
+        sst[k] = mk(0.0, 0.0);
+        if (k < nmodes) {
+            cd ex = mk(__shfl_up(sinc[k].re, 1), __shfl_up(sinc[k].im, 1));
+            if (lane == 0) ex = mk(0.0, 0.0);
+            const cd pw = mk(ot->pwave[k][0], ot->pwave[k][1]);
+            cd wp = mk(0.0, 0.0);                    // state at the start of this wave
+            for (int wv = 0; wv < wave; ++wv) wp = cfma(pw, wp, wtot[k * 4 + wv]);
+            sst[k] = cfma(mk(ot->plane[k][lane][0], ot->plane[k][lane][1]), wp, ex);
+        }
+    }
+    const double Dd = ot->D;
+    for (int e = 0; e < E; ++e) {
+        if (t0 + e < m) {
+            const double x = zb[t0 + e];
+            double yv = Dd * x;
+#pragma unroll
+            for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
+                if (k < nmodes) {
+                    const cd r = mk(ot->r[k][0], ot->r[k][1]), p = mk(ot->p[k][0], ot->p[k][1]);
+                    yv += r.re * sst[k].re - r.im * sst[k].im;
+                    sst[k] = cfma(p, sst[k], mk(x, 0.0));
+                }
+            }
+            out[t0 + e] = yv;
         }
     }
 }
@@ -364,66 +474,56 @@ __global__ void mfma_selftest_kernel(const double *A, const double *B, double *D
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------------------
-size_t decim_lds_bytes(int n, int L, int m, bool nco) {
-    const int nblk = n / L, nt = nblk / SDRT_TB;
-    size_t cds = (size_t) nblk + m + 2 * (size_t) nt * 8 + 2 * (size_t) (nt + 1) * 8 + 2 * (SDRT_EDGE + 1);
-    if (nco) cds += (size_t) SDRT_TB * L;
-    return cds * 16;
-}
+size_t chain_lds_bytes(int n, int L, int m, bool nco, bool fm) { return (size_t) lds_layout(n, L, m, nco, fm).total * 16; }
 
 template <int L, int DT>
-static hipError_t launch_decim_ldt(const DecimArgs &a, bool nco, dim3 grid, size_t lds, hipStream_t s) {
+static hipError_t launch_chain_ldt(const DecimArgs &a, bool nco, dim3 grid, size_t lds, hipStream_t s) {
     // more than 64 KiB of dynamic LDS has to be opted into per kernel (gfx950 has 160 KiB per workgroup)
     if (nco) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void *) decim_demod_kernel<L, DT, true>,
+            hipError_t e = hipFuncSetAttribute((const void *) chain_kernel<L, DT, true>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL((decim_demod_kernel<L, DT, true>), grid, dim3(256), lds, s, a);
+        hipLaunchKernelGGL((chain_kernel<L, DT, true>), grid, dim3(256), lds, s, a);
     } else {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void *) decim_demod_kernel<L, DT, false>,
+            hipError_t e = hipFuncSetAttribute((const void *) chain_kernel<L, DT, false>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL((decim_demod_kernel<L, DT, false>), grid, dim3(256), lds, s, a);
+        hipLaunchKernelGGL((chain_kernel<L, DT, false>), grid, dim3(256), lds, s, a);
     }
     return hipGetLastError();
 }
 
 template <int L>
-static hipError_t launch_decim_l(const DecimArgs &a, int dt, bool nco, dim3 grid, size_t lds, hipStream_t s) {
+static hipError_t launch_chain_l(const DecimArgs &a, int dt, bool nco, dim3 grid, size_t lds, hipStream_t s) {
     switch (dt) {
-        case SDRT_S8: return launch_decim_ldt<L, SDRT_S8>(a, nco, grid, lds, s);
-        case SDRT_U8: return launch_decim_ldt<L, SDRT_U8>(a, nco, grid, lds, s);
-        case SDRT_S16: return launch_decim_ldt<L, SDRT_S16>(a, nco, grid, lds, s);
-        case SDRT_U16: return launch_decim_ldt<L, SDRT_U16>(a, nco, grid, lds, s);
-        case SDRT_S32: return launch_decim_ldt<L, SDRT_S32>(a, nco, grid, lds, s);
-        case SDRT_U32: return launch_decim_ldt<L, SDRT_U32>(a, nco, grid, lds, s);
-        case SDRT_F32: return launch_decim_ldt<L, SDRT_F32>(a, nco, grid, lds, s);
-        case SDRT_F64: return launch_decim_ldt<L, SDRT_F64>(a, nco, grid, lds, s);
+        case SDRT_S8: return launch_chain_ldt<L, SDRT_S8>(a, nco, grid, lds, s);
+        case SDRT_U8: return launch_chain_ldt<L, SDRT_U8>(a, nco, grid, lds, s);
+        case SDRT_S16: return launch_chain_ldt<L, SDRT_S16>(a, nco, grid, lds, s);
+        case SDRT_U16: return launch_chain_ldt<L, SDRT_U16>(a, nco, grid, lds, s);
+        case SDRT_S32: return launch_chain_ldt<L, SDRT_S32>(a, nco, grid, lds, s);
+        case SDRT_U32: return launch_chain_ldt<L, SDRT_U32>(a, nco, grid, lds, s);
+        case SDRT_F32: return launch_chain_ldt<L, SDRT_F32>(a, nco, grid, lds, s);
+        case SDRT_F64: return launch_chain_ldt<L, SDRT_F64>(a, nco, grid, lds, s);
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_decim(const DecimArgs &a, int L, int dt, bool nco, size_t n_chunks, hipStream_t s) {
-    const dim3 grid((unsigned) (n_chunks * (size_t) a.rows));
-    const size_t lds = decim_lds_bytes(a.n, L, a.m, nco);
+hipError_t launch_chain(const DecimArgs &a, int L, int dt, bool nco, size_t n_chunks, hipStream_t s) {
+    // ids are (slot << 3 | xcd): round the chunk count up to a multiple of 8, surplus blocks exit at once
+    const size_t groups = (n_chunks + 7) / 8;
+    const dim3 grid((unsigned) (groups * 8 * (size_t) a.rows));
+    const size_t lds = chain_lds_bytes(a.n, L, a.m, nco, a.mode == SDRT_FM);
     switch (L) {
-        case 8: return launch_decim_l<8>(a, dt, nco, grid, lds, s);
-        case 16: return launch_decim_l<16>(a, dt, nco, grid, lds, s);
-        case 32: return launch_decim_l<32>(a, dt, nco, grid, lds, s);
-        case 64: return launch_decim_l<64>(a, dt, nco, grid, lds, s);
+        case 8: return launch_chain_l<8>(a, dt, nco, grid, lds, s);
+        case 16: return launch_chain_l<16>(a, dt, nco, grid, lds, s);
+        case 32: return launch_chain_l<32>(a, dt, nco, grid, lds, s);
+        case 64: return launch_chain_l<64>(a, dt, nco, grid, lds, s);
     }
     return hipErrorInvalidValue;
-}
-
-size_t post_lds_bytes(int m, int mode) { return (size_t) (mode == SDRT_FM ? 2 * m : m) * sizeof(double); }
-
-hipError_t launch_post(const PostArgs &a, size_t items, hipStream_t s) {
-    hipLaunchKernelGGL(post_kernel, dim3((unsigned) items), dim3(256), post_lds_bytes(a.m, a.mode), s, a);
-    return hipGetLastError();
 }
 
 hipError_t launch_mfma_selftest(const double *A, const double *B, double *D, hipStream_t s) {

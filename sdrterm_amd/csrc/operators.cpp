@@ -208,7 +208,83 @@ extern "C" int sdrt_build_decim_tables(const double *sos, int sections, int q, D
     return 0;
 }
 
+extern "C" int sdrt_build_out_tables(const double *sos, int sections, int m, OutTables *out) {
+    std::memset(out, 0, sizeof(*out));
+    out->nmodes = -1;
+    out->E = m >= 256 ? m / 256 : 1;
+    if (sections < 1 || sections > 8) return 0;
+    C poles[16];
+    int npoles = 0;
+    struct Num { R c[3]; int deg; } nums[8];
+    R D = 1;
+    for (int s = 0; s < sections; ++s) {
+        R a0 = sos[6 * s + 3];
+        if (a0 == 0) return 0;
+        R b0 = (R) sos[6 * s] / a0, b1 = (R) sos[6 * s + 1] / a0, b2 = (R) sos[6 * s + 2] / a0;
+        R a1 = (R) sos[6 * s + 4] / a0, a2 = (R) sos[6 * s + 5] / a0;
+        D = D * b0;
+        if (a2 != 0) {
+            R disc = a1 * a1 - 4 * a2;
+            if (disc == 0) return 0;                       // repeated pole
+            if (disc < 0) {
+                R sq = rsqrt128(-disc);
+                poles[npoles++] = C(-a1 / 2, sq / 2);
+                poles[npoles++] = C(-a1 / 2, -sq / 2);
+            } else {
+                R sq = rsqrt128(disc);
+                poles[npoles++] = C((-a1 + sq) / 2);
+                poles[npoles++] = C((-a1 - sq) / 2);
+            }
+            nums[s].c[0] = b0; nums[s].c[1] = b1; nums[s].c[2] = b2; nums[s].deg = 2;   // b0 z^2 + b1 z + b2
+        } else if (a1 != 0) {
+            if (b2 != 0) return 0;                         // improper: extra pole at z = 0
+            poles[npoles++] = C(-a1);
+            nums[s].c[0] = b0; nums[s].c[1] = b1; nums[s].c[2] = 0; nums[s].deg = 1;    // b0 z + b1
+        } else {
+            if (b1 != 0 || b2 != 0) return 0;              // FIR section
+            nums[s].c[0] = b0; nums[s].deg = 0;
+        }
+    }
+    // distinctness
+    for (int i = 0; i < npoles; ++i)
+        for (int j = i + 1; j < npoles; ++j) {
+            C d = poles[i] - poles[j];
+            if ((double) (d.re * d.re + d.im * d.im) < 1e-24) return 0;
+        }
+    int nm = 0;
+    C rp[16], rr[16];
+    for (int i = 0; i < npoles; ++i) {
+        if (poles[i].im < 0) continue;                     // represented by its conjugate
+        C num(1), den(1), p = poles[i];
+        for (int s = 0; s < sections; ++s) {
+            C v;
+            if (nums[s].deg == 2) v = C(nums[s].c[0]) * p * p + C(nums[s].c[1]) * p + C(nums[s].c[2]);
+            else if (nums[s].deg == 1) v = C(nums[s].c[0]) * p + C(nums[s].c[1]);
+            else v = C(nums[s].c[0]);
+            num = num * v;
+        }
+        for (int j = 0; j < npoles; ++j) if (j != i) den = den * (p - poles[j]);
+        C r = num / den;
+        if (poles[i].im > 0) r = r * C(2);
+        rp[nm] = p;
+        rr[nm] = r;
+        ++nm;
+    }
+    if (nm > SDRT_OUT_MAXMODES) return 0;
+    out->D = (double) D;
+    for (int k = 0; k < nm; ++k) {
+        put(out->r[k], rr[k]);
+        put(out->p[k], rp[k]);
+        for (int i = 0; i < 6; ++i) put(out->pstep[k][i], cpow(rp[k], out->E * (1 << i)));
+        put(out->pwave[k], cpow(rp[k], out->E * 64));
+        for (int l = 0; l < 64; ++l) put(out->plane[k][l], cpow(rp[k], out->E * l));
+    }
+    out->nmodes = nm;
+    return 0;
+}
+
 extern "C" void sdrt_build_nco(double f, double fs, int tile_len, int n_tiles, double *tile, double *tilephase) {
+    // tile[t], t < tile_len: exp(-2 pi i (f/fs) t);  tilephase[T], T < n_tiles: exp(-2 pi i (f/fs) tile_len T)
     const long double two_pi = 6.283185307179586476925286766559005768L;
     auto phasor = [&](long double t, double *dst) {
         // exp(-2 pi i (f/fs) t): reduce f*t modulo fs before scaling so the angle stays in (-2pi, 2pi)

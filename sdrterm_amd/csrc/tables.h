@@ -27,9 +27,28 @@ struct DecimTables {
     double tailU[SDRT_NMODE][SDRT_EDGE + 1][2];
 };
 
+// Output lowpass (scipy sosfilt, zero initial state per chunk) in parallel modal form for a 256-thread scan:
+//   y[t] = D x[t] + sum_k Re(r_k s_k(t)),   s_k(t+1) = p_k s_k(t) + x[t],   s_k(0) = 0
+// r_k already carries the weight 2 for a complex pole that stands for its conjugate pair too.
+#define SDRT_OUT_MAXMODES 4
+struct OutTables {
+    int32_t nmodes;          // 0..SDRT_OUT_MAXMODES; -1: not representable -> kernel uses the sequential SOS form
+    int32_t E;               // consecutive samples per thread: max(1, m / 256)
+    double D;
+    double r[SDRT_OUT_MAXMODES][2];
+    double p[SDRT_OUT_MAXMODES][2];
+    double pstep[SDRT_OUT_MAXMODES][6][2];   // p^(E * 2^i): wave scan multipliers
+    double pwave[SDRT_OUT_MAXMODES][2];      // p^(E * 64)
+    double plane[SDRT_OUT_MAXMODES][64][2];  // p^(E * lane)
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+// Modal form of an SOS cascade for m outputs per chunk.  Returns 0; out->nmodes == -1 when the cascade has
+// repeated poles, FIR sections or more than SDRT_OUT_MAXMODES modes (the caller then uses the sequential form).
+int sdrt_build_out_tables(const double *sos, int sections, int m, struct OutTables *out);
+
 // Builds the tables from the decimator SOS (scipy layout [sections][6]).  Returns 0 or a negative code;
 // on failure *err (if non-null) points to a static message.
 int sdrt_build_decim_tables(const double *sos, int sections, int q, struct DecimTables *out, const char **err);
