@@ -130,6 +130,11 @@ int sdrt_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes);
 int sdrt_device_synchronize(void);
 int sdrt_set_device(int device);
 
+/* Diagnostic: one sdrt_process_device call in which the first n_wgs workgroups record s_memtime at their phase
+ * boundaries; stamps_host receives n_wgs*4*8 uint64 ([workgroup][wave][8]).  Not for production use. */
+int sdrt_debug_stamps(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, double *out_dev,
+                      unsigned long long *stamps_host, int n_wgs);
+
 /* Self-test of the f64 MFMA operand layout the decimator relies on (runs a 16x16x4 product on the GPU). */
 int sdrt_selftest_mfma(double *max_abs_err);
 

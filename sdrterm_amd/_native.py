@@ -22,7 +22,7 @@ EXPORTS = (
     'sdrt_process_device_debug', 'sdrt_get_iq_offset', 'sdrt_set_iq_offset', 'sdrt_profile_enable',
     'sdrt_kernel_time', 'sdrt_profile_reset', 'sdrt_kernel_name', 'sdrt_malloc', 'sdrt_free',
     'sdrt_memcpy_h2d', 'sdrt_memcpy_d2h', 'sdrt_memcpy_d2d', 'sdrt_device_synchronize', 'sdrt_set_device',
-    'sdrt_selftest_mfma',
+    'sdrt_selftest_mfma', 'sdrt_debug_stamps',
 )
 
 

@@ -51,6 +51,8 @@ struct sdrt_ctx {
     double *d_out = nullptr;
     size_t stage_cap_chunks = 0;
     double iq_re = 0.0, iq_im = 0.0;
+    unsigned long long *stamps_dev = nullptr;   // diagnostic only (sdrt_debug_stamps)
+    int stamp_wgs = 0;
     bool profile = false;
     std::vector<Pending> pending;
     std::vector<hipEvent_t> free_events;
@@ -267,6 +269,8 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     da.out_sections = c->cfg.out_sections;
     da.out = out_dev;
     da.ydec = ydec_dev;
+    da.stamps = c->stamps_dev;
+    da.stamp_wgs = c->stamp_wgs;
     da.n_chunks = n_chunks;
     da.n = c->cfg.n_samples;
     da.m = c->m;
@@ -379,6 +383,24 @@ int sdrt_memcpy_d2d(void *d, const void *s, size_t b) {
 }
 int sdrt_device_synchronize(void) {
     HIP_TRY(hipDeviceSynchronize());
+    return SDRT_OK;
+}
+
+int sdrt_debug_stamps(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *out_dev, unsigned long long *stamps_host,
+                      int n_wgs) {
+    if (!c || !stamps_host || n_wgs < 1) return fail(SDRT_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const size_t bytes = (size_t) n_wgs * 4 * 8 * sizeof(unsigned long long);
+    HIP_TRY(hipMalloc((void **) &c->stamps_dev, bytes));
+    HIP_TRY(hipMemset(c->stamps_dev, 0, bytes));
+    c->stamp_wgs = n_wgs;
+    int rc = sdrt_process_device(c, raw_dev, n_chunks, out_dev, nullptr);
+    hipError_t e = hipMemcpy(stamps_host, c->stamps_dev, bytes, hipMemcpyDeviceToHost);
+    (void) hipFree(c->stamps_dev);
+    c->stamps_dev = nullptr;
+    c->stamp_wgs = 0;
+    if (rc != SDRT_OK) return rc;
+    if (e != hipSuccess) return fail(SDRT_EHIP, "stamp copy failed: %s", hipGetErrorString(e));
     return SDRT_OK;
 }
 

@@ -18,6 +18,8 @@ struct DecimArgs {
     const double *out_sos;      // [out_sections][6], used only by the sequential fallback
     double *out;                // [row][chunk][m]
     double *ydec;               // optional [row][chunk][m][2]
+    unsigned long long *stamps; // optional diagnostic: [wg < stamp_wgs][wave][8] s_memtime at phase boundaries
+    int stamp_wgs;
     size_t n_chunks;
     int n, m, n_tiles, rows, mode, swap, out_sections;
     double norm_scale, norm_bias;   // re' = re*scale + bias, im' = im*scale (identity: 1, 0)

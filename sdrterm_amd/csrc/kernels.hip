@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -39,6 +41,52 @@ __device__ __forceinline__ double dpp_row(double v) {
 template <int CTRL>
 __device__ __forceinline__ cd dpp_row(cd v) { return mk(dpp_row<CTRL>(v.re), dpp_row<CTRL>(v.im)); }
 
+// compile-time loop: f(std::integral_constant<int, S>{}) for S = 0 .. N-1 (DPP controls must be literal constants)
+template <int S, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (S < N) {
+        f(std::integral_constant<int, S>{});
+        static_for<S + 1, N>(f);
+    }
+}
+
+// Hillis-Steele inclusive scan along the lanes of one wave: S_l = sum_{j<=l} mu^(l-j) x_j  (x = 0 beyond the data).
+__device__ __forceinline__ cd wave_scan_geometric(cd x, cd mu, int lane) {
+    cd mpow = mu;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int d = 1 << i;
+        cd t = mk(__shfl_up(x.re, d), __shfl_up(x.im, d));
+        if (lane < d) t = mk(0.0, 0.0);
+        x = cfma(mpow, t, x);
+        mpow = cmul(mpow, mpow);
+    }
+    return x;
+}
+
+// Partial circulant product for the FM resampler: this wave covers k in [wave*N/4, (wave+1)*N/4), lane l the R outputs
+// j = R*l + r.  z_odd[j] = sum_k a[k] hr[(k - j) mod N].  A sliding register window feeds the R outputs from one new
+// LDS value of hr per k.
+template <int R>
+__device__ __forceinline__ void resample_partial(const double *a, const double *hr, double *part, int N, int wave,
+                                                 int lane) {
+    const int kq = N >> 2, k0 = wave * kq, j0 = R * lane, msk = N - 1;
+    double acc[R], B[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { acc[r] = 0.0; B[r] = r ? hr[(k0 - j0 - r) & msk] : 0.0; }
+    for (int k = k0; k < k0 + kq; k += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            B[(R - u) % R] = hr[(k + u - j0) & msk];
+            const double ak = a[k + u];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = fma(ak, B[(r - u + R) % R], acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) part[wave * N + j0 + r] = acc[r];
+}
+
 // ---- input decoding (read_file.py:51,100-101; file_util.py:44-56) -------------------------------------------------
 template <int DT> struct Enc;
 template <> struct Enc<SDRT_S8> { typedef int8_t raw; static constexpr int size = 1; };
@@ -62,20 +110,34 @@ __device__ __forceinline__ double decode(typename Enc<DT>::raw v, bool swap) {
     else { uint64_t u = swap ? __builtin_bswap64(v) : v; return __longlong_as_double((long long) u); }
 }
 
-// BYTES contiguous bytes per lane, BYTES-aligned, widest loads available.
+// BYTES contiguous bytes per lane (BYTES-aligned) into 32-bit words held in registers, widest loads available.
 template <int BYTES>
-__device__ __forceinline__ void load_bytes(const unsigned char *p, void *dst) {
+__device__ __forceinline__ void load_words(const unsigned char *p, uint32_t *dst) {
     if constexpr (BYTES % 16 == 0) {
 #pragma unroll
-        for (int i = 0; i < BYTES / 16; ++i) ((uint4 *) dst)[i] = ((const uint4 *) p)[i];
+        for (int i = 0; i < BYTES / 16; ++i) {
+            const uint4 v = ((const uint4 *) p)[i];
+            dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+        }
     } else if constexpr (BYTES == 8) {
-        *(uint2 *) dst = *(const uint2 *) p;
+        const uint2 v = *(const uint2 *) p;
+        dst[0] = v.x; dst[1] = v.y;
     } else if constexpr (BYTES == 4) {
-        *(uint32_t *) dst = *(const uint32_t *) p;
+        dst[0] = *(const uint32_t *) p;
     } else {
         static_assert(BYTES == 2, "unsupported per-lane byte count");
-        *(uint16_t *) dst = *(const uint16_t *) p;
+        dst[0] = *(const uint16_t *) p;
     }
+}
+
+// item IDX (compile-time) of the encoding out of the word array: pure register arithmetic, no memory punning
+template <int DT, int IDX>
+__device__ __forceinline__ typename Enc<DT>::raw get_item(const uint32_t *wds) {
+    constexpr int SZ = Enc<DT>::size;
+    if constexpr (SZ == 1) return (typename Enc<DT>::raw) ((wds[IDX >> 2] >> (8 * (IDX & 3))) & 0xffu);
+    else if constexpr (SZ == 2) return (typename Enc<DT>::raw) ((wds[IDX >> 1] >> (16 * (IDX & 1))) & 0xffffu);
+    else if constexpr (SZ == 4) return (typename Enc<DT>::raw) wds[IDX];
+    else return (typename Enc<DT>::raw) ((uint64_t) wds[2 * IDX] | ((uint64_t) wds[2 * IDX + 1] << 32));
 }
 
 }  // namespace
@@ -87,17 +149,16 @@ __device__ __forceinline__ void load_bytes(const unsigned char *p, void *dst) {
 // tile: they are the k-slices {4s+g} of the MFMA B operand for block nb (column nb).
 // ---------------------------------------------------------------------------------------------------------------
 struct LdsLayout {
-    int o, y, carF, carG, edge, cF, cG, tailF, tailFc, f0, gu, nco, hr, wtot, total;   // offsets in 16-byte units
+    int o, y, carF, carG, cF, cG, tailF, tailFc, f0, gu, hr, wtot, total;   // offsets in 16-byte units
 };
 __host__ __device__ inline LdsLayout lds_layout(int n, int L, int m, bool nco, bool fm) {
     const int nblk = n / L, nt = nblk / SDRT_TB;
     LdsLayout l;
     int p = 0;
     l.o = p; p += nblk;                      // local output parts; reused as the real work area (2*nblk doubles)
-    l.y = p; p += m;                         // decimated complex samples
+    l.y = p; p += m > 64 ? m : 64;           // decimated complex samples; later the resampler's partial sums
     l.carF = p; p += (nt + 1) * 8;           // [t][mode][stream]
     l.carG = p; p += (nt + 1) * 8;
-    l.edge = p; p += 2 * (SDRT_EDGE + 1);
     l.cF = p; p += SDRT_TB * 4;
     l.cG = p; p += SDRT_TB * 4;
     l.tailF = p; p += 16;
@@ -105,19 +166,18 @@ __host__ __device__ inline LdsLayout lds_layout(int n, int L, int m, bool nco, b
     l.f0 = p; p += 8;
     l.gu = p; p += 8;
     l.wtot = p; p += SDRT_OUT_MAXMODES * 4;
-    l.nco = p; p += nco ? L : 0;
     l.hr = p; p += fm ? (m / 2 + 1) / 2 : 0; // m/2 doubles
     l.total = p;
     return l;
 }
 
 template <int L, int DT, bool NCO>
-__global__ __launch_bounds__(256) void chain_kernel(DecimArgs a) {
+__global__ __launch_bounds__(256, 4) void chain_kernel(DecimArgs a) {
     constexpr int KS = L / 4;                       // k-steps == samples per lane per tile
     constexpr int ITEM = Enc<DT>::size;
     constexpr int BYTES = KS * 2 * ITEM;            // per lane per tile
     constexpr int TILE = SDRT_TB * L;               // samples per tile
-    constexpr int NBUF = BYTES < 16 ? 16 : BYTES;
+    constexpr int NW = BYTES < 4 ? 1 : BYTES / 4;    // 32-bit words per lane per tile
     typedef typename Enc<DT>::raw raw_t;
 
     extern __shared__ __align__(16) unsigned char smem[];
@@ -136,12 +196,16 @@ __global__ __launch_bounds__(256) void chain_kernel(DecimArgs a) {
     const int g = lane >> 4, nb = lane & 15;
     const bool swap = a.swap != 0;
 
+    // diagnostic phase stamps (a.stamps == nullptr in every production call)
+    unsigned long long *stp = (a.stamps && (int) bid < a.stamp_wgs && lane == 0) ? a.stamps + ((size_t) bid * 4 + wave) * 8 : nullptr;
+#define SDRT_STAMP(i) do { if (stp) stp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    SDRT_STAMP(0);
+
     const LdsLayout lo = lds_layout(n, L, m, NCO, fm);
     cd *base = (cd *) smem;
     cd *o_lds = base + lo.o, *y_lds = base + lo.y, *carF = base + lo.carF, *carG = base + lo.carG;
-    cd *edge_u = base + lo.edge, *cF = base + lo.cF, *cG = base + lo.cG, *tailF = base + lo.tailF;
+    cd *cF = base + lo.cF, *cG = base + lo.cG, *tailF = base + lo.tailF;
     cd *tailFc = base + lo.tailFc, *F0 = base + lo.f0, *Gu = base + lo.gu, *wtot = base + lo.wtot;
-    cd *nco_lds = base + lo.nco;
     double *hr = (double *) (base + lo.hr);
     double *work = (double *) o_lds;                 // after phase 3: a[] at work[0..m/2), z[] at work[m..2m)
 
@@ -149,38 +213,6 @@ __global__ __launch_bounds__(256) void chain_kernel(DecimArgs a) {
     const double nsc = a.norm_scale, nbias = a.norm_bias;
     const cd *nco_samp_g = (const cd *) a.nco_tile + (size_t) row * L;              // exp(i theta j), j < L
     const cd *nco_blk_g = (const cd *) a.nco_phase + (size_t) row * (size_t) (n / L);   // exp(i theta L B), B < n/L
-
-    // ---- prologue: tables to LDS, edge samples --------------------------------------------------------------------
-    if constexpr (NCO) {
-        for (int i = tid; i < L; i += 256) nco_lds[i] = nco_samp_g[i];
-    }
-    if (tid < 64) {
-        cF[tid] = mk(tab->cF[tid >> 2][tid & 3][0], tab->cF[tid >> 2][tid & 3][1]);
-        cG[tid] = mk(tab->cG[tid >> 2][tid & 3][0], tab->cG[tid >> 2][tid & 3][1]);
-    } else if (tid < 80) {
-        const int i = tid - 64;
-        tailF[i] = mk(tab->tailF[i >> 2][i & 3][0], tab->tailF[i >> 2][i & 3][1]);
-        tailFc[i] = mk(tab->tailFc[i >> 2][i & 3][0], tab->tailFc[i >> 2][i & 3][1]);
-    }
-    if (fm) {
-        const int N = m >> 1;
-        for (int i = tid; i < N; i += 256) hr[i] = a.resample_odd[i == 0 ? 0 : N - i];   // hr[i] = h[(-i) mod N]
-    }
-    if (tid >= 128 && tid < 128 + 2 * (SDRT_EDGE + 1)) {
-        const int e = tid - 128;
-        const int which = e / (SDRT_EDGE + 1), l = e % (SDRT_EDGE + 1);
-        const long idx = which ? (long) n - (SDRT_EDGE + 1) + l : l;
-        const raw_t *rp = (const raw_t *) chunk_raw + 2 * idx;
-        double xr = fma(decode<DT>(rp[0], swap), nsc, nbias);
-        double xi = decode<DT>(rp[1], swap) * nsc;
-        if constexpr (NCO) {
-            const cd c = cmul(nco_samp_g[idx % L], nco_blk_g[idx / L]);
-            const cd u = cmul(mk(xr, xi), c);
-            xr = u.re;
-            xi = u.im;
-        }
-        edge_u[e] = mk(xr, xi);
-    }
 
     // Stage-A weights for this lane: A operand of v_mfma_f64_16x16x4: lane holds A[row = l&15][k = l>>4].
     double w[KS];
@@ -191,47 +223,32 @@ __global__ __launch_bounds__(256) void chain_kernel(DecimArgs a) {
     for (int k = 0; k < 4; ++k) mup[k] = mk(tab->mu_pow[k][g][0], tab->mu_pow[k][g][1]);
     const double d0p = tab->d0p;
 
-    alignas(16) unsigned char cur[NBUF], nxt[NBUF];
-    const size_t lane_off = ((size_t) nb * L + (size_t) g * KS) * 2 * ITEM;
-    if (wave < nt) load_bytes<BYTES>(chunk_raw + (size_t) wave * TILE * 2 * ITEM + lane_off, cur);
-
-    __syncthreads();
-
-    // Edge operators (they only need the 56 edge samples): F0 = head . u_head, Gu = tailU . u_tail, per (mode, stream).
-    {
-        const int o = tid >> 5, l = tid & 31, mode = o >> 1, st = o & 1;
-        cd f = mk(0.0, 0.0), gq = mk(0.0, 0.0);
-        if (l <= SDRT_EDGE) {
-            const cd eh = edge_u[l], et = edge_u[(SDRT_EDGE + 1) + l];
-            const double uh = st ? eh.im : eh.re, ut = st ? et.im : et.re;
-            f = mk(tab->head[mode][l][0] * uh, tab->head[mode][l][1] * uh);
-            gq = mk(tab->tailU[mode][l][0] * ut, tab->tailU[mode][l][1] * ut);
-        }
+    uint32_t cur[NW], nxt[NW];
 #pragma unroll
-        for (int d = 16; d >= 1; d >>= 1) {
-            f.re += __shfl_xor(f.re, d);
-            f.im += __shfl_xor(f.im, d);
-            gq.re += __shfl_xor(gq.re, d);
-            gq.im += __shfl_xor(gq.im, d);
-        }
-        if (l == 0) { F0[o] = f; Gu[o] = gq; }
-    }
+    for (int i = 0; i < NW; ++i) { cur[i] = 0; nxt[i] = 0; }
+    const size_t lane_off = ((size_t) nb * L + (size_t) g * KS) * 2 * ITEM;
+    if (wave < nt) load_words<BYTES>(chunk_raw + (size_t) wave * TILE * 2 * ITEM + lane_off, cur);
 
+    // NCO: lane (g, nb) keeps exp(i theta (g*KS + nb % KS)); k-step s broadcasts entry s of each 16-lane row (DPP
+    // row_newbcast), which is the phasor of the sample that row's lanes feed to the MFMA in that step.
+    cd ncoL = mk(1.0, 0.0);
+    if constexpr (NCO) ncoL = nco_samp_g[g * KS + (nb % KS)];
+
+    SDRT_STAMP(1);
     // ---- main loop over this wave's tiles, next tile's bytes prefetched ----------------------------------------------
     for (int tile = wave; tile < nt; tile += 4) {
-        if (tile + 4 < nt) load_bytes<BYTES>(chunk_raw + (size_t) (tile + 4) * TILE * 2 * ITEM + lane_off, nxt);
-        const raw_t *rb = (const raw_t *) cur;
+        if (tile + 4 < nt) load_words<BYTES>(chunk_raw + (size_t) (tile + 4) * TILE * 2 * ITEM + lane_off, nxt);
         cd psi = mk(1.0, 0.0);
         if constexpr (NCO) psi = nco_blk_g[tile * SDRT_TB + nb];   // phasor common to this lane's block
 
         v4d acc_r = {0.0, 0.0, 0.0, 0.0}, acc_i = {0.0, 0.0, 0.0, 0.0};
         double u0r = 0.0, u0i = 0.0;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            double xr = fma(decode<DT>(rb[2 * s], swap), nsc, nbias);
-            double xi = decode<DT>(rb[2 * s + 1], swap) * nsc;
+        static_for<0, KS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            double xr = fma(decode<DT>(get_item<DT, 2 * s>(cur), swap), nsc, nbias);
+            double xi = decode<DT>(get_item<DT, 2 * s + 1>(cur), swap) * nsc;
             if constexpr (NCO) {
-                const cd c = nco_lds[g * KS + s];
+                const cd c = dpp_row<0x150 + s>(ncoL);
                 const double tr = xr * c.re - xi * c.im;
                 xi = xr * c.im + xi * c.re;
                 xr = tr;
@@ -239,7 +256,7 @@ __global__ __launch_bounds__(256) void chain_kernel(DecimArgs a) {
             if (s == 0) { u0r = xr; u0i = xi; }
             acc_r = __builtin_amdgcn_mfma_f64_16x16x4f64(w[s], xr, acc_r, 0, 0, 0);
             acc_i = __builtin_amdgcn_mfma_f64_16x16x4f64(w[s], xi, acc_i, 0, 0, 0);
-        }
+        });
         // D layout: lane (g, nb), register v holds row g + 4v of column nb:
         //   v=0 Re causal(mode g), v=1 Im causal, v=2 Re anticausal, v=3 Im anticausal; acc_r / acc_i = re / im stream.
         cd Cr = mk(acc_r[0], acc_r[1]), Ar = mk(acc_r[2], acc_r[3]);
@@ -288,40 +305,93 @@ __global__ __launch_bounds__(256) void chain_kernel(DecimArgs a) {
         pi += __shfl_xor(pi, 32);
         if (g == 0) o_lds[tile * SDRT_TB + nb] = mk(pr, pi);
 #pragma unroll
-        for (int i = 0; i < NBUF / 4; ++i) ((uint32_t *) cur)[i] = ((const uint32_t *) nxt)[i];
+        for (int i = 0; i < NW; ++i) cur[i] = nxt[i];
+    }
+    SDRT_STAMP(2);
+    // ---- tables for the later phases and the edge operators (all loads issued together, one round trip) -------------
+    {
+        const int o = tid >> 5, l = tid & 31, mode = o >> 1, st = o & 1;
+        cd f = mk(0.0, 0.0), gq = mk(0.0, 0.0);
+        if (l <= SDRT_EDGE) {
+            // head sample l and tail sample n-28+l of this chunk, after normalise and NCO; this thread needs stream st
+            const long ih = l, it = (long) n - (SDRT_EDGE + 1) + l;
+            const raw_t *rh = (const raw_t *) chunk_raw + 2 * ih, *rt = (const raw_t *) chunk_raw + 2 * it;
+            double hr_ = fma(decode<DT>(rh[0], swap), nsc, nbias), hi_ = decode<DT>(rh[1], swap) * nsc;
+            double tr_ = fma(decode<DT>(rt[0], swap), nsc, nbias), ti_ = decode<DT>(rt[1], swap) * nsc;
+            if constexpr (NCO) {
+                const cd ch = cmul(nco_samp_g[ih % L], nco_blk_g[ih / L]), ct = cmul(nco_samp_g[it % L], nco_blk_g[it / L]);
+                const cd uh = cmul(mk(hr_, hi_), ch), ut = cmul(mk(tr_, ti_), ct);
+                hr_ = uh.re; hi_ = uh.im; tr_ = ut.re; ti_ = ut.im;
+            }
+            const double uh = st ? hi_ : hr_, ut = st ? ti_ : tr_;
+            f = mk(tab->head[mode][l][0] * uh, tab->head[mode][l][1] * uh);
+            gq = mk(tab->tailU[mode][l][0] * ut, tab->tailU[mode][l][1] * ut);
+        }
+        if (tid < 64) {
+            cF[tid] = mk(tab->cF[tid >> 2][tid & 3][0], tab->cF[tid >> 2][tid & 3][1]);
+            cG[tid] = mk(tab->cG[tid >> 2][tid & 3][0], tab->cG[tid >> 2][tid & 3][1]);
+        } else if (tid < 80) {
+            const int i = tid - 64;
+            tailF[i] = mk(tab->tailF[i >> 2][i & 3][0], tab->tailF[i >> 2][i & 3][1]);
+            tailFc[i] = mk(tab->tailFc[i >> 2][i & 3][0], tab->tailFc[i >> 2][i & 3][1]);
+        }
+        if (fm) {
+            const int N = m >> 1;
+            for (int i = tid; i < N; i += 256) hr[i] = a.resample_odd[i == 0 ? 0 : N - i];   // hr[i] = h[(-i) mod N]
+        }
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) {
+            f.re += __shfl_xor(f.re, d);
+            f.im += __shfl_xor(f.im, d);
+            gq.re += __shfl_xor(gq.re, d);
+            gq.im += __shfl_xor(gq.im, d);
+        }
+        if (l == 0) { F0[o] = f; Gu[o] = gq; }
     }
     __syncthreads();
+    SDRT_STAMP(3);
 
-    // ---- phase 2: carries across tiles.  Threads 0..7 = (mode, stream), o = mode*2 + stream ------------------------------
-    if (tid < 8) {
-        const int mode = tid >> 1;
+    // ---- phase 2: carries across tiles as wave-level scans.  Chain o = mode*2 + stream; wave w owns chains 2w, 2w+1.
+    // F[t+1] = mu16 F[t] + aggF[t]  (slots of carF),  G[t] = mu16 G[t+1] + aggG[t]  (slots of carG).
+    for (int cc = 0; cc < 2; ++cc) {
+        const int o = wave * 2 + cc, mode = o >> 1;
         const cd mu16 = mk(tab->mu_pow[4][mode][0], tab->mu_pow[4][mode][1]);
-        cd F = F0[tid];
-        carF[tid] = F;
-        for (int t = 0; t < nt; ++t) {
-            F = cfma(mu16, F, carF[(t + 1) * 8 + tid]);
-            carF[(t + 1) * 8 + tid] = F;
+        cd carry = F0[o];
+        if (lane == 0) carF[o] = carry;
+        for (int t0 = 0; t0 < nt; t0 += 64) {
+            const int t = t0 + lane;
+            cd x = t < nt ? carF[(t + 1) * 8 + o] : mk(0.0, 0.0);
+            if (lane == 0) x = cfma(mu16, carry, x);
+            x = wave_scan_geometric(x, mu16, lane);
+            if (t < nt) carF[(t + 1) * 8 + o] = x;
+            carry = mk(__shfl(x.re, 63), __shfl(x.im, 63));
         }
     }
     __syncthreads();
-    if (tid < 8) {
-        const int mode = tid >> 1, st = tid & 1;
+    for (int cc = 0; cc < 2; ++cc) {
+        const int o = wave * 2 + cc, mode = o >> 1, st = o & 1;
         const cd mu16 = mk(tab->mu_pow[4][mode][0], tab->mu_pow[4][mode][1]);
-        cd G = Gu[tid];
+        cd G = Gu[o];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const cd Fj = carF[nt * 8 + j * 2 + st];
             G = cfma(tailF[mode * 4 + j], Fj, G);
             G = cfma(tailFc[mode * 4 + j], mk(Fj.re, -Fj.im), G);
         }
-        carG[nt * 8 + tid] = G;
-        for (int t = nt - 1; t >= 0; --t) {
-            G = cfma(mu16, G, carG[t * 8 + tid]);
-            carG[t * 8 + tid] = G;
+        if (lane == 0) carG[nt * 8 + o] = G;
+        cd carry = G;
+        for (int t0 = 0; t0 < nt; t0 += 64) {
+            const int t = nt - 1 - (t0 + lane);              // lanes walk the tiles from the right edge
+            cd x = t >= 0 ? carG[t * 8 + o] : mk(0.0, 0.0);
+            if (lane == 0) x = cfma(mu16, carry, x);
+            x = wave_scan_geometric(x, mu16, lane);
+            if (t >= 0) carG[t * 8 + o] = x;
+            carry = mk(__shfl(x.re, 63), __shfl(x.im, 63));
         }
     }
     __syncthreads();
 
+    SDRT_STAMP(4);
     // ---- phase 3: add the carried parts at the output blocks -> decimated samples y ----------------------------------
     const int stride = tab->out_stride;
     for (int k = tid; k < m; k += 256) {
@@ -344,6 +414,7 @@ __global__ __launch_bounds__(256) void chain_kernel(DecimArgs a) {
     }
     __syncthreads();
 
+    SDRT_STAMP(5);
     // ---- phase 4: demodulate (demodulation.py:25-32 pair angle; :41-48 |d^2|) into work[] ------------------------------
     double *zb = work + m;          // [m] demodulated samples at the decimated rate
     if (fm) {
@@ -357,21 +428,30 @@ __global__ __launch_bounds__(256) void chain_kernel(DecimArgs a) {
         __syncthreads();
         // phase 5: scipy.signal.resample N -> 2N (demodulation.py:35-38): even samples are the input, odd samples
         // a circulant product with the half-sample Dirichlet kernel: z[2j+1] = sum_k a[k] hr[(k - j) mod N].
-        for (int j = tid; j < N; j += 256) {
-            double s0 = 0.0, s1 = 0.0;
-            int k = 0;
-            for (; k + 1 < j; k += 2) {
-                s0 = fma(work[k], hr[k - j + N], s0);
-                s1 = fma(work[k + 1], hr[k + 1 - j + N], s1);
+        double *part = (double *) y_lds;    // y is dead now: [4][N] partial sums, one k-quarter per wave
+        const int R = N >> 6;
+        bool tiled = true;
+        switch (R) {
+            case 1: resample_partial<1>(work, hr, part, N, wave, lane); break;
+            case 2: resample_partial<2>(work, hr, part, N, wave, lane); break;
+            case 4: resample_partial<4>(work, hr, part, N, wave, lane); break;
+            case 8: resample_partial<8>(work, hr, part, N, wave, lane); break;
+            case 16: resample_partial<16>(work, hr, part, N, wave, lane); break;
+            default: tiled = false;
+        }
+        if (tiled) {
+            __syncthreads();
+            for (int j = tid; j < N; j += 256) {
+                zb[2 * j] = work[j];
+                zb[2 * j + 1] = (part[j] + part[N + j]) + (part[2 * N + j] + part[3 * N + j]);
             }
-            for (; k < j; ++k) s0 = fma(work[k], hr[k - j + N], s0);
-            for (; k + 1 < N; k += 2) {
-                s0 = fma(work[k], hr[k - j], s0);
-                s1 = fma(work[k + 1], hr[k + 1 - j], s1);
+        } else {
+            for (int j = tid; j < N; j += 256) {
+                double s0 = 0.0;
+                for (int k = 0; k < N; ++k) s0 = fma(work[k], hr[(k - j + N) % N], s0);
+                zb[2 * j] = work[j];
+                zb[2 * j + 1] = s0;
             }
-            for (; k < N; ++k) s0 = fma(work[k], hr[k - j], s0);
-            zb[2 * j] = work[j];
-            zb[2 * j + 1] = s0 + s1;
         }
     } else {
         for (int k = tid; k < m; k += 256) {
@@ -381,6 +461,7 @@ __global__ __launch_bounds__(256) void chain_kernel(DecimArgs a) {
     }
     __syncthreads();
 
+    SDRT_STAMP(6);
     // ---- phase 6: output lowpass (dsp_processor.py:32-36,149: sosfilt, zero state per chunk) --------------------------------
     double *out = a.out + ((size_t) row * a.n_chunks + chunk) * m;
     const int nmodes = ot->nmodes;
@@ -458,6 +539,7 @@ __global__ __launch_bounds__(256) void chain_kernel(DecimArgs a) {
             out[t0 + e] = yv;
         }
     }
+    SDRT_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
