@@ -50,7 +50,12 @@ struct sdrt_ctx {
     void *d_raw = nullptr;
     double *d_out = nullptr;
     size_t stage_cap_chunks = 0;
-    double iq_re = 0.0, iq_im = 0.0;
+    bool iq = false;
+    double *d_iq_state = nullptr;     // [2] carried offset, lives on the device
+    double *d_iq_pow = nullptr;       // [n/GS + 1]
+    double *d_iq_group = nullptr, *d_iq_agg = nullptr, *d_iq_chunk = nullptr;
+    size_t iq_cap_chunks = 0;
+    double iq_pow_e = 1.0, iq_pow_n = 1.0;
     unsigned long long *stamps_dev = nullptr;   // diagnostic only (sdrt_debug_stamps)
     int stamp_wgs = 0;
     bool profile = false;
@@ -161,7 +166,8 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     if (n % q) return fail(SDRT_EINVAL, "decimation must divide n_samples");   // dsp_processor.py:147,173
     const int m = n / q;
     if (cfg->mode == SDRT_FM && (m < 2 || (m & 1))) return fail(SDRT_EINVAL, "FM needs an even number of outputs per chunk");
-    if (cfg->correct_iq) return fail(SDRT_EINVAL, "correct_iq is not implemented in this build");
+    if (cfg->correct_iq && (n % 256 || (n / 256) % (L / 4)))
+        return fail(SDRT_EINVAL, "correct_iq needs n_samples to be a multiple of %d", 256 * (L / 4));
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -181,10 +187,12 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     c->rows = cfg->n_rows;
     c->nco = cfg->apply_shift != 0;
     if (cfg->normalize) {
-        // read_file.py:96: 1.6*(z - xmin)*d - 0.8 with complex z: only Re is offset.
+        // read_file.py:96: 1.6*(z - xmin)*d - 0.8 with complex z: only Re is offset.  Written as scale*(x + bias):
+        // the bias is added per sample, the scale is folded into the (linear) operator tables below.
         c->norm_scale = 1.6 * cfg->norm_inv_range;
-        c->norm_bias = -1.6 * cfg->norm_xmin * cfg->norm_inv_range - 0.8;
+        c->norm_bias = -cfg->norm_xmin - 0.5 / cfg->norm_inv_range;
     }
+    c->iq = cfg->correct_iq != 0;
     const size_t lds = chain_lds_bytes(n, L, m, c->nco, cfg->mode == SDRT_FM);
     if (lds > 160 * 1024) {
         delete c;
@@ -198,7 +206,35 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         delete c;
         return fail(SDRT_EINVAL, "decimator tables: %s", msg ? msg : "failed");
     }
+    if (c->norm_scale != 1.0) {
+        // everything up to the decimated samples is linear in the data: scaling the data == scaling these tables
+        const double k = c->norm_scale;
+        for (int r = 0; r < 16; ++r) for (int j = 0; j < SDRT_MAXL; ++j) tab.W[r][j] *= k;
+        tab.d0p *= k;
+        for (int i = 0; i < SDRT_NMODE; ++i)
+            for (int l = 0; l <= SDRT_EDGE; ++l)
+                for (int z = 0; z < 2; ++z) { tab.head[i][l][z] *= k; tab.tailU[i][l][z] *= k; }
+    }
     rc = upload(&c->d_tab, &tab, sizeof(tab));
+    if (rc == SDRT_OK && c->iq) {
+        // with normalisation the reference corrects the NORMALISED samples (read_file.py:102-103): the offset lives in
+        // normalised units, while the kernels work on x + bias (un-scaled) and scale at the end; off' = off / scale obeys
+        // the same recurrence, so the device state is kept in un-scaled units and converted in get/set.
+        const int gs = L / 4, ng = n / gs;
+        std::vector<double> pw((size_t) ng + 1);
+        sdrt_build_iq_pow(cfg->iq_inductance, ng, pw.data());          // (1-lambda)^k, k <= ng
+        std::vector<double> pwg((size_t) ng + 1);
+        std::vector<double> tmp((size_t) n + 1);
+        sdrt_build_iq_pow(cfg->iq_inductance, n, tmp.data());
+        for (int k = 0; k <= ng; ++k) pwg[k] = tmp[(size_t) k * gs];
+        c->iq_pow_e = tmp[n / 256];
+        c->iq_pow_n = tmp[n];
+        rc = upload(&c->d_iq_pow, pwg.data(), pwg.size() * sizeof(double));
+        if (rc == SDRT_OK) {
+            const double zero[2] = {0.0, 0.0};
+            rc = upload(&c->d_iq_state, zero, sizeof(zero));
+        }
+    }
     if (rc == SDRT_OK) rc = upload(&c->d_out_sos, cfg->out_sos, sizeof(double) * 6 * cfg->out_sections);
     if (rc == SDRT_OK) {
         OutTables otab;
@@ -240,6 +276,11 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_resample);
     (void) hipFree(c->d_out_sos);
     (void) hipFree(c->d_otab);
+    (void) hipFree(c->d_iq_state);
+    (void) hipFree(c->d_iq_pow);
+    (void) hipFree(c->d_iq_group);
+    (void) hipFree(c->d_iq_agg);
+    (void) hipFree(c->d_iq_chunk);
     (void) hipFree(c->d_raw);
     (void) hipFree(c->d_out);
     delete c;
@@ -278,11 +319,50 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     da.rows = c->rows;
     da.mode = c->cfg.mode;
     da.swap = c->cfg.swap_endianness && kItemSize[c->cfg.dtype] > 1;
-    da.norm_scale = c->norm_scale;
     da.norm_bias = c->norm_bias;
+    da.iq_group_off = nullptr;
+    da.iq_chunk_off = nullptr;
+    da.iq_pow = c->d_iq_pow;
+    da.iq_lambda = c->cfg.iq_inductance;
+    if (c->iq) {
+        const int gs = c->L / 4;
+        if (n_chunks > c->iq_cap_chunks) {
+            (void) hipFree(c->d_iq_group);
+            (void) hipFree(c->d_iq_agg);
+            (void) hipFree(c->d_iq_chunk);
+            c->d_iq_group = c->d_iq_agg = c->d_iq_chunk = nullptr;
+            c->iq_cap_chunks = 0;
+            HIP_TRY(hipMalloc((void **) &c->d_iq_group, n_chunks * (size_t) (c->cfg.n_samples / gs) * 2 * sizeof(double)));
+            HIP_TRY(hipMalloc((void **) &c->d_iq_agg, n_chunks * 2 * sizeof(double)));
+            HIP_TRY(hipMalloc((void **) &c->d_iq_chunk, (n_chunks + 1) * 2 * sizeof(double)));
+            c->iq_cap_chunks = n_chunks;
+        }
+        IqArgs ia;
+        ia.raw = raw_dev;
+        ia.group_off = c->d_iq_group;
+        ia.chunk_agg = c->d_iq_agg;
+        ia.chunk_off = c->d_iq_chunk;
+        ia.state = c->d_iq_state;
+        ia.n_chunks = n_chunks;
+        ia.n = c->cfg.n_samples;
+        ia.gs = gs;
+        ia.dt = c->cfg.dtype;
+        ia.swap = da.swap;
+        ia.norm_bias = c->norm_bias;
+        ia.lambda = c->cfg.iq_inductance;
+        ia.pow_e = c->iq_pow_e;
+        ia.pow_n = c->iq_pow_n;
+        {
+            Timed t(c, s, 2);
+            HIP_TRY(launch_iq_local(ia, s));
+            HIP_TRY(launch_iq_scan(ia, s));
+        }
+        da.iq_group_off = c->d_iq_group;
+        da.iq_chunk_off = c->d_iq_chunk;
+    }
     {
         Timed t(c, s, 0);
-        HIP_TRY(launch_chain(da, c->L, c->cfg.dtype, c->nco, n_chunks, s));
+        HIP_TRY(launch_chain(da, c->L, c->cfg.dtype, c->nco, c->iq, n_chunks, s));
     }
     return SDRT_OK;
 }
@@ -317,15 +397,22 @@ int sdrt_process_host(sdrt_ctx *c, const void *raw_host, size_t n_chunks, double
 
 int sdrt_get_iq_offset(sdrt_ctx *c, double *re, double *im) {
     if (!c) return fail(SDRT_EINVAL, "null context");
-    if (re) *re = c->iq_re;
-    if (im) *im = c->iq_im;
+    double v[2] = {0.0, 0.0};
+    if (c->d_iq_state) {
+        HIP_TRY(hipSetDevice(c->cfg.device));
+        HIP_TRY(hipMemcpy(v, c->d_iq_state, sizeof(v), hipMemcpyDeviceToHost));
+    }
+    if (re) *re = v[0] * c->norm_scale;      // device state is in un-scaled units (see sdrt_create)
+    if (im) *im = v[1] * c->norm_scale;
     return SDRT_OK;
 }
 
 int sdrt_set_iq_offset(sdrt_ctx *c, double re, double im) {
     if (!c) return fail(SDRT_EINVAL, "null context");
-    c->iq_re = re;
-    c->iq_im = im;
+    if (!c->d_iq_state) return fail(SDRT_EINVAL, "context was created without correct_iq");
+    const double v[2] = {re / c->norm_scale, im / c->norm_scale};
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpy(c->d_iq_state, v, sizeof(v), hipMemcpyHostToDevice));
     return SDRT_OK;
 }
 

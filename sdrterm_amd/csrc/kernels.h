@@ -22,9 +22,29 @@ struct DecimArgs {
     int stamp_wgs;
     size_t n_chunks;
     int n, m, n_tiles, rows, mode, swap, out_sections;
-    double norm_scale, norm_bias;   // re' = re*scale + bias, im' = im*scale (identity: 1, 0)
+    double norm_bias;           // added to Re before everything else (normalisation offset / scale; the scale itself is
+                                // folded into the operator tables on the host)
+    // IQ correction (read_file.py:64-77), only read when the IQ template flag is set:
+    const double *iq_group_off; // [chunk][n/GS][2] offset at the start of every GS-sample group, relative to a zero offset
+                                //                  at the start of its chunk (GS = L/4)
+    const double *iq_chunk_off; // [chunk+1][2]     true offset at the start of every chunk
+    const double *iq_pow;       // [n/GS + 1]       (1-lambda)^(GS*k)
+    double iq_lambda;
 };
 
+struct IqArgs {
+    const void *raw;
+    double *group_off;          // out: [chunk][n/GS][2]
+    double *chunk_agg;          // out: [chunk][2]  offset at the end of the chunk when it starts from zero
+    double *chunk_off;          // [chunk+1][2]     (scan kernel) true offsets at chunk starts; [n_chunks] = carried out
+    double *state;              // [2] carried offset (in/out, scan kernel)
+    size_t n_chunks;
+    int n, gs, dt, swap;
+    double norm_bias, lambda, pow_e /* (1-lambda)^(n/256) */, pow_n /* (1-lambda)^n */;
+};
+hipError_t launch_iq_local(const IqArgs &a, hipStream_t s);
+hipError_t launch_iq_scan(const IqArgs &a, hipStream_t s);
+
 size_t chain_lds_bytes(int n, int L, int m, bool nco, bool fm);
-hipError_t launch_chain(const DecimArgs &a, int L, int dt, bool nco, size_t n_chunks, hipStream_t s);
+hipError_t launch_chain(const DecimArgs &a, int L, int dt, bool nco, bool iq, size_t n_chunks, hipStream_t s);
 hipError_t launch_mfma_selftest(const double *A, const double *B, double *D, hipStream_t s);

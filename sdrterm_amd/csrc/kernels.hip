@@ -171,7 +171,7 @@ __host__ __device__ inline LdsLayout lds_layout(int n, int L, int m, bool nco, b
     return l;
 }
 
-template <int L, int DT, bool NCO>
+template <int L, int DT, bool NCO, bool IQ>
 __global__ __launch_bounds__(256, 4) void chain_kernel(DecimArgs a) {
     constexpr int KS = L / 4;                       // k-steps == samples per lane per tile
     constexpr int ITEM = Enc<DT>::size;
@@ -210,7 +210,12 @@ __global__ __launch_bounds__(256, 4) void chain_kernel(DecimArgs a) {
     double *work = (double *) o_lds;                 // after phase 3: a[] at work[0..m/2), z[] at work[m..2m)
 
     const unsigned char *chunk_raw = (const unsigned char *) a.raw + (size_t) chunk * (size_t) n * 2 * ITEM;
-    const double nsc = a.norm_scale, nbias = a.norm_bias;
+    const double nbias = a.norm_bias;
+    const int ngroups = n / KS;                      // IQ correction: offsets are tabulated per KS-sample group
+    const cd *iq_goff = IQ ? (const cd *) a.iq_group_off + (size_t) chunk * ngroups : nullptr;
+    cd iq_c0 = mk(0.0, 0.0);
+    if constexpr (IQ) iq_c0 = ((const cd *) a.iq_chunk_off)[chunk];
+    const double lam = a.iq_lambda;
     const cd *nco_samp_g = (const cd *) a.nco_tile + (size_t) row * L;              // exp(i theta j), j < L
     const cd *nco_blk_g = (const cd *) a.nco_phase + (size_t) row * (size_t) (n / L);   // exp(i theta L B), B < n/L
 
@@ -240,13 +245,26 @@ __global__ __launch_bounds__(256, 4) void chain_kernel(DecimArgs a) {
         if (tile + 4 < nt) load_words<BYTES>(chunk_raw + (size_t) (tile + 4) * TILE * 2 * ITEM + lane_off, nxt);
         cd psi = mk(1.0, 0.0);
         if constexpr (NCO) psi = nco_blk_g[tile * SDRT_TB + nb];   // phasor common to this lane's block
+        cd off = mk(0.0, 0.0);
+        if constexpr (IQ) {
+            const int grp = (tile * SDRT_TB + nb) * 4 + g;          // this lane's KS-sample group within the chunk
+            const cd go = iq_goff[grp];
+            const double pw = a.iq_pow[grp];
+            off = mk(fma(pw, iq_c0.re, go.re), fma(pw, iq_c0.im, go.im));
+        }
 
         v4d acc_r = {0.0, 0.0, 0.0, 0.0}, acc_i = {0.0, 0.0, 0.0, 0.0};
         double u0r = 0.0, u0i = 0.0;
         static_for<0, KS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            double xr = fma(decode<DT>(get_item<DT, 2 * s>(cur), swap), nsc, nbias);
-            double xi = decode<DT>(get_item<DT, 2 * s + 1>(cur), swap) * nsc;
+            double xr = decode<DT>(get_item<DT, 2 * s>(cur), swap) + nbias;
+            double xi = decode<DT>(get_item<DT, 2 * s + 1>(cur), swap);
+            if constexpr (IQ) {          // z = x - off; off += z * lambda  (read_file.py:74-76)
+                xr -= off.re;
+                xi -= off.im;
+                off.re = fma(xr, lam, off.re);
+                off.im = fma(xi, lam, off.im);
+            }
             if constexpr (NCO) {
                 const cd c = dpp_row<0x150 + s>(ncoL);
                 const double tr = xr * c.re - xi * c.im;
@@ -316,8 +334,27 @@ __global__ __launch_bounds__(256, 4) void chain_kernel(DecimArgs a) {
             // head sample l and tail sample n-28+l of this chunk, after normalise and NCO; this thread needs stream st
             const long ih = l, it = (long) n - (SDRT_EDGE + 1) + l;
             const raw_t *rh = (const raw_t *) chunk_raw + 2 * ih, *rt = (const raw_t *) chunk_raw + 2 * it;
-            double hr_ = fma(decode<DT>(rh[0], swap), nsc, nbias), hi_ = decode<DT>(rh[1], swap) * nsc;
-            double tr_ = fma(decode<DT>(rt[0], swap), nsc, nbias), ti_ = decode<DT>(rt[1], swap) * nsc;
+            double hr_ = decode<DT>(rh[0], swap) + nbias, hi_ = decode<DT>(rh[1], swap);
+            double tr_ = decode<DT>(rt[0], swap) + nbias, ti_ = decode<DT>(rt[1], swap);
+            if constexpr (IQ) {
+                // corrected sample = x - off(sample): walk from the start of the sample's group
+                const long idx2[2] = {ih, it};
+                double *dst[2][2] = {{&hr_, &hi_}, {&tr_, &ti_}};
+                for (int w2 = 0; w2 < 2; ++w2) {
+                    const long grp = idx2[w2] / KS;
+                    const cd go = iq_goff[grp];
+                    const double pw = a.iq_pow[grp];
+                    cd o2 = mk(fma(pw, iq_c0.re, go.re), fma(pw, iq_c0.im, go.im));
+                    for (long j = grp * KS; j < idx2[w2]; ++j) {
+                        const raw_t *rj = (const raw_t *) chunk_raw + 2 * j;
+                        const double zr = decode<DT>(rj[0], swap) + nbias - o2.re, zi = decode<DT>(rj[1], swap) - o2.im;
+                        o2.re = fma(zr, lam, o2.re);
+                        o2.im = fma(zi, lam, o2.im);
+                    }
+                    *dst[w2][0] -= o2.re;
+                    *dst[w2][1] -= o2.im;
+                }
+            }
             if constexpr (NCO) {
                 const cd ch = cmul(nco_samp_g[ih % L], nco_blk_g[ih / L]), ct = cmul(nco_samp_g[it % L], nco_blk_g[it / L]);
                 const cd uh = cmul(mk(hr_, hi_), ch), ut = cmul(mk(tr_, ti_), ct);
@@ -543,6 +580,129 @@ __global__ __launch_bounds__(256, 4) void chain_kernel(DecimArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// IQ correction prefix (read_file.py:64-77: z[i] -= off; off += z[i]*L, off carried across chunks).
+// off obeys off' = (1-lambda) off + lambda x, a first-order linear recurrence, so offsets at group starts are a prefix
+// scan: iq_local_kernel scans inside each chunk from a zero start (one workgroup per chunk) and records the chunk's
+// end value; iq_scan_kernel chains the chunks (and carries the stream state); the chain kernel then adds
+// (1-lambda)^position * offset(chunk start) to the local values.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ void iq_load(const unsigned char *chunk_raw, long j, bool swap, double nbias, double &xr, double &xi) {
+    typedef typename Enc<DT>::raw raw_t;
+    const raw_t *rp = (const raw_t *) chunk_raw + 2 * j;
+    xr = decode<DT>(rp[0], swap) + nbias;
+    xi = decode<DT>(rp[1], swap);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void iq_local_kernel(IqArgs a) {
+    __shared__ cd wtot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long chunk = blockIdx.x;
+    const int n = a.n, E = n / 256, gs = a.gs;          // E consecutive samples per thread, E % gs == 0
+    const unsigned char *chunk_raw = (const unsigned char *) a.raw + (size_t) chunk * (size_t) n * 2 * Enc<DT>::size;
+    const bool swap = a.swap != 0;
+    const double lam = a.lambda, om = 1.0 - lam;
+    // pass 1: this thread's E samples from a zero offset
+    cd s = mk(0.0, 0.0);
+    for (int e = 0; e < E; ++e) {
+        double xr, xi;
+        iq_load<DT>(chunk_raw, (long) tid * E + e, swap, a.norm_bias, xr, xi);
+        s.re = fma(om, s.re, lam * xr);
+        s.im = fma(om, s.im, lam * xi);
+    }
+    // scan over threads with multiplier (1-lambda)^E (real): wave-level Hillis-Steele, then wave totals
+    double mp = a.pow_e;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int d = 1 << i;
+        double tr = __shfl_up(s.re, d), ti = __shfl_up(s.im, d);
+        if (lane < d) { tr = 0.0; ti = 0.0; }
+        s.re = fma(mp, tr, s.re);
+        s.im = fma(mp, ti, s.im);
+        mp *= mp;
+    }
+    if (lane == 63) wtot[wave] = s;
+    __syncthreads();
+    const double pw64 = mp;                          // (1-lambda)^(64E)
+    cd ex = mk(__shfl_up(s.re, 1), __shfl_up(s.im, 1));
+    if (lane == 0) ex = mk(0.0, 0.0);
+    cd wp = mk(0.0, 0.0);
+    for (int wv = 0; wv < wave; ++wv) wp = mk(fma(pw64, wp.re, wtot[wv].re), fma(pw64, wp.im, wtot[wv].im));
+    double pl = 1.0;                                 // (1-lambda)^(E*lane)
+    for (int i = 0; i < lane; ++i) pl *= a.pow_e;
+    cd off = mk(fma(pl, wp.re, ex.re), fma(pl, wp.im, ex.im));   // offset at this thread's first sample
+    // pass 2: replay from the true local start, tabulating the offset at every group start
+    cd *gout = (cd *) a.group_off + (size_t) chunk * (size_t) (n / gs) + (size_t) tid * (E / gs);
+    for (int e = 0; e < E; ++e) {
+        if (e % gs == 0) gout[e / gs] = off;
+        double xr, xi;
+        iq_load<DT>(chunk_raw, (long) tid * E + e, swap, a.norm_bias, xr, xi);
+        off.re = fma(om, off.re, lam * xr);
+        off.im = fma(om, off.im, lam * xi);
+    }
+    if (tid == 255) ((cd *) a.chunk_agg)[chunk] = off;
+}
+
+// one workgroup: chunk offsets off[c+1] = (1-lambda)^n off[c] + agg[c], off[0] = carried state
+__global__ __launch_bounds__(256) void iq_scan_kernel(IqArgs a) {
+    __shared__ cd tot[256];
+    __shared__ double pw[256];
+    const int tid = threadIdx.x;
+    const size_t nc = a.n_chunks, per = (nc + 255) / 256;
+    const size_t c0 = (size_t) tid * per, c1 = c0 + per < nc ? c0 + per : nc;
+    const cd *agg = (const cd *) a.chunk_agg;
+    cd *offc = (cd *) a.chunk_off;
+    cd s = mk(0.0, 0.0);
+    double p = 1.0;
+    for (size_t c = c0; c < c1; ++c) {
+        s = mk(fma(a.pow_n, s.re, agg[c].re), fma(a.pow_n, s.im, agg[c].im));
+        p *= a.pow_n;
+    }
+    tot[tid] = s;
+    pw[tid] = p;
+    __syncthreads();
+    if (tid == 0) {
+        cd run = mk(a.state[0], a.state[1]);
+        for (int t = 0; t < 256; ++t) {
+            const cd mine = tot[t];
+            tot[t] = run;                                   // offset at the start of thread t's range
+            run = mk(fma(pw[t], run.re, mine.re), fma(pw[t], run.im, mine.im));
+        }
+        offc[nc] = run;
+        a.state[0] = run.re;
+        a.state[1] = run.im;
+    }
+    __syncthreads();
+    cd o = tot[tid];
+    for (size_t c = c0; c < c1; ++c) {
+        offc[c] = o;
+        o = mk(fma(a.pow_n, o.re, agg[c].re), fma(a.pow_n, o.im, agg[c].im));
+    }
+}
+
+hipError_t launch_iq_local(const IqArgs &a, hipStream_t s) {
+    const dim3 grid((unsigned) a.n_chunks);
+    switch (a.dt) {
+        case SDRT_S8: hipLaunchKernelGGL(iq_local_kernel<SDRT_S8>, grid, dim3(256), 0, s, a); break;
+        case SDRT_U8: hipLaunchKernelGGL(iq_local_kernel<SDRT_U8>, grid, dim3(256), 0, s, a); break;
+        case SDRT_S16: hipLaunchKernelGGL(iq_local_kernel<SDRT_S16>, grid, dim3(256), 0, s, a); break;
+        case SDRT_U16: hipLaunchKernelGGL(iq_local_kernel<SDRT_U16>, grid, dim3(256), 0, s, a); break;
+        case SDRT_S32: hipLaunchKernelGGL(iq_local_kernel<SDRT_S32>, grid, dim3(256), 0, s, a); break;
+        case SDRT_U32: hipLaunchKernelGGL(iq_local_kernel<SDRT_U32>, grid, dim3(256), 0, s, a); break;
+        case SDRT_F32: hipLaunchKernelGGL(iq_local_kernel<SDRT_F32>, grid, dim3(256), 0, s, a); break;
+        case SDRT_F64: hipLaunchKernelGGL(iq_local_kernel<SDRT_F64>, grid, dim3(256), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_iq_scan(const IqArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(iq_scan_kernel, dim3(1), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // MFMA layout self-test: D = A(16x4) * B(4x16) with one v_mfma_f64_16x16x4 and the operand maps K1 assumes.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void mfma_selftest_kernel(const double *A, const double *B, double *D) {
@@ -558,52 +718,49 @@ __global__ void mfma_selftest_kernel(const double *A, const double *B, double *D
 // ---- launch helpers ------------------------------------------------------------------------------------------
 size_t chain_lds_bytes(int n, int L, int m, bool nco, bool fm) { return (size_t) lds_layout(n, L, m, nco, fm).total * 16; }
 
-template <int L, int DT>
-static hipError_t launch_chain_ldt(const DecimArgs &a, bool nco, dim3 grid, size_t lds, hipStream_t s) {
+template <int L, int DT, bool NCO, bool IQ>
+static hipError_t launch_chain_k(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     // more than 64 KiB of dynamic LDS has to be opted into per kernel (gfx950 has 160 KiB per workgroup)
-    if (nco) {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void *) chain_kernel<L, DT, true>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL((chain_kernel<L, DT, true>), grid, dim3(256), lds, s, a);
-    } else {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void *) chain_kernel<L, DT, false>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL((chain_kernel<L, DT, false>), grid, dim3(256), lds, s, a);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *) chain_kernel<L, DT, NCO, IQ>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
     }
+    hipLaunchKernelGGL((chain_kernel<L, DT, NCO, IQ>), grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
+template <int L, int DT>
+static hipError_t launch_chain_ldt(const DecimArgs &a, bool nco, bool iq, dim3 grid, size_t lds, hipStream_t s) {
+    if (nco) return iq ? launch_chain_k<L, DT, true, true>(a, grid, lds, s) : launch_chain_k<L, DT, true, false>(a, grid, lds, s);
+    return iq ? launch_chain_k<L, DT, false, true>(a, grid, lds, s) : launch_chain_k<L, DT, false, false>(a, grid, lds, s);
+}
+
 template <int L>
-static hipError_t launch_chain_l(const DecimArgs &a, int dt, bool nco, dim3 grid, size_t lds, hipStream_t s) {
+static hipError_t launch_chain_l(const DecimArgs &a, int dt, bool nco, bool iq, dim3 grid, size_t lds, hipStream_t s) {
     switch (dt) {
-        case SDRT_S8: return launch_chain_ldt<L, SDRT_S8>(a, nco, grid, lds, s);
-        case SDRT_U8: return launch_chain_ldt<L, SDRT_U8>(a, nco, grid, lds, s);
-        case SDRT_S16: return launch_chain_ldt<L, SDRT_S16>(a, nco, grid, lds, s);
-        case SDRT_U16: return launch_chain_ldt<L, SDRT_U16>(a, nco, grid, lds, s);
-        case SDRT_S32: return launch_chain_ldt<L, SDRT_S32>(a, nco, grid, lds, s);
-        case SDRT_U32: return launch_chain_ldt<L, SDRT_U32>(a, nco, grid, lds, s);
-        case SDRT_F32: return launch_chain_ldt<L, SDRT_F32>(a, nco, grid, lds, s);
-        case SDRT_F64: return launch_chain_ldt<L, SDRT_F64>(a, nco, grid, lds, s);
+        case SDRT_S8: return launch_chain_ldt<L, SDRT_S8>(a, nco, iq, grid, lds, s);
+        case SDRT_U8: return launch_chain_ldt<L, SDRT_U8>(a, nco, iq, grid, lds, s);
+        case SDRT_S16: return launch_chain_ldt<L, SDRT_S16>(a, nco, iq, grid, lds, s);
+        case SDRT_U16: return launch_chain_ldt<L, SDRT_U16>(a, nco, iq, grid, lds, s);
+        case SDRT_S32: return launch_chain_ldt<L, SDRT_S32>(a, nco, iq, grid, lds, s);
+        case SDRT_U32: return launch_chain_ldt<L, SDRT_U32>(a, nco, iq, grid, lds, s);
+        case SDRT_F32: return launch_chain_ldt<L, SDRT_F32>(a, nco, iq, grid, lds, s);
+        case SDRT_F64: return launch_chain_ldt<L, SDRT_F64>(a, nco, iq, grid, lds, s);
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_chain(const DecimArgs &a, int L, int dt, bool nco, size_t n_chunks, hipStream_t s) {
+hipError_t launch_chain(const DecimArgs &a, int L, int dt, bool nco, bool iq, size_t n_chunks, hipStream_t s) {
     // ids are (slot << 3 | xcd): round the chunk count up to a multiple of 8, surplus blocks exit at once
     const size_t groups = (n_chunks + 7) / 8;
     const dim3 grid((unsigned) (groups * 8 * (size_t) a.rows));
     const size_t lds = chain_lds_bytes(a.n, L, a.m, nco, a.mode == SDRT_FM);
     switch (L) {
-        case 8: return launch_chain_l<8>(a, dt, nco, grid, lds, s);
-        case 16: return launch_chain_l<16>(a, dt, nco, grid, lds, s);
-        case 32: return launch_chain_l<32>(a, dt, nco, grid, lds, s);
-        case 64: return launch_chain_l<64>(a, dt, nco, grid, lds, s);
+        case 8: return launch_chain_l<8>(a, dt, nco, iq, grid, lds, s);
+        case 16: return launch_chain_l<16>(a, dt, nco, iq, grid, lds, s);
+        case 32: return launch_chain_l<32>(a, dt, nco, iq, grid, lds, s);
+        case 64: return launch_chain_l<64>(a, dt, nco, iq, grid, lds, s);
     }
     return hipErrorInvalidValue;
 }

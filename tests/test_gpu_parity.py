@@ -30,8 +30,6 @@ def test_mfma_layout_selftest():
 def test_golden_parity(case, golden):
     z, _ = golden
     name = case['name']
-    if case.get('correct_iq'):
-        pytest.skip('correct_iq lands in a later commit')
     eng = _engine(case)
     raw = case_raw(case)
     out, y = eng.process_debug(raw)
