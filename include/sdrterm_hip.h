@@ -74,6 +74,7 @@ typedef struct sdrt_config {
 
 /* Library / device discovery. */
 int sdrt_abi_version(void);
+size_t sdrt_config_size(void);       /* sizeof(sdrt_config) the library was built with (binding self-check) */
 int sdrt_device_count(int *count);
 const char *sdrt_last_error(void);   /* thread-local, valid until the next call on the same thread */
 
@@ -129,6 +130,13 @@ int sdrt_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int sdrt_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes);
 int sdrt_device_synchronize(void);
 int sdrt_set_device(int device);
+
+/*
+ * Stand-alone discriminators on already-decimated samples: fmDemod / amDemod / realOutput / imagOutput of
+ * src/dsp/demodulation.py:25-68 (mode 0 FM: pair angle + FFT-equivalent resample m/2 -> m; 1 AM: re^2+im^2; 2 re; 3 im).
+ *   y_host : rows * m interleaved (re, im) float64;  out_host : rows * m float64.  Host buffers, synchronous.
+ */
+int sdrt_demodulate_host(int mode, const double *y_host, int rows, int m, double *out_host);
 
 /* Diagnostic: one sdrt_process_device call in which the first n_wgs workgroups record s_memtime at their phase
  * boundaries; stamps_host receives n_wgs*4*8 uint64 ([workgroup][wave][8]).  Not for production use. */

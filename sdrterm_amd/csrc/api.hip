@@ -125,6 +125,8 @@ extern "C" {
 
 int sdrt_abi_version(void) { return SDRT_ABI_VERSION; }
 
+size_t sdrt_config_size(void) { return sizeof(sdrt_config); }
+
 const char *sdrt_last_error(void) { return g_err; }
 
 int sdrt_device_count(int *count) {
@@ -470,6 +472,31 @@ int sdrt_memcpy_d2d(void *d, const void *s, size_t b) {
 }
 int sdrt_device_synchronize(void) {
     HIP_TRY(hipDeviceSynchronize());
+    return SDRT_OK;
+}
+
+int sdrt_demodulate_host(int mode, const double *y_host, int rows, int m, double *out_host) {
+    if (!y_host || !out_host || rows < 1 || m < 1 || mode < 0 || mode > 3) return fail(SDRT_EINVAL, "bad argument");
+    if (mode == 0 && (m & 1)) return fail(SDRT_EINVAL, "FM needs an even number of samples per row");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(SDRT_ENODEVICE, "no HIP device available");
+    double *dy = nullptr, *dout = nullptr, *dh = nullptr;
+    const size_t ybytes = (size_t) rows * m * 2 * sizeof(double), obytes = (size_t) rows * m * sizeof(double);
+    HIP_TRY(hipMalloc((void **) &dy, ybytes));
+    HIP_TRY(hipMalloc((void **) &dout, obytes));
+    HIP_TRY(hipMemcpy(dy, y_host, ybytes, hipMemcpyHostToDevice));
+    if (mode == 0) {
+        std::vector<double> h((size_t) m / 2);
+        sdrt_build_resample_odd(m / 2, h.data());
+        HIP_TRY(hipMalloc((void **) &dh, h.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(dh, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    hipError_t e = launch_demod(dy, dout, dh, rows, m, mode, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_host, dout, obytes, hipMemcpyDeviceToHost);
+    (void) hipFree(dy);
+    (void) hipFree(dout);
+    (void) hipFree(dh);
+    if (e != hipSuccess) return fail(SDRT_EHIP, "demodulate failed: %s", hipGetErrorString(e));
     return SDRT_OK;
 }
 

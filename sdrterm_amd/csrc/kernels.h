@@ -48,3 +48,4 @@ hipError_t launch_iq_scan(const IqArgs &a, hipStream_t s);
 size_t chain_lds_bytes(int n, int L, int m, bool nco, bool fm);
 hipError_t launch_chain(const DecimArgs &a, int L, int dt, bool nco, bool iq, size_t n_chunks, hipStream_t s);
 hipError_t launch_mfma_selftest(const double *A, const double *B, double *D, hipStream_t s);
+hipError_t launch_demod(const double *y, double *out, const double *resample_odd, int rows, int m, int mode, hipStream_t s);

@@ -703,6 +703,48 @@ hipError_t launch_iq_scan(const IqArgs &a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Stand-alone discriminators on already-decimated samples (demodulation.py:25-68): one workgroup per row.
+// mode 0 FM (pair angle + resample m/2 -> m), 1 AM, 2 real part, 3 imaginary part.  Not on the streaming path (the chain
+// kernel has them fused); this backs sdrterm_amd.dsp.demodulation when called directly.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void demod_kernel(const double *y, double *out, const double *resample_odd, int m, int mode) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *av = (double *) smem;                 // [m/2] pair angles (FM)
+    const cd *yr = (const cd *) y + (size_t) blockIdx.x * m;
+    double *o = out + (size_t) blockIdx.x * m;
+    const int tid = threadIdx.x;
+    if (mode == 0) {
+        const int N = m >> 1;
+        for (int j = tid; j < N; j += 256) {
+            const cd p = yr[2 * j], c = yr[2 * j + 1];
+            av[j] = atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);
+        }
+        __syncthreads();
+        for (int j = tid; j < N; j += 256) {
+            double s0 = 0.0;
+            for (int k = 0; k < N; ++k) {
+                int d = j - k;
+                if (d < 0) d += N;
+                s0 = fma(av[k], resample_odd[d], s0);
+            }
+            o[2 * j] = av[j];
+            o[2 * j + 1] = s0;
+        }
+    } else {
+        for (int k = tid; k < m; k += 256) {
+            const cd v = yr[k];
+            o[k] = mode == 1 ? v.re * v.re + v.im * v.im : (mode == 2 ? v.re : v.im);
+        }
+    }
+}
+
+hipError_t launch_demod(const double *y, double *out, const double *resample_odd, int rows, int m, int mode, hipStream_t s) {
+    hipLaunchKernelGGL(demod_kernel, dim3((unsigned) rows), dim3(256), (size_t) (m / 2 + 1) * sizeof(double), s, y, out,
+                       resample_odd, m, mode);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // MFMA layout self-test: D = A(16x4) * B(4x16) with one v_mfma_f64_16x16x4 and the operand maps K1 assumes.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void mfma_selftest_kernel(const double *A, const double *B, double *D) {

@@ -1,0 +1,252 @@
+"""DspProcessor -- GPU-backed stand-in for the reference's src/dsp/dsp_processor.py.
+
+The public surface is the reference's (dsp_processor.py:48-220): the constructor keywords that IOArgs passes
+(io_args.py:111-118), the ``fs`` / ``decimation`` / ``decimatedFs`` properties with their error behaviour, the
+``selectOutput*`` methods, ``_setDemod``, ``_generateShift`` and the ``processData(isDead, buffer, f)`` consumer.
+What differs is the body: instead of numpy/scipy calls per chunk (dsp_processor.py:140-149) every queued chunk goes
+through one launch of the fused HIP chain kernel behind the C ABI (include/sdrterm_hip.h).
+
+Spawn safety: the CLI pickles the processor into a child process (sdrterm.py:182-188, io_args.py:92-95), so no
+ctypes or HIP handle exists until ``processData`` runs there; the GPU context is created from the first chunk,
+where the reference allocates its x/y/z buffers (dsp_processor.py:171-178).
+"""
+import json
+import sys
+from queue import Empty
+
+import numpy as np
+
+from . import demodulation
+from .data_processor import DataProcessor
+from ..misc.general_util import vprint
+
+
+def generateEllipFilter(fs: int, deg: int, Wn, btype: str):
+    """Output lowpass design: the same scipy call as dsp_processor.py:39-45 (1 dB ripple, 30 dB stop band, SOS)."""
+    from scipy.signal import ellip
+    return ellip(deg, 1, 30, Wn, btype=btype, analog=False, output='sos', fs=fs)
+
+
+#                 selector                 log line            bandwidth            has lowpass
+_SELECTIONS = {
+    'Fm': (demodulation.fmDemod, 'NFM Selected', 12500, True),          # dsp_processor.py:116-121
+    'Am': (demodulation.amDemod, 'AM Selected', 10000, True),           # dsp_processor.py:123-128
+    'Real': (demodulation.realOutput, 'I output Selected', None, False),  # dsp_processor.py:130-133
+    'Imag': (demodulation.imagOutput, 'Q output Selected', None, False),  # dsp_processor.py:135-138
+}
+
+
+class DspProcessor(DataProcessor):
+    _FILTER_DEGREE = 3
+    MAX_BATCH = 64      # chunks per GPU call when that many are already queued (1 == the reference's cadence)
+
+    def __init__(self, fs: int, center: int = 0, omegaOut: int = 0, tuned: int = 0, dec: int = 2,
+                 smooth: bool = False, fileInfo: dict = None, **kwargs):
+        self._decimationFactor = dec
+        self._fs = None
+        self._decimatedFs = None
+        self.fs = fs
+        self.centerFreq = center
+        self.tunedFreq = tuned
+        self.omegaOut = omegaOut
+        self.smooth = smooth
+        self.bandwidth = None
+        self.tmp = None
+        self._fileInfo = fileInfo
+        self._shift = None
+        self._isDead = False
+        self._outputFilters = []
+        self._nFreq = 1
+        self._engine = None
+        self._device = int(kwargs.get('device') or 0)
+
+    # ---- rates ----------------------------------------------------------------------------------------
+    @property
+    def fs(self) -> int:
+        return self._fs
+
+    @fs.setter
+    def fs(self, value: int) -> None:
+        self._fs = value
+        self._decimatedFs = value // self._decimationFactor     # integer division, as dsp_processor.py:86
+
+    @property
+    def decimation(self) -> int:
+        return self._decimationFactor
+
+    @decimation.setter
+    def decimation(self, value: int) -> None:
+        if value < 2:
+            raise ValueError("Decimation must be at least 2.")
+        self._decimationFactor = value
+        self.fs = self._fs
+
+    @property
+    def decimatedFs(self) -> int:       # read-only: assignment raises AttributeError like the reference property
+        return self._decimatedFs
+
+    # ---- demodulation selection -------------------------------------------------------------------------
+    def demod(self, *_, **__):
+        """Placeholder until a selectOutput*() installs a selector (dsp_processor.py:103-104)."""
+
+    def _setDemod(self, fun, *filters):
+        """Installs ``fun`` as ``self.demod`` and replaces the output filters (dsp_processor.py:106-114):
+        ValueError when ``fun`` is None, TypeError when the filters argument is not iterable."""
+        if fun is None:
+            raise ValueError("Demodulation function, or filters not defined")
+        self._outputFilters.clear()
+        if filters:
+            self._outputFilters.extend(*filters)
+        self.demod = fun
+        self._engine = None
+        return self.demod
+
+    def _select(self, key: str) -> None:
+        selector, message, bandwidth, lowpass = _SELECTIONS[key]
+        vprint(message)
+        self.bandwidth = bandwidth if bandwidth is not None else self.decimatedFs
+        if lowpass:
+            self._setDemod(selector, generateEllipFilter(self._decimatedFs, self._FILTER_DEGREE, self.omegaOut, 'lowpass'))
+        else:
+            self._setDemod(selector)
+
+    def selectOutputFm(self):
+        self._select('Fm')
+
+    def selectOutputAm(self):
+        self._select('Am')
+
+    def selectOutputReal(self):
+        self._select('Real')
+
+    def selectOutputImag(self):
+        self._select('Imag')
+
+    # ---- GPU context --------------------------------------------------------------------------------------
+    def _rowFreqs(self):
+        return [self.centerFreq]
+
+    def _applyShift(self) -> bool:
+        return bool(self.centerFreq)
+
+    @staticmethod
+    def _encodingOf(chunk: np.ndarray) -> str:
+        """Queue items are what the reader's ``re + 1j*im`` produced: complex128, or complex64 for float32 input."""
+        if chunk.dtype == np.complex128:
+            return 'd'
+        if chunk.dtype == np.complex64:
+            return 'f'
+        raise TypeError(f'chunks must be complex64 or complex128 arrays, not {chunk.dtype}')
+
+    def _getEngine(self, n: int, code: str):
+        eng = self._engine
+        if eng is not None and eng.n == n and eng.code == code:
+            return eng
+        mode = getattr(self.demod, 'mode', None)
+        if mode not in ('fm', 'am', 're', 'im'):
+            raise TypeError(f'{self.demod!r} is not a demodulation selector of this package')
+        if mode in ('re', 'im') or not len(self._outputFilters):
+            # the reference gets here with an empty filter list and scipy.signal.sosfilt([]) raises
+            # (dsp_processor.py:130-138,149); same exception type and text
+            raise ValueError('sos array must be 2D')
+        from ..engine import Engine
+        sos = np.asarray(self._outputFilters, dtype=np.float64).reshape(-1, 6)
+        self._engine = Engine(self._fs, self._decimationFactor, mode, code, n_samples=n, row_freqs=self._rowFreqs(),
+                              apply_shift=self._applyShift(), out_sos=sos, device=self._device)
+        return self._engine
+
+    def _requireNoSmoothing(self):
+        if self.smooth:
+            raise NotImplementedError('--smooth-output (Savitzky-Golay, dsp_processor.py:159-160) is not in the GPU build yet')
+
+    # ---- per-chunk API kept for callers/tests written against the reference -----------------------------------
+    def _processChunk(self, x: np.ndarray, y: np.ndarray, z: np.ndarray) -> None:
+        """x (nFreq, n) complex with the chunk in row 0; fills y (nFreq, n/q) decimated samples and z (nFreq, n/q) output."""
+        self._requireNoSmoothing()
+        eng = self._getEngine(x.shape[1], self._encodingOf(x))
+        out, dec = eng.process_debug(np.ascontiguousarray(x[0]), 1)
+        y[:] = dec
+        z[:] = out
+
+    def _transformData(self, x, y, z, file) -> None:
+        self._processChunk(x, y, z)
+        file.write(np.ascontiguousarray(z, dtype='=f8').tobytes())     # == pack('@Nd', *z.flat), dsp_processor.py:162
+
+    # ---- consumer loop ----------------------------------------------------------------------------------------
+    def _takeBatch(self, buffer):
+        """One blocking get, then whatever is already queued (at most MAX_BATCH).  Returns (chunks, saw_eof).
+        The reader signals EOF with b'' (read_file.py:169-171)."""
+        got = [buffer.get()]
+        while isinstance(got[-1], np.ndarray) and len(got) < self.MAX_BATCH:
+            try:
+                got.append(buffer.get_nowait())
+            except (Empty, ValueError, OSError):
+                break
+        eof = not isinstance(got[-1], np.ndarray)
+        return (got[:-1] if eof else got), eof
+
+    def _runBatch(self, chunks) -> np.ndarray:
+        self._requireNoSmoothing()
+        eng = self._getEngine(chunks[0].size, self._encodingOf(chunks[0]))
+        raw = np.ascontiguousarray(np.stack(chunks) if len(chunks) > 1 else chunks[0])
+        return eng.process(raw, len(chunks)).reshape(self._nFreq, len(chunks), eng.m)
+
+    def _emit(self, z: np.ndarray, file) -> None:
+        """z (nFreq, chunks, m): the reference writes chunk after chunk, native-endian doubles."""
+        for c in range(z.shape[1]):
+            file.write(np.ascontiguousarray(z[:, c, :], dtype='=f8').tobytes())
+
+    def _processData(self, isDead, buffer, file=None) -> None:
+        while not (self._isDead or isDead.value):
+            chunks, eof = self._takeBatch(buffer)
+            if chunks:
+                if self._shift is None:
+                    self._generateShift(chunks[0].size)
+                self._emit(self._runBatch(chunks), file)
+            if eof:
+                # the reference's loop ends on the ValueError numpy raises for ``x[0, :] = b''``
+                # (dsp_processor.py:170, swallowed by processData's finally/return)
+                raise ValueError('end of stream')
+
+    def _generateShift(self, c: int) -> None:
+        """Host copy of the NCO row for callers that inspect ``_shift`` (dsp_processor.py:185-187: only when
+        center != 0).  The kernel applies its own extended-precision table of the same sequence."""
+        if self.centerFreq:
+            k = np.arange(c)
+            self._shift = np.array([np.exp(-2j * np.pi * (self.centerFreq / self._fs) * k)])
+
+    def processData(self, isDead, buffer, f: str, *args, **kwargs) -> None:
+        sink = open(f, 'wb') if f is not None else open(sys.stdout.fileno(), 'wb', closefd=False)
+        with sink as file:
+            try:
+                self._processData(isDead, buffer, file)
+                file.flush()
+            except KeyboardInterrupt:
+                pass
+            finally:
+                # like the reference, whatever ended the loop is swallowed here -- unless closing the queue fails
+                buffer.close()
+                buffer.join_thread()
+                vprint('Standard writer halted')
+                return
+
+    # ---- reporting -----------------------------------------------------------------------------------------------
+    def __repr__(self):
+        """JSON of the public settings; example_simo.sh parses it, so the keys follow dsp_processor.py:206-217."""
+        shown = {}
+        for key, value in self.__dict__.items():
+            if key.startswith('_') or value is None or callable(value) or isinstance(value, np.ndarray):
+                continue
+            shown[key[:-3] if 'Str' in key else key] = value
+        shown['encoding'] = str(self._fileInfo['bitsPerSample'])
+        shown['fs'] = self._fs
+        shown['decimatedFs'] = self._decimatedFs
+        return json.dumps(shown, indent=2)
+
+    def __str__(self):
+        return type(self).__name__
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_engine'] = None       # ctypes / HIP handles never cross the spawn boundary
+        return state

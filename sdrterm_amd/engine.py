@@ -38,6 +38,18 @@ def output_sos(fs_dec: int, omega_out, degree: int = 3) -> np.ndarray:
         ellip(degree, 1, 30, omega_out, btype='lowpass', analog=False, output='sos', fs=fs_dec), dtype=np.float64)
 
 
+_DEMOD_MODES = {'fm': 0, 'am': 1, 're': 2, 'im': 3}
+
+
+def demodulate(mode: str, y: np.ndarray) -> np.ndarray:
+    """fmDemod / amDemod / realOutput / imagOutput (src/dsp/demodulation.py:25-68) of decimated samples
+    y (rows, m) on the GPU -> (rows, m) float64."""
+    y = np.ascontiguousarray(np.atleast_2d(y), dtype=np.complex128)
+    out = np.empty(y.shape, dtype=np.float64)
+    nat.check(nat.lib().sdrt_demodulate_host(_DEMOD_MODES[mode], y.ctypes.data, y.shape[0], y.shape[1], out.ctypes.data))
+    return out
+
+
 class Engine:
     """One GPU context == one reference processor (rows = VFO channels)."""
 

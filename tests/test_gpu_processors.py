@@ -1,0 +1,213 @@
+"""GPU end-to-end tests of the processor mirrors, the stand-alone discriminators and stream-level properties."""
+import multiprocessing as mp
+import os
+import socket
+import tempfile
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from tests.util import BY_NAME, case_raw, ref_tol, samples_per_chunk
+
+pytestmark = pytest.mark.gpu
+
+
+class _Flag:
+    value = 0
+
+
+class _ListQueue:
+    """Queue stand-in fed with the reader's chunks then b'' (read_file.py:169-171)."""
+
+    def __init__(self, items):
+        import queue
+        self.q = queue.Queue()
+        for it in items:
+            self.q.put(it)
+
+    def get(self):
+        return self.q.get()
+
+    def get_nowait(self):
+        return self.q.get_nowait()
+
+    def close(self):
+        pass
+
+    def join_thread(self):
+        pass
+
+
+def _reader_chunks(case):
+    """What the reference's reader would enqueue for this case (unpack/normalize/correctIq), via the oracle."""
+    from oracle import ref_chain
+    ch = ref_chain.Chain(case['fs'], case['q'], case['mode'], case['code'], center=case['center'],
+                         vfos=case.get('vfos'), omega_out=case['omega_out'], normalize=bool(case.get('normalize')),
+                         correct_iq=bool(case.get('correct_iq')), big_endian=bool(case.get('big_endian')))
+    raw = case_raw(case)
+    n = samples_per_chunk(case['code'])
+    item = len(raw) // (2 * n * case['n_chunks'])
+    return [ch.read(raw[c * 2 * n * item:(c + 1) * 2 * n * item]) for c in range(case['n_chunks'])]
+
+
+def test_dsp_processor_process_data_matches_reference(golden):
+    from sdrterm_amd.dsp import DspProcessor
+    z, _ = golden
+    case = BY_NAME['h_q64_fm_c']
+    p = DspProcessor(case['fs'], center=case['center'], omegaOut=case['omega_out'], dec=case['q'],
+                     fileInfo={'bitsPerSample': 'int16'})
+    p.selectOutputFm()
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, 'out.bin')
+        p.processData(_Flag(), _ListQueue(_reader_chunks(case) + [b'']), path)
+        got = np.fromfile(path, dtype='=f8')
+    exp = z['h_q64_fm_c/z']
+    assert got.size == exp.size
+    assert np.abs(got.reshape(exp.shape) - exp).max() <= ref_tol(case, exp)
+
+
+def test_process_chunk_signature_matches_reference(golden):
+    """_processChunk(x, y, z) as the reference's tests/tools call it (dsp_processor.py:140-149)."""
+    from sdrterm_amd.dsp import DspProcessor
+    z, _ = golden
+    case = BY_NAME['h_q64_am_norm_c']
+    chunks = _reader_chunks(case)
+    p = DspProcessor(case['fs'], center=case['center'], omegaOut=case['omega_out'], dec=case['q'])
+    p.selectOutputAm()
+    n = chunks[0].size
+    x = np.empty((1, n), complex)
+    y = np.empty((1, n // case['q']), complex)
+    out = np.empty((1, n // case['q']))
+    x[0, :] = chunks[0]
+    p._processChunk(x, y, out)
+    y0 = z['h_q64_am_norm_c/y0']
+    assert np.abs(y - y0).max() <= 1e-9 * np.abs(y0).max()
+    assert np.abs(out - z['h_q64_am_norm_c/z'][0]).max() <= ref_tol(case, z['h_q64_am_norm_c/z'][0])
+
+
+def _client(host, port, nbytes, sink, idx):
+    s = socket.create_connection((host, port), timeout=30)
+    buf = bytearray()
+    while len(buf) < nbytes:
+        b = s.recv(1 << 16)
+        if not b:
+            break
+        buf += b
+    sink[idx] = bytes(buf)
+    s.close()
+
+
+def test_vfo_processor_simo_fanout_matches_reference(golden):
+    """--simo: one TCP client per row, big-endian doubles, rows in the reference's order (vfo_processor.py:80-84)."""
+    from sdrterm_amd.dsp import VfoProcessor
+    from sdrterm_amd.misc.general_util import findPort
+    z, _ = golden
+    case = BY_NAME['h_q64_fm_vfo9']
+    exp = z['h_q64_fm_vfo9/z']                       # (chunks, 9, m)
+    nch, rows, m = exp.shape
+    port = findPort('127.0.0.1')
+    p = VfoProcessor(case['fs'], vfoHost=f'127.0.0.1:{port}', vfos=case['vfos'], center=case['center'],
+                     omegaOut=case['omega_out'], dec=case['q'], fileInfo={'bitsPerSample': 'int16'})
+    p.selectOutputFm()
+    q = _ListQueue(_reader_chunks(case) + [b''])
+    t = threading.Thread(target=p.processData, args=(_Flag(), q))
+    t.start()
+    sink = [None] * rows
+    clients = []
+    for k in range(rows):                            # connect in row order, like example_simo.sh does with a delay
+        for _ in range(100):
+            try:
+                c = threading.Thread(target=_client, args=('127.0.0.1', port, nch * m * 8, sink, k))
+                c.start()
+                clients.append(c)
+                break
+            except OSError:
+                time.sleep(0.05)
+        time.sleep(0.15)
+    for c in clients:
+        c.join(60)
+    t.join(60)
+    assert not t.is_alive()
+    for k in range(rows):
+        got = np.frombuffer(sink[k], dtype='>f8')
+        assert got.size == nch * m
+        assert np.abs(got.reshape(nch, m) - exp[:, k, :]).max() <= ref_tol(case, exp)
+
+
+def test_standalone_discriminators_known_answers(golden):
+    """The reference's 8-sample KATs (test/dsp/demodulation_test.py:19-50) against the GPU discriminators."""
+    from sdrterm_amd.dsp import demodulation as dem
+    z, _ = golden
+    inp = z['kat_in']
+    for fn, key in ((dem.fmDemod, 'kat_fm'), (dem.amDemod, 'kat_am'), (dem.realOutput, 'kat_re'), (dem.imagOutput, 'kat_im')):
+        out = np.empty((1, 8))
+        fn(np.array(inp), out)
+        assert np.abs(out - z[key]).max() < 1e-12, key
+
+
+def test_stream_properties_at_scale():
+    """512 chunks (16.8 M samples): batching invariance (bitwise), chunk independence, and oracle parity on a sample."""
+    from sdrterm_amd.engine import Engine
+    from oracle import c_chain, ref_chain
+    from tests.golden import prng
+    fs, q, n, nch = 256_000_000, 64, 32768, 512
+    raw = prng.raw_bytes('h', n * nch, seed=77, amp=8000)
+    eng = Engine(fs, q, 'fm', 'h', row_freqs=[15000], omega_out=12500)
+    full = eng.process(raw)                                              # one call
+    assert np.isfinite(full).all()
+    cb = eng.chunk_bytes
+    parts = [eng.process(raw[i * cb:(i + 64) * cb]) for i in range(0, nch, 64)]   # eight calls of 64 chunks
+    assert np.array_equal(full, np.concatenate(parts, axis=1))          # chunks are independent: identical bits
+    # permuting chunks permutes outputs
+    perm = np.random.default_rng(0).permutation(nch)
+    rawp = b''.join(raw[i * cb:(i + 1) * cb] for i in perm)
+    outp = eng.process(rawp).reshape(nch, eng.m)
+    assert np.array_equal(outp, full.reshape(nch, eng.m)[perm])
+    # oracle on 16 sampled chunks
+    pick = [0, 1, 2, 3, 100, 101, 255, 256, 300, 400, 500, 508, 509, 510, 511, 257]
+    sub = b''.join(raw[i * cb:(i + 1) * cb] for i in pick)
+    shift = c_chain.shift_table([15000], fs, n)
+    exp, _ = c_chain.process_stream(sub, 'h', n, q, 'fm', shift, ref_chain.cheby_sos(q), ref_chain.ellip_sos(fs // q, 12500),
+                                    threads=4)
+    got = full.reshape(nch, eng.m)[pick]
+    assert np.abs(got - exp[:, 0, :]).max() < 1e-6
+
+
+def test_iq_offset_carries_across_calls():
+    """--correct-iq keeps one scalar across chunks (read_file.py:53,103): 1 call of 6 chunks == 6 calls of 1 chunk."""
+    from sdrterm_amd.engine import Engine
+    from oracle import c_chain, ref_chain
+    from tests.golden import prng
+    fs, q, n, nch = 1024000, 64, 32768, 6
+    raw = prng.raw_bytes('h', n * nch, seed=5, amp=3000, dc=(700, -400))
+    a = Engine(fs, q, 'fm', 'h', row_freqs=[15700], omega_out=5000, correct_iq=True)
+    b = Engine(fs, q, 'fm', 'h', row_freqs=[15700], omega_out=5000, correct_iq=True)
+    one = a.process(raw)
+    cb = a.chunk_bytes
+    six = np.concatenate([b.process(raw[i * cb:(i + 1) * cb]) for i in range(nch)], axis=1)
+    assert np.abs(one - six).max() < 1e-9
+    assert abs(a.iq_offset - b.iq_offset) < 1e-9
+    shift = c_chain.shift_table([15700], fs, n)
+    exp, off = c_chain.process_stream(raw, 'h', n, q, 'fm', shift, ref_chain.cheby_sos(q), ref_chain.ellip_sos(fs // q, 5000),
+                                      iq_inductance=50 / fs)
+    assert np.abs(one - exp[:, 0, :].reshape(1, -1)).max() < 1e-6
+    assert abs(a.iq_offset - off) < 1e-8 * max(1.0, abs(off))
+    a.iq_offset = 0j
+    again = a.process(raw)
+    assert np.abs(again - one).max() < 1e-9
+
+
+def test_linearity_of_the_decimator():
+    """decimate is linear: y(a*x1 + x2) == a*y(x1) + y(x2) on integer inputs (checked on the debug output)."""
+    from sdrterm_amd.engine import Engine
+    from tests.golden import prng
+    n = 32768
+    x1 = np.frombuffer(prng.raw_bytes('h', n, 1, 2000), dtype='<i2').astype(np.int32)
+    x2 = np.frombuffer(prng.raw_bytes('h', n, 2, 2000), dtype='<i2').astype(np.int32)
+    eng = Engine(1024000, 64, 'am', 'h', row_freqs=[15700], omega_out=5000)
+    _, y1 = eng.process_debug((x1).astype('<i2').tobytes())
+    _, y2 = eng.process_debug((x2).astype('<i2').tobytes())
+    _, y3 = eng.process_debug((3 * x1 + x2).astype('<i2').tobytes())
+    assert np.abs(y3 - (3 * y1 + y2)).max() <= 1e-9 * np.abs(y3).max()

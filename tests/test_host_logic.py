@@ -1,0 +1,188 @@
+"""CPU-only tests: host logic of the processor mirrors (modelled on the reference's test/dsp/dsp_processor_test.py
+and test/misc/*), the C-ABI surface of the shared library, and the multi-GPU partitioning under gloo."""
+import ctypes
+import json
+import math
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+from sdrterm_amd import _native
+from sdrterm_amd.dsp import demodulation as dem
+from sdrterm_amd.dsp.data_processor import DataProcessor
+from sdrterm_amd.dsp.dsp_processor import DspProcessor
+from sdrterm_amd.dsp.vfo_processor import VfoProcessor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEFAULT_FS = 48000
+DEFAULT_CENTER = -1000
+
+
+@pytest.fixture
+def processor():
+    return DspProcessor(DEFAULT_FS, omegaOut=250)
+
+
+def test_processor_properties_and_errors(processor):
+    """Same checks as the reference's test_init (test/dsp/dsp_processor_test.py:21-75)."""
+    assert processor.fs == DEFAULT_FS
+    assert processor.decimation == 2
+    assert processor.decimatedFs == DEFAULT_FS >> 1
+    processor.selectOutputFm()
+    assert processor.demod == dem.fmDemod
+    processor.selectOutputAm()
+    assert processor.demod == dem.amDemod
+    assert np.asarray(processor._outputFilters).shape == (2, 6)
+    with pytest.raises(ValueError):
+        processor.decimation = 1
+    with pytest.raises(AttributeError):
+        processor.decimatedFs = 1
+    with pytest.raises(ValueError):
+        processor._setDemod(None, ())
+    with pytest.raises(TypeError):
+        processor._setDemod("asdf", None)
+    processor.decimation = 3
+    assert processor.decimation == 3
+    assert processor.decimatedFs == DEFAULT_FS / 3
+    processor._generateShift(8)
+    assert processor._shift is None
+    processor.centerFreq = DEFAULT_CENTER
+    processor._generateShift(8)
+    assert processor._shift.size == 8
+    for k in range(8):
+        assert processor._shift[0][k] == np.pow(math.e, -2j * math.pi * (DEFAULT_CENTER / DEFAULT_FS) * k)
+    with pytest.raises(FileNotFoundError):
+        processor.processData(None, None, '')
+    with pytest.raises(AttributeError):
+        processor.processData(None, None, None)
+    with pytest.raises(TypeError):
+        DataProcessor()
+    DataProcessor.processData(None)
+
+
+def test_processor_is_spawn_safe_and_reports_json():
+    p = DspProcessor(1024000, center=15000, omegaOut=5000, dec=64, fileInfo={'bitsPerSample': 'int16'})
+    p.selectOutputFm()
+    q = pickle.loads(pickle.dumps(p))          # what multiprocessing 'spawn' does (sdrterm.py:182-188)
+    assert q.fs == 1024000 and q.decimation == 64 and q.demod == dem.fmDemod and q._engine is None
+    d = json.loads(repr(p))
+    assert d['fs'] == 1024000 and d['decimatedFs'] == 16000 and d['encoding'] == 'int16'
+    assert d['centerFreq'] == 15000 and d['omegaOut'] == 5000 and d['bandwidth'] == 12500
+    assert str(p) == 'DspProcessor'
+
+
+def test_vfo_processor_rows_and_host_parsing():
+    with pytest.raises(ValueError):
+        VfoProcessor(1024000)
+    with pytest.raises(ValueError):
+        VfoProcessor(1024000, vfos='')
+    v = VfoProcessor(1024000, vfoHost='localhost:12345', vfos='-200000,50000', center=15700, omegaOut=5000, dec=64,
+                     fileInfo={'bitsPerSample': 'int16'})
+    assert (v.host, v.port) == ('localhost', 12345)
+    assert list(v.vfos) == [-200000 + 15700, 50000 + 15700, 15700]      # csv rows, then center LAST
+    assert v._nFreq == 3 and v._rowFreqs() == [-184300.0, 65700.0, 15700.0] and v._applyShift()
+    auto = VfoProcessor(1024000, vfoHost='localhost', vfos='0')
+    assert isinstance(auto.port, int) and auto.port > 0
+    d = json.loads(repr(v))
+    assert d['vfos'] == '-200000,50000,0' and d['host'] == 'localhost' and d['port'] == 12345
+    w = pickle.loads(pickle.dumps(v))
+    assert w._fanout is None and list(w.vfos) == list(v.vfos)
+    assert str(v) == 'VfoProcessor'
+
+
+def test_unsupported_selections_fail_like_the_reference():
+    p = DspProcessor(1024000, omegaOut=5000, dec=64)
+    p.selectOutputReal()
+    assert p.bandwidth == p.decimatedFs
+    with pytest.raises(ValueError, match='sos array must be 2D'):       # scipy's message for sosfilt([])
+        p._getEngine(32768, 'd')
+    p.selectOutputFm()
+    p.smooth = 5
+    with pytest.raises(NotImplementedError):
+        p._runBatch([np.zeros(32768, complex)])
+
+
+def test_shared_library_exports_every_declared_symbol():
+    """include/sdrterm_hip.h is the contract: every function it declares must be exported (no compute calls here)."""
+    hdr = open(os.path.join(ROOT, 'include', 'sdrterm_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    names = set(re.findall(r'\b(sdrt_[a-z0-9_]+)\s*\(', hdr))
+    assert len(names) >= 25
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for n in sorted(names):
+        assert hasattr(lib, n), f'{n} declared in the header but not exported'
+    assert set(_native.EXPORTS) <= names
+    assert _native.lib().sdrt_abi_version() == 1
+    assert ctypes.sizeof(_native.Config) == _native.lib().sdrt_config_size()
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    if _native.device_count() > 0:
+        pytest.skip('a GPU is present')
+    from sdrterm_amd.engine import Engine
+    with pytest.raises(_native.SdrtError) as e:
+        Engine(1024000, 64, 'fm', 'h', row_freqs=[0], omega_out=5000)
+    assert e.value.code == _native.ENODEVICE
+
+
+def test_config_validation_messages():
+    """Argument checks of sdrt_create that do not need a device."""
+    from sdrterm_amd.engine import Engine
+    with pytest.raises(_native.SdrtError, match='Decimation must be at least 2'):
+        Engine(1024000, 1, 'fm', 'h', omega_out=5000)
+    with pytest.raises(_native.SdrtError, match='powers of two'):
+        Engine(1024000, 48, 'fm', 'h', omega_out=5000)
+    with pytest.raises(ValueError):
+        Engine(1024000, 64, 'usb', 'h', omega_out=5000)
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from sdrterm_amd import parallel
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rows = [float(100 * i) for i in range(9)]
+    mine, (lo, hi) = parallel.shard_rows(rows, world, rank)
+    c0, c1 = parallel.shard_chunks(37, world, rank)
+    block = torch.arange(4096, dtype=torch.int16) * (1 if rank == 0 else 0)     # only rank 0 holds the IQ block
+    parallel.broadcast_block(block, src=0)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, {'rows': (lo, hi), 'chunks': (c0, c1), 'sum': int(block.sum())})
+    slow = parallel.max_over_ranks(1.0 + rank)
+    if rank == 0:
+        q.put((gathered, slow))
+    dist.destroy_process_group()
+
+
+def test_two_rank_partition_and_broadcast_under_gloo():
+    import torch.multiprocessing as mp
+    from sdrterm_amd.misc.general_util import findPort
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    world, port = 2, findPort('127.0.0.1')
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered, slow = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [g['rows'] for g in gathered] == [(0, 5), (5, 9)]
+    assert [g['chunks'] for g in gathered] == [(0, 19), (19, 37)]
+    assert gathered[0]['sum'] == gathered[1]['sum'] == int(np.arange(4096).sum())
+    assert slow == 2.0
+
+
+def test_split_range_covers_everything():
+    from sdrterm_amd.parallel import split_range
+    for total in (0, 1, 7, 64, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [split_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
