@@ -18,7 +18,11 @@ import numpy as np
 
 from . import demodulation
 from .data_processor import DataProcessor
-from ..misc.general_util import vprint
+from ..misc.general_util import eprint, vprint
+
+
+class _EndOfStream(ValueError):
+    """Raised where the reference's ``x[0, :] = b''`` raises ValueError (dsp_processor.py:170) to end the loop."""
 
 
 def generateEllipFilter(fs: int, deg: int, Wn, btype: str):
@@ -206,7 +210,7 @@ class DspProcessor(DataProcessor):
             if eof:
                 # the reference's loop ends on the ValueError numpy raises for ``x[0, :] = b''``
                 # (dsp_processor.py:170, swallowed by processData's finally/return)
-                raise ValueError('end of stream')
+                raise _EndOfStream('end of stream')
 
     def _generateShift(self, c: int) -> None:
         """Host copy of the NCO row for callers that inspect ``_shift`` (dsp_processor.py:185-187: only when
@@ -223,6 +227,13 @@ class DspProcessor(DataProcessor):
                 file.flush()
             except KeyboardInterrupt:
                 pass
+            except _EndOfStream:
+                file.flush()
+            except Exception:
+                # the reference swallows everything here; a GPU/library failure must at least be visible
+                import traceback
+                eprint(f'{self} stopped on an error:')
+                traceback.print_exc(file=sys.stderr)
             finally:
                 # like the reference, whatever ended the loop is swallowed here -- unless closing the queue fails
                 buffer.close()

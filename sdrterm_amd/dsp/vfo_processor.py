@@ -10,9 +10,9 @@ chain kernel (the NCO rows live in the kernel's tables); the socket side is ``fa
 """
 import numpy as np
 
-from .dsp_processor import DspProcessor
+from .dsp_processor import DspProcessor, _EndOfStream
 from .fanout import RowFanOut
-from ..misc.general_util import findPort, vprint
+from ..misc.general_util import eprint, findPort, vprint
 
 
 def _parse_host(spec: str):
@@ -65,8 +65,13 @@ class VfoProcessor(DspProcessor):
         try:
             self._fanout.start()
             self._processData(isDead, buffer)
-        except KeyboardInterrupt:
+        except (KeyboardInterrupt, _EndOfStream):
             pass
+        except Exception:
+            import sys
+            import traceback
+            eprint(f'{self} stopped on an error:')
+            traceback.print_exc(file=sys.stderr)
         finally:
             self._isDead = True
             self._fanout.close()
