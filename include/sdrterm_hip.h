@@ -143,8 +143,13 @@ int sdrt_demodulate_host(int mode, const double *y_host, int rows, int m, double
 int sdrt_debug_stamps(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, double *out_dev,
                       unsigned long long *stamps_host, int n_wgs);
 
-/* Self-test of the f64 MFMA operand layout the decimator relies on (runs a 16x16x4 product on the GPU). */
+/* Self-tests of the matrix-core operand layouts the decimator relies on (one 16x16x4 f64 / 32x32x32 int8 product). */
 int sdrt_selftest_mfma(double *max_abs_err);
+int sdrt_selftest_mfma_i8(int *mismatches);
+
+/* Which stage-A kernel the context uses: 0 = fp64 matrix cores, 1 = int8 matrix cores with exact integer slicing
+ * (integer encodings without --correct-iq).  Both meet the same tolerance; environment SDRTERM_STAGE_A=f64 forces 0. */
+int sdrt_stage_a_kind(const sdrt_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ EXPORTS = (
     'sdrt_process_device_debug', 'sdrt_get_iq_offset', 'sdrt_set_iq_offset', 'sdrt_profile_enable',
     'sdrt_kernel_time', 'sdrt_profile_reset', 'sdrt_kernel_name', 'sdrt_malloc', 'sdrt_free',
     'sdrt_memcpy_h2d', 'sdrt_memcpy_d2h', 'sdrt_memcpy_d2d', 'sdrt_device_synchronize', 'sdrt_set_device',
-    'sdrt_selftest_mfma', 'sdrt_debug_stamps', 'sdrt_demodulate_host',
+    'sdrt_selftest_mfma', 'sdrt_selftest_mfma_i8', 'sdrt_stage_a_kind', 'sdrt_debug_stamps', 'sdrt_demodulate_host',
 )
 
 
@@ -91,6 +91,8 @@ def lib():
     l.sdrt_set_device.argtypes = [C.c_int]
     l.sdrt_device_count.argtypes = [C.POINTER(C.c_int)]
     l.sdrt_selftest_mfma.argtypes = [C.POINTER(C.c_double)]
+    l.sdrt_selftest_mfma_i8.argtypes = [C.POINTER(C.c_int)]
+    l.sdrt_stage_a_kind.argtypes = [C.c_void_p]
     l.sdrt_demodulate_host.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     l.sdrt_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     l.sdrt_config_size.restype = C.c_size_t

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -50,6 +51,10 @@ struct sdrt_ctx {
     void *d_raw = nullptr;
     double *d_out = nullptr;
     size_t stage_cap_chunks = 0;
+    bool use_i8 = false;              // stage A on the int8 matrix cores (integer encodings, no IQ correction)
+    signed char *d_w8 = nullptr;
+    double *d_ybias = nullptr;
+    double w8_combine = 0.0, x_offset = 0.0;
     bool iq = false;
     double *d_iq_state = nullptr;     // [2] carried offset, lives on the device
     double *d_iq_pow = nullptr;       // [n/GS + 1]
@@ -258,6 +263,70 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         sdrt_build_resample_odd(m / 2, h.data());
         rc = upload(&c->d_resample, h.data(), h.size() * sizeof(double));
     }
+    if (rc == SDRT_OK) {
+        const char *force = getenv("SDRTERM_STAGE_A");      // diagnostics: "f64" forces the fp64 matrix-core kernel
+        const bool want_i8 = !(force && strcmp(force, "f64") == 0);
+        c->use_i8 = want_i8 && !c->iq && chain_i8_supported(L, cfg->dtype) &&
+                    chain_i8_lds_bytes(n, L, m, cfg->mode == SDRT_FM) <= 160 * 1024;
+    }
+    if (rc == SDRT_OK && c->use_i8) {
+        // digit planes per row (the NCO's within-block phasor is folded into the weights, so they differ per row)
+        const int S = SDRT_I8_DIGITS;
+        const size_t per_row = (size_t) S * (L / 16) * 64 * 16;
+        std::vector<signed char> w8(per_row * c->rows);
+        std::vector<double> samp((size_t) L * 2), blk((size_t) (n / L) * 2);
+        for (int r = 0; r < c->rows && rc == SDRT_OK; ++r) {
+            double comb = 0.0;
+            if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, L, n / L, samp.data(), blk.data());
+            if (sdrt_build_i8_weights(&tab, c->nco ? samp.data() : nullptr, S, w8.data() + per_row * r, &comb) != 0)
+                rc = fail(SDRT_EINVAL, "int8 weight quantisation failed");
+            // one power-of-two scale per context keeps the kernel's recombination uniform: rows only differ by a
+            // rotation of the weights, so their maxima agree to within a factor < 2; take the first and verify
+            if (r == 0) c->w8_combine = comb;
+            else if (comb != c->w8_combine) { c->use_i8 = false; break; }
+        }
+        static const double kOff[8] = {0.0, 128.0, 128.0, 32896.0, 0, 0, 0, 0};
+        c->x_offset = kOff[cfg->dtype];
+        if (rc == SDRT_OK && c->use_i8) rc = upload(&c->d_w8, w8.data(), w8.size());
+        if (rc == SDRT_OK && c->use_i8 && (c->x_offset != 0.0 || c->norm_bias != 0.0)) {
+            // response of the (linear) decimator to the constant the slices leave out: run the f64 kernel once on a
+            // constant chunk and keep its decimated samples
+            const double cre = c->x_offset + c->norm_bias, cim = c->x_offset;
+            std::vector<double> cz((size_t) n * 2);
+            for (int i = 0; i < n; ++i) { cz[2 * i] = cre; cz[2 * i + 1] = cim; }
+            double *d_cz = nullptr, *d_tmp = nullptr;
+            rc = upload(&d_cz, cz.data(), cz.size() * sizeof(double));
+            if (rc == SDRT_OK && hipMalloc((void **) &d_tmp, (size_t) c->rows * m * sizeof(double)) != hipSuccess)
+                rc = fail(SDRT_ENOMEM, "hipMalloc failed");
+            if (rc == SDRT_OK && hipMalloc((void **) &c->d_ybias, (size_t) c->rows * m * 2 * sizeof(double)) != hipSuccess)
+                rc = fail(SDRT_ENOMEM, "hipMalloc failed");
+            if (rc == SDRT_OK) {
+                DecimArgs da;
+                memset(&da, 0, sizeof(da));
+                da.raw = d_cz;
+                da.tab = c->d_tab;
+                da.otab = c->d_otab;
+                da.nco_tile = c->d_nco_tile;
+                da.nco_phase = c->d_nco_phase;
+                da.resample_odd = c->d_resample;
+                da.out_sos = c->d_out_sos;
+                da.out_sections = cfg->out_sections;
+                da.out = d_tmp;
+                da.ydec = c->d_ybias;
+                da.n_chunks = 1;
+                da.n = n;
+                da.m = m;
+                da.n_tiles = c->n_tiles;
+                da.rows = c->rows;
+                da.mode = cfg->mode;
+                hipError_t e = launch_chain(da, L, SDRT_F64, c->nco, false, 1, nullptr);
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+                if (e != hipSuccess) rc = fail(SDRT_EHIP, "ybias kernel failed: %s", hipGetErrorString(e));
+            }
+            (void) hipFree(d_cz);
+            (void) hipFree(d_tmp);
+        }
+    }
     if (rc != SDRT_OK) {
         sdrt_destroy(c);
         return rc;
@@ -278,6 +347,8 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_resample);
     (void) hipFree(c->d_out_sos);
     (void) hipFree(c->d_otab);
+    (void) hipFree(c->d_w8);
+    (void) hipFree(c->d_ybias);
     (void) hipFree(c->d_iq_state);
     (void) hipFree(c->d_iq_pow);
     (void) hipFree(c->d_iq_group);
@@ -362,9 +433,18 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
         da.iq_group_off = c->d_iq_group;
         da.iq_chunk_off = c->d_iq_chunk;
     }
+    da.w8 = c->d_w8;
+    da.ybias = c->d_ybias;
+    da.w8_combine = c->w8_combine;
+    da.x_offset = c->x_offset;
     {
         Timed t(c, s, 0);
-        HIP_TRY(launch_chain(da, c->L, c->cfg.dtype, c->nco, c->iq, n_chunks, s));
+        if (c->use_i8) {
+            // the int8 kernel feeds x - x_offset to the matrix cores; normalisation bias and offset come back via ybias
+            HIP_TRY(launch_chain_i8(da, c->L, c->cfg.dtype, c->nco, n_chunks, s));
+        } else {
+            HIP_TRY(launch_chain(da, c->L, c->cfg.dtype, c->nco, c->iq, n_chunks, s));
+        }
     }
     return SDRT_OK;
 }
@@ -516,6 +596,36 @@ int sdrt_debug_stamps(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double 
     if (rc != SDRT_OK) return rc;
     if (e != hipSuccess) return fail(SDRT_EHIP, "stamp copy failed: %s", hipGetErrorString(e));
     return SDRT_OK;
+}
+
+int sdrt_stage_a_kind(const sdrt_ctx *c) { return c ? (c->use_i8 ? 1 : 0) : -1; }
+
+int sdrt_selftest_mfma_i8(int *mismatches) {
+    int A[1024], B[1024], D[1024], *dA = nullptr, *dB = nullptr, *dD = nullptr;
+    for (int i = 0; i < 32; ++i)
+        for (int k = 0; k < 32; ++k) {
+            A[i * 32 + k] = ((i * 7 + k * 3) % 23) - 11;          // asymmetric small integers, both signs
+            B[k * 32 + i] = ((k * 5 - i * 2 + 64) % 19) - 9;
+        }
+    HIP_TRY(hipMalloc((void **) &dA, sizeof(A)));
+    HIP_TRY(hipMalloc((void **) &dB, sizeof(B)));
+    HIP_TRY(hipMalloc((void **) &dD, sizeof(D)));
+    HIP_TRY(hipMemcpy(dA, A, sizeof(A), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dB, B, sizeof(B), hipMemcpyHostToDevice));
+    HIP_TRY(launch_i8_selftest(dA, dB, dD, nullptr));
+    HIP_TRY(hipMemcpy(D, dD, sizeof(D), hipMemcpyDeviceToHost));
+    (void) hipFree(dA);
+    (void) hipFree(dB);
+    (void) hipFree(dD);
+    int bad = 0;
+    for (int i = 0; i < 32; ++i)
+        for (int j = 0; j < 32; ++j) {
+            int ref = 0;
+            for (int k = 0; k < 32; ++k) ref += A[i * 32 + k] * B[k * 32 + j];
+            if (ref != D[i * 32 + j]) ++bad;
+        }
+    if (mismatches) *mismatches = bad;
+    return bad == 0 ? SDRT_OK : fail(SDRT_EHIP, "MFMA i8 32x32x32 operand layout mismatch (%d of 1024 wrong)", bad);
 }
 
 int sdrt_selftest_mfma(double *max_abs_err) {

@@ -1,0 +1,424 @@
+#pragma once
+// Shared device helpers of the MI355X-native sdrterm DSP hot path (gfx950 only).  Included by kernels*.hip.
+//
+// chain_kernel   one workgroup per (chunk, row), everything fused:
+//                 unpack -> normalise -> [IQ correction] -> NCO -> zero-phase order-8 decimator in modal block form
+//                 (stage A on the f64 matrix cores, in-tile scans with DPP row shifts, tile carries through LDS)
+//                 -> FM pair-angle + resample m/2 -> m, or AM -> output lowpass as a 256-thread modal scan -> store.
+//
+// Reference steps replaced (peads/sdrterm, paths relative to its root):
+//   read_file.py:100-103 (unpack/_normalize/_correctIq), demodulation.py:71-79 (shiftFreq),
+//   dsp_processor.py:147 (scipy decimate), demodulation.py:25-48 (fmDemod/amDemod), dsp_processor.py:32-36,149
+//   (applyFilters/sosfilt).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "kernels.h"
+
+// Shared device code of the chain kernels (kernels.hip: f64 stage A; kernels_i8.hip: int8-sliced stage A).
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct cd {
+    double re, im;
+};
+__device__ __forceinline__ cd mk(double r, double i) { cd c; c.re = r; c.im = i; return c; }
+__device__ __forceinline__ cd cmul(cd a, cd b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+__device__ __forceinline__ cd cadd(cd a, cd b) { return mk(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ cd cfma(cd a, cd b, cd c) {  // a*b + c
+    return mk(fma(a.re, b.re, fma(-a.im, b.im, c.re)), fma(a.re, b.im, fma(a.im, b.re, c.im)));
+}
+
+// DPP row shifts inside each 16-lane row, zero fill at the row boundary.  row_shr:n = 0x110+n, row_shl:n = 0x100+n.
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ cd dpp_row(cd v) { return mk(dpp_row<CTRL>(v.re), dpp_row<CTRL>(v.im)); }
+
+// compile-time loop: f(std::integral_constant<int, S>{}) for S = 0 .. N-1 (DPP controls must be literal constants)
+template <int S, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (S < N) {
+        f(std::integral_constant<int, S>{});
+        static_for<S + 1, N>(f);
+    }
+}
+
+// Hillis-Steele inclusive scan along the lanes of one wave: S_l = sum_{j<=l} mu^(l-j) x_j  (x = 0 beyond the data).
+__device__ __forceinline__ cd wave_scan_geometric(cd x, cd mu, int lane) {
+    cd mpow = mu;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int d = 1 << i;
+        cd t = mk(__shfl_up(x.re, d), __shfl_up(x.im, d));
+        if (lane < d) t = mk(0.0, 0.0);
+        x = cfma(mpow, t, x);
+        mpow = cmul(mpow, mpow);
+    }
+    return x;
+}
+
+// Partial circulant product for the FM resampler: this wave covers k in [wave*N/4, (wave+1)*N/4), lane l the R outputs
+// j = R*l + r.  z_odd[j] = sum_k a[k] hr[(k - j) mod N].  A sliding register window feeds the R outputs from one new
+// LDS value of hr per k.
+template <int R>
+__device__ __forceinline__ void resample_partial(const double *a, const double *hr, double *part, int N, int wave,
+                                                 int lane) {
+    const int kq = N >> 2, k0 = wave * kq, j0 = R * lane, msk = N - 1;
+    double acc[R], B[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { acc[r] = 0.0; B[r] = r ? hr[(k0 - j0 - r) & msk] : 0.0; }
+    for (int k = k0; k < k0 + kq; k += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            B[(R - u) % R] = hr[(k + u - j0) & msk];
+            const double ak = a[k + u];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = fma(ak, B[(r - u + R) % R], acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) part[wave * N + j0 + r] = acc[r];
+}
+
+// ---- input decoding (read_file.py:51,100-101; file_util.py:44-56) -------------------------------------------------
+template <int DT> struct Enc;
+template <> struct Enc<SDRT_S8> { typedef int8_t raw; static constexpr int size = 1; };
+template <> struct Enc<SDRT_U8> { typedef uint8_t raw; static constexpr int size = 1; };
+template <> struct Enc<SDRT_S16> { typedef uint16_t raw; static constexpr int size = 2; };
+template <> struct Enc<SDRT_U16> { typedef uint16_t raw; static constexpr int size = 2; };
+template <> struct Enc<SDRT_S32> { typedef uint32_t raw; static constexpr int size = 4; };
+template <> struct Enc<SDRT_U32> { typedef uint32_t raw; static constexpr int size = 4; };
+template <> struct Enc<SDRT_F32> { typedef uint32_t raw; static constexpr int size = 4; };
+template <> struct Enc<SDRT_F64> { typedef uint64_t raw; static constexpr int size = 8; };
+
+template <int DT>
+__device__ __forceinline__ double decode(typename Enc<DT>::raw v, bool swap) {
+    if constexpr (DT == SDRT_S8) return (double) (int) v;
+    else if constexpr (DT == SDRT_U8) return (double) (unsigned) v;
+    else if constexpr (DT == SDRT_S16) { uint16_t u = swap ? __builtin_bswap16(v) : v; return (double) (int) (int16_t) u; }
+    else if constexpr (DT == SDRT_U16) { uint16_t u = swap ? __builtin_bswap16(v) : v; return (double) (unsigned) u; }
+    else if constexpr (DT == SDRT_S32) { uint32_t u = swap ? __builtin_bswap32(v) : v; return (double) (int32_t) u; }
+    else if constexpr (DT == SDRT_U32) { uint32_t u = swap ? __builtin_bswap32(v) : v; return (double) u; }
+    else if constexpr (DT == SDRT_F32) { uint32_t u = swap ? __builtin_bswap32(v) : v; return (double) __uint_as_float(u); }
+    else { uint64_t u = swap ? __builtin_bswap64(v) : v; return __longlong_as_double((long long) u); }
+}
+
+// BYTES contiguous bytes per lane (BYTES-aligned) into 32-bit words held in registers, widest loads available.
+template <int BYTES>
+__device__ __forceinline__ void load_words(const unsigned char *p, uint32_t *dst) {
+    if constexpr (BYTES % 16 == 0) {
+#pragma unroll
+        for (int i = 0; i < BYTES / 16; ++i) {
+            const uint4 v = ((const uint4 *) p)[i];
+            dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+        }
+    } else if constexpr (BYTES == 8) {
+        const uint2 v = *(const uint2 *) p;
+        dst[0] = v.x; dst[1] = v.y;
+    } else if constexpr (BYTES == 4) {
+        dst[0] = *(const uint32_t *) p;
+    } else {
+        static_assert(BYTES == 2, "unsupported per-lane byte count");
+        dst[0] = *(const uint16_t *) p;
+    }
+}
+
+// item IDX (compile-time) of the encoding out of the word array: pure register arithmetic, no memory punning
+template <int DT, int IDX>
+__device__ __forceinline__ typename Enc<DT>::raw get_item(const uint32_t *wds) {
+    constexpr int SZ = Enc<DT>::size;
+    if constexpr (SZ == 1) return (typename Enc<DT>::raw) ((wds[IDX >> 2] >> (8 * (IDX & 3))) & 0xffu);
+    else if constexpr (SZ == 2) return (typename Enc<DT>::raw) ((wds[IDX >> 1] >> (16 * (IDX & 1))) & 0xffffu);
+    else if constexpr (SZ == 4) return (typename Enc<DT>::raw) wds[IDX];
+    else return (typename Enc<DT>::raw) ((uint64_t) wds[2 * IDX] | ((uint64_t) wds[2 * IDX + 1] << 32));
+}
+
+
+struct LdsLayout {
+    int o, y, carF, carG, cF, cG, tailF, tailFc, f0, gu, hr, wtot, total;   // offsets in 16-byte units
+};
+__host__ __device__ inline LdsLayout lds_layout(int n, int L, int m, bool fm) {
+    const int nblk = n / L, nt = nblk / SDRT_TB;
+    LdsLayout l;
+    int p = 0;
+    l.o = p; p += nblk;                      // local output parts; reused as the real work area (2*nblk doubles)
+    l.y = p; p += m > 64 ? m : 64;           // decimated complex samples; later the resampler's partial sums
+    l.carF = p; p += (nt + 1) * 8;           // [t][mode][stream]
+    l.carG = p; p += (nt + 1) * 8;
+    l.cF = p; p += SDRT_TB * 4;
+    l.cG = p; p += SDRT_TB * 4;
+    l.tailF = p; p += 16;
+    l.tailFc = p; p += 16;
+    l.f0 = p; p += 8;
+    l.gu = p; p += 8;
+    l.wtot = p; p += SDRT_OUT_MAXMODES * 4;
+    l.hr = p; p += fm ? (m / 2 + 1) / 2 : 0; // m/2 doubles
+    l.total = p;
+    return l;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Everything after the main loop, shared by both chain kernels: tables + edge operators, tile carries, combine,
+// demodulate, FM resample, output lowpass, store.  `edge(idx)` returns sample idx of this chunk as the decimator sees
+// it (after bias / IQ correction / NCO).  `ybias` (optional, [m]) is added to the decimated samples: the int8 kernel
+// filters x - offset and adds the filter's response to the constant offset here.
+// ---------------------------------------------------------------------------------------------------------------
+template <class EdgeFn>
+__device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, const int row, const long chunk, unsigned char *smem,
+                                           unsigned long long *stp, EdgeFn edge, const cd *ybias) {
+#define SDRT_STAMP(i) do { if (stp) stp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    const DecimTables *__restrict__ tab = a.tab;
+    const OutTables *__restrict__ ot = a.otab;
+    const int n = a.n, m = a.m, nt = a.n_tiles;
+    const bool fm = a.mode == SDRT_FM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const LdsLayout lo = lds_layout(n, L, m, fm);
+    cd *base = (cd *) smem;
+    cd *o_lds = base + lo.o, *y_lds = base + lo.y, *carF = base + lo.carF, *carG = base + lo.carG;
+    cd *cF = base + lo.cF, *cG = base + lo.cG, *tailF = base + lo.tailF;
+    cd *tailFc = base + lo.tailFc, *F0 = base + lo.f0, *Gu = base + lo.gu, *wtot = base + lo.wtot;
+    double *hr = (double *) (base + lo.hr);
+    double *work = (double *) o_lds;                 // after phase 3: a[] at work[0..m/2), z[] at work[m..2m)
+    // ---- tables for the later phases and the edge operators (all loads issued together, one round trip) -------------
+    {
+        const int o = tid >> 5, l = tid & 31, mode = o >> 1, st = o & 1;
+        cd f = mk(0.0, 0.0), gq = mk(0.0, 0.0);
+        if (l <= SDRT_EDGE) {
+            // head sample l and tail sample n-28+l of this chunk, after normalise / IQ correction / NCO; this thread
+            // needs stream st
+            const long ih = l, it = (long) n - (SDRT_EDGE + 1) + l;
+            const cd eh = edge(ih), et = edge(it);
+            const double hr_ = eh.re, hi_ = eh.im, tr_ = et.re, ti_ = et.im;
+            const double uh = st ? hi_ : hr_, ut = st ? ti_ : tr_;
+            f = mk(tab->head[mode][l][0] * uh, tab->head[mode][l][1] * uh);
+            gq = mk(tab->tailU[mode][l][0] * ut, tab->tailU[mode][l][1] * ut);
+        }
+        if (tid < 64) {
+            cF[tid] = mk(tab->cF[tid >> 2][tid & 3][0], tab->cF[tid >> 2][tid & 3][1]);
+            cG[tid] = mk(tab->cG[tid >> 2][tid & 3][0], tab->cG[tid >> 2][tid & 3][1]);
+        } else if (tid < 80) {
+            const int i = tid - 64;
+            tailF[i] = mk(tab->tailF[i >> 2][i & 3][0], tab->tailF[i >> 2][i & 3][1]);
+            tailFc[i] = mk(tab->tailFc[i >> 2][i & 3][0], tab->tailFc[i >> 2][i & 3][1]);
+        }
+        if (fm) {
+            const int N = m >> 1;
+            for (int i = tid; i < N; i += 256) hr[i] = a.resample_odd[i == 0 ? 0 : N - i];   // hr[i] = h[(-i) mod N]
+        }
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) {
+            f.re += __shfl_xor(f.re, d);
+            f.im += __shfl_xor(f.im, d);
+            gq.re += __shfl_xor(gq.re, d);
+            gq.im += __shfl_xor(gq.im, d);
+        }
+        if (l == 0) { F0[o] = f; Gu[o] = gq; }
+    }
+    __syncthreads();
+    SDRT_STAMP(3);
+
+    // ---- phase 2: carries across tiles as wave-level scans.  Chain o = mode*2 + stream; wave w owns chains 2w, 2w+1.
+    // F[t+1] = mu16 F[t] + aggF[t]  (slots of carF),  G[t] = mu16 G[t+1] + aggG[t]  (slots of carG).
+    for (int cc = 0; cc < 2; ++cc) {
+        const int o = wave * 2 + cc, mode = o >> 1;
+        const cd mu16 = mk(tab->mu_pow[4][mode][0], tab->mu_pow[4][mode][1]);
+        cd carry = F0[o];
+        if (lane == 0) carF[o] = carry;
+        for (int t0 = 0; t0 < nt; t0 += 64) {
+            const int t = t0 + lane;
+            cd x = t < nt ? carF[(t + 1) * 8 + o] : mk(0.0, 0.0);
+            if (lane == 0) x = cfma(mu16, carry, x);
+            x = wave_scan_geometric(x, mu16, lane);
+            if (t < nt) carF[(t + 1) * 8 + o] = x;
+            carry = mk(__shfl(x.re, 63), __shfl(x.im, 63));
+        }
+    }
+    __syncthreads();
+    for (int cc = 0; cc < 2; ++cc) {
+        const int o = wave * 2 + cc, mode = o >> 1, st = o & 1;
+        const cd mu16 = mk(tab->mu_pow[4][mode][0], tab->mu_pow[4][mode][1]);
+        cd G = Gu[o];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const cd Fj = carF[nt * 8 + j * 2 + st];
+            G = cfma(tailF[mode * 4 + j], Fj, G);
+            G = cfma(tailFc[mode * 4 + j], mk(Fj.re, -Fj.im), G);
+        }
+        if (lane == 0) carG[nt * 8 + o] = G;
+        cd carry = G;
+        for (int t0 = 0; t0 < nt; t0 += 64) {
+            const int t = nt - 1 - (t0 + lane);              // lanes walk the tiles from the right edge
+            cd x = t >= 0 ? carG[t * 8 + o] : mk(0.0, 0.0);
+            if (lane == 0) x = cfma(mu16, carry, x);
+            x = wave_scan_geometric(x, mu16, lane);
+            if (t >= 0) carG[t * 8 + o] = x;
+            carry = mk(__shfl(x.re, 63), __shfl(x.im, 63));
+        }
+    }
+    __syncthreads();
+
+    SDRT_STAMP(4);
+    // ---- phase 3: add the carried parts at the output blocks -> decimated samples y ----------------------------------
+    const int stride = tab->out_stride;
+    for (int k = tid; k < m; k += 256) {
+        const int kb = k * stride, tile = kb >> 4, nbk = kb & 15;
+        cd v = o_lds[kb];
+#pragma unroll
+        for (int mode = 0; mode < 4; ++mode) {
+            const cd f = cF[nbk * 4 + mode], gq = cG[nbk * 4 + mode];
+            const cd Fa = carF[tile * 8 + mode * 2 + 0], Fb = carF[tile * 8 + mode * 2 + 1];
+            const cd Ga = carG[(tile + 1) * 8 + mode * 2 + 0], Gb = carG[(tile + 1) * 8 + mode * 2 + 1];
+            v.re += 2.0 * (f.re * Fa.re - f.im * Fa.im + gq.re * Ga.re - gq.im * Ga.im);
+            v.im += 2.0 * (f.re * Fb.re - f.im * Fb.im + gq.re * Gb.re - gq.im * Gb.im);
+        }
+        if (ybias) { v.re += ybias[k].re; v.im += ybias[k].im; }
+        y_lds[k] = v;
+        if (a.ydec) {
+            double *yd = a.ydec + (((size_t) row * a.n_chunks + chunk) * m + k) * 2;
+            yd[0] = v.re;
+            yd[1] = v.im;
+        }
+    }
+    __syncthreads();
+
+    SDRT_STAMP(5);
+    // ---- phase 4: demodulate (demodulation.py:25-32 pair angle; :41-48 |d^2|) into work[] ------------------------------
+    double *zb = work + m;          // [m] demodulated samples at the decimated rate
+    if (fm) {
+        const int N = m >> 1;
+        for (int j = tid; j < N; j += 256) {
+            const cd p = y_lds[2 * j], c = y_lds[2 * j + 1];
+            const double re = p.re * c.re + p.im * c.im;   // d[i] * conj(d[i+1])
+            const double im = p.im * c.re - p.re * c.im;
+            work[j] = atan2(im, re);
+        }
+        __syncthreads();
+        // phase 5: scipy.signal.resample N -> 2N (demodulation.py:35-38): even samples are the input, odd samples
+        // a circulant product with the half-sample Dirichlet kernel: z[2j+1] = sum_k a[k] hr[(k - j) mod N].
+        double *part = (double *) y_lds;    // y is dead now: [4][N] partial sums, one k-quarter per wave
+        const int R = N >> 6;
+        bool tiled = true;
+        switch (R) {
+            case 1: resample_partial<1>(work, hr, part, N, wave, lane); break;
+            case 2: resample_partial<2>(work, hr, part, N, wave, lane); break;
+            case 4: resample_partial<4>(work, hr, part, N, wave, lane); break;
+            case 8: resample_partial<8>(work, hr, part, N, wave, lane); break;
+            case 16: resample_partial<16>(work, hr, part, N, wave, lane); break;
+            default: tiled = false;
+        }
+        if (tiled) {
+            __syncthreads();
+            for (int j = tid; j < N; j += 256) {
+                zb[2 * j] = work[j];
+                zb[2 * j + 1] = (part[j] + part[N + j]) + (part[2 * N + j] + part[3 * N + j]);
+            }
+        } else {
+            for (int j = tid; j < N; j += 256) {
+                double s0 = 0.0;
+                for (int k = 0; k < N; ++k) s0 = fma(work[k], hr[(k - j + N) % N], s0);
+                zb[2 * j] = work[j];
+                zb[2 * j + 1] = s0;
+            }
+        }
+    } else {
+        for (int k = tid; k < m; k += 256) {
+            const cd v = y_lds[k];
+            zb[k] = v.re * v.re + v.im * v.im;
+        }
+    }
+    __syncthreads();
+
+    SDRT_STAMP(6);
+    // ---- phase 6: output lowpass (dsp_processor.py:32-36,149: sosfilt, zero state per chunk) --------------------------------
+    double *out = a.out + ((size_t) row * a.n_chunks + chunk) * m;
+    const int nmodes = ot->nmodes;
+    if (nmodes < 0) {
+        // sequential transposed-direct-form-II cascade (any SOS); used only when the modal form is not available
+        if (tid == 0) {
+            double st[2 * SDRT_MAX_OUT_SECTIONS];
+            for (int s = 0; s < 2 * SDRT_MAX_OUT_SECTIONS; ++s) st[s] = 0.0;
+            for (int i = 0; i < m; ++i) {
+                double xc = zb[i];
+                for (int s = 0; s < a.out_sections; ++s) {
+                    const double *c = a.out_sos + 6 * s;
+                    const double xn = fma(c[0], xc, st[2 * s]);
+                    st[2 * s] = fma(c[1], xc, fma(-c[4], xn, st[2 * s + 1]));
+                    st[2 * s + 1] = fma(c[2], xc, -c[5] * xn);
+                    xc = xn;
+                }
+                out[i] = xc;
+            }
+        }
+        return;
+    }
+    // modal form: y[t] = D x[t] + sum_k Re(r_k s_k(t)), s_k(t+1) = p_k s_k(t) + x[t].  Thread tid owns samples
+    // [tid*E, tid*E+E).  Per mode: local end state -> inclusive scan over the wave (shuffles) -> wave totals via LDS.
+    const int E = ot->E, t0 = tid * E;
+    cd sinc[SDRT_OUT_MAXMODES];
+#pragma unroll
+    for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
+        sinc[k] = mk(0.0, 0.0);
+        if (k < nmodes) {
+            const cd p = mk(ot->p[k][0], ot->p[k][1]);
+            cd s = mk(0.0, 0.0);
+            for (int e = 0; e < E; ++e) {
+                const double x = (t0 + e < m) ? zb[t0 + e] : 0.0;
+                s = cfma(p, s, mk(x, 0.0));
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int d = 1 << i;
+                cd t = mk(__shfl_up(s.re, d), __shfl_up(s.im, d));
+                if (lane < d) t = mk(0.0, 0.0);
+                s = cfma(mk(ot->pstep[k][i][0], ot->pstep[k][i][1]), t, s);
+            }
+            sinc[k] = s;
+            if (lane == 63) wtot[k * 4 + wave] = s;
+        }
+    }
+    __syncthreads();
+    cd sst[SDRT_OUT_MAXMODES];
+#pragma unroll
+    for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
+        sst[k] = mk(0.0, 0.0);
+        if (k < nmodes) {
+            cd ex = mk(__shfl_up(sinc[k].re, 1), __shfl_up(sinc[k].im, 1));
+            if (lane == 0) ex = mk(0.0, 0.0);
+            const cd pw = mk(ot->pwave[k][0], ot->pwave[k][1]);
+            cd wp = mk(0.0, 0.0);                    // state at the start of this wave
+            for (int wv = 0; wv < wave; ++wv) wp = cfma(pw, wp, wtot[k * 4 + wv]);
+            sst[k] = cfma(mk(ot->plane[k][lane][0], ot->plane[k][lane][1]), wp, ex);
+        }
+    }
+    const double Dd = ot->D;
+    for (int e = 0; e < E; ++e) {
+        if (t0 + e < m) {
+            const double x = zb[t0 + e];
+            double yv = Dd * x;
+#pragma unroll
+            for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
+                if (k < nmodes) {
+                    const cd r = mk(ot->r[k][0], ot->r[k][1]), p = mk(ot->p[k][0], ot->p[k][1]);
+                    yv += r.re * sst[k].re - r.im * sst[k].im;
+                    sst[k] = cfma(p, sst[k], mk(x, 0.0));
+                }
+            }
+            out[t0 + e] = yv;
+        }
+    }
+    SDRT_STAMP(7);
+}
+#undef SDRT_STAMP
+
+}  // namespace

@@ -315,6 +315,49 @@ extern "C" void sdrt_build_resample_odd(int N, double *h) {
     }
 }
 
+extern "C" int sdrt_build_i8_weights(const DecimTables *tab, const double *nco_samp, int S, signed char *out, double *combine) {
+    const int L = tab->L, cols = 2 * L, KS8 = L / 16;
+    static double Wf[32][2 * SDRT_MAXL];
+    double maxabs = 0.0;
+    for (int mode = 0; mode < 4; ++mode)
+        for (int kind = 0; kind < 2; ++kind)
+            for (int j = 0; j < L; ++j) {
+                const double wr = tab->W[8 * kind + mode][j], wi = tab->W[8 * kind + 4 + mode][j];
+                const double tr = nco_samp ? nco_samp[2 * j] : 1.0, ti = nco_samp ? nco_samp[2 * j + 1] : 0.0;
+                // u = x t:  u_re = xr tr - xi ti,  u_im = xr ti + xi tr;  state(stream) = sum_j w[j] u_stream[j]
+                const double cxr[2][2] = {{wr * tr, wi * tr}, {wr * ti, wi * ti}};        // [stream][part] coefficient of xr
+                const double cxi[2][2] = {{-wr * ti, -wi * ti}, {wr * tr, wi * tr}};      // coefficient of xi
+                for (int stream = 0; stream < 2; ++stream)
+                    for (int part = 0; part < 2; ++part) {
+                        const int r = part + 2 * stream + 4 * (mode >> 1) + 8 * (kind + 2 * (mode & 1));
+                        Wf[r][2 * j] = cxr[stream][part];
+                        Wf[r][2 * j + 1] = cxi[stream][part];
+                        maxabs = std::fmax(maxabs, std::fmax(std::fabs(cxr[stream][part]), std::fabs(cxi[stream][part])));
+                    }
+            }
+    if (!(maxabs > 0.0)) return -1;
+    int e = 0;
+    std::frexp(maxabs * 1.002, &e);                  // maxabs*1.002 = f * 2^e, f in [0.5, 1)
+    const double scale = std::ldexp(1.0, e);         // power of two >= maxabs*1.002
+    const int B = 8 * S - 1;
+    *combine = std::ldexp(scale, -B);
+    for (int r = 0; r < 32; ++r)
+        for (int c = 0; c < cols; ++c) {
+            // exact: Wf/scale is in (-1, 1); times 2^B, rounded to the nearest integer (B <= 47 fits a long long)
+            long long I = std::llround(std::ldexp(Wf[r][c] / scale, B));
+            const int sample = c >> 1, comp = c & 1;
+            const int h = sample / (L / 2), within = sample % (L / 2), ks = within / 8, j = 2 * (within % 8) + comp;
+            const int lane = r + 32 * h;
+            for (int d = 0; d < S; ++d) {
+                long long dig = ((I + 128) % 256 + 256) % 256 - 128;      // balanced digit in [-128, 127]
+                I = (I - dig) / 256;
+                out[(((size_t) d * KS8 + ks) * 64 + lane) * 16 + j] = (signed char) dig;
+            }
+            if (I != 0) return -1;
+        }
+    return 0;
+}
+
 extern "C" void sdrt_build_iq_pow(double lambda, int count, double *pw) {
     R a = (R) 1 - (R) lambda;
     R v = 1;

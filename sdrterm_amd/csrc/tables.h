@@ -60,6 +60,14 @@ void sdrt_build_nco(double f, double fs, int tile_len, int n_tiles, double *tile
 // Odd-sample kernel of scipy.signal.resample(a, 2N) for real a of length N: y[2j+1] = sum_k a[k] h[(j-k) mod N].
 void sdrt_build_resample_odd(int N, double *h /*[N]*/);
 
+// Stage-A weights for the int8 matrix-core path: the 16 complex-mode rows, with the within-block NCO phasor folded in, as a
+// real 32 x 2L matrix (rows: part + 2*stream + 4*(mode>>1) + 8*(kind + 2*(mode&1)); columns: (sample, re/im)), quantised to
+// S signed base-256 digits against one power-of-two scale.  Output layout = MFMA A operand order:
+//   out[((digit*(L/16) + kstep)*64 + lane)*16 + j],  lane = row + 32*h,  column = sample h*L/2 + 8*kstep + (j>>1), comp j&1.
+// *combine = scale * 2^-(8S-1): value = combine * sum_d 256^d * (integer dot product of digit d).
+// nco_samp: [L][2] within-block phasors, or NULL (no shift).  Returns 0, or -1 if a digit overflowed.
+int sdrt_build_i8_weights(const struct DecimTables *tab, const double *nco_samp, int S, signed char *out, double *combine);
+
 // IQ-correction geometric weights: pw[j] = (1-lambda)^j, j <= count.
 void sdrt_build_iq_pow(double lambda, int count, double *pw);
 #ifdef __cplusplus

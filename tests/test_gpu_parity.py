@@ -24,13 +24,31 @@ def test_mfma_layout_selftest():
     err = ctypes.c_double(-1)
     _native.check(_native.lib().sdrt_selftest_mfma(ctypes.byref(err)))
     assert err.value == 0.0
+    bad = ctypes.c_int(-1)
+    _native.check(_native.lib().sdrt_selftest_mfma_i8(ctypes.byref(bad)))
+    assert bad.value == 0
+
+
+@pytest.fixture(params=['auto', 'f64'])
+def stage_a(request, monkeypatch):
+    """Every golden case runs twice: with the kernel the library picks (int8 matrix cores for integer encodings) and with
+    the fp64 matrix-core kernel forced."""
+    if request.param == 'f64':
+        monkeypatch.setenv('SDRTERM_STAGE_A', 'f64')
+    else:
+        monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    return request.param
 
 
 @pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
-def test_golden_parity(case, golden):
+def test_golden_parity(case, golden, stage_a):
     z, _ = golden
     name = case['name']
     eng = _engine(case)
+    if stage_a == 'f64':
+        assert eng.stage_a == 'f64'
+    elif eng.stage_a == 'f64':
+        pytest.skip('library picks the f64 kernel for this case (covered by the forced run)')
     raw = case_raw(case)
     out, y = eng.process_debug(raw)
     exp = z[f'{name}/z']                       # (chunks, N, m)
@@ -40,6 +58,6 @@ def test_golden_parity(case, golden):
     gy0 = y.reshape(rows, nch, m)[:, 0, :]
     yerr = np.abs(gy0 - y0).max() / np.abs(y0).max()
     err = np.abs(got - exp).max()
-    print(f'{name}: decimated rel err {yerr:.3e}, output max abs err {err:.3e} (tol {ref_tol(case, exp):.1e})')
+    print(f'{name} [{eng.stage_a}]: decimated rel err {yerr:.3e}, output max abs err {err:.3e} (tol {ref_tol(case, exp):.1e})')
     assert yerr <= (1e-3 if case['code'] == 'f' else 1e-9)
     assert err <= ref_tol(case, exp)
