@@ -135,6 +135,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     k_ms, k_n = eng.kernel_time(0)
+    p_ms, p_n = eng.kernel_time(1)
     eng.profile(False)
     assert bool(torch.isfinite(out).all()), 'non-finite output'
 
@@ -157,7 +158,8 @@ def main():
                          'traffic': None, 'avg_kernel_ms': round(k_avg_s * 1e3, 4), 'launches': k_n,
                          'alg_bytes_per_sample': ALG_BYTES_PER_SAMPLE,
                          'fp64_frac': round(FP64_FLOP_PER_SAMPLE * n_samples / k_avg_s / 1e12 / FP64_PEAK_TFLOPS, 4)},
-            'kernels_ms': {'chain_kernel': round(k_ms / max(k_n, 1), 4)},
+            'kernels_ms': {'chain_kernel': round(k_ms / max(k_n, 1), 4), 'post_kernel': round(p_ms / max(p_n, 1), 4)},
+            'stage_a': eng.stage_a,
         }
         if not args.no_cpu_baseline and world == 1:
             sample = raw[:min(n_samples, 4096 * N)].cpu().numpy().tobytes()

@@ -114,7 +114,7 @@ int sdrt_set_iq_offset(sdrt_ctx *ctx, double re, double im);
 /*
  * Per-kernel device timing with HIP events recorded on the launch stream (for bench.py's roofline line).
  * enable != 0 makes every sdrt_process_* call bracket each kernel with events; sdrt_kernel_time returns the
- * accumulated milliseconds and launch count for kernel `which` (0 = fused chain kernel, 1 = unused,
+ * accumulated milliseconds and launch count for kernel `which` (0 = chain kernel: unpack..decimate, 1 = post kernel: demodulate/resample/output lowpass,
  * 2 = IQ-correction prefix kernels) and resets nothing; sdrt_profile_reset clears the accumulators.
  */
 int sdrt_profile_enable(sdrt_ctx *ctx, int enable);

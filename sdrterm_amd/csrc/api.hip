@@ -48,6 +48,8 @@ struct sdrt_ctx {
     DecimTables *d_tab = nullptr;
     OutTables *d_otab = nullptr;
     double *d_nco_tile = nullptr, *d_nco_phase = nullptr, *d_resample = nullptr, *d_out_sos = nullptr;
+    double *d_y = nullptr;            // [row][chunk][m][2] decimated samples between the two kernels
+    size_t y_cap_chunks = 0;
     void *d_raw = nullptr;
     double *d_out = nullptr;
     size_t stage_cap_chunks = 0;
@@ -200,7 +202,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         c->norm_bias = -cfg->norm_xmin - 0.5 / cfg->norm_inv_range;
     }
     c->iq = cfg->correct_iq != 0;
-    const size_t lds = chain_lds_bytes(n, L, m, c->nco, cfg->mode == SDRT_FM);
+    const size_t lds = chain_lds_bytes(n, L, m);
     if (lds > 160 * 1024) {
         delete c;
         return fail(SDRT_EINVAL, "chunk needs %zu bytes of LDS (> 160 KiB): n_samples/decimation combination unsupported", lds);
@@ -267,7 +269,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         const char *force = getenv("SDRTERM_STAGE_A");      // diagnostics: "f64" forces the fp64 matrix-core kernel
         const bool want_i8 = !(force && strcmp(force, "f64") == 0);
         c->use_i8 = want_i8 && !c->iq && chain_i8_supported(L, cfg->dtype) &&
-                    chain_i8_lds_bytes(n, L, m, cfg->mode == SDRT_FM) <= 160 * 1024;
+                    chain_i8_lds_bytes(n, L, m) <= 160 * 1024;
     }
     if (rc == SDRT_OK && c->use_i8) {
         // digit planes per row (the NCO's within-block phasor is folded into the weights, so they differ per row)
@@ -294,10 +296,8 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
             const double cre = c->x_offset + c->norm_bias, cim = c->x_offset;
             std::vector<double> cz((size_t) n * 2);
             for (int i = 0; i < n; ++i) { cz[2 * i] = cre; cz[2 * i + 1] = cim; }
-            double *d_cz = nullptr, *d_tmp = nullptr;
+            double *d_cz = nullptr;
             rc = upload(&d_cz, cz.data(), cz.size() * sizeof(double));
-            if (rc == SDRT_OK && hipMalloc((void **) &d_tmp, (size_t) c->rows * m * sizeof(double)) != hipSuccess)
-                rc = fail(SDRT_ENOMEM, "hipMalloc failed");
             if (rc == SDRT_OK && hipMalloc((void **) &c->d_ybias, (size_t) c->rows * m * 2 * sizeof(double)) != hipSuccess)
                 rc = fail(SDRT_ENOMEM, "hipMalloc failed");
             if (rc == SDRT_OK) {
@@ -305,26 +305,19 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
                 memset(&da, 0, sizeof(da));
                 da.raw = d_cz;
                 da.tab = c->d_tab;
-                da.otab = c->d_otab;
                 da.nco_tile = c->d_nco_tile;
                 da.nco_phase = c->d_nco_phase;
-                da.resample_odd = c->d_resample;
-                da.out_sos = c->d_out_sos;
-                da.out_sections = cfg->out_sections;
-                da.out = d_tmp;
                 da.ydec = c->d_ybias;
                 da.n_chunks = 1;
                 da.n = n;
                 da.m = m;
                 da.n_tiles = c->n_tiles;
                 da.rows = c->rows;
-                da.mode = cfg->mode;
                 hipError_t e = launch_chain(da, L, SDRT_F64, c->nco, false, 1, nullptr);
                 if (e == hipSuccess) e = hipDeviceSynchronize();
                 if (e != hipSuccess) rc = fail(SDRT_EHIP, "ybias kernel failed: %s", hipGetErrorString(e));
             }
             (void) hipFree(d_cz);
-            (void) hipFree(d_tmp);
         }
     }
     if (rc != SDRT_OK) {
@@ -347,6 +340,7 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_resample);
     (void) hipFree(c->d_out_sos);
     (void) hipFree(c->d_otab);
+    (void) hipFree(c->d_y);
     (void) hipFree(c->d_w8);
     (void) hipFree(c->d_ybias);
     (void) hipFree(c->d_iq_state);
@@ -374,15 +368,21 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
 
     DecimArgs da;
     da.raw = raw_dev;
+    double *ybuf = ydec_dev;
+    if (!ybuf) {
+        if (n_chunks > c->y_cap_chunks) {
+            (void) hipFree(c->d_y);
+            c->d_y = nullptr;
+            c->y_cap_chunks = 0;
+            HIP_TRY(hipMalloc((void **) &c->d_y, n_chunks * (size_t) c->rows * c->m * 2 * sizeof(double)));
+            c->y_cap_chunks = n_chunks;
+        }
+        ybuf = c->d_y;
+    }
     da.tab = c->d_tab;
-    da.otab = c->d_otab;
     da.nco_tile = c->d_nco_tile;
     da.nco_phase = c->d_nco_phase;
-    da.resample_odd = c->d_resample;
-    da.out_sos = c->d_out_sos;
-    da.out_sections = c->cfg.out_sections;
-    da.out = out_dev;
-    da.ydec = ydec_dev;
+    da.ydec = ybuf;
     da.stamps = c->stamps_dev;
     da.stamp_wgs = c->stamp_wgs;
     da.n_chunks = n_chunks;
@@ -390,7 +390,6 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     da.m = c->m;
     da.n_tiles = c->n_tiles;
     da.rows = c->rows;
-    da.mode = c->cfg.mode;
     da.swap = c->cfg.swap_endianness && kItemSize[c->cfg.dtype] > 1;
     da.norm_bias = c->norm_bias;
     da.iq_group_off = nullptr;
@@ -445,6 +444,20 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
         } else {
             HIP_TRY(launch_chain(da, c->L, c->cfg.dtype, c->nco, c->iq, n_chunks, s));
         }
+    }
+    PostArgs pa;
+    pa.y = ybuf;
+    pa.resample_odd = c->d_resample;
+    pa.otab = c->d_otab;
+    pa.out_sos = c->d_out_sos;
+    pa.out = out_dev;
+    pa.items = n_chunks * (size_t) c->rows;
+    pa.m = c->m;
+    pa.mode = c->cfg.mode;
+    pa.out_sections = c->cfg.out_sections;
+    {
+        Timed t(c, s, 1);
+        HIP_TRY(launch_post(pa, s));
     }
     return SDRT_OK;
 }
@@ -522,8 +535,8 @@ int sdrt_profile_reset(sdrt_ctx *c) {
 
 const char *sdrt_kernel_name(int which) {
     switch (which) {
-        case 0: return "chain_kernel";
-        case 1: return "(unused)";
+        case 0: return "chain_kernel / chain_i8_kernel (unpack..decimate)";
+        case 1: return "post_kernel (demodulate, resample, output lowpass)";
         case 2: return "iq_prefix_kernels";
     }
     return "";

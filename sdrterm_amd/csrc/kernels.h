@@ -14,14 +14,11 @@ struct DecimArgs {
     const OutTables *otab;      // device copy
     const double *nco_tile;     // [rows][L][2]     exp(i theta j), j < L            (sample within block)
     const double *nco_phase;    // [rows][n/L][2]   exp(i theta L B), B < n/L        (block within chunk)
-    const double *resample_odd; // [m/2] (FM)
-    const double *out_sos;      // [out_sections][6], used only by the sequential fallback
-    double *out;                // [row][chunk][m]
-    double *ydec;               // optional [row][chunk][m][2]
+    double *ydec;               // [row][chunk][m][2] decimated complex samples (input of the post kernel)
     unsigned long long *stamps; // optional diagnostic: [wg < stamp_wgs][wave][8] s_memtime at phase boundaries
     int stamp_wgs;
     size_t n_chunks;
-    int n, m, n_tiles, rows, mode, swap, out_sections;
+    int n, m, n_tiles, rows, swap;
     double norm_bias;           // added to Re before everything else (normalisation offset / scale; the scale itself is
                                 // folded into the operator tables on the host)
     // IQ correction (read_file.py:64-77), only read when the IQ template flag is set:
@@ -50,11 +47,24 @@ struct IqArgs {
 hipError_t launch_iq_local(const IqArgs &a, hipStream_t s);
 hipError_t launch_iq_scan(const IqArgs &a, hipStream_t s);
 
-size_t chain_lds_bytes(int n, int L, int m, bool nco, bool fm);
+size_t chain_lds_bytes(int n, int L, int m);
+
+// demodulate + FM resample + output lowpass of decimated samples: one wave per (row, chunk) item
+struct PostArgs {
+    const double *y;            // [items][m][2]
+    const double *resample_odd; // [m/2] (FM)
+    const OutTables *otab;
+    const double *out_sos;      // [out_sections][6], used only by the sequential fallback
+    double *out;                // [items][m]
+    size_t items;
+    int m, mode, out_sections;
+};
+size_t post_lds_bytes(int m, int mode);
+hipError_t launch_post(const PostArgs &a, hipStream_t s);
 hipError_t launch_chain(const DecimArgs &a, int L, int dt, bool nco, bool iq, size_t n_chunks, hipStream_t s);
 #define SDRT_I8_DIGITS 5
 bool chain_i8_supported(int L, int dt);
-size_t chain_i8_lds_bytes(int n, int L, int m, bool fm);
+size_t chain_i8_lds_bytes(int n, int L, int m);
 hipError_t launch_chain_i8(const DecimArgs &a, int L, int dt, bool nco, size_t n_chunks, hipStream_t s);
 hipError_t launch_i8_selftest(const int *A, const int *B, int *D, hipStream_t s);
 hipError_t launch_mfma_selftest(const double *A, const double *B, double *D, hipStream_t s);

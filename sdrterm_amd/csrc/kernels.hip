@@ -13,7 +13,6 @@ __global__ __launch_bounds__(256, 4) void chain_kernel(DecimArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DecimTables *__restrict__ tab = a.tab;
     const int n = a.n, m = a.m, nt = a.n_tiles;
-    const bool fm = a.mode == SDRT_FM;
     // (chunk, row) from the block id: all rows of a chunk get ids that share an XCD (ids are dealt round-robin
     // over 8 XCDs), so the chunk is pulled through one L2 only.  Placement changes speed only, never results.
     const unsigned bid = blockIdx.x;
@@ -30,7 +29,7 @@ __global__ __launch_bounds__(256, 4) void chain_kernel(DecimArgs a) {
 #define SDRT_STAMP(i) do { if (stp) stp[i] = __builtin_amdgcn_s_memtime(); } while (0)
     SDRT_STAMP(0);
 
-    const LdsLayout lo = lds_layout(n, L, m, fm);
+    const LdsLayout lo = lds_layout(n, L, m);
     cd *base = (cd *) smem;
     cd *o_lds = base + lo.o, *carF = base + lo.carF, *carG = base + lo.carG;
 
@@ -359,7 +358,7 @@ __global__ void mfma_selftest_kernel(const double *A, const double *B, double *D
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------------------
-size_t chain_lds_bytes(int n, int L, int m, bool nco, bool fm) { return (size_t) lds_layout(n, L, m, fm).total * 16; }
+size_t chain_lds_bytes(int n, int L, int m) { return (size_t) lds_layout(n, L, m).total * 16; }
 
 template <int L, int DT, bool NCO, bool IQ>
 static hipError_t launch_chain_k(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
@@ -398,7 +397,7 @@ hipError_t launch_chain(const DecimArgs &a, int L, int dt, bool nco, bool iq, si
     // ids are (slot << 3 | xcd): round the chunk count up to a multiple of 8, surplus blocks exit at once
     const size_t groups = (n_chunks + 7) / 8;
     const dim3 grid((unsigned) (groups * 8 * (size_t) a.rows));
-    const size_t lds = chain_lds_bytes(a.n, L, a.m, nco, a.mode == SDRT_FM);
+    const size_t lds = chain_lds_bytes(a.n, L, a.m);
     switch (L) {
         case 8: return launch_chain_l<8>(a, dt, nco, iq, grid, lds, s);
         case 16: return launch_chain_l<16>(a, dt, nco, iq, grid, lds, s);

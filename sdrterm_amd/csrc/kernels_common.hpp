@@ -67,13 +67,12 @@ __device__ __forceinline__ cd wave_scan_geometric(cd x, cd mu, int lane) {
     return x;
 }
 
-// Partial circulant product for the FM resampler: this wave covers k in [wave*N/4, (wave+1)*N/4), lane l the R outputs
-// j = R*l + r.  z_odd[j] = sum_k a[k] hr[(k - j) mod N].  A sliding register window feeds the R outputs from one new
-// LDS value of hr per k.
+// Circulant product of the FM resampler for one wave: lane l owns the R outputs j = R*l + r of
+// z_odd[j] = sum_k a[k] hr[(k - j) mod N], N = 64 R.  A sliding register window feeds the R outputs from one new LDS
+// value of hr per k; a[k] is a broadcast LDS read.
 template <int R>
-__device__ __forceinline__ void resample_partial(const double *a, const double *hr, double *part, int N, int wave,
-                                                 int lane) {
-    const int kq = N >> 2, k0 = wave * kq, j0 = R * lane, msk = N - 1;
+__device__ __forceinline__ void resample_wave(const double *a, const double *hr, double *zodd, int N, int lane) {
+    const int kq = N, k0 = 0, j0 = R * lane, msk = N - 1;
     double acc[R], B[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { acc[r] = 0.0; B[r] = r ? hr[(k0 - j0 - r) & msk] : 0.0; }
@@ -87,7 +86,7 @@ __device__ __forceinline__ void resample_partial(const double *a, const double *
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) part[wave * N + j0 + r] = acc[r];
+    for (int r = 0; r < R; ++r) zodd[2 * (j0 + r) + 1] = acc[r];
 }
 
 // ---- input decoding (read_file.py:51,100-101; file_util.py:44-56) -------------------------------------------------
@@ -145,14 +144,13 @@ __device__ __forceinline__ typename Enc<DT>::raw get_item(const uint32_t *wds) {
 
 
 struct LdsLayout {
-    int o, y, carF, carG, cF, cG, tailF, tailFc, f0, gu, hr, wtot, total;   // offsets in 16-byte units
+    int o, carF, carG, cF, cG, tailF, tailFc, f0, gu, total;   // offsets in 16-byte units
 };
-__host__ __device__ inline LdsLayout lds_layout(int n, int L, int m, bool fm) {
+__host__ __device__ inline LdsLayout lds_layout(int n, int L, int m) {
     const int nblk = n / L, nt = nblk / SDRT_TB;
     LdsLayout l;
     int p = 0;
-    l.o = p; p += nblk;                      // local output parts; reused as the real work area (2*nblk doubles)
-    l.y = p; p += m > 64 ? m : 64;           // decimated complex samples; later the resampler's partial sums
+    l.o = p; p += nblk;                      // local output part per block
     l.carF = p; p += (nt + 1) * 8;           // [t][mode][stream]
     l.carG = p; p += (nt + 1) * 8;
     l.cF = p; p += SDRT_TB * 4;
@@ -161,16 +159,14 @@ __host__ __device__ inline LdsLayout lds_layout(int n, int L, int m, bool fm) {
     l.tailFc = p; p += 16;
     l.f0 = p; p += 8;
     l.gu = p; p += 8;
-    l.wtot = p; p += SDRT_OUT_MAXMODES * 4;
-    l.hr = p; p += fm ? (m / 2 + 1) / 2 : 0; // m/2 doubles
     l.total = p;
     return l;
 }
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Everything after the main loop, shared by both chain kernels: tables + edge operators, tile carries, combine,
-// demodulate, FM resample, output lowpass, store.  `edge(idx)` returns sample idx of this chunk as the decimator sees
+// Everything after the main loop, shared by both chain kernels: tables + edge operators, tile carries, combine, store of
+// the decimated samples (the post kernel demodulates, resamples and low-passes them).  `edge(idx)` returns sample idx of this chunk as the decimator sees
 // it (after bias / IQ correction / NCO).  `ybias` (optional, [m]) is added to the decimated samples: the int8 kernel
 // filters x - offset and adds the filter's response to the constant offset here.
 // ---------------------------------------------------------------------------------------------------------------
@@ -179,17 +175,13 @@ __device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, cons
                                            unsigned long long *stp, EdgeFn edge, const cd *ybias) {
 #define SDRT_STAMP(i) do { if (stp) stp[i] = __builtin_amdgcn_s_memtime(); } while (0)
     const DecimTables *__restrict__ tab = a.tab;
-    const OutTables *__restrict__ ot = a.otab;
     const int n = a.n, m = a.m, nt = a.n_tiles;
-    const bool fm = a.mode == SDRT_FM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const LdsLayout lo = lds_layout(n, L, m, fm);
+    const LdsLayout lo = lds_layout(n, L, m);
     cd *base = (cd *) smem;
-    cd *o_lds = base + lo.o, *y_lds = base + lo.y, *carF = base + lo.carF, *carG = base + lo.carG;
+    cd *o_lds = base + lo.o, *carF = base + lo.carF, *carG = base + lo.carG;
     cd *cF = base + lo.cF, *cG = base + lo.cG, *tailF = base + lo.tailF;
-    cd *tailFc = base + lo.tailFc, *F0 = base + lo.f0, *Gu = base + lo.gu, *wtot = base + lo.wtot;
-    double *hr = (double *) (base + lo.hr);
-    double *work = (double *) o_lds;                 // after phase 3: a[] at work[0..m/2), z[] at work[m..2m)
+    cd *tailFc = base + lo.tailFc, *F0 = base + lo.f0, *Gu = base + lo.gu;
     // ---- tables for the later phases and the edge operators (all loads issued together, one round trip) -------------
     {
         const int o = tid >> 5, l = tid & 31, mode = o >> 1, st = o & 1;
@@ -211,10 +203,6 @@ __device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, cons
             const int i = tid - 64;
             tailF[i] = mk(tab->tailF[i >> 2][i & 3][0], tab->tailF[i >> 2][i & 3][1]);
             tailFc[i] = mk(tab->tailFc[i >> 2][i & 3][0], tab->tailFc[i >> 2][i & 3][1]);
-        }
-        if (fm) {
-            const int N = m >> 1;
-            for (int i = tid; i < N; i += 256) hr[i] = a.resample_odd[i == 0 ? 0 : N - i];   // hr[i] = h[(-i) mod N]
         }
 #pragma unroll
         for (int d = 16; d >= 1; d >>= 1) {
@@ -269,8 +257,9 @@ __device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, cons
     __syncthreads();
 
     SDRT_STAMP(4);
-    // ---- phase 3: add the carried parts at the output blocks -> decimated samples y ----------------------------------
+    // ---- phase 3: add the carried parts at the output blocks -> decimated samples y, stored for the post kernel ---------
     const int stride = tab->out_stride;
+    double *yd = a.ydec + ((size_t) row * a.n_chunks + chunk) * (size_t) m * 2;
     for (int k = tid; k < m; k += 256) {
         const int kb = k * stride, tile = kb >> 4, nbk = kb & 15;
         cd v = o_lds[kb];
@@ -283,141 +272,9 @@ __device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, cons
             v.im += 2.0 * (f.re * Fb.re - f.im * Fb.im + gq.re * Gb.re - gq.im * Gb.im);
         }
         if (ybias) { v.re += ybias[k].re; v.im += ybias[k].im; }
-        y_lds[k] = v;
-        if (a.ydec) {
-            double *yd = a.ydec + (((size_t) row * a.n_chunks + chunk) * m + k) * 2;
-            yd[0] = v.re;
-            yd[1] = v.im;
-        }
+        *(double2 *) (yd + 2 * (size_t) k) = make_double2(v.re, v.im);
     }
-    __syncthreads();
-
     SDRT_STAMP(5);
-    // ---- phase 4: demodulate (demodulation.py:25-32 pair angle; :41-48 |d^2|) into work[] ------------------------------
-    double *zb = work + m;          // [m] demodulated samples at the decimated rate
-    if (fm) {
-        const int N = m >> 1;
-        for (int j = tid; j < N; j += 256) {
-            const cd p = y_lds[2 * j], c = y_lds[2 * j + 1];
-            const double re = p.re * c.re + p.im * c.im;   // d[i] * conj(d[i+1])
-            const double im = p.im * c.re - p.re * c.im;
-            work[j] = atan2(im, re);
-        }
-        __syncthreads();
-        // phase 5: scipy.signal.resample N -> 2N (demodulation.py:35-38): even samples are the input, odd samples
-        // a circulant product with the half-sample Dirichlet kernel: z[2j+1] = sum_k a[k] hr[(k - j) mod N].
-        double *part = (double *) y_lds;    // y is dead now: [4][N] partial sums, one k-quarter per wave
-        const int R = N >> 6;
-        bool tiled = true;
-        switch (R) {
-            case 1: resample_partial<1>(work, hr, part, N, wave, lane); break;
-            case 2: resample_partial<2>(work, hr, part, N, wave, lane); break;
-            case 4: resample_partial<4>(work, hr, part, N, wave, lane); break;
-            case 8: resample_partial<8>(work, hr, part, N, wave, lane); break;
-            case 16: resample_partial<16>(work, hr, part, N, wave, lane); break;
-            default: tiled = false;
-        }
-        if (tiled) {
-            __syncthreads();
-            for (int j = tid; j < N; j += 256) {
-                zb[2 * j] = work[j];
-                zb[2 * j + 1] = (part[j] + part[N + j]) + (part[2 * N + j] + part[3 * N + j]);
-            }
-        } else {
-            for (int j = tid; j < N; j += 256) {
-                double s0 = 0.0;
-                for (int k = 0; k < N; ++k) s0 = fma(work[k], hr[(k - j + N) % N], s0);
-                zb[2 * j] = work[j];
-                zb[2 * j + 1] = s0;
-            }
-        }
-    } else {
-        for (int k = tid; k < m; k += 256) {
-            const cd v = y_lds[k];
-            zb[k] = v.re * v.re + v.im * v.im;
-        }
-    }
-    __syncthreads();
-
-    SDRT_STAMP(6);
-    // ---- phase 6: output lowpass (dsp_processor.py:32-36,149: sosfilt, zero state per chunk) --------------------------------
-    double *out = a.out + ((size_t) row * a.n_chunks + chunk) * m;
-    const int nmodes = ot->nmodes;
-    if (nmodes < 0) {
-        // sequential transposed-direct-form-II cascade (any SOS); used only when the modal form is not available
-        if (tid == 0) {
-            double st[2 * SDRT_MAX_OUT_SECTIONS];
-            for (int s = 0; s < 2 * SDRT_MAX_OUT_SECTIONS; ++s) st[s] = 0.0;
-            for (int i = 0; i < m; ++i) {
-                double xc = zb[i];
-                for (int s = 0; s < a.out_sections; ++s) {
-                    const double *c = a.out_sos + 6 * s;
-                    const double xn = fma(c[0], xc, st[2 * s]);
-                    st[2 * s] = fma(c[1], xc, fma(-c[4], xn, st[2 * s + 1]));
-                    st[2 * s + 1] = fma(c[2], xc, -c[5] * xn);
-                    xc = xn;
-                }
-                out[i] = xc;
-            }
-        }
-        return;
-    }
-    // modal form: y[t] = D x[t] + sum_k Re(r_k s_k(t)), s_k(t+1) = p_k s_k(t) + x[t].  Thread tid owns samples
-    // [tid*E, tid*E+E).  Per mode: local end state -> inclusive scan over the wave (shuffles) -> wave totals via LDS.
-    const int E = ot->E, t0 = tid * E;
-    cd sinc[SDRT_OUT_MAXMODES];
-#pragma unroll
-    for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
-        sinc[k] = mk(0.0, 0.0);
-        if (k < nmodes) {
-            const cd p = mk(ot->p[k][0], ot->p[k][1]);
-            cd s = mk(0.0, 0.0);
-            for (int e = 0; e < E; ++e) {
-                const double x = (t0 + e < m) ? zb[t0 + e] : 0.0;
-                s = cfma(p, s, mk(x, 0.0));
-            }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int d = 1 << i;
-                cd t = mk(__shfl_up(s.re, d), __shfl_up(s.im, d));
-                if (lane < d) t = mk(0.0, 0.0);
-                s = cfma(mk(ot->pstep[k][i][0], ot->pstep[k][i][1]), t, s);
-            }
-            sinc[k] = s;
-            if (lane == 63) wtot[k * 4 + wave] = s;
-        }
-    }
-    __syncthreads();
-    cd sst[SDRT_OUT_MAXMODES];
-#pragma unroll
-    for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
-        sst[k] = mk(0.0, 0.0);
-        if (k < nmodes) {
-            cd ex = mk(__shfl_up(sinc[k].re, 1), __shfl_up(sinc[k].im, 1));
-            if (lane == 0) ex = mk(0.0, 0.0);
-            const cd pw = mk(ot->pwave[k][0], ot->pwave[k][1]);
-            cd wp = mk(0.0, 0.0);                    // state at the start of this wave
-            for (int wv = 0; wv < wave; ++wv) wp = cfma(pw, wp, wtot[k * 4 + wv]);
-            sst[k] = cfma(mk(ot->plane[k][lane][0], ot->plane[k][lane][1]), wp, ex);
-        }
-    }
-    const double Dd = ot->D;
-    for (int e = 0; e < E; ++e) {
-        if (t0 + e < m) {
-            const double x = zb[t0 + e];
-            double yv = Dd * x;
-#pragma unroll
-            for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
-                if (k < nmodes) {
-                    const cd r = mk(ot->r[k][0], ot->r[k][1]), p = mk(ot->p[k][0], ot->p[k][1]);
-                    yv += r.re * sst[k].re - r.im * sst[k].im;
-                    sst[k] = cfma(p, sst[k], mk(x, 0.0));
-                }
-            }
-            out[t0 + e] = yv;
-        }
-    }
-    SDRT_STAMP(7);
 }
 #undef SDRT_STAMP
 

@@ -43,7 +43,6 @@ __global__ __launch_bounds__(256, 2) void chain_i8_kernel(DecimArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DecimTables *__restrict__ tab = a.tab;
     const int n = a.n, m = a.m, nt = a.n_tiles, nst = nt / 2;
-    const bool fm = a.mode == SDRT_FM;
     const unsigned bid = blockIdx.x;
     const unsigned xcd = bid & 7u, slot = bid >> 3;
     const long chunk = (long) (slot / (unsigned) a.rows) * 8 + xcd;
@@ -58,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void chain_i8_kernel(DecimArgs a) {
 #define SDRT_STAMP(i) do { if (stp) stp[i] = __builtin_amdgcn_s_memtime(); } while (0)
     SDRT_STAMP(0);
 
-    const LdsLayout lo = lds_layout(n, L, m, fm);
+    const LdsLayout lo = lds_layout(n, L, m);
     cd *base = (cd *) smem;
     cd *o_lds = base + lo.o, *carF = base + lo.carF, *carG = base + lo.carG;
     cd *mupL = base + lo.total;                              // [4 modes][4 powers]
@@ -79,7 +78,9 @@ __global__ __launch_bounds__(256, 2) void chain_i8_kernel(DecimArgs a) {
     const double cs = a.w8_combine;
 
     // raw samples of this lane: [n_blk*L + h*L/2, +L/2) of each super-tile; loaded one super-tile ahead, k-step by k-step
-    uint32_t raw[NRAW];
+    uint32_t raw[NRAW], nxt[NRAW];
+#pragma unroll
+    for (int i = 0; i < NRAW; ++i) { raw[i] = 0; nxt[i] = 0; }
     const size_t lane_off = ((size_t) (lane & 31) * L + (size_t) hh * (L / 2)) * 2 * ITEM;
     auto load_part = [&](int st, int part, uint32_t *dst) {   // RPK dwords of k-step `part`
         const unsigned char *p = chunk_raw + (size_t) st * ST * 2 * ITEM + lane_off + (size_t) part * RPK * 4;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void chain_i8_kernel(DecimArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) blo[i] = (int) (r[i] ^ I8Enc<DT>::xlo);
             }
-            if (more) load_part(st + 4, s, r);               // the registers are free again: prefetch the next super-tile
+            if (more) load_part(st + 4, s, nxt + s * RPK);   // next super-tile's k-step s, consumed one iteration later
             static_for<0, S>([&](auto dc) {
                 constexpr int d = decltype(dc)::value;
                 const v4i A = w8L[(d * KS8 + s) * 64 + lane];
@@ -193,6 +194,8 @@ __global__ __launch_bounds__(256, 2) void chain_i8_kernel(DecimArgs a) {
         pr += __shfl_xor(pr, 32);
         pi += __shfl_xor(pi, 32);
         if (hh == 0) o_lds[tile * SDRT_TB + nb] = mk(pr, pi);
+#pragma unroll
+        for (int i = 0; i < NRAW; ++i) raw[i] = nxt[i];
     }
     SDRT_STAMP(2);
 #undef SDRT_STAMP
@@ -239,8 +242,8 @@ bool chain_i8_supported(int L, int dt) {
     return (L == 16 || L == 32 || L == 64) && (dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16);
 }
 
-size_t chain_i8_lds_bytes(int n, int L, int m, bool fm) {
-    return ((size_t) lds_layout(n, L, m, fm).total + 16) * 16 + (size_t) SDRT_I8_DIGITS * (L / 16) * 64 * 16;
+size_t chain_i8_lds_bytes(int n, int L, int m) {
+    return ((size_t) lds_layout(n, L, m).total + 16) * 16 + (size_t) SDRT_I8_DIGITS * (L / 16) * 64 * 16;
 }
 
 template <int L, int DT>
@@ -269,7 +272,7 @@ hipError_t launch_chain_i8(const DecimArgs &a, int L, int dt, bool nco, size_t n
     (void) nco;
     const size_t groups = (n_chunks + 7) / 8;
     const dim3 grid((unsigned) (groups * 8 * (size_t) a.rows));
-    const size_t lds = chain_i8_lds_bytes(a.n, L, a.m, a.mode == SDRT_FM);
+    const size_t lds = chain_i8_lds_bytes(a.n, L, a.m);
     switch (L) {
         case 16: return launch_i8_l<16>(a, dt, grid, lds, s);
         case 32: return launch_i8_l<32>(a, dt, grid, lds, s);

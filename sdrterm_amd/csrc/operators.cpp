@@ -211,7 +211,7 @@ extern "C" int sdrt_build_decim_tables(const double *sos, int sections, int q, D
 extern "C" int sdrt_build_out_tables(const double *sos, int sections, int m, OutTables *out) {
     std::memset(out, 0, sizeof(*out));
     out->nmodes = -1;
-    out->E = m >= 256 ? m / 256 : 1;
+    out->E = m >= 64 ? m / 64 : 1;
     if (sections < 1 || sections > 8) return 0;
     C poles[16];
     int npoles = 0;
@@ -276,8 +276,6 @@ extern "C" int sdrt_build_out_tables(const double *sos, int sections, int m, Out
         put(out->r[k], rr[k]);
         put(out->p[k], rp[k]);
         for (int i = 0; i < 6; ++i) put(out->pstep[k][i], cpow(rp[k], out->E * (1 << i)));
-        put(out->pwave[k], cpow(rp[k], out->E * 64));
-        for (int l = 0; l < 64; ++l) put(out->plane[k][l], cpow(rp[k], out->E * l));
     }
     out->nmodes = nm;
     return 0;

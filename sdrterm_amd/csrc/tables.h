@@ -27,19 +27,17 @@ struct DecimTables {
     double tailU[SDRT_NMODE][SDRT_EDGE + 1][2];
 };
 
-// Output lowpass (scipy sosfilt, zero initial state per chunk) in parallel modal form for a 256-thread scan:
+// Output lowpass (scipy sosfilt, zero initial state per chunk) in parallel modal form for a 64-lane (one wave) scan:
 //   y[t] = D x[t] + sum_k Re(r_k s_k(t)),   s_k(t+1) = p_k s_k(t) + x[t],   s_k(0) = 0
 // r_k already carries the weight 2 for a complex pole that stands for its conjugate pair too.
 #define SDRT_OUT_MAXMODES 4
 struct OutTables {
     int32_t nmodes;          // 0..SDRT_OUT_MAXMODES; -1: not representable -> kernel uses the sequential SOS form
-    int32_t E;               // consecutive samples per thread: max(1, m / 256)
+    int32_t E;               // consecutive samples per lane: max(1, m / 64)
     double D;
     double r[SDRT_OUT_MAXMODES][2];
     double p[SDRT_OUT_MAXMODES][2];
     double pstep[SDRT_OUT_MAXMODES][6][2];   // p^(E * 2^i): wave scan multipliers
-    double pwave[SDRT_OUT_MAXMODES][2];      // p^(E * 64)
-    double plane[SDRT_OUT_MAXMODES][64][2];  // p^(E * lane)
 };
 
 #ifdef __cplusplus

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Hardware-counter passes over bench.py (run on the GPU box).  One rocprofv3 invocation per counter group, counters
+# only with --kernel-trace, program = python3 directly (no wrappers), as the pool requires.
+set -u
+export TMPDIR=/tmp
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/pmc
+mkdir -p "$OUT"
+cd /tmp
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
+pass() {
+    name=$1; shift
+    rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/$name.log" 2>&1
+    echo "$name exit=$?"
+}
+pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY
+pass sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_CVT
+pass fetch FETCH_SIZE GRBM_GUI_ACTIVE
+pass write WRITE_SIZE GRBM_GUI_ACTIVE
+python3 "$ROOT/tools/pmc_summary.py" "$OUT" | tee "$OUT/summary.txt"

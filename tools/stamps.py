@@ -26,13 +26,13 @@ def main():
     lib.sdrt_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     nat.check(lib.sdrt_debug_stamps(eng._ctx, d_raw.ptr, n_chunks, d_out.ptr, st.ctypes.data, nw))
     s = st.astype(np.int64)
-    names = ['prologue', 'main loop', 'wait barrier', 'phase2 carries', 'phase3 combine', 'phase4-5 demod+resample', 'phase6 lowpass']
+    names = ['prologue', 'main loop', 'tables+edge+barrier', 'phase2 carries', 'phase3 combine+store']
     valid = s[:, :, 0] > 0
     print('workgroups stamped', int(valid[:, 0].sum()))
-    for i, nm in enumerate(names[:7]):
+    for i, nm in enumerate(names):
         d = (s[:, :, i + 1] - s[:, :, i])[valid]
         print(f'{nm:28s} median {np.median(d):9.0f}  mean {d.mean():9.0f} cycles')
-    tot = (s[:, :, 7] - s[:, :, 0])[valid]
+    tot = (s[:, :, 5] - s[:, :, 0])[valid]
     print(f'{"start -> end":28s} median {np.median(tot):9.0f}  mean {tot.mean():9.0f} cycles')
 
 if __name__ == '__main__':
