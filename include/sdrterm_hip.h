@@ -139,7 +139,7 @@ int sdrt_set_device(int device);
 int sdrt_demodulate_host(int mode, const double *y_host, int rows, int m, double *out_host);
 
 /* Diagnostic: one sdrt_process_device call in which the first n_wgs workgroups record s_memtime at their phase
- * boundaries; stamps_host receives n_wgs*4*8 uint64 ([workgroup][wave][8]).  Not for production use. */
+ * boundaries; stamps_host receives n_wgs*4*16 uint64 ([workgroup][wave][16]).  Not for production use. */
 int sdrt_debug_stamps(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, double *out_dev,
                       unsigned long long *stamps_host, int n_wgs);
 
@@ -147,8 +147,9 @@ int sdrt_debug_stamps(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, doubl
 int sdrt_selftest_mfma(double *max_abs_err);
 int sdrt_selftest_mfma_i8(int *mismatches);
 
-/* Which stage-A kernel the context uses: 0 = fp64 matrix cores, 1 = int8 matrix cores with exact integer slicing
- * (integer encodings without --correct-iq).  Both meet the same tolerance; environment SDRTERM_STAGE_A=f64 forces 0. */
+/* Which stage-A kernel the context uses: 0 = fp64 matrix cores; 2 = int8 matrix cores (16x16x64 form) with exact integer
+ * slicing, the default for 8/16-bit integer encodings without --correct-iq; 1 = the 32x32x32 int8 form.  All meet the
+ * same tolerance.  Environment SDRTERM_STAGE_A=f64 or =i8x32 forces 0 or 1 (diagnostics). */
 int sdrt_stage_a_kind(const sdrt_ctx *ctx);
 
 #ifdef __cplusplus

@@ -54,9 +54,13 @@ struct sdrt_ctx {
     double *d_out = nullptr;
     size_t stage_cap_chunks = 0;
     bool use_i8 = false;              // stage A on the int8 matrix cores (integer encodings, no IQ correction)
-    signed char *d_w8 = nullptr;
+    bool use_i8t = false;             //   ... in the 16x16x64 form (default); otherwise the 32x32x32 form
+    signed char *d_w8 = nullptr, *d_w8mid = nullptr;
+    DecimTables *d_tab8 = nullptr;    // tables for columns of SDRT_I8_G blocks
+    double *d_nco_tile8 = nullptr, *d_nco_phase8 = nullptr;
     double *d_ybias = nullptr;
-    double w8_combine = 0.0, x_offset = 0.0;
+    double w8_combine = 0.0, w8mid_combine = 0.0, x_offset = 0.0;
+    int n_tiles8 = 0;
     bool iq = false;
     double *d_iq_state = nullptr;     // [2] carried offset, lives on the device
     double *d_iq_pow = nullptr;       // [n/GS + 1]
@@ -211,19 +215,21 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     int rc = SDRT_OK;
     DecimTables tab;
     const char *msg = nullptr;
-    if (sdrt_build_decim_tables(cfg->dec_sos, cfg->dec_sections, q, &tab, &msg) != 0) {
+    if (sdrt_build_decim_tables(cfg->dec_sos, cfg->dec_sections, q, 1, &tab, &msg) != 0) {
         delete c;
         return fail(SDRT_EINVAL, "decimator tables: %s", msg ? msg : "failed");
     }
-    if (c->norm_scale != 1.0) {
+    auto scale_tables = [&](DecimTables &t) {
         // everything up to the decimated samples is linear in the data: scaling the data == scaling these tables
         const double k = c->norm_scale;
-        for (int r = 0; r < 16; ++r) for (int j = 0; j < SDRT_MAXL; ++j) tab.W[r][j] *= k;
-        tab.d0p *= k;
+        if (k == 1.0) return;
+        for (int r = 0; r < 16; ++r) for (int j = 0; j < SDRT_MAXL; ++j) t.W[r][j] *= k;
+        t.d0p *= k;
         for (int i = 0; i < SDRT_NMODE; ++i)
             for (int l = 0; l <= SDRT_EDGE; ++l)
-                for (int z = 0; z < 2; ++z) { tab.head[i][l][z] *= k; tab.tailU[i][l][z] *= k; }
-    }
+                for (int z = 0; z < 2; ++z) { t.head[i][l][z] *= k; t.tailU[i][l][z] *= k; }
+    };
+    scale_tables(tab);
     rc = upload(&c->d_tab, &tab, sizeof(tab));
     if (rc == SDRT_OK && c->iq) {
         // with normalisation the reference corrects the NORMALISED samples (read_file.py:102-103): the offset lives in
@@ -268,28 +274,63 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     if (rc == SDRT_OK) {
         const char *force = getenv("SDRTERM_STAGE_A");      // diagnostics: "f64" forces the fp64 matrix-core kernel
         const bool want_i8 = !(force && strcmp(force, "f64") == 0);
-        c->use_i8 = want_i8 && !c->iq && chain_i8_supported(L, cfg->dtype) &&
-                    chain_i8_lds_bytes(n, L, m) <= 160 * 1024;
+        const bool want_x32 = force && strcmp(force, "i8x32") == 0;   // diagnostics: the 32x32x32 int8 kernel
+        c->use_i8t = want_i8 && !want_x32 && !c->iq && chain_i8t_supported(L, cfg->dtype, n) &&
+                     chain_i8t_lds_bytes(n, L, m) <= 160 * 1024;
+        c->use_i8 = c->use_i8t || (want_i8 && !c->iq && chain_i8_supported(L, cfg->dtype, n) &&
+                                   chain_i8_lds_bytes(n, L, m) <= 160 * 1024);
     }
-    if (rc == SDRT_OK && c->use_i8) {
-        // digit planes per row (the NCO's within-block phasor is folded into the weights, so they differ per row)
+    if (rc == SDRT_OK && c->use_i8t) {
         const int S = SDRT_I8_DIGITS;
-        const size_t per_row = (size_t) S * (L / 16) * 64 * 16;
+        const size_t per_row = (size_t) 2 * S * (L / 32) * 64 * 16;
         std::vector<signed char> w8(per_row * c->rows);
         std::vector<double> samp((size_t) L * 2), blk((size_t) (n / L) * 2);
         for (int r = 0; r < c->rows && rc == SDRT_OK; ++r) {
             double comb = 0.0;
             if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, L, n / L, samp.data(), blk.data());
-            if (sdrt_build_i8_weights(&tab, c->nco ? samp.data() : nullptr, S, w8.data() + per_row * r, &comb) != 0)
+            if (sdrt_build_i8_weights16(cfg->dec_sos, cfg->dec_sections, &tab, c->norm_scale, c->nco ? samp.data() : nullptr, S,
+                                        w8.data() + per_row * r, &comb) != 0)
+                rc = fail(SDRT_EINVAL, "int8 weight quantisation failed");
+            if (r == 0) c->w8_combine = comb;
+            else if (comb != c->w8_combine) { c->use_i8t = false; break; }     // falls back to the other int8 form
+        }
+        if (rc == SDRT_OK && c->use_i8t) rc = upload(&c->d_w8, w8.data(), w8.size());
+    }
+    if (rc == SDRT_OK && c->use_i8 && !c->use_i8t) {
+        // tables for columns of G blocks, digit planes per row (the NCO's within-column phasor is folded into the weights,
+        // so they differ per row)
+        const int S = SDRT_I8_DIGITS, G = SDRT_I8_G, LC = L * G, KS = LC / 16, NR = 2 * (G - 1);
+        DecimTables tab8;
+        if (sdrt_build_decim_tables(cfg->dec_sos, cfg->dec_sections, q, G, &tab8, &msg) != 0)
+            rc = fail(SDRT_EINVAL, "decimator tables: %s", msg ? msg : "failed");
+        scale_tables(tab8);
+        c->n_tiles8 = n / (SDRT_TB * LC);
+        if (rc == SDRT_OK) rc = upload(&c->d_tab8, &tab8, sizeof(tab8));
+        const size_t per_row = (size_t) S * KS * 64 * 16, per_row_mid = (size_t) S * KS * 2 * NR * 16;
+        std::vector<signed char> w8(per_row * c->rows), w8m(per_row_mid * c->rows + 16);
+        std::vector<double> samp((size_t) c->rows * LC * 2), blk((size_t) c->rows * (n / LC) * 2);
+        for (int r = 0; r < c->rows && rc == SDRT_OK; ++r) {
+            double comb = 0.0, combm = 0.0;
+            double *sp = &samp[(size_t) r * LC * 2], *bp = &blk[(size_t) r * (n / LC) * 2];
+            if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, LC, n / LC, sp, bp);
+            if (sdrt_build_i8_weights(cfg->dec_sos, cfg->dec_sections, &tab8, c->norm_scale, c->nco ? sp : nullptr, S,
+                                      w8.data() + per_row * r, &comb, w8m.data() + per_row_mid * r, &combm) != 0)
                 rc = fail(SDRT_EINVAL, "int8 weight quantisation failed");
             // one power-of-two scale per context keeps the kernel's recombination uniform: rows only differ by a
             // rotation of the weights, so their maxima agree to within a factor < 2; take the first and verify
-            if (r == 0) c->w8_combine = comb;
-            else if (comb != c->w8_combine) { c->use_i8 = false; break; }
+            if (r == 0) { c->w8_combine = comb; c->w8mid_combine = combm; }
+            else if (comb != c->w8_combine || combm != c->w8mid_combine) { c->use_i8 = false; break; }
         }
+        if (rc == SDRT_OK && c->use_i8 && c->nco) {
+            rc = upload(&c->d_nco_tile8, samp.data(), samp.size() * sizeof(double));
+            if (rc == SDRT_OK) rc = upload(&c->d_nco_phase8, blk.data(), blk.size() * sizeof(double));
+        }
+        if (rc == SDRT_OK && c->use_i8 && per_row_mid) rc = upload(&c->d_w8mid, w8m.data(), per_row_mid * c->rows);
+        if (rc == SDRT_OK && c->use_i8) rc = upload(&c->d_w8, w8.data(), w8.size());
+    }
+    if (rc == SDRT_OK && c->use_i8) {
         static const double kOff[8] = {0.0, 128.0, 128.0, 32896.0, 0, 0, 0, 0};
         c->x_offset = kOff[cfg->dtype];
-        if (rc == SDRT_OK && c->use_i8) rc = upload(&c->d_w8, w8.data(), w8.size());
         if (rc == SDRT_OK && c->use_i8 && (c->x_offset != 0.0 || c->norm_bias != 0.0)) {
             // response of the (linear) decimator to the constant the slices leave out: run the f64 kernel once on a
             // constant chunk and keep its decimated samples
@@ -342,6 +383,10 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_otab);
     (void) hipFree(c->d_y);
     (void) hipFree(c->d_w8);
+    (void) hipFree(c->d_w8mid);
+    (void) hipFree(c->d_tab8);
+    (void) hipFree(c->d_nco_tile8);
+    (void) hipFree(c->d_nco_phase8);
     (void) hipFree(c->d_ybias);
     (void) hipFree(c->d_iq_state);
     (void) hipFree(c->d_iq_pow);
@@ -433,13 +478,23 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
         da.iq_chunk_off = c->d_iq_chunk;
     }
     da.w8 = c->d_w8;
+    da.w8mid = c->d_w8mid;
     da.ybias = c->d_ybias;
     da.w8_combine = c->w8_combine;
+    da.w8mid_combine = c->w8mid_combine;
     da.x_offset = c->x_offset;
+    if (c->use_i8 && !c->use_i8t) {
+        da.tab = c->d_tab8;
+        da.n_tiles = c->n_tiles8;
+        da.nco_tile = c->d_nco_tile8;
+        da.nco_phase = c->d_nco_phase8;
+    }
     {
         Timed t(c, s, 0);
-        if (c->use_i8) {
-            // the int8 kernel feeds x - x_offset to the matrix cores; normalisation bias and offset come back via ybias
+        if (c->use_i8t) {
+            // the int8 kernels feed x - x_offset to the matrix cores; normalisation bias and offset come back via ybias
+            HIP_TRY(launch_chain_i8t(da, c->L, c->cfg.dtype, n_chunks, s));
+        } else if (c->use_i8) {
             HIP_TRY(launch_chain_i8(da, c->L, c->cfg.dtype, c->nco, n_chunks, s));
         } else {
             HIP_TRY(launch_chain(da, c->L, c->cfg.dtype, c->nco, c->iq, n_chunks, s));
@@ -597,7 +652,7 @@ int sdrt_debug_stamps(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double 
                       int n_wgs) {
     if (!c || !stamps_host || n_wgs < 1) return fail(SDRT_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    const size_t bytes = (size_t) n_wgs * 4 * 8 * sizeof(unsigned long long);
+    const size_t bytes = (size_t) n_wgs * 4 * 16 * sizeof(unsigned long long);
     HIP_TRY(hipMalloc((void **) &c->stamps_dev, bytes));
     HIP_TRY(hipMemset(c->stamps_dev, 0, bytes));
     c->stamp_wgs = n_wgs;
@@ -611,7 +666,7 @@ int sdrt_debug_stamps(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double 
     return SDRT_OK;
 }
 
-int sdrt_stage_a_kind(const sdrt_ctx *c) { return c ? (c->use_i8 ? 1 : 0) : -1; }
+int sdrt_stage_a_kind(const sdrt_ctx *c) { return c ? (c->use_i8t ? 2 : (c->use_i8 ? 1 : 0)) : -1; }
 
 int sdrt_selftest_mfma_i8(int *mismatches) {
     int A[1024], B[1024], D[1024], *dA = nullptr, *dB = nullptr, *dD = nullptr;
@@ -637,8 +692,34 @@ int sdrt_selftest_mfma_i8(int *mismatches) {
             for (int k = 0; k < 32; ++k) ref += A[i * 32 + k] * B[k * 32 + j];
             if (ref != D[i * 32 + j]) ++bad;
         }
+    // 16x16x64 form
+    {
+        static int A2[16 * 64], B2[64 * 16], D2[256];
+        int *eA = nullptr, *eB = nullptr, *eD = nullptr;
+        for (int i = 0; i < 16; ++i)
+            for (int k = 0; k < 64; ++k) {
+                A2[i * 64 + k] = ((i * 11 + k * 3) % 29) - 14;
+                B2[k * 16 + i] = ((k * 7 - i * 5 + 128) % 23) - 11;
+            }
+        HIP_TRY(hipMalloc((void **) &eA, sizeof(A2)));
+        HIP_TRY(hipMalloc((void **) &eB, sizeof(B2)));
+        HIP_TRY(hipMalloc((void **) &eD, sizeof(D2)));
+        HIP_TRY(hipMemcpy(eA, A2, sizeof(A2), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(eB, B2, sizeof(B2), hipMemcpyHostToDevice));
+        HIP_TRY(launch_i8t_selftest(eA, eB, eD, nullptr));
+        HIP_TRY(hipMemcpy(D2, eD, sizeof(D2), hipMemcpyDeviceToHost));
+        (void) hipFree(eA);
+        (void) hipFree(eB);
+        (void) hipFree(eD);
+        for (int i = 0; i < 16; ++i)
+            for (int j = 0; j < 16; ++j) {
+                int ref = 0;
+                for (int k = 0; k < 64; ++k) ref += A2[i * 64 + k] * B2[k * 16 + j];
+                if (ref != D2[i * 16 + j]) ++bad;
+            }
+    }
     if (mismatches) *mismatches = bad;
-    return bad == 0 ? SDRT_OK : fail(SDRT_EHIP, "MFMA i8 32x32x32 operand layout mismatch (%d of 1024 wrong)", bad);
+    return bad == 0 ? SDRT_OK : fail(SDRT_EHIP, "int8 MFMA operand layout mismatch (%d results wrong)", bad);
 }
 
 int sdrt_selftest_mfma(double *max_abs_err) {

@@ -28,7 +28,9 @@ struct DecimArgs {
     const double *iq_pow;       // [n/GS + 1]       (1-lambda)^(GS*k)
     double iq_lambda;
     // int8-sliced stage A (kernels_i8.hip) only:
-    const signed char *w8;      // [rows][S][L/16][64][16] digit planes in MFMA A-operand order
+    const signed char *w8;      // [rows][S][LC/16][64][16] main digit planes in MFMA A-operand order (LC = G*L)
+    const signed char *w8mid;   // [rows][S][LC/16][2][NR][16] mid-boundary digit planes (G > 1)
+    double w8mid_combine;
     const double *ybias;        // [rows][m][2] decimator response to the constant the slices leave out (or NULL)
     double w8_combine;          // scale * 2^-(8S-1)
     double x_offset;            // what the slices leave out of every component: x = x' + x_offset
@@ -63,9 +65,14 @@ size_t post_lds_bytes(int m, int mode);
 hipError_t launch_post(const PostArgs &a, hipStream_t s);
 hipError_t launch_chain(const DecimArgs &a, int L, int dt, bool nco, bool iq, size_t n_chunks, hipStream_t s);
 #define SDRT_I8_DIGITS 5
-bool chain_i8_supported(int L, int dt);
+#define SDRT_I8_G 1             // blocks per matrix-core column in the int8 kernel
+bool chain_i8_supported(int L, int dt, int n);
 size_t chain_i8_lds_bytes(int n, int L, int m);
 hipError_t launch_chain_i8(const DecimArgs &a, int L, int dt, bool nco, size_t n_chunks, hipStream_t s);
 hipError_t launch_i8_selftest(const int *A, const int *B, int *D, hipStream_t s);
 hipError_t launch_mfma_selftest(const double *A, const double *B, double *D, hipStream_t s);
 hipError_t launch_demod(const double *y, double *out, const double *resample_odd, int rows, int m, int mode, hipStream_t s);
+bool chain_i8t_supported(int L, int dt, int n);
+size_t chain_i8t_lds_bytes(int n, int L, int m);
+hipError_t launch_chain_i8t(const DecimArgs &a, int L, int dt, size_t n_chunks, hipStream_t s);
+hipError_t launch_i8t_selftest(const int *A, const int *B, int *D, hipStream_t s);

@@ -25,11 +25,11 @@ __global__ __launch_bounds__(256, 4) void chain_kernel(DecimArgs a) {
     const bool swap = a.swap != 0;
 
     // diagnostic phase stamps (a.stamps == nullptr in every production call)
-    unsigned long long *stp = (a.stamps && (int) bid < a.stamp_wgs && lane == 0) ? a.stamps + ((size_t) bid * 4 + wave) * 8 : nullptr;
+    unsigned long long *stp = (a.stamps && (int) bid < a.stamp_wgs && lane == 0) ? a.stamps + ((size_t) bid * 4 + wave) * 16 : nullptr;
 #define SDRT_STAMP(i) do { if (stp) stp[i] = __builtin_amdgcn_s_memtime(); } while (0)
     SDRT_STAMP(0);
 
-    const LdsLayout lo = lds_layout(n, L, m);
+    const LdsLayout lo = lds_layout(n, L, m, 1);
     cd *base = (cd *) smem;
     cd *o_lds = base + lo.o, *carF = base + lo.carF, *carG = base + lo.carG;
 
@@ -358,7 +358,7 @@ __global__ void mfma_selftest_kernel(const double *A, const double *B, double *D
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------------------
-size_t chain_lds_bytes(int n, int L, int m) { return (size_t) lds_layout(n, L, m).total * 16; }
+size_t chain_lds_bytes(int n, int L, int m) { return (size_t) lds_layout(n, L, m, 1).total * 16; }
 
 template <int L, int DT, bool NCO, bool IQ>
 static hipError_t launch_chain_k(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {

@@ -146,15 +146,15 @@ __device__ __forceinline__ typename Enc<DT>::raw get_item(const uint32_t *wds) {
 struct LdsLayout {
     int o, carF, carG, cF, cG, tailF, tailFc, f0, gu, total;   // offsets in 16-byte units
 };
-__host__ __device__ inline LdsLayout lds_layout(int n, int L, int m) {
-    const int nblk = n / L, nt = nblk / SDRT_TB;
+__host__ __device__ inline LdsLayout lds_layout(int n, int L, int m, int G) {
+    const int nblk = n / L, nt = nblk / (SDRT_TB * G);
     LdsLayout l;
     int p = 0;
     l.o = p; p += nblk;                      // local output part per block
     l.carF = p; p += (nt + 1) * 8;           // [t][mode][stream]
     l.carG = p; p += (nt + 1) * 8;
-    l.cF = p; p += SDRT_TB * 4;
-    l.cG = p; p += SDRT_TB * 4;
+    l.cF = p; p += SDRT_TB * G * 4;
+    l.cG = p; p += SDRT_TB * G * 4;
     l.tailF = p; p += 16;
     l.tailFc = p; p += 16;
     l.f0 = p; p += 8;
@@ -177,7 +177,8 @@ __device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, cons
     const DecimTables *__restrict__ tab = a.tab;
     const int n = a.n, m = a.m, nt = a.n_tiles;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const LdsLayout lo = lds_layout(n, L, m);
+    const int TBG = SDRT_TB * tab->G;                // blocks per tile
+    const LdsLayout lo = lds_layout(n, L, m, tab->G);
     cd *base = (cd *) smem;
     cd *o_lds = base + lo.o, *carF = base + lo.carF, *carG = base + lo.carG;
     cd *cF = base + lo.cF, *cG = base + lo.cG, *tailF = base + lo.tailF;
@@ -196,11 +197,11 @@ __device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, cons
             f = mk(tab->head[mode][l][0] * uh, tab->head[mode][l][1] * uh);
             gq = mk(tab->tailU[mode][l][0] * ut, tab->tailU[mode][l][1] * ut);
         }
-        if (tid < 64) {
+        if (tid < TBG * 4) {
             cF[tid] = mk(tab->cF[tid >> 2][tid & 3][0], tab->cF[tid >> 2][tid & 3][1]);
             cG[tid] = mk(tab->cG[tid >> 2][tid & 3][0], tab->cG[tid >> 2][tid & 3][1]);
-        } else if (tid < 80) {
-            const int i = tid - 64;
+        } else if (tid >= 128 && tid < 144) {
+            const int i = tid - 128;
             tailF[i] = mk(tab->tailF[i >> 2][i & 3][0], tab->tailF[i >> 2][i & 3][1]);
             tailFc[i] = mk(tab->tailFc[i >> 2][i & 3][0], tab->tailFc[i >> 2][i & 3][1]);
         }
@@ -261,7 +262,7 @@ __device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, cons
     const int stride = tab->out_stride;
     double *yd = a.ydec + ((size_t) row * a.n_chunks + chunk) * (size_t) m * 2;
     for (int k = tid; k < m; k += 256) {
-        const int kb = k * stride, tile = kb >> 4, nbk = kb & 15;
+        const int kb = k * stride, tile = kb / TBG, nbk = kb % TBG;
         cd v = o_lds[kb];
 #pragma unroll
         for (int mode = 0; mode < 4; ++mode) {

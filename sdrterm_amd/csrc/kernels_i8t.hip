@@ -1,0 +1,268 @@
+// chain_i8t_kernel: the chain kernel with stage A on the int8 matrix cores, v_mfma_i32_16x16x64_i8 form.
+// Same lane mapping, scans and tail as the f64 kernel (kernels.hip): lane (g, nb) = (sample quarter / mode, block of
+// the tile).  Only the stage-A product differs: the lane's L/4 samples are split into int8 slices (x = 256 hi + lo' +
+// offset) and multiplied with S signed base-256 digit planes of the weights (NCO phasor folded in) -- exact int32
+// accumulation, one fp64 recombination per output (see kernels_i8.hip for the scheme).
+#include "kernels_common.hpp"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+namespace {
+template <int DT> struct I8Enc;   // slices per component, what each slice XORs with
+template <> struct I8Enc<SDRT_S8> { static constexpr int slices = 1; static constexpr unsigned xlo = 0u, xhi = 0u; };
+template <> struct I8Enc<SDRT_U8> { static constexpr int slices = 1; static constexpr unsigned xlo = 0x80808080u, xhi = 0u; };
+template <> struct I8Enc<SDRT_S16> { static constexpr int slices = 2; static constexpr unsigned xlo = 0x80808080u, xhi = 0u; };
+template <> struct I8Enc<SDRT_U16> { static constexpr int slices = 2; static constexpr unsigned xlo = 0x80808080u, xhi = 0x80808080u; };
+}  // namespace
+
+template <int L, int DT, int S>
+__global__ __launch_bounds__(256, 3) void chain_i8t_kernel(DecimArgs a) {
+    constexpr int NSL = I8Enc<DT>::slices;
+    constexpr int KS64 = L / 32;                    // 64-deep MFMA k-steps per block (2 components x 8 samples x 4 lane groups)
+    constexpr int NLV = S + NSL - 1;                // accumulator levels (weight 256^level)
+    const bool nco = a.nco_tile != nullptr;
+    constexpr int KS = L / 4;                       // k-steps == samples per lane per tile
+    constexpr int ITEM = Enc<DT>::size;
+    constexpr int BYTES = KS * 2 * ITEM;            // per lane per tile
+    constexpr int TILE = SDRT_TB * L;               // samples per tile
+    constexpr int NW = BYTES < 4 ? 1 : BYTES / 4;    // 32-bit words per lane per tile
+    typedef typename Enc<DT>::raw raw_t;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    const DecimTables *__restrict__ tab = a.tab;
+    const int n = a.n, m = a.m, nt = a.n_tiles;
+    // (chunk, row) from the block id: all rows of a chunk get ids that share an XCD (ids are dealt round-robin
+    // over 8 XCDs), so the chunk is pulled through one L2 only.  Placement changes speed only, never results.
+    const unsigned bid = blockIdx.x;
+    const unsigned xcd = bid & 7u, slot = bid >> 3;
+    const long chunk = (long) (slot / (unsigned) a.rows) * 8 + xcd;
+    const int row = (int) (slot % (unsigned) a.rows);
+    if (chunk >= (long) a.n_chunks) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, nb = lane & 15;
+    const bool swap = a.swap != 0;
+
+    // diagnostic phase stamps (a.stamps == nullptr in every production call)
+    unsigned long long *stp = (a.stamps && (int) bid < a.stamp_wgs && lane == 0) ? a.stamps + ((size_t) bid * 4 + wave) * 16 : nullptr;
+#define SDRT_STAMP(i) do { if (stp) stp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    SDRT_STAMP(0);
+
+    const LdsLayout lo = lds_layout(n, L, m, 1);
+    cd *base = (cd *) smem;
+    cd *o_lds = base + lo.o, *carF = base + lo.carF, *carG = base + lo.carG;
+
+    const unsigned char *chunk_raw = (const unsigned char *) a.raw + (size_t) chunk * (size_t) n * 2 * ITEM;
+    const double xoff = a.x_offset;
+    const cd *nco_samp_g = nco ? (const cd *) a.nco_tile + (size_t) row * L : nullptr;              // exp(i theta j), j < L
+    const cd *nco_blk_g = nco ? (const cd *) a.nco_phase + (size_t) row * (size_t) (n / L) : nullptr;   // exp(i theta L B), B < n/L
+
+    // digit planes of this row -> LDS, in A-operand order [tile][digit][kstep][lane]
+    v4i *w8L = (v4i *) (base + lo.total);
+    {
+        const v4i *wg = (const v4i *) (a.w8 + (size_t) row * (size_t) (2 * S * KS64 * 64 * 16));
+        for (int i = tid; i < 2 * S * KS64 * 64; i += 256) w8L[i] = wg[i];
+    }
+    cd mup[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mup[k] = mk(tab->mu_pow[k][g][0], tab->mu_pow[k][g][1]);
+    const double d0p = tab->d0p;
+    const double cs = a.w8_combine;
+
+    uint32_t cur[NW], nxt[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { cur[i] = 0; nxt[i] = 0; }
+    const size_t lane_off = ((size_t) nb * L + (size_t) g * KS) * 2 * ITEM;
+    if (wave < nt) load_words<BYTES>(chunk_raw + (size_t) wave * TILE * 2 * ITEM + lane_off, cur);
+
+    __syncthreads();
+    SDRT_STAMP(1);
+    // ---- main loop over this wave's tiles, next tile's bytes prefetched ----------------------------------------------
+    for (int tile = wave; tile < nt; tile += 4) {
+        if (tile + 4 < nt) load_words<BYTES>(chunk_raw + (size_t) (tile + 4) * TILE * 2 * ITEM + lane_off, nxt);
+        cd psi = mk(1.0, 0.0);
+        if (nco) psi = nco_blk_g[tile * SDRT_TB + nb];   // phasor common to this lane's block
+
+        // slices of this lane's L/4 samples: dword = [re.lo re.hi im.lo im.hi] -> 8 samples (16 int8) per k-step and slice
+        double u0r, u0i;
+        v4i blo[KS64], bhi[KS64];
+        if constexpr (ITEM == 2) {
+            const unsigned sel_lo = swap ? 0x07050301u : 0x06040200u, sel_hi = swap ? 0x06040200u : 0x07050301u;
+            u0r = decode<DT>((uint16_t) (cur[0] & 0xffffu), swap) - xoff;
+            u0i = decode<DT>((uint16_t) (cur[0] >> 16), swap) - xoff;
+#pragma unroll
+            for (int s = 0; s < KS64; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    blo[s][i] = (int) (__builtin_amdgcn_perm(cur[8 * s + 2 * i + 1], cur[8 * s + 2 * i], sel_lo) ^ I8Enc<DT>::xlo);
+                    bhi[s][i] = (int) (__builtin_amdgcn_perm(cur[8 * s + 2 * i + 1], cur[8 * s + 2 * i], sel_hi) ^ I8Enc<DT>::xhi);
+                }
+        } else {
+            u0r = decode<DT>((raw_t) (cur[0] & 0xffu), swap) - xoff;
+            u0i = decode<DT>((raw_t) ((cur[0] >> 8) & 0xffu), swap) - xoff;
+#pragma unroll
+            for (int s = 0; s < KS64; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { blo[s][i] = (int) (cur[4 * s + i] ^ I8Enc<DT>::xlo); bhi[s][i] = 0; }
+        }
+        // stage A on the int8 matrix cores: per row tile (0 causal, 1 anticausal) S digit planes x slices, exact int32 sums
+        double val[8];
+        static_for<0, 2>([&](auto tc) {
+            constexpr int rt = decltype(tc)::value;
+            v4i acc[NLV];
+#pragma unroll
+            for (int q = 0; q < NLV; ++q) acc[q] = (v4i) {0, 0, 0, 0};
+            static_for<0, KS64>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                static_for<0, S>([&](auto dc) {
+                    constexpr int d = decltype(dc)::value;
+                    const v4i A = w8L[((rt * S + d) * KS64 + s) * 64 + lane];
+                    acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo[s], acc[d], 0, 0, 0);
+                    if constexpr (NSL == 2) acc[d + 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi[s], acc[d + 1], 0, 0, 0);
+                });
+            });
+            // value = cs * sum_q 256^q acc[q]: pairs of levels first in int32 (|acc| <= 2^22), then fp64
+            static_for<0, 4>([&](auto vc) {
+                constexpr int v = decltype(vc)::value;
+                double dsum = 0.0;
+                static_for<0, (NLV + 1) / 2>([&](auto pp) {
+                    constexpr int p = (NLV + 1) / 2 - 1 - decltype(pp)::value;
+                    int t = acc[2 * p][v];
+                    if constexpr (2 * p + 1 < NLV) t += acc[2 * p + 1][v] * 256;
+                    dsum = fma(dsum, 65536.0, (double) t);
+                });
+                val[4 * rt + v] = dsum * cs;
+            });
+        });
+        // result layout of the 16x16 tile: lane (g, nb) register v = row 4 g + v of column nb: mode g, v = 2*stream + part
+        cd Cr = mk(val[0], val[1]), Ci = mk(val[2], val[3]), Ar = mk(val[4], val[5]), Ai = mk(val[6], val[7]);
+        if (nco) {
+            // the block's common phasor multiplies the complex DATA: re' = pr*re - pi*im, im' = pi*re + pr*im
+            cd t;
+            t = mk(psi.re * Cr.re - psi.im * Ci.re, psi.re * Cr.im - psi.im * Ci.im);
+            Ci = mk(psi.im * Cr.re + psi.re * Ci.re, psi.im * Cr.im + psi.re * Ci.im);
+            Cr = t;
+            t = mk(psi.re * Ar.re - psi.im * Ai.re, psi.re * Ar.im - psi.im * Ai.im);
+            Ai = mk(psi.im * Ar.re + psi.re * Ai.re, psi.im * Ar.im + psi.re * Ai.im);
+            Ar = t;
+            const double tr = psi.re * u0r - psi.im * u0i;
+            u0i = psi.im * u0r + psi.re * u0i;
+            u0r = tr;
+        }
+        // in-tile inclusive scans over the 16 blocks (lanes of one DPP row): causal with row_shr, anticausal with row_shl
+        Cr = cfma(mup[0], dpp_row<0x111>(Cr), Cr);
+        Ci = cfma(mup[0], dpp_row<0x111>(Ci), Ci);
+        Ar = cfma(mup[0], dpp_row<0x101>(Ar), Ar);
+        Ai = cfma(mup[0], dpp_row<0x101>(Ai), Ai);
+        Cr = cfma(mup[1], dpp_row<0x112>(Cr), Cr);
+        Ci = cfma(mup[1], dpp_row<0x112>(Ci), Ci);
+        Ar = cfma(mup[1], dpp_row<0x102>(Ar), Ar);
+        Ai = cfma(mup[1], dpp_row<0x102>(Ai), Ai);
+        Cr = cfma(mup[2], dpp_row<0x114>(Cr), Cr);
+        Ci = cfma(mup[2], dpp_row<0x114>(Ci), Ci);
+        Ar = cfma(mup[2], dpp_row<0x104>(Ar), Ar);
+        Ai = cfma(mup[2], dpp_row<0x104>(Ai), Ai);
+        Cr = cfma(mup[3], dpp_row<0x118>(Cr), Cr);
+        Ci = cfma(mup[3], dpp_row<0x118>(Ci), Ci);
+        Ar = cfma(mup[3], dpp_row<0x108>(Ar), Ar);
+        Ai = cfma(mup[3], dpp_row<0x108>(Ai), Ai);
+        // tile aggregates go straight into the carry arrays: causal inclusive at the last block -> slot t+1,
+        // anticausal inclusive at the first block -> slot t.  Index = slot*8 + mode*2 + stream.
+        if (nb == 15) { carF[(tile + 1) * 8 + g * 2 + 0] = Cr; carF[(tile + 1) * 8 + g * 2 + 1] = Ci; }
+        if (nb == 0) { carG[tile * 8 + g * 2 + 0] = Ar; carG[tile * 8 + g * 2 + 1] = Ai; }
+        // local output part: direct term + 2 Re(exclusive causal + inclusive anticausal), summed over the 4 modes
+        const double cexr = dpp_row<0x111>(Cr.re), cexi = dpp_row<0x111>(Ci.re);
+        double pr = 2.0 * (cexr + Ar.re), pi = 2.0 * (cexi + Ai.re);
+        if (g == 0) { pr = fma(d0p, u0r, pr); pi = fma(d0p, u0i, pi); }
+        pr += __shfl_xor(pr, 16);
+        pi += __shfl_xor(pi, 16);
+        pr += __shfl_xor(pr, 32);
+        pi += __shfl_xor(pi, 32);
+        if (g == 0) o_lds[tile * SDRT_TB + nb] = mk(pr, pi);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) cur[i] = nxt[i];
+    }
+    SDRT_STAMP(2);
+#undef SDRT_STAMP
+    auto edge = [&](long idx) -> cd {
+        const raw_t *rp = (const raw_t *) chunk_raw + 2 * idx;
+        double xr = decode<DT>(rp[0], swap) - xoff, xi = decode<DT>(rp[1], swap) - xoff;
+        if (nco) {
+            const cd u = cmul(mk(xr, xi), cmul(nco_samp_g[idx % L], nco_blk_g[idx / L]));
+            xr = u.re;
+            xi = u.im;
+        }
+        return mk(xr, xi);
+    };
+    chain_tail(a, L, row, chunk, smem, stp, edge, a.ybias ? (const cd *) a.ybias + (size_t) row * m : (const cd *) nullptr);
+}
+
+
+// MFMA i8 16x16x64 self-test: D(16x16) = A(16x64) * B(64x16), operands packed as the kernel assumes (lane = row/col + 16 kg,
+// byte j of the lane's 16 <-> inner index 16 kg + j; result row 4 (lane >> 4) + v, col lane & 15).
+__global__ void i8t_selftest_kernel(const int *A, const int *B, int *D) {
+    const int lane = threadIdx.x & 63, rc = lane & 15, kg = lane >> 4;
+    v4i av, bv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned pa = 0, pb = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int k = 16 * kg + 4 * i + b;
+            pa |= ((unsigned) (A[rc * 64 + k] & 0xff)) << (8 * b);
+            pb |= ((unsigned) (B[k * 16 + rc] & 0xff)) << (8 * b);
+        }
+        av[i] = (int) pa;
+        bv[i] = (int) pb;
+    }
+    v4i acc = {0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, acc, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) D[(4 * kg + v) * 16 + rc] = acc[v];
+}
+
+// ---- launch helpers -----------------------------------------------------------------------------------------------
+bool chain_i8t_supported(int L, int dt, int n) {
+    return (L == 32 || L == 64) && (dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16) && n % (SDRT_TB * L) == 0;
+}
+
+size_t chain_i8t_lds_bytes(int n, int L, int m) {
+    return (size_t) lds_layout(n, L, m, 1).total * 16 + (size_t) 2 * SDRT_I8_DIGITS * (L / 32) * 64 * 16;
+}
+
+template <int L, int DT>
+static hipError_t launch_i8t_k(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *) chain_i8t_kernel<L, DT, SDRT_I8_DIGITS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((chain_i8t_kernel<L, DT, SDRT_I8_DIGITS>), grid, dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int L>
+static hipError_t launch_i8t_l(const DecimArgs &a, int dt, dim3 grid, size_t lds, hipStream_t s) {
+    switch (dt) {
+        case SDRT_S8: return launch_i8t_k<L, SDRT_S8>(a, grid, lds, s);
+        case SDRT_U8: return launch_i8t_k<L, SDRT_U8>(a, grid, lds, s);
+        case SDRT_S16: return launch_i8t_k<L, SDRT_S16>(a, grid, lds, s);
+        case SDRT_U16: return launch_i8t_k<L, SDRT_U16>(a, grid, lds, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_chain_i8t(const DecimArgs &a, int L, int dt, size_t n_chunks, hipStream_t s) {
+    const size_t groups = (n_chunks + 7) / 8;
+    const dim3 grid((unsigned) (groups * 8 * (size_t) a.rows));
+    const size_t lds = chain_i8t_lds_bytes(a.n, L, a.m);
+    switch (L) {
+        case 32: return launch_i8t_l<32>(a, dt, grid, lds, s);
+        case 64: return launch_i8t_l<64>(a, dt, grid, lds, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_i8t_selftest(const int *A, const int *B, int *D, hipStream_t s) {
+    hipLaunchKernelGGL(i8t_selftest_kernel, dim3(1), dim3(64), 0, s, A, B, D);
+    return hipGetLastError();
+}

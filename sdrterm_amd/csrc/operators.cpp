@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 namespace {
 
@@ -100,7 +101,8 @@ bool build_modal(const double *sos, int nsec, Modal &m, const char **err) {
 
 }  // namespace
 
-extern "C" int sdrt_build_decim_tables(const double *sos, int sections, int q, DecimTables *out, const char **err) {
+extern "C" int sdrt_build_decim_tables(const double *sos, int sections, int q, int G, DecimTables *out, const char **err) {
+    if (G < 1 || G > SDRT_GMAX) { if (err) *err = "unsupported blocks-per-column"; return -3; }
     static const char *kBadQ = "decimation must be a power of two >= 4 for the MFMA path";
     if (q < 4 || (q & (q - 1))) { if (err) *err = kBadQ; return -1; }
     Modal m;
@@ -111,6 +113,7 @@ extern "C" int sdrt_build_decim_tables(const double *sos, int sections, int q, D
     out->ksteps = L / 4;
     out->out_stride = q / L;
     out->edge = SDRT_EDGE;
+    out->G = G;
 
     C P[4], ac[4], aa[4], mu[4];
     C sum_a_over_p(0);
@@ -132,10 +135,10 @@ extern "C" int sdrt_build_decim_tables(const double *sos, int sections, int q, D
             out->W[12 + i][j] = (double) wa.im;
         }
         const int pw[5] = {1, 2, 4, 8, 16};
-        for (int k = 0; k < 5; ++k) put(out->mu_pow[k][i], cpow(mu[i], pw[k]));
-        for (int nb = 0; nb < SDRT_TB; ++nb) {
+        for (int k = 0; k < 5; ++k) put(out->mu_pow[k][i], cpow(mu[i], G * pw[k]));      // column-to-column powers
+        for (int nb = 0; nb < SDRT_TB * G; ++nb) {
             put(out->cF[nb][i], cpow(mu[i], nb));
-            put(out->cG[nb][i], cpow(mu[i], SDRT_TB - nb));
+            put(out->cG[nb][i], cpow(mu[i], SDRT_TB * G - nb));
         }
     }
 
@@ -313,47 +316,140 @@ extern "C" void sdrt_build_resample_odd(int N, double *h) {
     }
 }
 
-extern "C" int sdrt_build_i8_weights(const DecimTables *tab, const double *nco_samp, int S, signed char *out, double *combine) {
-    const int L = tab->L, cols = 2 * L, KS8 = L / 16;
-    static double Wf[32][2 * SDRT_MAXL];
+namespace {
+
+// quantise rows x cols reals (row-major, leading dimension ld) to S balanced base-256 digits against one power-of-two
+// scale; emit(d, r, c, digit) receives every digit.  Returns the combine factor scale * 2^-(8S-1), or 0 on overflow.
+template <class Emit>
+double quantise_planes(const double *W, int rows, int cols, int ld, int S, Emit emit) {
     double maxabs = 0.0;
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) maxabs = std::fmax(maxabs, std::fabs(W[(size_t) r * ld + c]));
+    if (!(maxabs > 0.0)) return 0.0;
+    int e = 0;
+    std::frexp(maxabs * 1.002, &e);
+    const double scale = std::ldexp(1.0, e);
+    const int B = 8 * S - 1;
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            long long I = std::llround(std::ldexp(W[(size_t) r * ld + c] / scale, B));
+            for (int d = 0; d < S; ++d) {
+                const long long dig = ((I + 128) % 256 + 256) % 256 - 128;      // balanced digit in [-128, 127]
+                I = (I - dig) / 256;
+                emit(d, r, c, (signed char) dig);
+            }
+            if (I != 0) return 0.0;
+        }
+    return std::ldexp(scale, -B);
+}
+
+}  // namespace
+
+extern "C" int sdrt_build_i8_weights(const double *sos, int sections, const DecimTables *tab, double data_scale,
+                                     const double *nco_samp, int S, signed char *main_out, double *main_combine,
+                                     signed char *mid_out, double *mid_combine) {
+    Modal m;
+    const char *err = nullptr;
+    if (!build_modal(sos, sections, m, &err)) return -2;
+    const int L = tab->L, G = tab->G, LC = L * G, cols = 2 * LC, KS = LC / 16;
+    std::vector<double> Wf((size_t) 32 * cols, 0.0);
+    C P[4], ac[4], aa[4];
+    C sum_a_over_p(0);
+    for (int i = 0; i < 8; ++i) sum_a_over_p = sum_a_over_p + m.alpha[i] / m.p[i];
+    const double d0p = (double) (m.d0 - sum_a_over_p.re) * data_scale;
+    for (int i = 0; i < 4; ++i) { P[i] = m.p[2 * i]; ac[i] = m.alpha[2 * i]; aa[i] = m.alpha[2 * i] / P[i]; }
+    auto tr = [&](int t) { return nco_samp ? nco_samp[2 * t] : 1.0; };
+    auto ti = [&](int t) { return nco_samp ? nco_samp[2 * t + 1] : 0.0; };
+    // main rows: column aggregates.  causal: alpha p^(LC-1-t), anticausal: (alpha/p) p^t  (scaled with the data)
     for (int mode = 0; mode < 4; ++mode)
         for (int kind = 0; kind < 2; ++kind)
-            for (int j = 0; j < L; ++j) {
-                const double wr = tab->W[8 * kind + mode][j], wi = tab->W[8 * kind + 4 + mode][j];
-                const double tr = nco_samp ? nco_samp[2 * j] : 1.0, ti = nco_samp ? nco_samp[2 * j + 1] : 0.0;
-                // u = x t:  u_re = xr tr - xi ti,  u_im = xr ti + xi tr;  state(stream) = sum_j w[j] u_stream[j]
-                const double cxr[2][2] = {{wr * tr, wi * tr}, {wr * ti, wi * ti}};        // [stream][part] coefficient of xr
-                const double cxi[2][2] = {{-wr * ti, -wi * ti}, {wr * tr, wi * tr}};      // coefficient of xi
+            for (int t = 0; t < LC; ++t) {
+                const C w = kind == 0 ? ac[mode] * cpow(P[mode], LC - 1 - t) : aa[mode] * cpow(P[mode], t);
+                const double wr = (double) w.re * data_scale, wi = (double) w.im * data_scale;
+                // u = x e^{i theta t}: u_re = xr tr - xi ti, u_im = xr ti + xi tr; state(stream) = sum_t w[t] u_stream[t]
+                const double cxr[2][2] = {{wr * tr(t), wi * tr(t)}, {wr * ti(t), wi * ti(t)}};      // [stream][part], coefficient of xr
+                const double cxi[2][2] = {{-wr * ti(t), -wi * ti(t)}, {wr * tr(t), wi * tr(t)}};    // coefficient of xi
                 for (int stream = 0; stream < 2; ++stream)
                     for (int part = 0; part < 2; ++part) {
                         const int r = part + 2 * stream + 4 * (mode >> 1) + 8 * (kind + 2 * (mode & 1));
-                        Wf[r][2 * j] = cxr[stream][part];
-                        Wf[r][2 * j + 1] = cxi[stream][part];
-                        maxabs = std::fmax(maxabs, std::fmax(std::fabs(cxr[stream][part]), std::fabs(cxi[stream][part])));
+                        Wf[(size_t) r * cols + 2 * t] = cxr[stream][part];
+                        Wf[(size_t) r * cols + 2 * t + 1] = cxi[stream][part];
                     }
             }
-    if (!(maxabs > 0.0)) return -1;
-    int e = 0;
-    std::frexp(maxabs * 1.002, &e);                  // maxabs*1.002 = f * 2^e, f in [0.5, 1)
-    const double scale = std::ldexp(1.0, e);         // power of two >= maxabs*1.002
-    const int B = 8 * S - 1;
-    *combine = std::ldexp(scale, -B);
-    for (int r = 0; r < 32; ++r)
-        for (int c = 0; c < cols; ++c) {
-            // exact: Wf/scale is in (-1, 1); times 2^B, rounded to the nearest integer (B <= 47 fits a long long)
-            long long I = std::llround(std::ldexp(Wf[r][c] / scale, B));
-            const int sample = c >> 1, comp = c & 1;
-            const int h = sample / (L / 2), within = sample % (L / 2), ks = within / 8, j = 2 * (within % 8) + comp;
-            const int lane = r + 32 * h;
-            for (int d = 0; d < S; ++d) {
-                long long dig = ((I + 128) % 256 + 256) % 256 - 128;      // balanced digit in [-128, 127]
-                I = (I - dig) / 256;
-                out[(((size_t) d * KS8 + ks) * 64 + lane) * 16 + j] = (signed char) dig;
+    auto col_pos = [&](int c, int &ks, int &h, int &j) {
+        const int sample = c >> 1, comp = c & 1;
+        h = sample / (LC / 2);
+        const int within = sample % (LC / 2);
+        ks = within / 8;
+        j = 2 * (within % 8) + comp;
+    };
+    *main_combine = quantise_planes(Wf.data(), 32, cols, cols, S, [&](int d, int r, int c, signed char dig) {
+        int ks, h, j;
+        col_pos(c, ks, h, j);
+        main_out[((((size_t) d * KS + ks) * 64) + (r + 32 * h)) * 16 + j] = dig;
+    });
+    if (*main_combine == 0.0) return -1;
+    if (G > 1) {
+        // mid rows: output at the start of block g of the column, column-local part:
+        //   d0' u[L g] + sum_i 2 Re( alpha_i sum_{t < L g} p_i^(L g - 1 - t) u[t] + (alpha_i/p_i) sum_{t >= L g} p_i^(t - L g) u[t] )
+        const int NR = 2 * (G - 1);
+        std::vector<double> Wm((size_t) NR * cols, 0.0);
+        for (int g = 1; g < G; ++g)
+            for (int t = 0; t < LC; ++t) {
+                R acc = 0;
+                for (int i = 0; i < 4; ++i) {
+                    const C w = t < L * g ? ac[i] * cpow(P[i], L * g - 1 - t) : aa[i] * cpow(P[i], t - L * g);
+                    acc = acc + 2 * w.re;
+                }
+                double mt = (double) acc * data_scale;
+                if (t == L * g) mt += d0p;
+                // stream re: mt (xr tr - xi ti);  stream im: mt (xr ti + xi tr)
+                Wm[(size_t) (0 + 2 * (g - 1)) * cols + 2 * t] = mt * tr(t);
+                Wm[(size_t) (0 + 2 * (g - 1)) * cols + 2 * t + 1] = -mt * ti(t);
+                Wm[(size_t) (1 + 2 * (g - 1)) * cols + 2 * t] = mt * ti(t);
+                Wm[(size_t) (1 + 2 * (g - 1)) * cols + 2 * t + 1] = mt * tr(t);
             }
-            if (I != 0) return -1;
-        }
+        *mid_combine = quantise_planes(Wm.data(), NR, cols, cols, S, [&](int d, int r, int c, signed char dig) {
+            int ks, h, j;
+            col_pos(c, ks, h, j);
+            mid_out[(((((size_t) d * KS + ks) * 2 + h) * NR) + r) * 16 + j] = dig;
+        });
+        if (*mid_combine == 0.0) return -1;
+    }
     return 0;
+}
+
+extern "C" int sdrt_build_i8_weights16(const double *sos, int sections, const DecimTables *tab, double data_scale,
+                                       const double *nco_samp, int S, signed char *out, double *combine) {
+    Modal m;
+    const char *err = nullptr;
+    if (!build_modal(sos, sections, m, &err)) return -2;
+    const int L = tab->L, cols = 2 * L, KS = L / 32;
+    if (L % 32) return -3;
+    std::vector<double> Wf((size_t) 32 * cols, 0.0);          // rows 0..15 causal tile, 16..31 anticausal tile
+    for (int mode = 0; mode < 4; ++mode) {
+        const C P = m.p[2 * mode], ac = m.alpha[2 * mode], aa = m.alpha[2 * mode] / P;
+        for (int kind = 0; kind < 2; ++kind)
+            for (int t = 0; t < L; ++t) {
+                const C w = kind == 0 ? ac * cpow(P, L - 1 - t) : aa * cpow(P, t);
+                const double wr = (double) w.re * data_scale, wi = (double) w.im * data_scale;
+                const double tr = nco_samp ? nco_samp[2 * t] : 1.0, ti = nco_samp ? nco_samp[2 * t + 1] : 0.0;
+                const double cxr[2][2] = {{wr * tr, wi * tr}, {wr * ti, wi * ti}};        // [stream][part], coefficient of xr
+                const double cxi[2][2] = {{-wr * ti, -wi * ti}, {wr * tr, wi * tr}};      // coefficient of xi
+                for (int stream = 0; stream < 2; ++stream)
+                    for (int part = 0; part < 2; ++part) {
+                        const int r = 16 * kind + 4 * mode + 2 * stream + part;
+                        Wf[(size_t) r * cols + 2 * t] = cxr[stream][part];
+                        Wf[(size_t) r * cols + 2 * t + 1] = cxi[stream][part];
+                    }
+            }
+    }
+    *combine = quantise_planes(Wf.data(), 32, cols, cols, S, [&](int d, int r, int c, signed char dig) {
+        const int tile = r >> 4, row = r & 15, sample = c >> 1, comp = c & 1;
+        const int kg = sample / (L / 4), within = sample % (L / 4), ks = within / 8, j = 2 * (within % 8) + comp;
+        out[(((((size_t) tile * S + d) * KS + ks) * 64) + (row + 16 * kg)) * 16 + j] = dig;
+    });
+    return *combine == 0.0 ? -1 : 0;
 }
 
 extern "C" void sdrt_build_iq_pow(double lambda, int count, double *pw) {

@@ -4,7 +4,8 @@
 #include <stdint.h>
 
 #define SDRT_MAXL 64        // samples per block (K dimension of the stage-A MFMA contraction)
-#define SDRT_TB 16          // blocks per tile == MFMA N dimension
+#define SDRT_TB 16          // columns per tile (one DPP row of lanes); a column is G consecutive blocks
+#define SDRT_GMAX 2         // blocks per column: 1 (f64 kernel), 1 or 2 (int8 kernel)
 #define SDRT_EDGE 27        // sosfiltfilt odd-extension length for the order-8 decimator (3 * (2*4+1))
 #define SDRT_NMODE 4        // conjugate pole pairs of the order-8 decimator
 
@@ -14,12 +15,14 @@ struct DecimTables {
     int32_t ksteps;         // L / 4 MFMA k-steps per block
     int32_t out_stride;     // one output every out_stride blocks: q / L
     int32_t edge;           // == SDRT_EDGE
+    int32_t G;              // blocks per column (tile = 16 columns = 16 G blocks)
+    int32_t reserved;
     // Stage-A weights, row r = mode (r & 3), kind (r >> 2): 0 Re causal, 1 Im causal, 2 Re anticausal, 3 Im anticausal.
     // causal row i:  alpha_i * p_i^(L-1-j);  anticausal row i: (alpha_i / p_i) * p_i^j.
     double W[16][SDRT_MAXL];
-    double mu_pow[5][SDRT_NMODE][2];    // mu_i^(1,2,4,8,16), mu_i = p_i^L
-    double cF[SDRT_TB][SDRT_NMODE][2];  // mu_i^nb        (carry-in of the causal state to block nb of a tile)
-    double cG[SDRT_TB][SDRT_NMODE][2];  // mu_i^(16-nb)   (carry-in of the anticausal state)
+    double mu_pow[5][SDRT_NMODE][2];    // mu_i^(1,2,4,8,16), mu_i = p_i^(L G)   (column-to-column multiplier)
+    double cF[SDRT_TB * SDRT_GMAX][SDRT_NMODE][2];  // p_i^(L nb)          carry-in of the causal state to block nb of a tile
+    double cG[SDRT_TB * SDRT_GMAX][SDRT_NMODE][2];  // p_i^(L (16 G - nb)) carry-in of the anticausal state
     double d0p;                          // direct term
     double head[SDRT_NMODE][SDRT_EDGE + 1][2];   // F_0,i = sum_l head[i][l] * u[l]            (per real stream)
     double tailF[SDRT_NMODE][SDRT_NMODE][2];     // G_end,i = sum_j tailF[i][j] F_j + tailFc[i][j] conj(F_j)
@@ -49,7 +52,7 @@ int sdrt_build_out_tables(const double *sos, int sections, int m, struct OutTabl
 
 // Builds the tables from the decimator SOS (scipy layout [sections][6]).  Returns 0 or a negative code;
 // on failure *err (if non-null) points to a static message.
-int sdrt_build_decim_tables(const double *sos, int sections, int q, struct DecimTables *out, const char **err);
+int sdrt_build_decim_tables(const double *sos, int sections, int q, int G, struct DecimTables *out, const char **err);
 
 // NCO tables for one row: tile[t] = exp(-2*pi*i*(f/fs)*t), t < tile_len; tilephase[T] = exp(-2*pi*i*(f/fs)*tile_len*T).
 void sdrt_build_nco(double f, double fs, int tile_len, int n_tiles, double *tile /*[tile_len][2]*/,
@@ -58,13 +61,28 @@ void sdrt_build_nco(double f, double fs, int tile_len, int n_tiles, double *tile
 // Odd-sample kernel of scipy.signal.resample(a, 2N) for real a of length N: y[2j+1] = sum_k a[k] h[(j-k) mod N].
 void sdrt_build_resample_odd(int N, double *h /*[N]*/);
 
-// Stage-A weights for the int8 matrix-core path: the 16 complex-mode rows, with the within-block NCO phasor folded in, as a
-// real 32 x 2L matrix (rows: part + 2*stream + 4*(mode>>1) + 8*(kind + 2*(mode&1)); columns: (sample, re/im)), quantised to
-// S signed base-256 digits against one power-of-two scale.  Output layout = MFMA A operand order:
-//   out[((digit*(L/16) + kstep)*64 + lane)*16 + j],  lane = row + 32*h,  column = sample h*L/2 + 8*kstep + (j>>1), comp j&1.
+// Stage-A weights for the int8 matrix-core path.  A column is LC = G*L samples.  Main matrix: the 16 complex-mode rows
+// (column aggregates) with the within-column NCO phasor folded in, as a real 32 x 2LC matrix (rows: part + 2*stream +
+// 4*(mode>>1) + 8*(kind + 2*(mode&1)); columns: (sample, re/im)).  Mid matrix (G > 1): for every internal block boundary
+// g = 1..G-1 and stream one real row, the part of that boundary's output that depends on this column only (row
+// stream + 2*(g-1)).  Both are quantised to S signed base-256 digits against one power-of-two scale each.
+// Layouts (MFMA A-operand order, KS = LC/16 k-steps):
+//   main[((digit*KS + kstep)*64 + lane)*16 + j],  lane = row + 32*h,  column = sample h*LC/2 + 8*kstep + (j>>1), comp j&1
+//   mid [(((digit*KS + kstep)*2 + h)*NR + row)*16 + j],  NR = 2*(G-1)
 // *combine = scale * 2^-(8S-1): value = combine * sum_d 256^d * (integer dot product of digit d).
-// nco_samp: [L][2] within-block phasors, or NULL (no shift).  Returns 0, or -1 if a digit overflowed.
-int sdrt_build_i8_weights(const struct DecimTables *tab, const double *nco_samp, int S, signed char *out, double *combine);
+// `tab` must have been built with the same G.  nco_samp: [LC][2] within-column phasors, or NULL (no shift).
+// Returns 0, or -1 if a digit overflowed.
+int sdrt_build_i8_weights(const double *sos, int sections, const struct DecimTables *tab, double data_scale,
+                          const double *nco_samp, int S, signed char *main_out, double *main_combine,
+                          signed char *mid_out, double *mid_combine);
+
+// Digit planes for the 16x16x64 int8 matrix-core kernel (chain_i8t_kernel): two row tiles of 16 rows, tile 0 = causal,
+// tile 1 = anticausal aggregates of a block of L samples; row = 4*mode + 2*stream + part.  Layout = MFMA A-operand order:
+//   out[(((tile*S + digit)*(L/32) + kstep)*64 + lane)*16 + j],  lane = row + 16*kg,
+//   K position (kstep, kg, j) <-> sample kg*(L/4) + 8*kstep + (j>>1), component j&1.
+// One power-of-two scale for both tiles; *combine as above.  nco_samp: [L][2] or NULL.  `tab` built with G = 1.
+int sdrt_build_i8_weights16(const double *sos, int sections, const struct DecimTables *tab, double data_scale,
+                            const double *nco_samp, int S, signed char *out, double *combine);
 
 // IQ-correction geometric weights: pw[j] = (1-lambda)^j, j <= count.
 void sdrt_build_iq_pow(double lambda, int count, double *pw);

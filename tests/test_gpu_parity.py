@@ -29,14 +29,14 @@ def test_mfma_layout_selftest():
     assert bad.value == 0
 
 
-@pytest.fixture(params=['auto', 'f64'])
+@pytest.fixture(params=['auto', 'f64', 'i8x32'])
 def stage_a(request, monkeypatch):
-    """Every golden case runs twice: with the kernel the library picks (int8 matrix cores for integer encodings) and with
-    the fp64 matrix-core kernel forced."""
-    if request.param == 'f64':
-        monkeypatch.setenv('SDRTERM_STAGE_A', 'f64')
-    else:
+    """Every golden case runs with the kernel the library picks (int8 matrix cores, 16x16x64 form, for 8/16-bit integer
+    encodings), with the fp64 matrix-core kernel forced, and with the 32x32x32 int8 form forced."""
+    if request.param == 'auto':
         monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    else:
+        monkeypatch.setenv('SDRTERM_STAGE_A', request.param)
     return request.param
 
 
@@ -47,8 +47,8 @@ def test_golden_parity(case, golden, stage_a):
     eng = _engine(case)
     if stage_a == 'f64':
         assert eng.stage_a == 'f64'
-    elif eng.stage_a == 'f64':
-        pytest.skip('library picks the f64 kernel for this case (covered by the forced run)')
+    elif eng.stage_a != ('i8' if stage_a == 'auto' else stage_a):
+        pytest.skip(f'{stage_a}: the library uses {eng.stage_a} for this case (covered by another run)')
     raw = case_raw(case)
     out, y = eng.process_debug(raw)
     exp = z[f'{name}/z']                       # (chunks, N, m)

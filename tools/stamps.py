@@ -21,7 +21,7 @@ def main():
         eng.process_device(d_raw.ptr, n_chunks, d_out.ptr)
     nat.check(nat.lib().sdrt_device_synchronize())
     nw = min(n_chunks, 4096)
-    st = np.zeros((nw, 4, 8), dtype=np.uint64)
+    st = np.zeros((nw, 4, 16), dtype=np.uint64)
     lib = nat.lib()
     lib.sdrt_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     nat.check(lib.sdrt_debug_stamps(eng._ctx, d_raw.ptr, n_chunks, d_out.ptr, st.ctypes.data, nw))
@@ -32,6 +32,12 @@ def main():
     for i, nm in enumerate(names):
         d = (s[:, :, i + 1] - s[:, :, i])[valid]
         print(f'{nm:28s} median {np.median(d):9.0f}  mean {d.mean():9.0f} cycles')
+    if (s[:, :, 13] > 0).any():
+        inner = ['pass0 k-loop (issue)', 'pass0 combine (MFMA drain)', 'pass1 k-loop (issue)', 'pass1 combine', 'phasor+scans', 'aggregates+outputs']
+        pts = [1, 8, 9, 10, 11, 12, 13]
+        for i, nm in enumerate(inner):
+            d = (s[:, :, pts[i + 1]] - s[:, :, pts[i]])[valid]
+            print(f'  first super-tile: {nm:28s} median {np.median(d):9.0f}  mean {d.mean():9.0f} cycles')
     tot = (s[:, :, 5] - s[:, :, 0])[valid]
     print(f'{"start -> end":28s} median {np.median(tot):9.0f}  mean {tot.mean():9.0f} cycles')
 
