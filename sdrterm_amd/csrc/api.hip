@@ -281,20 +281,38 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
                                    chain_i8_lds_bytes(n, L, m) <= 160 * 1024);
     }
     if (rc == SDRT_OK && c->use_i8t) {
-        const int S = SDRT_I8_DIGITS;
-        const size_t per_row = (size_t) 2 * S * (L / 32) * 64 * 16;
-        std::vector<signed char> w8(per_row * c->rows);
-        std::vector<double> samp((size_t) L * 2), blk((size_t) (n / L) * 2);
+        // columns of G blocks: tables, NCO phasors per column, digit planes per row (NCO folded in, so they differ per row)
+        const int S = SDRT_I8_DIGITS, G = SDRT_I8T_G, LC = L * G, KS = LC / 32, NR = 2 * (G - 1);
+        DecimTables tab8;
+        if (sdrt_build_decim_tables(cfg->dec_sos, cfg->dec_sections, q, G, &tab8, &msg) != 0)
+            rc = fail(SDRT_EINVAL, "decimator tables: %s", msg ? msg : "failed");
+        scale_tables(tab8);
+        c->n_tiles8 = n / (SDRT_TB * LC);
+        if (rc == SDRT_OK) rc = upload(&c->d_tab8, &tab8, sizeof(tab8));
+        const size_t per_row = (size_t) 2 * S * KS * 64 * 16, per_row_mid = (size_t) S * KS * 4 * NR * 16;
+        std::vector<signed char> w8(per_row * c->rows), w8m(per_row_mid * c->rows + 16);
+        std::vector<double> samp((size_t) c->rows * LC * 2), blk((size_t) c->rows * (n / LC) * 2);
         for (int r = 0; r < c->rows && rc == SDRT_OK; ++r) {
-            double comb = 0.0;
-            if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, L, n / L, samp.data(), blk.data());
-            if (sdrt_build_i8_weights16(cfg->dec_sos, cfg->dec_sections, &tab, c->norm_scale, c->nco ? samp.data() : nullptr, S,
-                                        w8.data() + per_row * r, &comb) != 0)
+            double comb = 0.0, combm = 0.0;
+            double *sp = &samp[(size_t) r * LC * 2], *bp = &blk[(size_t) r * (n / LC) * 2];
+            if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, LC, n / LC, sp, bp);
+            if (sdrt_build_i8_weights16(cfg->dec_sos, cfg->dec_sections, &tab8, c->norm_scale, c->nco ? sp : nullptr, S,
+                                        w8.data() + per_row * r, &comb, w8m.data() + per_row_mid * r, &combm) != 0)
                 rc = fail(SDRT_EINVAL, "int8 weight quantisation failed");
-            if (r == 0) c->w8_combine = comb;
-            else if (comb != c->w8_combine) { c->use_i8t = false; break; }     // falls back to the other int8 form
+            if (r == 0) { c->w8_combine = comb; c->w8mid_combine = combm; }
+            else if (comb != c->w8_combine || combm != c->w8mid_combine) { c->use_i8t = false; break; }   // other int8 form
+        }
+        if (rc == SDRT_OK && c->use_i8t && c->nco) {
+            rc = upload(&c->d_nco_tile8, samp.data(), samp.size() * sizeof(double));
+            if (rc == SDRT_OK) rc = upload(&c->d_nco_phase8, blk.data(), blk.size() * sizeof(double));
         }
         if (rc == SDRT_OK && c->use_i8t) rc = upload(&c->d_w8, w8.data(), w8.size());
+        if (rc == SDRT_OK && c->use_i8t && per_row_mid) rc = upload(&c->d_w8mid, w8m.data(), per_row_mid * c->rows);
+        if (!c->use_i8t) {      // clean up for the fallback form, which builds its own tables
+            (void) hipFree(c->d_tab8); c->d_tab8 = nullptr;
+            (void) hipFree(c->d_nco_tile8); c->d_nco_tile8 = nullptr;
+            (void) hipFree(c->d_nco_phase8); c->d_nco_phase8 = nullptr;
+        }
     }
     if (rc == SDRT_OK && c->use_i8 && !c->use_i8t) {
         // tables for columns of G blocks, digit planes per row (the NCO's within-column phasor is folded into the weights,
@@ -483,7 +501,7 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     da.w8_combine = c->w8_combine;
     da.w8mid_combine = c->w8mid_combine;
     da.x_offset = c->x_offset;
-    if (c->use_i8 && !c->use_i8t) {
+    if (c->use_i8) {
         da.tab = c->d_tab8;
         da.n_tiles = c->n_tiles8;
         da.nco_tile = c->d_nco_tile8;

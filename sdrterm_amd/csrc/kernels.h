@@ -65,7 +65,8 @@ size_t post_lds_bytes(int m, int mode);
 hipError_t launch_post(const PostArgs &a, hipStream_t s);
 hipError_t launch_chain(const DecimArgs &a, int L, int dt, bool nco, bool iq, size_t n_chunks, hipStream_t s);
 #define SDRT_I8_DIGITS 5
-#define SDRT_I8_G 1             // blocks per matrix-core column in the int8 kernel
+#define SDRT_I8_G 1             // blocks per matrix-core column in the 32x32x32 int8 kernel (diagnostic variant)
+#define SDRT_I8T_G 1            // blocks per matrix-core column in the 16x16x64 int8 kernel (the default path)
 bool chain_i8_supported(int L, int dt, int n);
 size_t chain_i8_lds_bytes(int n, int L, int m);
 hipError_t launch_chain_i8(const DecimArgs &a, int L, int dt, bool nco, size_t n_chunks, hipStream_t s);

@@ -37,8 +37,8 @@ __device__ __forceinline__ cd cfma(cd a, cd b, cd c) {  // a*b + c
 template <int CTRL>
 __device__ __forceinline__ double dpp_row(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);     // bound_ctrl: lanes shifted in from outside the row read 0
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
@@ -144,7 +144,7 @@ __device__ __forceinline__ typename Enc<DT>::raw get_item(const uint32_t *wds) {
 
 
 struct LdsLayout {
-    int o, carF, carG, cF, cG, tailF, tailFc, f0, gu, total;   // offsets in 16-byte units
+    int o, carF, carG, cF, cG, tailF, tailFc, f0, gu, tpow, total;   // offsets in 16-byte units
 };
 __host__ __device__ inline LdsLayout lds_layout(int n, int L, int m, int G) {
     const int nblk = n / L, nt = nblk / (SDRT_TB * G);
@@ -159,6 +159,7 @@ __host__ __device__ inline LdsLayout lds_layout(int n, int L, int m, int G) {
     l.tailFc = p; p += 16;
     l.f0 = p; p += 8;
     l.gu = p; p += 8;
+    l.tpow = p; p += nt <= SDRT_TPOW ? (nt + 1) * 4 : 0;   // tile multiplier powers [k][mode]
     l.total = p;
     return l;
 }
@@ -172,7 +173,7 @@ __host__ __device__ inline LdsLayout lds_layout(int n, int L, int m, int G) {
 // ---------------------------------------------------------------------------------------------------------------
 template <class EdgeFn>
 __device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, const int row, const long chunk, unsigned char *smem,
-                                           unsigned long long *stp, EdgeFn edge, const cd *ybias) {
+                                           unsigned long long *stp, EdgeFn edge, const cd *ybias, const bool copy_tables = true) {
 #define SDRT_STAMP(i) do { if (stp) stp[i] = __builtin_amdgcn_s_memtime(); } while (0)
     const DecimTables *__restrict__ tab = a.tab;
     const int n = a.n, m = a.m, nt = a.n_tiles;
@@ -182,7 +183,7 @@ __device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, cons
     cd *base = (cd *) smem;
     cd *o_lds = base + lo.o, *carF = base + lo.carF, *carG = base + lo.carG;
     cd *cF = base + lo.cF, *cG = base + lo.cG, *tailF = base + lo.tailF;
-    cd *tailFc = base + lo.tailFc, *F0 = base + lo.f0, *Gu = base + lo.gu;
+    cd *tailFc = base + lo.tailFc, *F0 = base + lo.f0, *Gu = base + lo.gu, *tpw = base + lo.tpow;
     // ---- tables for the later phases and the edge operators (all loads issued together, one round trip) -------------
     {
         const int o = tid >> 5, l = tid & 31, mode = o >> 1, st = o & 1;
@@ -197,13 +198,17 @@ __device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, cons
             f = mk(tab->head[mode][l][0] * uh, tab->head[mode][l][1] * uh);
             gq = mk(tab->tailU[mode][l][0] * ut, tab->tailU[mode][l][1] * ut);
         }
-        if (tid < TBG * 4) {
-            cF[tid] = mk(tab->cF[tid >> 2][tid & 3][0], tab->cF[tid >> 2][tid & 3][1]);
-            cG[tid] = mk(tab->cG[tid >> 2][tid & 3][0], tab->cG[tid >> 2][tid & 3][1]);
-        } else if (tid >= 128 && tid < 144) {
-            const int i = tid - 128;
-            tailF[i] = mk(tab->tailF[i >> 2][i & 3][0], tab->tailF[i >> 2][i & 3][1]);
-            tailFc[i] = mk(tab->tailFc[i >> 2][i & 3][0], tab->tailFc[i >> 2][i & 3][1]);
+        if (copy_tables) {
+            if (tid < TBG * 4) {
+                cF[tid] = mk(tab->cF[tid >> 2][tid & 3][0], tab->cF[tid >> 2][tid & 3][1]);
+                cG[tid] = mk(tab->cG[tid >> 2][tid & 3][0], tab->cG[tid >> 2][tid & 3][1]);
+            } else if (tid >= 128 && tid < 144) {
+                const int i = tid - 128;
+                tailF[i] = mk(tab->tailF[i >> 2][i & 3][0], tab->tailF[i >> 2][i & 3][1]);
+                tailFc[i] = mk(tab->tailFc[i >> 2][i & 3][0], tab->tailFc[i >> 2][i & 3][1]);
+            }
+            if (nt <= SDRT_TPOW)
+                for (int i = tid; i < (nt + 1) * 4; i += 256) tpw[i] = mk(tab->tpow[i >> 2][i & 3][0], tab->tpow[i >> 2][i & 3][1]);
         }
 #pragma unroll
         for (int d = 16; d >= 1; d >>= 1) {
@@ -219,44 +224,46 @@ __device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, cons
 
     // ---- phase 2: carries across tiles as wave-level scans.  Chain o = mode*2 + stream; wave w owns chains 2w, 2w+1.
     // F[t+1] = mu16 F[t] + aggF[t]  (slots of carF),  G[t] = mu16 G[t+1] + aggG[t]  (slots of carG).
-    for (int cc = 0; cc < 2; ++cc) {
-        const int o = wave * 2 + cc, mode = o >> 1;
-        const cd mu16 = mk(tab->mu_pow[4][mode][0], tab->mu_pow[4][mode][1]);
-        cd carry = F0[o];
-        if (lane == 0) carF[o] = carry;
-        for (int t0 = 0; t0 < nt; t0 += 64) {
-            const int t = t0 + lane;
-            cd x = t < nt ? carF[(t + 1) * 8 + o] : mk(0.0, 0.0);
-            if (lane == 0) x = cfma(mu16, carry, x);
-            x = wave_scan_geometric(x, mu16, lane);
-            if (t < nt) carF[(t + 1) * 8 + o] = x;
-            carry = mk(__shfl(x.re, 63), __shfl(x.im, 63));
+    {
+        for (int cc = 0; cc < 2; ++cc) {
+            const int o = wave * 2 + cc, mode = o >> 1;
+            const cd mu16 = mk(tab->mu_pow[4][mode][0], tab->mu_pow[4][mode][1]);
+            cd carry = F0[o];
+            if (lane == 0) carF[o] = carry;
+            for (int t0 = 0; t0 < nt; t0 += 64) {
+                const int t = t0 + lane;
+                cd x = t < nt ? carF[(t + 1) * 8 + o] : mk(0.0, 0.0);
+                if (lane == 0) x = cfma(mu16, carry, x);
+                x = wave_scan_geometric(x, mu16, lane);
+                if (t < nt) carF[(t + 1) * 8 + o] = x;
+                carry = mk(__shfl(x.re, 63), __shfl(x.im, 63));
+            }
         }
-    }
-    __syncthreads();
-    for (int cc = 0; cc < 2; ++cc) {
-        const int o = wave * 2 + cc, mode = o >> 1, st = o & 1;
-        const cd mu16 = mk(tab->mu_pow[4][mode][0], tab->mu_pow[4][mode][1]);
-        cd G = Gu[o];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const cd Fj = carF[nt * 8 + j * 2 + st];
-            G = cfma(tailF[mode * 4 + j], Fj, G);
-            G = cfma(tailFc[mode * 4 + j], mk(Fj.re, -Fj.im), G);
+        __syncthreads();
+        for (int cc = 0; cc < 2; ++cc) {
+            const int o = wave * 2 + cc, mode = o >> 1, st = o & 1;
+            const cd mu16 = mk(tab->mu_pow[4][mode][0], tab->mu_pow[4][mode][1]);
+            cd G = Gu[o];
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const cd Fj = carF[nt * 8 + j * 2 + st];
+                G = cfma(tailF[mode * 4 + j], Fj, G);
+                G = cfma(tailFc[mode * 4 + j], mk(Fj.re, -Fj.im), G);
+            }
+            if (lane == 0) carG[nt * 8 + o] = G;
+            cd carry = G;
+            for (int t0 = 0; t0 < nt; t0 += 64) {
+                const int t = nt - 1 - (t0 + lane);              // lanes walk the tiles from the right edge
+                cd x = t >= 0 ? carG[t * 8 + o] : mk(0.0, 0.0);
+                if (lane == 0) x = cfma(mu16, carry, x);
+                x = wave_scan_geometric(x, mu16, lane);
+                if (t >= 0) carG[t * 8 + o] = x;
+                carry = mk(__shfl(x.re, 63), __shfl(x.im, 63));
+            }
         }
-        if (lane == 0) carG[nt * 8 + o] = G;
-        cd carry = G;
-        for (int t0 = 0; t0 < nt; t0 += 64) {
-            const int t = nt - 1 - (t0 + lane);              // lanes walk the tiles from the right edge
-            cd x = t >= 0 ? carG[t * 8 + o] : mk(0.0, 0.0);
-            if (lane == 0) x = cfma(mu16, carry, x);
-            x = wave_scan_geometric(x, mu16, lane);
-            if (t >= 0) carG[t * 8 + o] = x;
-            carry = mk(__shfl(x.re, 63), __shfl(x.im, 63));
-        }
-    }
-    __syncthreads();
+        __syncthreads();
 
+    }
     SDRT_STAMP(4);
     // ---- phase 3: add the carried parts at the output blocks -> decimated samples y, stored for the post kernel ---------
     const int stride = tab->out_stride;

@@ -15,13 +15,17 @@ template <> struct I8Enc<SDRT_S16> { static constexpr int slices = 2; static con
 template <> struct I8Enc<SDRT_U16> { static constexpr int slices = 2; static constexpr unsigned xlo = 0x80808080u, xhi = 0x80808080u; };
 }  // namespace
 
-template <int L, int DT, int S>
-__global__ __launch_bounds__(256, 3) void chain_i8t_kernel(DecimArgs a) {
+template <int LB, int DT, int S, int G>
+__global__ __launch_bounds__(256, (G > 1 ? 2 : 3)) void chain_i8t_kernel(DecimArgs a) {
+    // LB = block length (output spacing), a matrix-core column is G consecutive blocks: L = G * LB samples
+    constexpr int L = LB * G;
     constexpr int NSL = I8Enc<DT>::slices;
-    constexpr int KS64 = L / 32;                    // 64-deep MFMA k-steps per block (2 components x 8 samples x 4 lane groups)
+    constexpr int KS64 = L / 32;                    // 64-deep MFMA k-steps per column (2 components x 8 samples x 4 lane groups)
     constexpr int NLV = S + NSL - 1;                // accumulator levels (weight 256^level)
+    constexpr int NR = 2 * (G - 1);                 // rows of the compact mid tile
+    static_assert(G == 1 || G == 2, "columns of 1 or 2 blocks");
     const bool nco = a.nco_tile != nullptr;
-    constexpr int KS = L / 4;                       // k-steps == samples per lane per tile
+    constexpr int KS = L / 4;                       // samples per lane per tile
     constexpr int ITEM = Enc<DT>::size;
     constexpr int BYTES = KS * 2 * ITEM;            // per lane per tile
     constexpr int TILE = SDRT_TB * L;               // samples per tile
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256, 3) void chain_i8t_kernel(DecimArgs a) {
 #define SDRT_STAMP(i) do { if (stp) stp[i] = __builtin_amdgcn_s_memtime(); } while (0)
     SDRT_STAMP(0);
 
-    const LdsLayout lo = lds_layout(n, L, m, 1);
+    const LdsLayout lo = lds_layout(n, LB, m, G);
     cd *base = (cd *) smem;
     cd *o_lds = base + lo.o, *carF = base + lo.carF, *carG = base + lo.carG;
 
@@ -56,21 +60,29 @@ __global__ __launch_bounds__(256, 3) void chain_i8t_kernel(DecimArgs a) {
     const cd *nco_samp_g = nco ? (const cd *) a.nco_tile + (size_t) row * L : nullptr;              // exp(i theta j), j < L
     const cd *nco_blk_g = nco ? (const cd *) a.nco_phase + (size_t) row * (size_t) (n / L) : nullptr;   // exp(i theta L B), B < n/L
 
-    // digit planes of this row -> LDS, in A-operand order [tile][digit][kstep][lane]
+    // digit planes of this row -> LDS, in A-operand order [tile][digit][kstep][lane]; compact mid tile [digit][kstep][kg][NR]
     v4i *w8L = (v4i *) (base + lo.total);
+    v4i *wmL = w8L + 2 * S * KS64 * 64;
     {
         const v4i *wg = (const v4i *) (a.w8 + (size_t) row * (size_t) (2 * S * KS64 * 64 * 16));
         for (int i = tid; i < 2 * S * KS64 * 64; i += 256) w8L[i] = wg[i];
+        if constexpr (G > 1) {
+            const v4i *wm = (const v4i *) (a.w8mid + (size_t) row * (size_t) (S * KS64 * 4 * NR * 16));
+            for (int i = tid; i < S * KS64 * 4 * NR; i += 256) wmL[i] = wm[i];
+        }
     }
+    cd mh = mk(1.0, 0.0);                            // p_g^LB: carries a column-edge state to the mid boundary (G = 2)
+    if constexpr (G > 1) mh = mk(tab->cF[1][g][0], tab->cF[1][g][1]);
+    const double csm = a.w8mid_combine;
     cd mup[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) mup[k] = mk(tab->mu_pow[k][g][0], tab->mu_pow[k][g][1]);
     const double d0p = tab->d0p;
     const double cs = a.w8_combine;
 
-    uint32_t cur[NW], nxt[NW];
+    uint32_t cur[NW];
 #pragma unroll
-    for (int i = 0; i < NW; ++i) { cur[i] = 0; nxt[i] = 0; }
+    for (int i = 0; i < NW; ++i) cur[i] = 0;
     const size_t lane_off = ((size_t) nb * L + (size_t) g * KS) * 2 * ITEM;
     if (wave < nt) load_words<BYTES>(chunk_raw + (size_t) wave * TILE * 2 * ITEM + lane_off, cur);
 
@@ -78,7 +90,6 @@ __global__ __launch_bounds__(256, 3) void chain_i8t_kernel(DecimArgs a) {
     SDRT_STAMP(1);
     // ---- main loop over this wave's tiles, next tile's bytes prefetched ----------------------------------------------
     for (int tile = wave; tile < nt; tile += 4) {
-        if (tile + 4 < nt) load_words<BYTES>(chunk_raw + (size_t) (tile + 4) * TILE * 2 * ITEM + lane_off, nxt);
         cd psi = mk(1.0, 0.0);
         if (nco) psi = nco_blk_g[tile * SDRT_TB + nb];   // phasor common to this lane's block
 
@@ -105,33 +116,58 @@ __global__ __launch_bounds__(256, 3) void chain_i8t_kernel(DecimArgs a) {
                 for (int i = 0; i < 4; ++i) { blo[s][i] = (int) (cur[4 * s + i] ^ I8Enc<DT>::xlo); bhi[s][i] = 0; }
         }
         // stage A on the int8 matrix cores: per row tile (0 causal, 1 anticausal) S digit planes x slices, exact int32 sums
-        double val[8];
-        static_for<0, 2>([&](auto tc) {
-            constexpr int rt = decltype(tc)::value;
-            v4i acc[NLV];
+        // the slices are extracted: the raw words are free, start the next tile's loads right away (a full tile of lead)
+        if (tile + 4 < nt) load_words<BYTES>(chunk_raw + (size_t) (tile + 4) * TILE * 2 * ITEM + lane_off, cur);
+        double val[8], midv[NR > 0 ? NR : 1];
+        // Stage A on the int8 matrix cores.  Steps = (row tile, k-step) pairs; the S digit-plane fragments of step i+1 are
+        // read from LDS while the 2S matrix instructions of step i issue (two register sets, statically alternated).
+        constexpr int NT = G > 1 ? 3 : 2, NSTEP = NT * KS64;
+        v4i Afrag[2][S];
+        auto load_frags = [&](auto ic, v4i *dst) {
+            constexpr int i = decltype(ic)::value, rt = i / KS64, s = i % KS64;
+            static_for<0, S>([&](auto dc) {
+                constexpr int d = decltype(dc)::value;
+                if constexpr (rt < 2) {
+                    dst[d] = w8L[((rt * S + d) * KS64 + s) * 64 + lane];
+                } else {
+                    dst[d] = (v4i) {0, 0, 0, 0};
+                    if (nb < NR) dst[d] = wmL[((d * KS64 + s) * 4 + g) * NR + nb];    // A operand: lane = row + 16 kg
+                }
+            });
+        };
+        load_frags(std::integral_constant<int, 0>{}, Afrag[0]);
+        v4i acc[NLV];
+        static_for<0, NSTEP>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, rt = i / KS64, s = i % KS64;
+            if constexpr (s == 0) {
 #pragma unroll
-            for (int q = 0; q < NLV; ++q) acc[q] = (v4i) {0, 0, 0, 0};
-            static_for<0, KS64>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                static_for<0, S>([&](auto dc) {
-                    constexpr int d = decltype(dc)::value;
-                    const v4i A = w8L[((rt * S + d) * KS64 + s) * 64 + lane];
-                    acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo[s], acc[d], 0, 0, 0);
-                    if constexpr (NSL == 2) acc[d + 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi[s], acc[d + 1], 0, 0, 0);
-                });
+                for (int q = 0; q < NLV; ++q) acc[q] = (v4i) {0, 0, 0, 0};
+            }
+            // keep the order: next step's LDS reads first, then this step's matrix instructions (hipcc would otherwise sink
+            // every read to just before its consumer and wait for it there)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i + 1 < NSTEP) load_frags(std::integral_constant<int, i + 1>{}, Afrag[(i + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, S>([&](auto dc) {
+                constexpr int d = decltype(dc)::value;
+                acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Afrag[i & 1][d], blo[s], acc[d], 0, 0, 0);
+                if constexpr (NSL == 2) acc[d + 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Afrag[i & 1][d], bhi[s], acc[d + 1], 0, 0, 0);
             });
-            // value = cs * sum_q 256^q acc[q]: pairs of levels first in int32 (|acc| <= 2^22), then fp64
-            static_for<0, 4>([&](auto vc) {
-                constexpr int v = decltype(vc)::value;
-                double dsum = 0.0;
-                static_for<0, (NLV + 1) / 2>([&](auto pp) {
-                    constexpr int p = (NLV + 1) / 2 - 1 - decltype(pp)::value;
-                    int t = acc[2 * p][v];
-                    if constexpr (2 * p + 1 < NLV) t += acc[2 * p + 1][v] * 256;
-                    dsum = fma(dsum, 65536.0, (double) t);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (s == KS64 - 1) {
+                // value = cs * sum_q 256^q acc[q]: pairs of levels first in int32 (|acc| <= 2^22), then fp64
+                static_for<0, (rt < 2 ? 4 : NR)>([&](auto vc) {
+                    constexpr int v = decltype(vc)::value;
+                    double dsum = 0.0;
+                    static_for<0, (NLV + 1) / 2>([&](auto pp) {
+                        constexpr int p = (NLV + 1) / 2 - 1 - decltype(pp)::value;
+                        int t = acc[2 * p][v];
+                        if constexpr (2 * p + 1 < NLV) t += acc[2 * p + 1][v] * 256;
+                        dsum = fma(dsum, 65536.0, (double) t);
+                    });
+                    if constexpr (rt < 2) val[4 * rt + v] = dsum * cs; else midv[v] = dsum * csm;
                 });
-                val[4 * rt + v] = dsum * cs;
-            });
+            }
         });
         // result layout of the 16x16 tile: lane (g, nb) register v = row 4 g + v of column nb: mode g, v = 2*stream + part
         cd Cr = mk(val[0], val[1]), Ci = mk(val[2], val[3]), Ar = mk(val[4], val[5]), Ai = mk(val[6], val[7]);
@@ -147,6 +183,11 @@ __global__ __launch_bounds__(256, 3) void chain_i8t_kernel(DecimArgs a) {
             const double tr = psi.re * u0r - psi.im * u0i;
             u0i = psi.im * u0r + psi.re * u0i;
             u0r = tr;
+            if constexpr (G > 1) {
+                const double t2 = psi.re * midv[0] - psi.im * midv[1];
+                midv[1] = psi.im * midv[0] + psi.re * midv[1];
+                midv[0] = t2;
+            }
         }
         // in-tile inclusive scans over the 16 blocks (lanes of one DPP row): causal with row_shr, anticausal with row_shl
         Cr = cfma(mup[0], dpp_row<0x111>(Cr), Cr);
@@ -177,9 +218,21 @@ __global__ __launch_bounds__(256, 3) void chain_i8t_kernel(DecimArgs a) {
         pi += __shfl_xor(pi, 16);
         pr += __shfl_xor(pr, 32);
         pi += __shfl_xor(pi, 32);
-        if (g == 0) o_lds[tile * SDRT_TB + nb] = mk(pr, pi);
-#pragma unroll
-        for (int i = 0; i < NW; ++i) cur[i] = nxt[i];
+        if (g == 0) o_lds[(tile * SDRT_TB + nb) * G] = mk(pr, pi);
+        if constexpr (G > 1) {
+            // output at the mid boundary: column-local part (mid tile, valid in the g == 0 lanes) + the states at the column's
+            // edges carried by p^LB: 2 Re sum_modes p^LB ( causal state at the column start + anticausal state at its end )
+            const cd Cxr = mk(cexr, dpp_row<0x111>(Cr.im)), Cxi = mk(cexi, dpp_row<0x111>(Ci.im));
+            const cd Axr = dpp_row<0x101>(Ar), Axi = dpp_row<0x101>(Ai);
+            double qr = 2.0 * (mh.re * (Cxr.re + Axr.re) - mh.im * (Cxr.im + Axr.im));
+            double qi = 2.0 * (mh.re * (Cxi.re + Axi.re) - mh.im * (Cxi.im + Axi.im));
+            if (g == 0) { qr += midv[0]; qi += midv[1]; }
+            qr += __shfl_xor(qr, 16);
+            qi += __shfl_xor(qi, 16);
+            qr += __shfl_xor(qr, 32);
+            qi += __shfl_xor(qi, 32);
+            if (g == 0) o_lds[(tile * SDRT_TB + nb) * G + 1] = mk(qr, qi);
+        }
     }
     SDRT_STAMP(2);
 #undef SDRT_STAMP
@@ -193,7 +246,7 @@ __global__ __launch_bounds__(256, 3) void chain_i8t_kernel(DecimArgs a) {
         }
         return mk(xr, xi);
     };
-    chain_tail(a, L, row, chunk, smem, stp, edge, a.ybias ? (const cd *) a.ybias + (size_t) row * m : (const cd *) nullptr);
+    chain_tail(a, LB, row, chunk, smem, stp, edge, a.ybias ? (const cd *) a.ybias + (size_t) row * m : (const cd *) nullptr);
 }
 
 
@@ -222,21 +275,23 @@ __global__ void i8t_selftest_kernel(const int *A, const int *B, int *D) {
 
 // ---- launch helpers -----------------------------------------------------------------------------------------------
 bool chain_i8t_supported(int L, int dt, int n) {
-    return (L == 32 || L == 64) && (dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16) && n % (SDRT_TB * L) == 0;
+    return (L == 32 || L == 64) && (dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16) &&
+           n % (SDRT_TB * L * SDRT_I8T_G) == 0;
 }
 
 size_t chain_i8t_lds_bytes(int n, int L, int m) {
-    return (size_t) lds_layout(n, L, m, 1).total * 16 + (size_t) 2 * SDRT_I8_DIGITS * (L / 32) * 64 * 16;
+    const int G = SDRT_I8T_G, KS = L * G / 32, NR = 2 * (G - 1);
+    return (size_t) lds_layout(n, L, m, G).total * 16 + (size_t) SDRT_I8_DIGITS * KS * (2 * 64 + 4 * NR) * 16;
 }
 
 template <int L, int DT>
 static hipError_t launch_i8t_k(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *) chain_i8t_kernel<L, DT, SDRT_I8_DIGITS>,
+        hipError_t e = hipFuncSetAttribute((const void *) chain_i8t_kernel<L, DT, SDRT_I8_DIGITS, SDRT_I8T_G>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((chain_i8t_kernel<L, DT, SDRT_I8_DIGITS>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((chain_i8t_kernel<L, DT, SDRT_I8_DIGITS, SDRT_I8T_G>), grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

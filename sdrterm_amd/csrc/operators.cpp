@@ -136,6 +136,7 @@ extern "C" int sdrt_build_decim_tables(const double *sos, int sections, int q, i
         }
         const int pw[5] = {1, 2, 4, 8, 16};
         for (int k = 0; k < 5; ++k) put(out->mu_pow[k][i], cpow(mu[i], G * pw[k]));      // column-to-column powers
+        for (int k = 0; k <= SDRT_TPOW; ++k) put(out->tpow[k][i], cpow(mu[i], SDRT_TB * G * k));
         for (int nb = 0; nb < SDRT_TB * G; ++nb) {
             put(out->cF[nb][i], cpow(mu[i], nb));
             put(out->cG[nb][i], cpow(mu[i], SDRT_TB * G - nb));
@@ -420,22 +421,32 @@ extern "C" int sdrt_build_i8_weights(const double *sos, int sections, const Deci
 }
 
 extern "C" int sdrt_build_i8_weights16(const double *sos, int sections, const DecimTables *tab, double data_scale,
-                                       const double *nco_samp, int S, signed char *out, double *combine) {
+                                       const double *nco_samp, int S, signed char *out, double *combine,
+                                       signed char *mid_out, double *mid_combine) {
     Modal m;
     const char *err = nullptr;
     if (!build_modal(sos, sections, m, &err)) return -2;
-    const int L = tab->L, cols = 2 * L, KS = L / 32;
-    if (L % 32) return -3;
+    const int L = tab->L, G = tab->G, LC = L * G, cols = 2 * LC, KS = LC / 32;
+    if (LC % 32) return -3;
+    auto tr = [&](int t) { return nco_samp ? nco_samp[2 * t] : 1.0; };
+    auto ti = [&](int t) { return nco_samp ? nco_samp[2 * t + 1] : 0.0; };
+    auto kpos = [&](int c, int &ks, int &kg, int &j) {
+        const int sample = c >> 1, comp = c & 1;
+        kg = sample / (LC / 4);
+        const int within = sample % (LC / 4);
+        ks = within / 8;
+        j = 2 * (within % 8) + comp;
+    };
     std::vector<double> Wf((size_t) 32 * cols, 0.0);          // rows 0..15 causal tile, 16..31 anticausal tile
-    for (int mode = 0; mode < 4; ++mode) {
-        const C P = m.p[2 * mode], ac = m.alpha[2 * mode], aa = m.alpha[2 * mode] / P;
+    C P[4], ac[4], aa[4];
+    for (int i = 0; i < 4; ++i) { P[i] = m.p[2 * i]; ac[i] = m.alpha[2 * i]; aa[i] = m.alpha[2 * i] / P[i]; }
+    for (int mode = 0; mode < 4; ++mode)
         for (int kind = 0; kind < 2; ++kind)
-            for (int t = 0; t < L; ++t) {
-                const C w = kind == 0 ? ac * cpow(P, L - 1 - t) : aa * cpow(P, t);
+            for (int t = 0; t < LC; ++t) {
+                const C w = kind == 0 ? ac[mode] * cpow(P[mode], LC - 1 - t) : aa[mode] * cpow(P[mode], t);
                 const double wr = (double) w.re * data_scale, wi = (double) w.im * data_scale;
-                const double tr = nco_samp ? nco_samp[2 * t] : 1.0, ti = nco_samp ? nco_samp[2 * t + 1] : 0.0;
-                const double cxr[2][2] = {{wr * tr, wi * tr}, {wr * ti, wi * ti}};        // [stream][part], coefficient of xr
-                const double cxi[2][2] = {{-wr * ti, -wi * ti}, {wr * tr, wi * tr}};      // coefficient of xi
+                const double cxr[2][2] = {{wr * tr(t), wi * tr(t)}, {wr * ti(t), wi * ti(t)}};      // [stream][part], coefficient of xr
+                const double cxi[2][2] = {{-wr * ti(t), -wi * ti(t)}, {wr * tr(t), wi * tr(t)}};    // coefficient of xi
                 for (int stream = 0; stream < 2; ++stream)
                     for (int part = 0; part < 2; ++part) {
                         const int r = 16 * kind + 4 * mode + 2 * stream + part;
@@ -443,13 +454,40 @@ extern "C" int sdrt_build_i8_weights16(const double *sos, int sections, const De
                         Wf[(size_t) r * cols + 2 * t + 1] = cxi[stream][part];
                     }
             }
-    }
     *combine = quantise_planes(Wf.data(), 32, cols, cols, S, [&](int d, int r, int c, signed char dig) {
-        const int tile = r >> 4, row = r & 15, sample = c >> 1, comp = c & 1;
-        const int kg = sample / (L / 4), within = sample % (L / 4), ks = within / 8, j = 2 * (within % 8) + comp;
-        out[(((((size_t) tile * S + d) * KS + ks) * 64) + (row + 16 * kg)) * 16 + j] = dig;
+        int ks, kg, j;
+        kpos(c, ks, kg, j);
+        out[(((((size_t) (r >> 4) * S + d) * KS + ks) * 64) + ((r & 15) + 16 * kg)) * 16 + j] = dig;
     });
-    return *combine == 0.0 ? -1 : 0;
+    if (*combine == 0.0) return -1;
+    if (G > 1) {
+        const int NR = 2 * (G - 1);
+        C sum_a_over_p(0);
+        for (int i = 0; i < 8; ++i) sum_a_over_p = sum_a_over_p + m.alpha[i] / m.p[i];
+        const double d0p = (double) (m.d0 - sum_a_over_p.re) * data_scale;
+        std::vector<double> Wm((size_t) NR * cols, 0.0);
+        for (int g = 1; g < G; ++g)
+            for (int t = 0; t < LC; ++t) {
+                R acc = 0;
+                for (int i = 0; i < 4; ++i) {
+                    const C w = t < L * g ? ac[i] * cpow(P[i], L * g - 1 - t) : aa[i] * cpow(P[i], t - L * g);
+                    acc = acc + 2 * w.re;
+                }
+                double mt = (double) acc * data_scale;
+                if (t == L * g) mt += d0p;
+                Wm[(size_t) (0 + 2 * (g - 1)) * cols + 2 * t] = mt * tr(t);        // stream re: mt (xr tr - xi ti)
+                Wm[(size_t) (0 + 2 * (g - 1)) * cols + 2 * t + 1] = -mt * ti(t);
+                Wm[(size_t) (1 + 2 * (g - 1)) * cols + 2 * t] = mt * ti(t);        // stream im: mt (xr ti + xi tr)
+                Wm[(size_t) (1 + 2 * (g - 1)) * cols + 2 * t + 1] = mt * tr(t);
+            }
+        *mid_combine = quantise_planes(Wm.data(), NR, cols, cols, S, [&](int d, int r, int c, signed char dig) {
+            int ks, kg, j;
+            kpos(c, ks, kg, j);
+            mid_out[(((((size_t) d * KS + ks) * 4 + kg) * NR) + r) * 16 + j] = dig;
+        });
+        if (*mid_combine == 0.0) return -1;
+    }
+    return 0;
 }
 
 extern "C" void sdrt_build_iq_pow(double lambda, int count, double *pw) {

@@ -8,6 +8,7 @@
 #define SDRT_GMAX 2         // blocks per column: 1 (f64 kernel), 1 or 2 (int8 kernel)
 #define SDRT_EDGE 27        // sosfiltfilt odd-extension length for the order-8 decimator (3 * (2*4+1))
 #define SDRT_NMODE 4        // conjugate pole pairs of the order-8 decimator
+#define SDRT_TPOW 64        // tile-carry chains up to this many tiles are summed directly (powers tabulated), longer ones scanned
 
 // Zero-phase decimator in modal block form (see DESIGN.md "Decimator").  All complex numbers are {re, im}.
 struct DecimTables {
@@ -23,6 +24,7 @@ struct DecimTables {
     double mu_pow[5][SDRT_NMODE][2];    // mu_i^(1,2,4,8,16), mu_i = p_i^(L G)   (column-to-column multiplier)
     double cF[SDRT_TB * SDRT_GMAX][SDRT_NMODE][2];  // p_i^(L nb)          carry-in of the causal state to block nb of a tile
     double cG[SDRT_TB * SDRT_GMAX][SDRT_NMODE][2];  // p_i^(L (16 G - nb)) carry-in of the anticausal state
+    double tpow[SDRT_TPOW + 1][SDRT_NMODE][2];      // (p_i^(16 G L))^k: tile-to-tile multiplier powers
     double d0p;                          // direct term
     double head[SDRT_NMODE][SDRT_EDGE + 1][2];   // F_0,i = sum_l head[i][l] * u[l]            (per real stream)
     double tailF[SDRT_NMODE][SDRT_NMODE][2];     // G_end,i = sum_j tailF[i][j] F_j + tailFc[i][j] conj(F_j)
@@ -76,13 +78,18 @@ int sdrt_build_i8_weights(const double *sos, int sections, const struct DecimTab
                           const double *nco_samp, int S, signed char *main_out, double *main_combine,
                           signed char *mid_out, double *mid_combine);
 
-// Digit planes for the 16x16x64 int8 matrix-core kernel (chain_i8t_kernel): two row tiles of 16 rows, tile 0 = causal,
-// tile 1 = anticausal aggregates of a block of L samples; row = 4*mode + 2*stream + part.  Layout = MFMA A-operand order:
-//   out[(((tile*S + digit)*(L/32) + kstep)*64 + lane)*16 + j],  lane = row + 16*kg,
-//   K position (kstep, kg, j) <-> sample kg*(L/4) + 8*kstep + (j>>1), component j&1.
-// One power-of-two scale for both tiles; *combine as above.  nco_samp: [L][2] or NULL.  `tab` built with G = 1.
+// Digit planes for the 16x16x64 int8 matrix-core kernel (chain_i8t_kernel).  A column is LC = G*L samples.  Two row tiles
+// of 16 rows: tile 0 = causal, tile 1 = anticausal aggregates of the column; row = 4*mode + 2*stream + part.  For G > 1 a
+// third, compact tile holds per internal block boundary g and stream the column-local part of that boundary's output
+// (row stream + 2*(g-1), NR = 2*(G-1) rows).  Layouts (MFMA A-operand order, KS = LC/32 k-steps):
+//   out [(((tile*S + digit)*KS + kstep)*64 + lane)*16 + j],  lane = row + 16*kg
+//   mid [((((digit*KS + kstep)*4 + kg)*NR) + row)*16 + j]
+//   K position (kstep, kg, j) <-> sample kg*(LC/4) + 8*kstep + (j>>1), component j&1.
+// One power-of-two scale for tiles 0/1 (*combine) and one for the mid tile (*mid_combine).  nco_samp: [LC][2] or NULL.
+// `tab` must have been built with the same G.
 int sdrt_build_i8_weights16(const double *sos, int sections, const struct DecimTables *tab, double data_scale,
-                            const double *nco_samp, int S, signed char *out, double *combine);
+                            const double *nco_samp, int S, signed char *out, double *combine, signed char *mid_out,
+                            double *mid_combine);
 
 // IQ-correction geometric weights: pw[j] = (1-lambda)^j, j <= count.
 void sdrt_build_iq_pow(double lambda, int count, double *pw);
