@@ -62,13 +62,13 @@ def cpu_baseline(raw_bytes, budget_s=12.0):
     dec, outs = ref_chain.cheby_sos(Q), ref_chain.ellip_sos(FS // Q, OMEGA_OUT)
     chunk_b = N * 4
     avail = len(raw_bytes) // chunk_b
-    probe = min(avail, 2 * threads)
+    want = max(threads, (avail // threads) * threads)
+    # warm (thread pool, page faults), then a timed probe pass to size the bounded sample to ~budget_s of CPU work
+    c_chain.process_stream(raw_bytes[:want * chunk_b], 'h', N, Q, 'fm', shift, dec, outs, threads=threads)
     t0 = time.perf_counter()
-    c_chain.process_stream(raw_bytes[:probe * chunk_b], 'h', N, Q, 'fm', shift, dec, outs, threads=threads)
-    dt = max(time.perf_counter() - t0, 1e-6)
-    want = int(min(avail, max(probe, probe * budget_s / dt)))
-    want = max(threads, (want // threads) * threads)
-    reps = max(1, int(round(probe * budget_s / dt / want)))
+    c_chain.process_stream(raw_bytes[:want * chunk_b], 'h', N, Q, 'fm', shift, dec, outs, threads=threads)
+    dt1 = max(time.perf_counter() - t0, 1e-6)
+    reps = max(1, min(200, int(round(budget_s / dt1))))
     t0 = time.perf_counter()
     for _ in range(reps):
         c_chain.process_stream(raw_bytes[:want * chunk_b], 'h', N, Q, 'fm', shift, dec, outs, threads=threads)
@@ -76,6 +76,19 @@ def cpu_baseline(raw_bytes, budget_s=12.0):
     return {'value': round(reps * want * N / dt / 1e6, 3), 'unit': 'MSamples/s', 'cores': threads, 'kind': 'port',
             'sample': f'{reps} pass(es) over {want} chunks x {N} samples of the same int16 FM stream, oracle/chain.c '
                       f'(fp64 C port of the reference chain), {threads} OpenMP threads, {dt:.1f} s'}
+
+
+def measured_traffic(kernel_name, n_chunks):
+    """HBM bytes per launch of the chain kernel from the rocprofv3 PMC passes (tools/pmc.sh; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE), if a measurement of this workload is committed."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if rec.get('chunks_per_step_per_gpu') != n_chunks or rec.get('kernel') not in kernel_name:
+        return None
+    return rec.get('hbm_bytes_per_launch')
 
 
 def main():
@@ -153,9 +166,10 @@ def main():
                                    f'dec={Q}, single VFO, center={CENTER} Hz, {n_chunks} chunks x {N} samples per GPU per step, '
                                    'inputs resident in HBM',
                        'chunks_per_step_per_gpu': n_chunks, 'samples_per_chunk': N, 'parallelism': f'chunk-sharded x{world}'},
-            'roofline': {'bound': 'hbm', 'kernel': 'chain_kernel', 'achieved': round(achieved, 1),
+            'roofline': {'bound': 'hbm', 'kernel': 'chain_i8t_kernel' if eng.stage_a == 'i8' else 'chain_kernel', 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': None, 'avg_kernel_ms': round(k_avg_s * 1e3, 4), 'launches': k_n,
+                         'traffic': measured_traffic('chain_i8t_kernel' if eng.stage_a == 'i8' else 'chain_kernel', n_chunks),
+                         'avg_kernel_ms': round(k_avg_s * 1e3, 4), 'launches': k_n,
                          'alg_bytes_per_sample': ALG_BYTES_PER_SAMPLE,
                          'fp64_frac': round(FP64_FLOP_PER_SAMPLE * n_samples / k_avg_s / 1e12 / FP64_PEAK_TFLOPS, 4)},
             'kernels_ms': {'chain_kernel': round(k_ms / max(k_n, 1), 4), 'post_kernel': round(p_ms / max(p_n, 1), 4)},
