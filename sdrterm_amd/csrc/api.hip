@@ -179,8 +179,8 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     if (n % q) return fail(SDRT_EINVAL, "decimation must divide n_samples");   // dsp_processor.py:147,173
     const int m = n / q;
     if (cfg->mode == SDRT_FM && (m < 2 || (m & 1))) return fail(SDRT_EINVAL, "FM needs an even number of outputs per chunk");
-    if (cfg->correct_iq && (n % 256 || (n / 256) % (L / 4)))
-        return fail(SDRT_EINVAL, "correct_iq needs n_samples to be a multiple of %d", 256 * (L / 4));
+    if (cfg->correct_iq && n / (L / 4) < 256)
+        return fail(SDRT_EINVAL, "correct_iq needs at least %d samples per chunk", 256 * (L / 4));
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -242,7 +242,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         std::vector<double> tmp((size_t) n + 1);
         sdrt_build_iq_pow(cfg->iq_inductance, n, tmp.data());
         for (int k = 0; k <= ng; ++k) pwg[k] = tmp[(size_t) k * gs];
-        c->iq_pow_e = tmp[n / 256];
+        c->iq_pow_e = tmp[gs];                 // (1-lambda)^GS
         c->iq_pow_n = tmp[n];
         rc = upload(&c->d_iq_pow, pwg.data(), pwg.size() * sizeof(double));
         if (rc == SDRT_OK) {
@@ -485,7 +485,8 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
         ia.swap = da.swap;
         ia.norm_bias = c->norm_bias;
         ia.lambda = c->cfg.iq_inductance;
-        ia.pow_e = c->iq_pow_e;
+        ia.pow_tab = c->d_iq_pow;
+        ia.pow_g = c->iq_pow_e;
         ia.pow_n = c->iq_pow_n;
         {
             Timed t(c, s, 2);

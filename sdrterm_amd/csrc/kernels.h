@@ -44,7 +44,8 @@ struct IqArgs {
     double *state;              // [2] carried offset (in/out, scan kernel)
     size_t n_chunks;
     int n, gs, dt, swap;
-    double norm_bias, lambda, pow_e /* (1-lambda)^(n/256) */, pow_n /* (1-lambda)^n */;
+    const double *pow_tab;      // [n/GS + 1] (1-lambda)^(GS k)  (same table the chain kernel uses)
+    double norm_bias, lambda, pow_g /* (1-lambda)^GS */, pow_n /* (1-lambda)^n */;
 };
 hipError_t launch_iq_local(const IqArgs &a, hipStream_t s);
 hipError_t launch_iq_scan(const IqArgs &a, hipStream_t s);

@@ -186,62 +186,72 @@ __global__ __launch_bounds__(256, 4) void chain_kernel(DecimArgs a) {
 // end value; iq_scan_kernel chains the chunks (and carries the stream state); the chain kernel then adds
 // (1-lambda)^position * offset(chunk start) to the local values.
 // ---------------------------------------------------------------------------------------------------------------
-template <int DT>
-__device__ __forceinline__ void iq_load(const unsigned char *chunk_raw, long j, bool swap, double nbias, double &xr, double &xi) {
-    typedef typename Enc<DT>::raw raw_t;
-    const raw_t *rp = (const raw_t *) chunk_raw + 2 * j;
-    xr = decode<DT>(rp[0], swap) + nbias;
-    xi = decode<DT>(rp[1], swap);
-}
 
-template <int DT>
+// One workgroup per chunk, one pass over the data.  Lane = one group of GS consecutive samples (a contiguous 2*GS*item
+// bytes, read with the widest loads); 256 groups per sweep, n/(256 GS) sweeps.  Per sweep: the lane's own aggregate
+// (GS steps of the recurrence from zero), an inclusive scan of the aggregates over the 256 lanes with multiplier
+// (1-lambda)^GS (wave shuffles + 4 wave totals through LDS), and the carry of the previous sweeps.  The exclusive value is
+// the offset at the group's first sample when the chunk starts from zero.
+template <int DT, int GS>
 __global__ __launch_bounds__(256) void iq_local_kernel(IqArgs a) {
+    constexpr int ITEM = Enc<DT>::size;
+    constexpr int BYTES = GS * 2 * ITEM;
+    constexpr int NW = BYTES < 4 ? 1 : BYTES / 4;
     __shared__ cd wtot[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long chunk = blockIdx.x;
-    const int n = a.n, E = n / 256, gs = a.gs;          // E consecutive samples per thread, E % gs == 0
-    const unsigned char *chunk_raw = (const unsigned char *) a.raw + (size_t) chunk * (size_t) n * 2 * Enc<DT>::size;
+    const int n = a.n, ngroups = n / GS;
+    const unsigned char *chunk_raw = (const unsigned char *) a.raw + (size_t) chunk * (size_t) n * 2 * ITEM;
     const bool swap = a.swap != 0;
-    const double lam = a.lambda, om = 1.0 - lam;
-    // pass 1: this thread's E samples from a zero offset
-    cd s = mk(0.0, 0.0);
-    for (int e = 0; e < E; ++e) {
-        double xr, xi;
-        iq_load<DT>(chunk_raw, (long) tid * E + e, swap, a.norm_bias, xr, xi);
-        s.re = fma(om, s.re, lam * xr);
-        s.im = fma(om, s.im, lam * xi);
-    }
-    // scan over threads with multiplier (1-lambda)^E (real): wave-level Hillis-Steele, then wave totals
-    double mp = a.pow_e;
+    const double lam = a.lambda, om = 1.0 - lam, nbias = a.norm_bias;
+    const double ag = a.pow_g;                         // (1-lambda)^GS
+    double mp[6];                                      // ag^(1,2,4,...,32)
+    mp[0] = ag;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int d = 1 << i;
-        double tr = __shfl_up(s.re, d), ti = __shfl_up(s.im, d);
-        if (lane < d) { tr = 0.0; ti = 0.0; }
-        s.re = fma(mp, tr, s.re);
-        s.im = fma(mp, ti, s.im);
-        mp *= mp;
+    for (int i = 1; i < 6; ++i) mp[i] = mp[i - 1] * mp[i - 1];
+    const double ag64 = mp[5] * mp[5];                 // (1-lambda)^(64 GS): one wave
+    const double plane = a.pow_tab[lane], ptid = a.pow_tab[tid];          // (1-lambda)^(GS lane), (1-lambda)^(GS tid)
+    const double ag256 = a.pow_tab[256];
+    cd carry = mk(0.0, 0.0);                           // offset at the first sample of the current sweep
+    cd *gout = (cd *) a.group_off + (size_t) chunk * (size_t) ngroups;
+    for (int g0 = 0; g0 < ngroups; g0 += 256) {
+        const int grp = g0 + tid;
+        cd s = mk(0.0, 0.0);
+        if (grp < ngroups) {
+            uint32_t wds[NW];
+            load_words<BYTES>(chunk_raw + (size_t) grp * BYTES, wds);
+            static_for<0, GS>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const double xr = decode<DT>(get_item<DT, 2 * j>(wds), swap) + nbias;
+                const double xi = decode<DT>(get_item<DT, 2 * j + 1>(wds), swap);
+                s.re = fma(om, s.re, lam * xr);
+                s.im = fma(om, s.im, lam * xi);
+            });
+        }
+        __syncthreads();                               // wtot of the previous sweep has been consumed
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int d = 1 << i;
+            double tr = __shfl_up(s.re, d), ti = __shfl_up(s.im, d);
+            if (lane < d) { tr = 0.0; ti = 0.0; }
+            s.re = fma(mp[i], tr, s.re);
+            s.im = fma(mp[i], ti, s.im);
+        }
+        if (lane == 63) wtot[wave] = s;
+        __syncthreads();
+        cd ex = mk(__shfl_up(s.re, 1), __shfl_up(s.im, 1));
+        if (lane == 0) ex = mk(0.0, 0.0);
+        cd wp = mk(0.0, 0.0);                          // offset at the start of this wave, relative to the sweep start
+        for (int wv = 0; wv < wave; ++wv) wp = mk(fma(ag64, wp.re, wtot[wv].re), fma(ag64, wp.im, wtot[wv].im));
+        // offset at this group's first sample = (carry propagated over tid groups) + (wave start propagated over lane groups) + ex
+        const cd off = mk(fma(ptid, carry.re, fma(plane, wp.re, ex.re)), fma(ptid, carry.im, fma(plane, wp.im, ex.im)));
+        if (grp < ngroups) gout[grp] = off;
+        // carry to the next sweep: everything of this sweep + the old carry over 256 groups
+        cd tot = mk(0.0, 0.0);
+        for (int wv = 0; wv < 4; ++wv) tot = mk(fma(ag64, tot.re, wtot[wv].re), fma(ag64, tot.im, wtot[wv].im));
+        carry = mk(fma(ag256, carry.re, tot.re), fma(ag256, carry.im, tot.im));
     }
-    if (lane == 63) wtot[wave] = s;
-    __syncthreads();
-    const double pw64 = mp;                          // (1-lambda)^(64E)
-    cd ex = mk(__shfl_up(s.re, 1), __shfl_up(s.im, 1));
-    if (lane == 0) ex = mk(0.0, 0.0);
-    cd wp = mk(0.0, 0.0);
-    for (int wv = 0; wv < wave; ++wv) wp = mk(fma(pw64, wp.re, wtot[wv].re), fma(pw64, wp.im, wtot[wv].im));
-    double pl = 1.0;                                 // (1-lambda)^(E*lane)
-    for (int i = 0; i < lane; ++i) pl *= a.pow_e;
-    cd off = mk(fma(pl, wp.re, ex.re), fma(pl, wp.im, ex.im));   // offset at this thread's first sample
-    // pass 2: replay from the true local start, tabulating the offset at every group start
-    cd *gout = (cd *) a.group_off + (size_t) chunk * (size_t) (n / gs) + (size_t) tid * (E / gs);
-    for (int e = 0; e < E; ++e) {
-        if (e % gs == 0) gout[e / gs] = off;
-        double xr, xi;
-        iq_load<DT>(chunk_raw, (long) tid * E + e, swap, a.norm_bias, xr, xi);
-        off.re = fma(om, off.re, lam * xr);
-        off.im = fma(om, off.im, lam * xi);
-    }
-    if (tid == 255) ((cd *) a.chunk_agg)[chunk] = off;
+    if (tid == 0) ((cd *) a.chunk_agg)[chunk] = carry;     // offset at the end of the chunk when it starts from zero
 }
 
 // one workgroup: chunk offsets off[c+1] = (1-lambda)^n off[c] + agg[c], off[0] = carried state
@@ -281,20 +291,31 @@ __global__ __launch_bounds__(256) void iq_scan_kernel(IqArgs a) {
     }
 }
 
-hipError_t launch_iq_local(const IqArgs &a, hipStream_t s) {
-    const dim3 grid((unsigned) a.n_chunks);
-    switch (a.dt) {
-        case SDRT_S8: hipLaunchKernelGGL(iq_local_kernel<SDRT_S8>, grid, dim3(256), 0, s, a); break;
-        case SDRT_U8: hipLaunchKernelGGL(iq_local_kernel<SDRT_U8>, grid, dim3(256), 0, s, a); break;
-        case SDRT_S16: hipLaunchKernelGGL(iq_local_kernel<SDRT_S16>, grid, dim3(256), 0, s, a); break;
-        case SDRT_U16: hipLaunchKernelGGL(iq_local_kernel<SDRT_U16>, grid, dim3(256), 0, s, a); break;
-        case SDRT_S32: hipLaunchKernelGGL(iq_local_kernel<SDRT_S32>, grid, dim3(256), 0, s, a); break;
-        case SDRT_U32: hipLaunchKernelGGL(iq_local_kernel<SDRT_U32>, grid, dim3(256), 0, s, a); break;
-        case SDRT_F32: hipLaunchKernelGGL(iq_local_kernel<SDRT_F32>, grid, dim3(256), 0, s, a); break;
-        case SDRT_F64: hipLaunchKernelGGL(iq_local_kernel<SDRT_F64>, grid, dim3(256), 0, s, a); break;
+template <int DT>
+static hipError_t launch_iq_local_dt(const IqArgs &a, dim3 grid, hipStream_t s) {
+    switch (a.gs) {
+        case 2: hipLaunchKernelGGL((iq_local_kernel<DT, 2>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((iq_local_kernel<DT, 4>), grid, dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((iq_local_kernel<DT, 8>), grid, dim3(256), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((iq_local_kernel<DT, 16>), grid, dim3(256), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+hipError_t launch_iq_local(const IqArgs &a, hipStream_t s) {
+    const dim3 grid((unsigned) a.n_chunks);
+    switch (a.dt) {
+        case SDRT_S8: return launch_iq_local_dt<SDRT_S8>(a, grid, s);
+        case SDRT_U8: return launch_iq_local_dt<SDRT_U8>(a, grid, s);
+        case SDRT_S16: return launch_iq_local_dt<SDRT_S16>(a, grid, s);
+        case SDRT_U16: return launch_iq_local_dt<SDRT_U16>(a, grid, s);
+        case SDRT_S32: return launch_iq_local_dt<SDRT_S32>(a, grid, s);
+        case SDRT_U32: return launch_iq_local_dt<SDRT_U32>(a, grid, s);
+        case SDRT_F32: return launch_iq_local_dt<SDRT_F32>(a, grid, s);
+        case SDRT_F64: return launch_iq_local_dt<SDRT_F64>(a, grid, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_iq_scan(const IqArgs &a, hipStream_t s) {
