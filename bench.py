@@ -152,6 +152,7 @@ def main():
     eng.profile(False)
     assert bool(torch.isfinite(out).all()), 'non-finite output'
 
+    KERNEL_OF = {'i8w': 'chain_i8w_kernel', 'i8t': 'chain_i8t_kernel', 'i8x32': 'chain_i8_kernel', 'f64': 'chain_kernel'}
     if rank == 0:
         total_samples = float(n_samples) * args.steps * world
         value = total_samples / elapsed / 1e6
@@ -166,9 +167,9 @@ def main():
                                    f'dec={Q}, single VFO, center={CENTER} Hz, {n_chunks} chunks x {N} samples per GPU per step, '
                                    'inputs resident in HBM',
                        'chunks_per_step_per_gpu': n_chunks, 'samples_per_chunk': N, 'parallelism': f'chunk-sharded x{world}'},
-            'roofline': {'bound': 'hbm', 'kernel': 'chain_i8t_kernel' if eng.stage_a == 'i8' else 'chain_kernel', 'achieved': round(achieved, 1),
+            'roofline': {'bound': 'hbm', 'kernel': KERNEL_OF[eng.stage_a], 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': measured_traffic('chain_i8t_kernel' if eng.stage_a == 'i8' else 'chain_kernel', n_chunks),
+                         'traffic': measured_traffic(KERNEL_OF[eng.stage_a], n_chunks),
                          'avg_kernel_ms': round(k_avg_s * 1e3, 4), 'launches': k_n,
                          'alg_bytes_per_sample': ALG_BYTES_PER_SAMPLE,
                          'fp64_frac': round(FP64_FLOP_PER_SAMPLE * n_samples / k_avg_s / 1e12 / FP64_PEAK_TFLOPS, 4)},

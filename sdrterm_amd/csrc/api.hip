@@ -54,7 +54,10 @@ struct sdrt_ctx {
     double *d_out = nullptr;
     size_t stage_cap_chunks = 0;
     bool use_i8 = false;              // stage A on the int8 matrix cores (integer encodings, no IQ correction)
-    bool use_i8t = false;             //   ... in the 16x16x64 form (default); otherwise the 32x32x32 form
+    bool use_i8t = false;             //   ... in the 16x16x64 form; otherwise the 32x32x32 form
+    bool use_i8w = false;             //   ... wide columns, persistent workgroups (default where supported)
+    WideTables *d_wtab = nullptr;
+    int n_cus = 256;
     signed char *d_w8 = nullptr, *d_w8mid = nullptr;
     DecimTables *d_tab8 = nullptr;    // tables for columns of SDRT_I8_G blocks
     double *d_nco_tile8 = nullptr, *d_nco_phase8 = nullptr;
@@ -77,6 +80,10 @@ struct sdrt_ctx {
 };
 
 namespace {
+
+bool want_i8_fallback_t(int L, int dt, int n, int m) {
+    return chain_i8t_supported(L, dt, n) && chain_i8t_lds_bytes(n, L, m) <= 160 * 1024;
+}
 
 hipEvent_t get_event(sdrt_ctx *c) {
     if (!c->free_events.empty()) {
@@ -275,10 +282,47 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         const char *force = getenv("SDRTERM_STAGE_A");      // diagnostics: "f64" forces the fp64 matrix-core kernel
         const bool want_i8 = !(force && strcmp(force, "f64") == 0);
         const bool want_x32 = force && strcmp(force, "i8x32") == 0;   // diagnostics: the 32x32x32 int8 kernel
-        c->use_i8t = want_i8 && !want_x32 && !c->iq && chain_i8t_supported(L, cfg->dtype, n) &&
+        const bool want_t = force && strcmp(force, "i8t") == 0;       // diagnostics: the one-block-per-column 16x16x64 kernel
+        c->use_i8w = want_i8 && !want_x32 && !want_t && !c->iq && chain_i8w_supported(q, cfg->dtype, n) &&
+                     chain_i8w_lds_bytes(q, n) <= 160 * 1024;
+        c->use_i8t = !c->use_i8w && want_i8 && !want_x32 && !c->iq && chain_i8t_supported(L, cfg->dtype, n) &&
                      chain_i8t_lds_bytes(n, L, m) <= 160 * 1024;
-        c->use_i8 = c->use_i8t || (want_i8 && !c->iq && chain_i8_supported(L, cfg->dtype, n) &&
-                                   chain_i8_lds_bytes(n, L, m) <= 160 * 1024);
+        c->use_i8 = c->use_i8w || c->use_i8t || (want_i8 && !c->iq && chain_i8_supported(L, cfg->dtype, n) &&
+                                                 chain_i8_lds_bytes(n, L, m) <= 160 * 1024);
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->n_cus = cus;
+    }
+    if (rc == SDRT_OK && c->use_i8w) {
+        // wide columns (256 samples): tables, NCO phasors per column, digit planes per row (NCO folded in)
+        const int S = SDRT_I8_DIGITS, LC = SDRT_WIDE_LC, KS = LC / 32, NR = 2 * (LC / q);
+        WideTables wtab;
+        if (sdrt_build_wide_tables(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, &wtab, &msg) != 0)
+            rc = fail(SDRT_EINVAL, "wide-column tables: %s", msg ? msg : "failed");
+        if (rc == SDRT_OK) rc = upload(&c->d_wtab, &wtab, sizeof(wtab));
+        const size_t per_row = (size_t) 2 * S * KS * 64 * 16, per_row_loc = (size_t) S * KS * 4 * NR * 16;
+        std::vector<signed char> w8(per_row * c->rows), w8l(per_row_loc * c->rows);
+        std::vector<double> samp((size_t) c->rows * LC * 2), blk((size_t) c->rows * (n / LC) * 2);
+        for (int r = 0; r < c->rows && rc == SDRT_OK; ++r) {
+            double comb = 0.0, combl = 0.0;
+            double *sp = &samp[(size_t) r * LC * 2], *bp = &blk[(size_t) r * (n / LC) * 2];
+            if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, LC, n / LC, sp, bp);
+            if (sdrt_build_i8_weights_wide(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, c->nco ? sp : nullptr, S,
+                                           w8.data() + per_row * r, &comb, w8l.data() + per_row_loc * r, &combl) != 0)
+                rc = fail(SDRT_EINVAL, "int8 weight quantisation failed");
+            // one power-of-two scale per context (rows differ by a rotation of the weights only); otherwise the other form
+            if (r == 0) { c->w8_combine = comb; c->w8mid_combine = combl; }
+            else if (comb != c->w8_combine || combl != c->w8mid_combine) { c->use_i8w = false; break; }
+        }
+        if (rc == SDRT_OK && c->use_i8w && c->nco) {
+            rc = upload(&c->d_nco_tile8, samp.data(), samp.size() * sizeof(double));
+            if (rc == SDRT_OK) rc = upload(&c->d_nco_phase8, blk.data(), blk.size() * sizeof(double));
+        }
+        if (rc == SDRT_OK && c->use_i8w) rc = upload(&c->d_w8, w8.data(), w8.size());
+        if (rc == SDRT_OK && c->use_i8w) rc = upload(&c->d_w8mid, w8l.data(), w8l.size());
+        if (!c->use_i8w) {
+            (void) hipFree(c->d_wtab); c->d_wtab = nullptr;
+            c->use_i8t = want_i8_fallback_t(L, cfg->dtype, n, m);
+        }
     }
     if (rc == SDRT_OK && c->use_i8t) {
         // columns of G blocks: tables, NCO phasors per column, digit planes per row (NCO folded in, so they differ per row)
@@ -314,7 +358,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
             (void) hipFree(c->d_nco_phase8); c->d_nco_phase8 = nullptr;
         }
     }
-    if (rc == SDRT_OK && c->use_i8 && !c->use_i8t) {
+    if (rc == SDRT_OK && c->use_i8 && !c->use_i8t && !c->use_i8w) {
         // tables for columns of G blocks, digit planes per row (the NCO's within-column phasor is folded into the weights,
         // so they differ per row)
         const int S = SDRT_I8_DIGITS, G = SDRT_I8_G, LC = L * G, KS = LC / 16, NR = 2 * (G - 1);
@@ -403,6 +447,7 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_w8);
     (void) hipFree(c->d_w8mid);
     (void) hipFree(c->d_tab8);
+    (void) hipFree(c->d_wtab);
     (void) hipFree(c->d_nco_tile8);
     (void) hipFree(c->d_nco_phase8);
     (void) hipFree(c->d_ybias);
@@ -502,6 +547,7 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     da.w8_combine = c->w8_combine;
     da.w8mid_combine = c->w8mid_combine;
     da.x_offset = c->x_offset;
+    da.wtab = c->d_wtab;
     if (c->use_i8) {
         da.tab = c->d_tab8;
         da.n_tiles = c->n_tiles8;
@@ -510,7 +556,9 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     }
     {
         Timed t(c, s, 0);
-        if (c->use_i8t) {
+        if (c->use_i8w) {
+            HIP_TRY(launch_chain_i8w(da, c->cfg.decimation, c->cfg.dtype, n_chunks, c->n_cus, s));
+        } else if (c->use_i8t) {
             // the int8 kernels feed x - x_offset to the matrix cores; normalisation bias and offset come back via ybias
             HIP_TRY(launch_chain_i8t(da, c->L, c->cfg.dtype, n_chunks, s));
         } else if (c->use_i8) {
@@ -685,7 +733,7 @@ int sdrt_debug_stamps(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double 
     return SDRT_OK;
 }
 
-int sdrt_stage_a_kind(const sdrt_ctx *c) { return c ? (c->use_i8t ? 2 : (c->use_i8 ? 1 : 0)) : -1; }
+int sdrt_stage_a_kind(const sdrt_ctx *c) { return c ? (c->use_i8w ? 3 : (c->use_i8t ? 2 : (c->use_i8 ? 1 : 0))) : -1; }
 
 int sdrt_selftest_mfma_i8(int *mismatches) {
     int A[1024], B[1024], D[1024], *dA = nullptr, *dB = nullptr, *dD = nullptr;
@@ -737,8 +785,30 @@ int sdrt_selftest_mfma_i8(int *mismatches) {
                 if (ref != D2[i * 16 + j]) ++bad;
             }
     }
+    // lane exchanges of the wide-column kernel's reduce-scatter (v_permlane32_swap / v_permlane16_swap)
+    {
+        double X[64], Y[64], O[128], *dX = nullptr, *dY = nullptr, *dO = nullptr;
+        for (int l = 0; l < 64; ++l) { X[l] = 1.0 + l; Y[l] = 1000.0 + 3.0 * l; }
+        HIP_TRY(hipMalloc((void **) &dX, sizeof(X)));
+        HIP_TRY(hipMalloc((void **) &dY, sizeof(Y)));
+        HIP_TRY(hipMalloc((void **) &dO, sizeof(O)));
+        HIP_TRY(hipMemcpy(dX, X, sizeof(X), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dY, Y, sizeof(Y), hipMemcpyHostToDevice));
+        HIP_TRY(launch_swap_selftest(dX, dY, dO, nullptr));
+        HIP_TRY(hipMemcpy(O, dO, sizeof(O), hipMemcpyDeviceToHost));
+        (void) hipFree(dX);
+        (void) hipFree(dY);
+        (void) hipFree(dO);
+        for (int l = 0; l < 64; ++l) {
+            const double e32 = l < 32 ? X[l] + X[l + 32] : Y[l - 32] + Y[l];
+            const int r = l >> 4;
+            const double e16 = (r & 1) == 0 ? X[l] + X[l + 16] : Y[l - 16] + Y[l];
+            if (O[l] != e32) ++bad;
+            if (O[64 + l] != e16) ++bad;
+        }
+    }
     if (mismatches) *mismatches = bad;
-    return bad == 0 ? SDRT_OK : fail(SDRT_EHIP, "int8 MFMA operand layout mismatch (%d results wrong)", bad);
+    return bad == 0 ? SDRT_OK : fail(SDRT_EHIP, "int8 MFMA operand layout / lane swap mismatch (%d results wrong)", bad);
 }
 
 int sdrt_selftest_mfma(double *max_abs_err) {

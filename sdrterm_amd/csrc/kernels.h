@@ -34,6 +34,7 @@ struct DecimArgs {
     const double *ybias;        // [rows][m][2] decimator response to the constant the slices leave out (or NULL)
     double w8_combine;          // scale * 2^-(8S-1)
     double x_offset;            // what the slices leave out of every component: x = x' + x_offset
+    const WideTables *wtab;     // wide-column kernel (kernels_i8w.hip) only; there w8mid holds the local-row planes
 };
 
 struct IqArgs {
@@ -78,3 +79,8 @@ bool chain_i8t_supported(int L, int dt, int n);
 size_t chain_i8t_lds_bytes(int n, int L, int m);
 hipError_t launch_chain_i8t(const DecimArgs &a, int L, int dt, size_t n_chunks, hipStream_t s);
 hipError_t launch_i8t_selftest(const int *A, const int *B, int *D, hipStream_t s);
+// wide-column persistent int8 kernel (kernels_i8w.hip): q in {32, 64}, 8/16-bit integer encodings, 8 or 16 tiles per chunk
+bool chain_i8w_supported(int q, int dt, int n);
+size_t chain_i8w_lds_bytes(int q, int n);
+hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, int n_cus, hipStream_t s);
+hipError_t launch_swap_selftest(const double *x, const double *y, double *out, hipStream_t s);

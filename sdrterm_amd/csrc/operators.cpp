@@ -498,3 +498,110 @@ extern "C" void sdrt_build_iq_pow(double lambda, int count, double *pw) {
         v = v * a;
     }
 }
+
+// ---- wide-column kernel (kernels_i8w.hip) --------------------------------------------------------------------------
+extern "C" int sdrt_build_wide_tables(const double *sos, int sections, int q, double data_scale, WideTables *out,
+                                      const char **err) {
+    const int LC = SDRT_WIDE_LC;
+    if (q < LC / SDRT_WIDE_MAXOUT || q > LC || (q & (q - 1))) { if (err) *err = "wide columns need 32 <= q <= 256"; return -1; }
+    Modal m;
+    if (!build_modal(sos, sections, m, err)) return -2;
+    DecimTables base;
+    if (int rc = sdrt_build_decim_tables(sos, sections, q, 1, &base, err)) return rc;
+    std::memset(out, 0, sizeof(*out));
+    out->q = q;
+    out->nout = LC / q;
+    const int nout = out->nout;
+    for (int i = 0; i < 4; ++i) {
+        const C P = m.p[2 * i];
+        const C mu = cpow(P, LC);
+        for (int k = 0; k < 4; ++k) put(out->mu_pow[k][i], cpow(mu, 1 << k));
+        for (int k = 0; k <= SDRT_WIDE_MAXTILES; ++k) put(out->tile_pow[k][i], cpow(mu, SDRT_TB * k));
+        for (int b = 0; b <= nout; ++b) put(out->bp2[b][i], C(2) * cpow(P, b * q));
+        for (int pos = 0; pos < SDRT_TB * nout; ++pos) {
+            put(out->cF2[pos][i], C(2) * cpow(P, pos * q));
+            put(out->cG2[pos][i], C(2) * cpow(P, (SDRT_TB * nout - pos) * q));
+        }
+    }
+    for (int i = 0; i < SDRT_NMODE; ++i) {
+        for (int l = 0; l <= SDRT_EDGE; ++l)
+            for (int z = 0; z < 2; ++z) {
+                out->head[i][l][z] = base.head[i][l][z] * data_scale;
+                out->tailU[i][l][z] = base.tailU[i][l][z] * data_scale;
+            }
+        for (int j = 0; j < SDRT_NMODE; ++j)
+            for (int z = 0; z < 2; ++z) { out->tailF[i][j][z] = base.tailF[i][j][z]; out->tailFc[i][j][z] = base.tailFc[i][j][z]; }
+    }
+    return 0;
+}
+
+extern "C" int sdrt_build_i8_weights_wide(const double *sos, int sections, int q, double data_scale, const double *nco_samp,
+                                          int S, signed char *main_out, double *main_combine, signed char *loc_out,
+                                          double *loc_combine) {
+    Modal m;
+    const char *err = nullptr;
+    if (!build_modal(sos, sections, m, &err)) return -2;
+    const int LC = SDRT_WIDE_LC, cols = 2 * LC, KS = LC / 32;
+    if (q < LC / SDRT_WIDE_MAXOUT || q > LC || (q & (q - 1))) return -3;
+    const int nout = LC / q, NR = 2 * nout;
+    auto tr = [&](int t) { return nco_samp ? nco_samp[2 * t] : 1.0; };
+    auto ti = [&](int t) { return nco_samp ? nco_samp[2 * t + 1] : 0.0; };
+    auto kpos = [&](int c, int &ks, int &kg, int &j) {
+        const int sample = c >> 1, comp = c & 1;
+        ks = sample / 32;
+        kg = (sample % 32) / 8;
+        j = 2 * (sample % 8) + comp;
+    };
+    C P[4], ac[4], aa[4];
+    for (int i = 0; i < 4; ++i) { P[i] = m.p[2 * i]; ac[i] = m.alpha[2 * i]; aa[i] = m.alpha[2 * i] / P[i]; }
+    // column aggregates: causal alpha p^(LC-1-t) (state handed to the next column), anticausal (alpha/p) p^t (state at
+    // the column start); u = x e^{i theta t} split into its real streams
+    std::vector<double> Wf((size_t) 32 * cols, 0.0);
+    for (int mode = 0; mode < 4; ++mode)
+        for (int kind = 0; kind < 2; ++kind)
+            for (int t = 0; t < LC; ++t) {
+                const C w = kind == 0 ? ac[mode] * cpow(P[mode], LC - 1 - t) : aa[mode] * cpow(P[mode], t);
+                const double wr = (double) w.re * data_scale, wi = (double) w.im * data_scale;
+                const double cxr[2][2] = {{wr * tr(t), wi * tr(t)}, {wr * ti(t), wi * ti(t)}};      // [stream][part], coefficient of xr
+                const double cxi[2][2] = {{-wr * ti(t), -wi * ti(t)}, {wr * tr(t), wi * tr(t)}};    // coefficient of xi
+                for (int stream = 0; stream < 2; ++stream)
+                    for (int part = 0; part < 2; ++part) {
+                        const int r = 16 * kind + 4 * mode + 2 * stream + part;
+                        Wf[(size_t) r * cols + 2 * t] = cxr[stream][part];
+                        Wf[(size_t) r * cols + 2 * t + 1] = cxi[stream][part];
+                    }
+            }
+    *main_combine = quantise_planes(Wf.data(), 32, cols, cols, S, [&](int d, int r, int c, signed char dig) {
+        int ks, kg, j;
+        kpos(c, ks, kg, j);
+        main_out[(((((size_t) (r >> 4) * S + d) * KS + ks) * 64) + ((r & 15) + 16 * kg)) * 16 + j] = dig;
+    });
+    if (*main_combine == 0.0) return -1;
+    // local rows: output at sample b q of the column, the part that depends on this column's samples:
+    //   d0' u[bq] + sum_i 2 Re( alpha_i sum_{t < bq} p_i^(bq-1-t) u[t] + (alpha_i/p_i) sum_{t >= bq} p_i^(t-bq) u[t] )
+    C sum_a_over_p(0);
+    for (int i = 0; i < 8; ++i) sum_a_over_p = sum_a_over_p + m.alpha[i] / m.p[i];
+    const double d0p = (double) (m.d0 - sum_a_over_p.re) * data_scale;
+    std::vector<double> Wl((size_t) NR * cols, 0.0);
+    for (int b = 0; b < nout; ++b)
+        for (int t = 0; t < LC; ++t) {
+            R acc = 0;
+            for (int i = 0; i < 4; ++i) {
+                const C w = t < b * q ? ac[i] * cpow(P[i], b * q - 1 - t) : aa[i] * cpow(P[i], t - b * q);
+                acc = acc + 2 * w.re;
+            }
+            double mt = (double) acc * data_scale;
+            if (t == b * q) mt += d0p;
+            Wl[(size_t) (2 * b) * cols + 2 * t] = mt * tr(t);            // stream re: mt (xr tr - xi ti)
+            Wl[(size_t) (2 * b) * cols + 2 * t + 1] = -mt * ti(t);
+            Wl[(size_t) (2 * b + 1) * cols + 2 * t] = mt * ti(t);        // stream im: mt (xr ti + xi tr)
+            Wl[(size_t) (2 * b + 1) * cols + 2 * t + 1] = mt * tr(t);
+        }
+    *loc_combine = quantise_planes(Wl.data(), NR, cols, cols, S, [&](int d, int r, int c, signed char dig) {
+        int ks, kg, j;
+        kpos(c, ks, kg, j);
+        loc_out[(((((size_t) d * KS + ks) * 4 + kg) * NR) + r) * 16 + j] = dig;
+    });
+    if (*loc_combine == 0.0) return -1;
+    return 0;
+}

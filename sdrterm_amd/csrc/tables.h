@@ -32,6 +32,26 @@ struct DecimTables {
     double tailU[SDRT_NMODE][SDRT_EDGE + 1][2];
 };
 
+// Tables of the wide-column int8 kernel (chain_i8w_kernel, kernels_i8w.hip).  A matrix-core column is LC = 256 consecutive
+// samples holding nout = LC/q outputs ("boundaries" b = 0..nout-1 at sample b*q of the column); a tile is 16 columns.
+// States are the alpha-scaled modal states of DecimTables; factors that only ever appear inside 2 Re(.) carry the 2.
+#define SDRT_WIDE_LC 256
+#define SDRT_WIDE_MAXOUT 8
+#define SDRT_WIDE_MAXTILES 16
+struct WideTables {
+    int32_t q, nout, reserved[2];
+    double mu_pow[4][SDRT_NMODE][2];                         // (p_i^LC)^(1,2,4,8): column-to-column scan inside a tile
+    double tile_pow[SDRT_WIDE_MAXTILES + 1][SDRT_NMODE][2];  // (p_i^(16 LC))^k: tile-to-tile carries
+    double bp2[SDRT_WIDE_MAXOUT + 1][SDRT_NMODE][2];         // 2 p_i^(b q): state at the column start -> boundary b;
+                                                             //   state at the column end -> boundary b uses bp2[nout - b]
+    double cF2[SDRT_TB * SDRT_WIDE_MAXOUT][SDRT_NMODE][2];   // 2 p_i^(pos q): causal state at the tile start -> output pos
+    double cG2[SDRT_TB * SDRT_WIDE_MAXOUT][SDRT_NMODE][2];   // 2 p_i^((16 nout - pos) q): anticausal state at the tile end
+    double head[SDRT_NMODE][SDRT_EDGE + 1][2];               // edge operators, as in DecimTables
+    double tailF[SDRT_NMODE][SDRT_NMODE][2];
+    double tailFc[SDRT_NMODE][SDRT_NMODE][2];
+    double tailU[SDRT_NMODE][SDRT_EDGE + 1][2];
+};
+
 // Output lowpass (scipy sosfilt, zero initial state per chunk) in parallel modal form for a 64-lane (one wave) scan:
 //   y[t] = D x[t] + sum_k Re(r_k s_k(t)),   s_k(t+1) = p_k s_k(t) + x[t],   s_k(0) = 0
 // r_k already carries the weight 2 for a complex pole that stands for its conjugate pair too.
@@ -90,6 +110,18 @@ int sdrt_build_i8_weights(const double *sos, int sections, const struct DecimTab
 int sdrt_build_i8_weights16(const double *sos, int sections, const struct DecimTables *tab, double data_scale,
                             const double *nco_samp, int S, signed char *out, double *combine, signed char *mid_out,
                             double *mid_combine);
+
+// Wide-column kernel: tables for decimation q (32 <= q <= 256, power of two); data_scale multiplies the edge operators
+// (the digit planes take it through sdrt_build_i8_weights_wide).
+int sdrt_build_wide_tables(const double *sos, int sections, int q, double data_scale, struct WideTables *out, const char **err);
+
+// Digit planes of the wide-column kernel.  Column = SDRT_WIDE_LC samples, KS = 8 k-steps of 64; K position (kstep, kg, j)
+// <-> sample 32*kstep + 8*kg + (j>>1), component j&1.  Row tiles 0/1 (causal / anticausal column aggregates, row =
+// 4*mode + 2*stream + part) go to  main[(((tile*S + digit)*KS + kstep)*64 + row + 16*kg)*16 + j];  the local tile (row =
+// 2*b + stream: the part of output b of the column that depends on this column's samples only, direct term included,
+// NR = 2*nout rows) goes to  loc[((((digit*KS + kstep)*4 + kg)*NR) + row)*16 + j].  One power-of-two scale each.
+int sdrt_build_i8_weights_wide(const double *sos, int sections, int q, double data_scale, const double *nco_samp, int S,
+                               signed char *main_out, double *main_combine, signed char *loc_out, double *loc_combine);
 
 // IQ-correction geometric weights: pw[j] = (1-lambda)^j, j <= count.
 void sdrt_build_iq_pow(double lambda, int count, double *pw);

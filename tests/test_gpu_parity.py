@@ -29,10 +29,11 @@ def test_mfma_layout_selftest():
     assert bad.value == 0
 
 
-@pytest.fixture(params=['auto', 'f64', 'i8x32'])
+@pytest.fixture(params=['auto', 'f64', 'i8x32', 'i8t'])
 def stage_a(request, monkeypatch):
-    """Every golden case runs with the kernel the library picks (int8 matrix cores, 16x16x64 form, for 8/16-bit integer
-    encodings), with the fp64 matrix-core kernel forced, and with the 32x32x32 int8 form forced."""
+    """Every golden case runs with the kernel the library picks (int8 matrix cores: wide-column persistent kernel where it
+    applies, else the one-block-per-column 16x16x64 form, for 8/16-bit integer encodings), with the fp64 matrix-core kernel
+    forced, and with the 32x32x32 and one-block 16x16x64 int8 forms forced."""
     if request.param == 'auto':
         monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
     else:
@@ -47,7 +48,9 @@ def test_golden_parity(case, golden, stage_a):
     eng = _engine(case)
     if stage_a == 'f64':
         assert eng.stage_a == 'f64'
-    elif eng.stage_a != ('i8' if stage_a == 'auto' else stage_a):
+    elif stage_a == 'auto' and eng.stage_a not in ('i8w', 'i8t'):
+        pytest.skip(f'auto: the library uses {eng.stage_a} for this case (covered by another run)')
+    elif stage_a != 'auto' and eng.stage_a != stage_a:
         pytest.skip(f'{stage_a}: the library uses {eng.stage_a} for this case (covered by another run)')
     raw = case_raw(case)
     out, y = eng.process_debug(raw)
