@@ -421,6 +421,11 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
                 if (e != hipSuccess) rc = fail(SDRT_EHIP, "ybias kernel failed: %s", hipGetErrorString(e));
             }
             (void) hipFree(d_cz);
+        } else if (rc == SDRT_OK && c->use_i8w) {
+            // the wide-column kernel always adds its ybias operand (no branch in its inner loop): zeros here
+            const size_t bytes = (size_t) c->rows * m * 2 * sizeof(double);
+            if (hipMalloc((void **) &c->d_ybias, bytes) != hipSuccess) rc = fail(SDRT_ENOMEM, "hipMalloc failed");
+            else if (hipMemset(c->d_ybias, 0, bytes) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemset failed");
         }
     }
     if (rc != SDRT_OK) {

@@ -45,7 +45,7 @@ __device__ __forceinline__ double swap16_add(double x, double y) {
 }
 
 struct WideLds {        // byte offsets
-    int wmain, wloc, cF, cG, bp, tpw, tailF, tailFc, buf, buf_stride, total;
+    int wmain, wloc, cF, cG, bp, mup, tpw, tailF, tailFc, psi, buf, buf_stride, total;
     // per buffer (offsets in 16-byte units from its start): carF [(NT+1)*8], carG [(NT+1)*8], F0 [8], Gu [8]
 };
 __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt) {
@@ -56,9 +56,11 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt) {
     l.cF = p; p += SDRT_TB * nout * 4 * 16;
     l.cG = p; p += SDRT_TB * nout * 4 * 16;
     l.bp = p; p += (nout + 1) * 4 * 16;
+    l.mup = p; p += 4 * 4 * 16;
     l.tpw = p; p += (SDRT_WIDE_MAXTILES + 1) * 4 * 16;
     l.tailF = p; p += 16 * 16;
     l.tailFc = p; p += 16 * 16;
+    l.psi = p; p += nt * SDRT_TB * 16;              // column phasors of the row
     l.buf = p;
     l.buf_stride = (2 * (nt + 1) * 8 + 16) * 16;
     p += 3 * l.buf_stride;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     constexpr int WPK = 4 * ITEM;                    // 32-bit words per lane and k-step (8 complex samples)
     constexpr int TILE = SDRT_TB * LC;               // samples per tile
     constexpr int NSTEP = KS * TPW;                  // k-steps per wave and item
-    constexpr int PF = 3;                            // k-steps of raw samples in flight
+    constexpr int PF = 2;                            // k-steps of raw samples in flight
     static_assert(NOUT == 4 || NOUT == 8, "4 or 8 outputs per column");
     static_assert(NT == 8 || NT == 16, "8 or 16 tiles per chunk");
     typedef typename Enc<DT>::raw raw_t;
@@ -93,8 +95,8 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     const WideLds lo = wide_lds(S, NOUT, NT);
     const v4i *wmainL = (const v4i *) (smem + lo.wmain);
     const v4i *wlocL = (const v4i *) (smem + lo.wloc);
-    cd *cFL = (cd *) (smem + lo.cF), *cGL = (cd *) (smem + lo.cG), *bpL = (cd *) (smem + lo.bp), *tpwL = (cd *) (smem + lo.tpw);
-    cd *tailFL = (cd *) (smem + lo.tailF), *tailFcL = (cd *) (smem + lo.tailFc);
+    cd *cFL = (cd *) (smem + lo.cF), *cGL = (cd *) (smem + lo.cG), *bpL = (cd *) (smem + lo.bp), *mupL = (cd *) (smem + lo.mup), *tpwL = (cd *) (smem + lo.tpw);
+    cd *tailFL = (cd *) (smem + lo.tailF), *tailFcL = (cd *) (smem + lo.tailFc), *psiL = (cd *) (smem + lo.psi);
     auto carF = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride); };
     auto carG = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + (NT + 1) * 8; };
     auto F0L = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + 2 * (NT + 1) * 8; };
@@ -119,9 +121,11 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     auto chunk_of = [&](int k) -> long { return ((long) k * (long) nstreams + (long) stream) * 8 + (long) xcd; };
 
     // ---- tables that do not depend on the row -> LDS ------------------------------------------------------------------
-    for (int i = tid; i < SDRT_TB * NOUT * 4; i += 512) {
-        cFL[i] = mk(wt->cF2[i >> 2][i & 3][0], wt->cF2[i >> 2][i & 3][1]);
-        cGL[i] = mk(wt->cG2[i >> 2][i & 3][0], wt->cG2[i >> 2][i & 3][1]);
+    // stored in the order P3 reads them, [e][mode][lane]: lane (g, nb) finishes output b = g + 4e of column nb, pos = nb*NOUT + b
+    for (int i = tid; i < OPL * 4 * 64; i += 512) {
+        const int l = i & 63, md = (i >> 6) & 3, e = i >> 8, pos = (l & 15) * NOUT + (l >> 4) + 4 * e;
+        cFL[i] = mk(wt->cF2[pos][md][0], wt->cF2[pos][md][1]);
+        cGL[i] = mk(wt->cG2[pos][md][0], wt->cG2[pos][md][1]);
     }
     if (tid < (NOUT + 1) * 4) bpL[tid] = mk(wt->bp2[tid >> 2][tid & 3][0], wt->bp2[tid >> 2][tid & 3][1]);
     if (tid >= 64 && tid < 64 + (SDRT_WIDE_MAXTILES + 1) * 4) {
@@ -133,12 +137,11 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         tailFL[i] = mk(wt->tailF[i >> 2][i & 3][0], wt->tailF[i >> 2][i & 3][1]);
         tailFcL[i] = mk(wt->tailFc[i >> 2][i & 3][0], wt->tailFc[i >> 2][i & 3][1]);
     }
-    cd mup[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) mup[k] = mk(wt->mu_pow[k][g][0], wt->mu_pow[k][g][1]);
+    if (tid >= 32 && tid < 48) mupL[tid - 32] = mk(wt->mu_pow[(tid - 32) >> 2][tid & 3][0], wt->mu_pow[(tid - 32) >> 2][tid & 3][1]);
     // edge operator of this thread: output o16 = tid >> 5 (kind: 0 head -> F0, 1 tail -> Gu; chain o = mode*2 + stream), sample l
     const int e_o16 = tid >> 5, e_l = tid & 31, e_kind = e_o16 >> 3, e_o = e_o16 & 7, e_mode = e_o >> 1, e_st = e_o & 1;
-    const long e_idx = e_kind ? (long) n - (SDRT_EDGE + 1) + e_l : (long) e_l;
+    const int e_lc = e_l <= SDRT_EDGE ? e_l : SDRT_EDGE;            // lanes 28..31 carry weight 0
+    const long e_idx = e_kind ? (long) n - (SDRT_EDGE + 1) + e_lc : (long) e_lc;
     cd e_tab = mk(0.0, 0.0);
     if (e_l <= SDRT_EDGE)
         e_tab = e_kind ? mk(wt->tailU[e_mode][e_l][0], wt->tailU[e_mode][e_l][1]) : mk(wt->head[e_mode][e_l][0], wt->head[e_mode][e_l][1]);
@@ -163,8 +166,9 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         const cd *nco_samp_g = nco ? (const cd *) a.nco_tile + (size_t) row * LC : nullptr;                // exp(i theta j), j < LC
         const cd *nco_blk_g = nco ? (const cd *) a.nco_phase + (size_t) row * (size_t) (n / LC) : nullptr;  // exp(i theta LC c)
         cd e_rot = mk(1.0, 0.0);
-        if (nco && e_l <= SDRT_EDGE) e_rot = cmul(nco_samp_g[e_idx % LC], nco_blk_g[e_idx / LC]);
-        const cd *ybias = a.ybias ? (const cd *) a.ybias + (size_t) row * m : nullptr;
+        if (nco) e_rot = cmul(nco_samp_g[e_idx % LC], nco_blk_g[e_idx / LC]);
+        for (int i = tid; i < NT * SDRT_TB; i += 512) psiL[i] = nco ? nco_blk_g[i] : mk(1.0, 0.0);
+        const cd *ybias = (const cd *) a.ybias + (size_t) row * m;      // always present for this kernel (zeros if there is no offset)
         __syncthreads();
 
         uint32_t raw[4][WPK];
@@ -178,70 +182,75 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             const unsigned char *c0 = (const unsigned char *) a.raw + (size_t) chunk_of(0) * chunk_bytes;
             static_for<0, PF>([&](auto sc) { issue(c0, sc); });
         }
-        cd yq[2][TPW][OPL];                          // column-local outputs of the two previous items
+        // Software pipeline over the items k = 0 .. cnt-1 of this workgroup; in iteration `it`:
+        //   K(it)     matrix-core phase of item it (all waves; wave w <-> tiles w, w+8): int32 sums -> fp64 column aggregates,
+        //             kept in registers (dC, dA, dl) for the next iteration
+        //   Q(it-1)   phasor, column scans, tile aggregates -> LDS, column-local outputs -> registers (yq)
+        //   P2(it-2)  tile carries (two waves, one per real stream)
+        //   P3(it-3)  carried states -> outputs, store
+        //   E(it)     edge operators -> LDS
+        // Q, P3 and E are cut into short pieces that run between the groups of matrix instructions of K, so that the wave
+        // sharing the SIMD finds the matrix pipe free meanwhile (and vice versa).  LDS carry buffers: item k uses k % 3.
+        cd yq[2][TPW][OPL], ynew[TPW][OPL];          // column-local outputs: [0] two iterations old (P3 finishes them now)
+        cd dC[TPW][2], dA[TPW][2];                   // [stream]: causal / anticausal states of (mode g, column nb) of the tile
+        double dl[TPW][4];                           // local rows of this lane: outputs 2g, 2g+1 x streams
+        cd pv[TPW][OPL];                             // P3 accumulators
+        double part[4][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < TPW; ++j) {
+#pragma unroll
+            for (int e = 0; e < OPL; ++e) yq[0][j][e] = yq[1][j][e] = ynew[j][e] = pv[j][e] = mk(0.0, 0.0);
+            dC[j][0] = dC[j][1] = dA[j][0] = dA[j][1] = mk(0.0, 0.0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dl[j][v] = 0.0;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) part[b][0] = part[b][1] = 0.0;
+
+        int bcur = 0;                                // it % 3
+        // One iteration; HAVE_K = there is an item whose matrix-core phase runs now (false only in the three drain iterations).
+        // With HAVE_K every global load and store below is issued unconditionally, so that the compiler can count them and
+        // wait for exactly the k-step it needs (s_waitcnt vmcnt(N)) instead of draining the whole prefetch ring.
+        auto iteration = [&](auto hk, const int it) {
+            constexpr bool HAVE_K = decltype(hk)::value;
+            const int bQ = bcur == 0 ? 2 : bcur - 1, bP2 = bcur == 2 ? 0 : bcur + 1, bP3 = bcur;   // (it-1)%3, (it-2)%3, (it-3)%3
+            const bool have_q = it >= 1 && it - 1 < cnt, have_p2 = it >= 2 && it - 2 < cnt, have_p3 = it >= 3;
+            // diagnostic phase stamps of iteration 6 (a.stamps == nullptr in every production call)
+            unsigned long long *stp = (a.stamps && it == 6 && (int) bid * 2 < a.stamp_wgs && lane == 0) ? a.stamps + ((size_t) bid * 8 + wave) * 16 : nullptr;
+#define SDRT_STAMP(i) do { if (stp) stp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+            SDRT_STAMP(0);
+            // small global loads first: everything issued later (the raw stream) is younger, so waiting for these never
+            // waits for the prefetch ring
+            const unsigned char *chunk_raw = (const unsigned char *) a.raw + (size_t) chunk_of(HAVE_K ? it : 0) * chunk_bytes;
+            raw_t e_re = 0, e_im = 0;
+            if constexpr (HAVE_K) {                  // raw edge sample of E(it) (lanes beyond the pad read sample 27, weight 0)
+                const raw_t *rp = (const raw_t *) chunk_raw + 2 * e_idx;
+                e_re = rp[0];
+                e_im = rp[1];
+            }
+            // outputs of item it-3 (the first three iterations store to item 0's place, which P3(0) rewrites in iteration 3)
+            double *yd = a.ydec + ((size_t) row * a.n_chunks + (size_t) chunk_of(have_p3 ? it - 3 : 0)) * (size_t) m * 2;
+            cd yb[TPW][OPL];
 #pragma unroll
             for (int j = 0; j < TPW; ++j)
 #pragma unroll
-                for (int e = 0; e < OPL; ++e) yq[i][j][e] = mk(0.0, 0.0);
-
-        int bcur = 0;                                // LDS buffer of iteration it; it-1 -> (bcur+2)%3, it-2 -> (bcur+1)%3
-        for (int it = 0; it < cnt + 2; ++it) {
-            const int b1 = bcur == 0 ? 2 : bcur - 1, b2 = bcur == 2 ? 0 : bcur + 1;
-            // ---- E(it): raw edge sample first (its latency hides behind P3/P2) --------------------------------------------
-            const bool have_m = it < cnt;
-            const unsigned char *chunk_raw = nullptr;
-            raw_t e_re = 0, e_im = 0;
-            if (have_m) {
-                chunk_raw = (const unsigned char *) a.raw + (size_t) chunk_of(it) * chunk_bytes;
-                if (e_l <= SDRT_EDGE) {
-                    const raw_t *rp = (const raw_t *) chunk_raw + 2 * e_idx;
-                    e_re = rp[0];
-                    e_im = rp[1];
-                }
-            }
-            // ---- P3(it-2): carried states -> outputs, store ---------------------------------------------------------------
-            if (it >= 2) {
-                const long chunk2 = chunk_of(it - 2);
-                double *yd = a.ydec + ((size_t) row * a.n_chunks + (size_t) chunk2) * (size_t) m * 2;
-                const cd *cf = carF(b2), *cg = carG(b2);
-#pragma unroll
-                for (int j = 0; j < TPW; ++j) {
-                    const int tile = wave + 8 * j;
-#pragma unroll
-                    for (int e = 0; e < OPL; ++e) {
-                        const int b = g + 4 * e, pos = nb * NOUT + b, k = (tile * SDRT_TB + nb) * NOUT + b;
-                        cd v = yq[0][j][e];
-#pragma unroll
-                        for (int mode = 0; mode < 4; ++mode) {
-                            const cd f = cFL[pos * 4 + mode], gq = cGL[pos * 4 + mode];
-                            const cd Fa = cf[tile * 8 + mode * 2 + 0], Fb = cf[tile * 8 + mode * 2 + 1];
-                            const cd Ga = cg[(tile + 1) * 8 + mode * 2 + 0], Gb = cg[(tile + 1) * 8 + mode * 2 + 1];
-                            v.re += f.re * Fa.re - f.im * Fa.im + gq.re * Ga.re - gq.im * Ga.im;
-                            v.im += f.re * Fb.re - f.im * Fb.im + gq.re * Gb.re - gq.im * Gb.im;
-                        }
-                        if (ybias) { const cd yb = ybias[k]; v.re += yb.re; v.im += yb.im; }
-                        *(double2 *) (yd + 2 * (size_t) k) = make_double2(v.re, v.im);
-                    }
-                }
-            }
-            // ---- P2(it-1): tile carries, one wave per real stream; DPP rows = modes, lanes of a row = tiles -----------------
-            if (it >= 1 && it - 1 < cnt && (wave >> 1) == (it & 3)) {
+                for (int e = 0; e < OPL; ++e) yb[j][e] = ybias[((wave + 8 * j) * SDRT_TB + nb) * NOUT + g + 4 * e];
+            // ---- P2(it-2): tile carries, one wave per real stream; DPP rows = modes, lanes of a row = tiles ------------------
+            if (have_p2 && (wave >> 1) == (it & 3)) {
                 const int st = wave & 1, o = g * 2 + st, t = nb;
-                cd *cf = carF(b1), *cg = carG(b1);
+                cd *cf = carF(bP2), *cg = carG(bP2);
                 const cd m1 = tpwL[1 * 4 + g], m2 = tpwL[2 * 4 + g], m4 = tpwL[4 * 4 + g], m8 = tpwL[8 * 4 + g];
                 cd x = t < NT ? cf[(t + 1) * 8 + o] : mk(0.0, 0.0);
                 x = cfma(m1, dpp_row<0x111>(x), x);
                 x = cfma(m2, dpp_row<0x112>(x), x);
                 x = cfma(m4, dpp_row<0x114>(x), x);
                 if constexpr (NT > 8) x = cfma(m8, dpp_row<0x118>(x), x);
-                const cd f0 = F0L(b1)[o];
+                const cd f0 = F0L(bP2)[o];
                 x = cfma(tpwL[(t < NT ? t + 1 : 0) * 4 + g], f0, x);
                 if (t < NT) cf[(t + 1) * 8 + o] = x;
                 if (t == 0) cf[o] = f0;
                 // anticausal state at the right edge from the causal states there (all four modes of this stream) + edge samples
-                cd G = GuL(b1)[o];
+                cd G = GuL(bP2)[o];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const cd Fj = cf[NT * 8 + j * 2 + st];
@@ -257,52 +266,132 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                 if (t < NT) cg[t * 8 + o] = y;
                 if (t == 0) cg[NT * 8 + o] = G;
             }
-            // the queue of column-local outputs moves on
-#pragma unroll
-            for (int j = 0; j < TPW; ++j)
-#pragma unroll
-                for (int e = 0; e < OPL; ++e) yq[0][j][e] = yq[1][j][e];
+            SDRT_STAMP(1);
 
-            if (have_m) {
-                // ---- E(it) ------------------------------------------------------------------------------------------------
-                {
-                    cd f = mk(0.0, 0.0);
-                    if (e_l <= SDRT_EDGE) {
-                        const double xr = decode<DT>(e_re, swap) - xoff, xi = decode<DT>(e_im, swap) - xoff;
-                        const cd u = cmul(mk(xr, xi), e_rot);
-                        const double us = e_st ? u.im : u.re;
-                        f = mk(e_tab.re * us, e_tab.im * us);
-                    }
+            // ---- the pieces of Q(it-1), P3(it-3) and E(it) that run after matrix-instruction group i of tile slot j ------------
+            constexpr int P3_0 = 12 + 3 * OPL;       // first P3 piece; the E piece comes after the last one
+            auto piece = [&](auto jc, auto ic) {
+                constexpr int j = decltype(jc)::value, i = decltype(ic)::value;
+                const int tile = wave + 8 * j;
+                if (have_q) {
+                    if constexpr (i == 1) {
+                        const cd ps = psiL[tile * SDRT_TB + nb];      // the column's common phasor multiplies the complex DATA
+                        cd t;
+                        t = mk(ps.re * dC[j][0].re - ps.im * dC[j][1].re, ps.re * dC[j][0].im - ps.im * dC[j][1].im);
+                        dC[j][1] = mk(ps.im * dC[j][0].re + ps.re * dC[j][1].re, ps.im * dC[j][0].im + ps.re * dC[j][1].im);
+                        dC[j][0] = t;
+                        t = mk(ps.re * dA[j][0].re - ps.im * dA[j][1].re, ps.re * dA[j][0].im - ps.im * dA[j][1].im);
+                        dA[j][1] = mk(ps.im * dA[j][0].re + ps.re * dA[j][1].re, ps.im * dA[j][0].im + ps.re * dA[j][1].im);
+                        dA[j][0] = t;
+                    } else if constexpr (i == 2) {
+                        const cd ps = psiL[tile * SDRT_TB + nb];
 #pragma unroll
-                    for (int d = 16; d >= 1; d >>= 1) {
-                        f.re += __shfl_xor(f.re, d);
-                        f.im += __shfl_xor(f.im, d);
-                    }
-                    if (e_l == 0) { if (e_kind) GuL(bcur)[e_o] = f; else F0L(bcur)[e_o] = f; }
-                }
-                // ---- M(it) ------------------------------------------------------------------------------------------------
-                cd *cf = carF(bcur), *cg = carG(bcur);
-                const unsigned char *next_raw = it + 1 < cnt ? (const unsigned char *) a.raw + (size_t) chunk_of(it + 1) * chunk_bytes : nullptr;
-                static_for<0, TPW>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    const int tile = wave + 8 * j;
-                    v4i acc[3][S];
-                    v4i Afrag[2][S];
-                    auto load_frags = [&](auto ic, v4i *dst) {
-                        constexpr int i = decltype(ic)::value, s = i / 3, rt = i % 3;
-                        static_for<0, S>([&](auto dc) {
-                            constexpr int d = decltype(dc)::value;
-                            if constexpr (rt < 2) {
-                                dst[d] = wmainL[((rt * S + d) * KS + s) * 64 + lane];
-                            } else {
-                                dst[d] = wlocL[(d * KS + s) * 64 + lane];
+                        for (int h = 0; h < 2; ++h) {
+                            const double t2 = ps.re * dl[j][2 * h] - ps.im * dl[j][2 * h + 1];
+                            dl[j][2 * h + 1] = ps.im * dl[j][2 * h] + ps.re * dl[j][2 * h + 1];
+                            dl[j][2 * h] = t2;
+                        }
+                    } else if constexpr (i >= 3 && i <= 10) {
+                        // inclusive scans over the 16 columns of the tile (lanes of one DPP row): step (i-3)/2, causal then anticausal
+                        constexpr int stp_ = (i - 3) / 2;
+                        const cd mu = mupL[stp_ * 4 + g];
+                        if constexpr (((i - 3) & 1) == 0) {
+                            dC[j][0] = cfma(mu, dpp_row<0x110 + (1 << stp_)>(dC[j][0]), dC[j][0]);
+                            dC[j][1] = cfma(mu, dpp_row<0x110 + (1 << stp_)>(dC[j][1]), dC[j][1]);
+                        } else {
+                            dA[j][0] = cfma(mu, dpp_row<0x100 + (1 << stp_)>(dA[j][0]), dA[j][0]);
+                            dA[j][1] = cfma(mu, dpp_row<0x100 + (1 << stp_)>(dA[j][1]), dA[j][1]);
+                        }
+                    } else if constexpr (i == 11) {
+                        // tile aggregates: causal inclusive at the last column -> slot tile+1, anticausal inclusive at the first -> slot tile
+                        cd *cf = carF(bQ), *cg = carG(bQ);
+                        if (nb == 15) { cf[(tile + 1) * 8 + g * 2 + 0] = dC[j][0]; cf[(tile + 1) * 8 + g * 2 + 1] = dC[j][1]; }
+                        if (nb == 0) { cg[tile * 8 + g * 2 + 0] = dA[j][0]; cg[tile * 8 + g * 2 + 1] = dA[j][1]; }
+                        // from here on: states at the column's edges from inside the tile (causal at its start, anticausal at its end)
+                        dC[j][0] = dpp_row<0x111>(dC[j][0]);
+                        dC[j][1] = dpp_row<0x111>(dC[j][1]);
+                        dA[j][0] = dpp_row<0x101>(dA[j][0]);
+                        dA[j][1] = dpp_row<0x101>(dA[j][1]);
+                    } else if constexpr (i >= 12 && i < P3_0) {
+                        constexpr int e = (i - 12) / 3, sub = (i - 12) % 3;
+                        if constexpr (sub < 2) {
+                            // this mode's share of outputs b of the column, plus the local rows where this lane holds them
+#pragma unroll
+                            for (int bb = 2 * sub; bb < 2 * sub + 2; ++bb) {
+                                const int b = 4 * e + bb;
+                                const cd bc = bpL[b * 4 + g], ba = bpL[(NOUT - b) * 4 + g];
+                                part[bb][0] = bc.re * dC[j][0].re - bc.im * dC[j][0].im + ba.re * dA[j][0].re - ba.im * dA[j][0].im;
+                                part[bb][1] = bc.re * dC[j][1].re - bc.im * dC[j][1].im + ba.re * dA[j][1].re - ba.im * dA[j][1].im;
+                                const double mine = (g == (b >> 1)) ? 1.0 : 0.0;
+                                part[bb][0] = fma(mine, dl[j][2 * (b & 1)], part[bb][0]);
+                                part[bb][1] = fma(mine, dl[j][2 * (b & 1) + 1], part[bb][1]);
                             }
-                        });
-                    };
-                    load_frags(std::integral_constant<int, 0>{}, Afrag[0]);
-                    v4i blo, bhi;
-                    static_for<0, KS * 3>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value, s = i / 3, rt = i % 3, stg = j * KS + s;
+                        } else {
+                            // sum over the four modes (lanes 16 apart) as a reduce-scatter: lane g ends up with output g + 4e
+                            const double r0 = swap32_add(part[0][0], part[2][0]), i0 = swap32_add(part[0][1], part[2][1]);
+                            const double r1 = swap32_add(part[1][0], part[3][0]), i1 = swap32_add(part[1][1], part[3][1]);
+                            ynew[j][e] = mk(swap16_add(r0, r1), swap16_add(i0, i1));
+                        }
+                    }
+                }
+                if constexpr (i >= P3_0 && i < P3_0 + 4) {
+                    if (have_p3) {
+                        constexpr int mode = i - P3_0;
+                        const cd *cf = carF(bP3), *cg = carG(bP3);
+                        const cd Fa = cf[tile * 8 + mode * 2 + 0], Fb = cf[tile * 8 + mode * 2 + 1];
+                        const cd Ga = cg[(tile + 1) * 8 + mode * 2 + 0], Gb = cg[(tile + 1) * 8 + mode * 2 + 1];
+#pragma unroll
+                        for (int e = 0; e < OPL; ++e) {
+                            const cd f = cFL[(e * 4 + mode) * 64 + lane], gq = cGL[(e * 4 + mode) * 64 + lane];
+                            if constexpr (mode == 0) pv[j][e] = mk(yq[0][j][e].re + yb[j][e].re, yq[0][j][e].im + yb[j][e].im);
+                            pv[j][e].re += f.re * Fa.re - f.im * Fa.im + (gq.re * Ga.re - gq.im * Ga.im);
+                            pv[j][e].im += f.re * Fb.re - f.im * Fb.im + (gq.re * Gb.re - gq.im * Gb.im);
+                        }
+                    }
+                } else if constexpr (i == P3_0 + 4) {
+#pragma unroll
+                    for (int e = 0; e < OPL; ++e) {
+                        const int k = (tile * SDRT_TB + nb) * NOUT + g + 4 * e;
+                        *(double2 *) (yd + 2 * (size_t) k) = make_double2(pv[j][e].re, pv[j][e].im);
+                    }
+                }
+                if constexpr (HAVE_K && j == 0 && i == P3_0 + 5) {
+                    // E(it): this thread's term of its edge operator, summed over the 32 lanes of the output: inside the DPP
+                    // rows, then across the two rows of each half
+                    const double xr = decode<DT>(e_re, swap) - xoff, xi = decode<DT>(e_im, swap) - xoff;
+                    const cd u = cmul(mk(xr, xi), e_rot);
+                    const double us = e_st ? u.im : u.re;
+                    cd f = mk(e_tab.re * us, e_tab.im * us);
+                    f = cadd(f, dpp_row<0x111>(f));
+                    f = cadd(f, dpp_row<0x112>(f));
+                    f = cadd(f, dpp_row<0x114>(f));
+                    f = cadd(f, dpp_row<0x118>(f));     // lane 15 of every row: the row's sum
+                    const double tot = swap16_add(f.re, f.im);   // even rows: re(row) + re(row+1); odd rows: im(row-1) + im(row)
+                    if (nb == 15) {
+                        double *dst = (double *) ((e_kind ? GuL(bcur) : F0L(bcur)) + e_o);
+                        dst[g & 1] = tot;
+                    }
+                }
+            };
+
+            // ---- K(it) with the pieces in between ----------------------------------------------------------------------------
+            const bool more = it + 1 < cnt;
+            const unsigned char *next_raw = (const unsigned char *) a.raw + (size_t) chunk_of(more ? it + 1 : it) * chunk_bytes;
+            static_for<0, TPW>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                v4i acc[3][S];
+                v4i F[S];                            // digit-plane fragments of the current group; each is reloaded for the next
+                                                     // group as soon as its last matrix instruction has been issued
+                auto frag = [&](auto ic, auto dc) -> v4i {
+                    constexpr int i = decltype(ic)::value, d = decltype(dc)::value, s = i / 3, rt = i % 3;
+                    if constexpr (rt < 2) return wmainL[((rt * S + d) * KS + s) * 64 + lane];
+                    else return wlocL[(d * KS + s) * 64 + lane];
+                };
+                if constexpr (HAVE_K) static_for<0, S>([&](auto dc) { F[decltype(dc)::value] = frag(std::integral_constant<int, 0>{}, dc); });
+                v4i blo, bhi;
+                static_for<0, KS * 3>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, s = i / 3, rt = i % 3, stg = j * KS + s;
+                    if constexpr (HAVE_K) {
                         if constexpr (rt == 0) {
                             // slices of this k-step's 8 complex samples; then its raw registers take the k-step PF ahead
                             const uint32_t *cur = raw[stg & 3];
@@ -317,16 +406,14 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
 #pragma unroll
                                 for (int w = 0; w < 4; ++w) { blo[w] = (int) (cur[w] ^ W8Enc<DT>::xlo); bhi[w] = 0; }
                             }
-                            if constexpr (stg + PF < NSTEP) {
-                                issue(chunk_raw, std::integral_constant<int, stg + PF>{});
-                            }
+                            if constexpr (stg + PF < NSTEP) issue(chunk_raw, std::integral_constant<int, stg + PF>{});
+                            // the next item's first k-steps follow in the same ring (in the last iteration: this item's again, unused)
+                            else issue(next_raw, std::integral_constant<int, stg + PF - NSTEP>{});
                         }
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (i + 1 < KS * 3) load_frags(std::integral_constant<int, i + 1>{}, Afrag[(i + 1) & 1]);
-                        __builtin_amdgcn_sched_barrier(0);
                         static_for<0, S>([&](auto dc) {
                             constexpr int d = decltype(dc)::value;
-                            const v4i A = Afrag[i & 1][d];
+                            __builtin_amdgcn_sched_barrier(0);
+                            const v4i A = F[d];
                             if constexpr (NSL == 2) {
                                 // digit d x high slice -> level d+1 (accumulator d); digit d x low slice -> level d (accumulator d-1)
                                 if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, (v4i) {0, 0, 0, 0}, 0, 0, 0);
@@ -336,15 +423,17 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                 if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
                                 else acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[rt][d], 0, 0, 0);
                             }
+                            if constexpr (i + 1 < KS * 3) F[d] = frag(std::integral_constant<int, i + 1>{}, dc);
                         });
                         __builtin_amdgcn_sched_barrier(0);
-                    });
-                    // the next item's first k-steps go out now (the ring is free), if this was the item's last tile
-                    if constexpr (j == TPW - 1) {
-                        if (next_raw) static_for<0, PF>([&](auto sc) { issue(next_raw, sc); });
                     }
-                    // int32 levels -> fp64: value = cs * sum_q 256^q acc[q]
-                    double val[8], locv[4];
+                    piece(jc, ic);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if constexpr (j == 0) SDRT_STAMP(2);
+                if constexpr (HAVE_K) {
+                    // int32 levels -> fp64: value = cs * sum_q 256^q acc[q]; lane (g, nb): rows 4g+v of column nb (v = 2*stream + part)
+                    double val[8];
                     static_for<0, 3>([&](auto rc) {
                         constexpr int rt = decltype(rc)::value;
 #pragma unroll
@@ -352,73 +441,28 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                             double dsum = (double) acc[rt][S - 1][v];
 #pragma unroll
                             for (int q = S - 2; q >= 0; --q) dsum = fma(dsum, 256.0, (double) acc[rt][q][v]);
-                            if constexpr (rt < 2) val[4 * rt + v] = dsum * cs_main; else locv[v] = dsum * cs_loc;
+                            if constexpr (rt < 2) val[4 * rt + v] = dsum * cs_main; else dl[j][v] = dsum * cs_loc;
                         }
                     });
-                    // lane (g, nb): mode g of column nb: rows 4g+v = 2*stream + part
-                    cd Cr = mk(val[0], val[1]), Ci = mk(val[2], val[3]), Ar = mk(val[4], val[5]), Ai = mk(val[6], val[7]);
-                    if (nco) {
-                        const cd psi = nco_blk_g[tile * SDRT_TB + nb];   // the column's common phasor multiplies the complex DATA
-                        cd t;
-                        t = mk(psi.re * Cr.re - psi.im * Ci.re, psi.re * Cr.im - psi.im * Ci.im);
-                        Ci = mk(psi.im * Cr.re + psi.re * Ci.re, psi.im * Cr.im + psi.re * Ci.im);
-                        Cr = t;
-                        t = mk(psi.re * Ar.re - psi.im * Ai.re, psi.re * Ar.im - psi.im * Ai.im);
-                        Ai = mk(psi.im * Ar.re + psi.re * Ai.re, psi.im * Ar.im + psi.re * Ai.im);
-                        Ar = t;
+                    dC[j][0] = mk(val[0], val[1]);
+                    dC[j][1] = mk(val[2], val[3]);
+                    dA[j][0] = mk(val[4], val[5]);
+                    dA[j][1] = mk(val[6], val[7]);
+                }
+            });
+            // the queue of column-local outputs moves on
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {      // local rows of this lane: outputs 2g, 2g+1, (stream re, stream im) each
-                            const double t2 = psi.re * locv[2 * h] - psi.im * locv[2 * h + 1];
-                            locv[2 * h + 1] = psi.im * locv[2 * h] + psi.re * locv[2 * h + 1];
-                            locv[2 * h] = t2;
-                        }
-                    }
-                    // inclusive scans over the 16 columns of the tile (lanes of one DPP row)
-                    Cr = cfma(mup[0], dpp_row<0x111>(Cr), Cr);
-                    Ci = cfma(mup[0], dpp_row<0x111>(Ci), Ci);
-                    Ar = cfma(mup[0], dpp_row<0x101>(Ar), Ar);
-                    Ai = cfma(mup[0], dpp_row<0x101>(Ai), Ai);
-                    Cr = cfma(mup[1], dpp_row<0x112>(Cr), Cr);
-                    Ci = cfma(mup[1], dpp_row<0x112>(Ci), Ci);
-                    Ar = cfma(mup[1], dpp_row<0x102>(Ar), Ar);
-                    Ai = cfma(mup[1], dpp_row<0x102>(Ai), Ai);
-                    Cr = cfma(mup[2], dpp_row<0x114>(Cr), Cr);
-                    Ci = cfma(mup[2], dpp_row<0x114>(Ci), Ci);
-                    Ar = cfma(mup[2], dpp_row<0x104>(Ar), Ar);
-                    Ai = cfma(mup[2], dpp_row<0x104>(Ai), Ai);
-                    Cr = cfma(mup[3], dpp_row<0x118>(Cr), Cr);
-                    Ci = cfma(mup[3], dpp_row<0x118>(Ci), Ci);
-                    Ar = cfma(mup[3], dpp_row<0x108>(Ar), Ar);
-                    Ai = cfma(mup[3], dpp_row<0x108>(Ai), Ai);
-                    // tile aggregates: causal inclusive at the last column -> slot tile+1, anticausal inclusive at the first -> slot tile
-                    if (nb == 15) { cf[(tile + 1) * 8 + g * 2 + 0] = Cr; cf[(tile + 1) * 8 + g * 2 + 1] = Ci; }
-                    if (nb == 0) { cg[tile * 8 + g * 2 + 0] = Ar; cg[tile * 8 + g * 2 + 1] = Ai; }
-                    // states at the column's edges from inside the tile: causal at its start, anticausal at its end
-                    const cd Cxr = dpp_row<0x111>(Cr), Cxi = dpp_row<0x111>(Ci), Axr = dpp_row<0x101>(Ar), Axi = dpp_row<0x101>(Ai);
-                    // this mode's share of every output of the column, plus the local rows where this lane holds them
-                    double part[NOUT][2];
+            for (int j = 0; j < TPW; ++j)
 #pragma unroll
-                    for (int b = 0; b < NOUT; ++b) {
-                        const cd bc = bpL[b * 4 + g], ba = bpL[(NOUT - b) * 4 + g];
-                        part[b][0] = bc.re * Cxr.re - bc.im * Cxr.im + ba.re * Axr.re - ba.im * Axr.im;
-                        part[b][1] = bc.re * Cxi.re - bc.im * Cxi.im + ba.re * Axi.re - ba.im * Axi.im;
-                        const double mine = (g == (b >> 1)) ? 1.0 : 0.0;
-                        part[b][0] = fma(mine, locv[2 * (b & 1)], part[b][0]);
-                        part[b][1] = fma(mine, locv[2 * (b & 1) + 1], part[b][1]);
-                    }
-                    // sum over the four modes (lanes 16 apart) as a reduce-scatter: lane g ends up with outputs g (+4)
-#pragma unroll
-                    for (int e = 0; e < OPL; ++e) {
-                        const int b0 = 4 * e;
-                        const double r0 = swap32_add(part[b0][0], part[b0 + 2][0]), i0 = swap32_add(part[b0][1], part[b0 + 2][1]);
-                        const double r1 = swap32_add(part[b0 + 1][0], part[b0 + 3][0]), i1 = swap32_add(part[b0 + 1][1], part[b0 + 3][1]);
-                        yq[1][j][e] = mk(swap16_add(r0, r1), swap16_add(i0, i1));
-                    }
-                });
-            }
+                for (int e = 0; e < OPL; ++e) { yq[0][j][e] = yq[1][j][e]; yq[1][j][e] = ynew[j][e]; }
+            SDRT_STAMP(3);
             __syncthreads();
+            SDRT_STAMP(4);
+#undef SDRT_STAMP
             bcur = bcur == 2 ? 0 : bcur + 1;
-        }
+        };
+        for (int it = 0; it < cnt; ++it) iteration(std::true_type{}, it);
+        for (int it = cnt; it < cnt + 3; ++it) iteration(std::false_type{}, it);
     }
 }
 

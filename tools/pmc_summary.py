@@ -34,11 +34,14 @@ for pas in ('fetch', 'write'):
                  if 'chain' in r.get('Kernel_Name', '') and r['Counter_Name'] == ('FETCH_SIZE' if pas == 'fetch' else 'WRITE_SIZE')
                  and float(r['Counter_Value']) > 1000]
         if vals:
+            # the workload's kernel is the one that moves the most bytes (sdrt_create also launches the fp64 kernel once)
+            top = max(vals)
+            sel = [v for v in vals if v > 0.5 * top]
             if pas == 'fetch':
-                fetch = sum(vals) / len(vals)
-                kname = names[0]
+                fetch = sum(sel) / len(sel)
+                kname = names[vals.index(top)]
             else:
-                write = sum(vals) / len(vals)
+                write = sum(sel) / len(sel)
 if fetch is not None and write is not None:
     m = re.search(r'(chain\w*kernel)', kname)
     rec = {'kernel': m.group(1) if m else kname, 'chunks_per_step_per_gpu': int(os.environ.get('BENCH_CHUNKS', '32768')),
