@@ -88,7 +88,15 @@ def test_process_chunk_signature_matches_reference(golden):
 
 
 def _client(host, port, nbytes, sink, idx):
-    s = socket.create_connection((host, port), timeout=30)
+    s = None
+    for _ in range(400):                             # the acceptor may not be listening yet: retry instead of giving up
+        try:
+            s = socket.create_connection((host, port), timeout=30)
+            break
+        except OSError:
+            time.sleep(0.05)
+    if s is None:
+        return
     buf = bytearray()
     while len(buf) < nbytes:
         b = s.recv(1 << 16)
@@ -112,19 +120,14 @@ def test_vfo_processor_simo_fanout_matches_reference(golden):
                      omegaOut=case['omega_out'], dec=case['q'], fileInfo={'bitsPerSample': 'int16'})
     p.selectOutputFm()
     q = _ListQueue(_reader_chunks(case) + [b''])
-    t = threading.Thread(target=p.processData, args=(_Flag(), q))
+    t = threading.Thread(target=p.processData, args=(_Flag(), q), daemon=True)
     t.start()
     sink = [None] * rows
     clients = []
     for k in range(rows):                            # connect in row order, like example_simo.sh does with a delay
-        for _ in range(100):
-            try:
-                c = threading.Thread(target=_client, args=('127.0.0.1', port, nch * m * 8, sink, k))
-                c.start()
-                clients.append(c)
-                break
-            except OSError:
-                time.sleep(0.05)
+        c = threading.Thread(target=_client, args=('127.0.0.1', port, nch * m * 8, sink, k), daemon=True)
+        c.start()
+        clients.append(c)
         time.sleep(0.15)
     for c in clients:
         c.join(60)
