@@ -48,6 +48,8 @@ struct sdrt_ctx {
     DecimTables *d_tab = nullptr;
     OutTables *d_otab = nullptr;
     double *d_nco_tile = nullptr, *d_nco_phase = nullptr, *d_resample = nullptr, *d_out_sos = nullptr;
+    double *d_fft_tw = nullptr, *d_fft_shift = nullptr;
+    bool fft_ok = false, out_modal = false;
     double *d_y = nullptr;            // [row][chunk][m][2] decimated samples between the two kernels
     size_t y_cap_chunks = 0;
     void *d_raw = nullptr;
@@ -262,6 +264,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         OutTables otab;
         sdrt_build_out_tables(cfg->out_sos, cfg->out_sections, m, &otab);
         rc = upload(&c->d_otab, &otab, sizeof(otab));
+        c->out_modal = otab.nmodes >= 0;
     }
     if (rc == SDRT_OK && c->nco) {
         // exp(i theta t) is factored as (sample within block) x (block within chunk): L + n/L table entries per row
@@ -277,6 +280,15 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         std::vector<double> h((size_t) m / 2);
         sdrt_build_resample_odd(m / 2, h.data());
         rc = upload(&c->d_resample, h.data(), h.size() * sizeof(double));
+        const int N = m / 2;
+        const char *pf = getenv("SDRTERM_RESAMPLE");             // diagnostics: "direct" forces the circulant product
+        if (rc == SDRT_OK && (N == 256 || N == 512 || N == 1024) && !(pf && strcmp(pf, "direct") == 0)) {
+            std::vector<double> tw((size_t) N * 2), sh((size_t) N * 2);
+            sdrt_build_fft_resample(N, tw.data(), sh.data());
+            rc = upload(&c->d_fft_tw, tw.data(), tw.size() * sizeof(double));
+            if (rc == SDRT_OK) rc = upload(&c->d_fft_shift, sh.data(), sh.size() * sizeof(double));
+            c->fft_ok = rc == SDRT_OK;
+        }
     }
     if (rc == SDRT_OK) {
         const char *force = getenv("SDRTERM_STAGE_A");      // diagnostics: "f64" forces the fp64 matrix-core kernel
@@ -446,6 +458,8 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_nco_tile);
     (void) hipFree(c->d_nco_phase);
     (void) hipFree(c->d_resample);
+    (void) hipFree(c->d_fft_tw);
+    (void) hipFree(c->d_fft_shift);
     (void) hipFree(c->d_out_sos);
     (void) hipFree(c->d_otab);
     (void) hipFree(c->d_y);
@@ -575,6 +589,9 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     PostArgs pa;
     pa.y = ybuf;
     pa.resample_odd = c->d_resample;
+    pa.fft_tw = c->d_fft_tw;
+    pa.fft_shift = c->d_fft_shift;
+    pa.fft_ok = c->fft_ok && c->out_modal;
     pa.otab = c->d_otab;
     pa.out_sos = c->d_out_sos;
     pa.out = out_dev;

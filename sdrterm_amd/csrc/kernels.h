@@ -57,11 +57,14 @@ size_t chain_lds_bytes(int n, int L, int m);
 struct PostArgs {
     const double *y;            // [items][m][2]
     const double *resample_odd; // [m/2] (FM)
+    const double *fft_tw;       // [m/2][2] exp(-2 pi i k/N)          (FM, FFT form of the resampler; may be NULL)
+    const double *fft_shift;    // [m/2][2] half-sample shift / N
     const OutTables *otab;
     const double *out_sos;      // [out_sections][6], used only by the sequential fallback
     double *out;                // [items][m]
     size_t items;
     int m, mode, out_sections;
+    int fft_ok;                 // host check: modal lowpass available (OutTables.nmodes >= 0) and not disabled
 };
 size_t post_lds_bytes(int m, int mode);
 hipError_t launch_post(const PostArgs &a, hipStream_t s);

@@ -4,6 +4,53 @@
 // modal scan along the lanes.  Small registers and 12 m bytes of LDS per wave keep many items in flight per CU.
 #include "kernels_common.hpp"
 
+// Output lowpass of one item in modal form, one wave: y[t] = D x[t] + sum_k Re(r_k s_k(t)), s_k(t+1) = p_k s_k(t) + x[t].
+// Lane l owns samples [l*E, l*E+E): local end state, inclusive scan along the wave, exclusive shift = state at the lane's
+// first sample.  zb: [m] demodulated samples (LDS), out: [m] (global).
+__device__ __forceinline__ void modal_lowpass_wave(const OutTables *__restrict__ ot, const double *zb, double *out, const int m, const int lane) {
+    const int nmodes = ot->nmodes;
+    const int E = ot->E, t0 = lane * E;
+    cd sst[SDRT_OUT_MAXMODES];
+#pragma unroll
+    for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
+        sst[k] = mk(0.0, 0.0);
+        if (k < nmodes) {
+            const cd p = mk(ot->p[k][0], ot->p[k][1]);
+            cd s = mk(0.0, 0.0);
+            for (int e = 0; e < E; ++e) {
+                const double x = (t0 + e < m) ? zb[t0 + e] : 0.0;
+                s = cfma(p, s, mk(x, 0.0));
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int d = 1 << i;
+                cd t = mk(__shfl_up(s.re, d), __shfl_up(s.im, d));
+                if (lane < d) t = mk(0.0, 0.0);
+                s = cfma(mk(ot->pstep[k][i][0], ot->pstep[k][i][1]), t, s);
+            }
+            cd ex = mk(__shfl_up(s.re, 1), __shfl_up(s.im, 1));
+            if (lane == 0) ex = mk(0.0, 0.0);
+            sst[k] = ex;
+        }
+    }
+    const double Dd = ot->D;
+    for (int e = 0; e < E; ++e) {
+        if (t0 + e < m) {
+            const double x = zb[t0 + e];
+            double yv = Dd * x;
+#pragma unroll
+            for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
+                if (k < nmodes) {
+                    const cd r = mk(ot->r[k][0], ot->r[k][1]), p = mk(ot->p[k][0], ot->p[k][1]);
+                    yv += r.re * sst[k].re - r.im * sst[k].im;
+                    sst[k] = cfma(p, sst[k], mk(x, 0.0));
+                }
+            }
+            out[t0 + e] = yv;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int m = a.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,48 +117,151 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
         }
         return;
     }
-    // modal form: y[t] = D x[t] + sum_k Re(r_k s_k(t)), s_k(t+1) = p_k s_k(t) + x[t].  Lane l owns samples [l*E, l*E+E):
-    // local end state, inclusive scan along the wave, exclusive shift = state at the lane's first sample.
-    const int E = ot->E, t0 = lane * E;
-    cd sst[SDRT_OUT_MAXMODES];
+    modal_lowpass_wave(ot, zb, out, m, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// post_fft_kernel: the FM post stage with scipy.signal.resample in the form the reference itself uses (demodulation.py:35-38
+// -> scipy: rfft, zero-pad, irfft): odd output samples = IDFT(DFT(a) * half-sample shift), even ones = a.  One wave per
+// item (the angle sequence as a complex sequence with zero imaginary part).  Transforms: Stockham radix-4 passes (+ one radix-2
+// pass when N is not a power of four) through a per-wave LDS buffer, in place: a wave executes all loads of a pass before
+// its stores.  N = 256 B.  O(N log N) instead of the O(N^2) circulant product of post_kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ cd csub(cd a, cd b) { return mk(a.re - b.re, a.im - b.im); }
+template <bool INV> __device__ __forceinline__ cd cmul_tw(cd v, cd w) {      // v * w (forward) or v * conj(w) (inverse)
+    if constexpr (INV) return mk(v.re * w.re + v.im * w.im, v.im * w.re - v.re * w.im);
+    else return mk(v.re * w.re - v.im * w.im, v.re * w.im + v.im * w.re);
+}
+
+// One radix-4 Stockham pass over N points held as x[b][k] = X[t + k N/4], t = lane + 64 b; sub-transform length n = N/s.
+// Results go to store(index, value).
+template <int B, int S_, bool INV, class Store>
+__device__ __forceinline__ void radix4_pass(cd (&x)[B][4], const cd *tw, const int lane, Store store) {
+    constexpr int N = 256 * B, n = N / S_;
 #pragma unroll
-    for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
-        sst[k] = mk(0.0, 0.0);
-        if (k < nmodes) {
-            const cd p = mk(ot->p[k][0], ot->p[k][1]);
-            cd s = mk(0.0, 0.0);
-            for (int e = 0; e < E; ++e) {
-                const double x = (t0 + e < m) ? zb[t0 + e] : 0.0;
-                s = cfma(p, s, mk(x, 0.0));
-            }
+    for (int b = 0; b < B; ++b) {
+        const int t = lane + 64 * b, p = t / S_, q = t % S_;
+        const cd a0 = x[b][0], a1 = x[b][1], a2 = x[b][2], a3 = x[b][3];
+        const cd t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = csub(a1, a3);
+        // forward: y1 = t1 - i t3, y3 = t1 + i t3; inverse: the other way round
+        const cd jt3 = INV ? mk(-t3.im, t3.re) : mk(t3.im, -t3.re);
+        cd y0 = cadd(t0, t2), y1 = cadd(t1, jt3), y2 = csub(t0, t2), y3 = csub(t1, jt3);
+        if constexpr (n > 4) {
+            y1 = cmul_tw<INV>(y1, tw[p * S_]);
+            y2 = cmul_tw<INV>(y2, tw[2 * p * S_]);
+            y3 = cmul_tw<INV>(y3, tw[3 * p * S_]);
+        }
+        const int o = q + S_ * 4 * p;
+        store(o, y0);
+        store(o + S_, y1);
+        store(o + 2 * S_, y2);
+        store(o + 3 * S_, y3);
+    }
+}
+
+template <int B, bool INV, class Load, class Store>
+__device__ __forceinline__ void fft_wave(cd (&x)[B][4], cd *X, const cd *tw, const int lane, Load load_first, Store store_last) {
+    constexpr int N = 256 * B;
+    constexpr bool R2 = (B == 2);                    // 512 = 2 * 4^4: a final radix-2 pass
+    auto ldX = [&]() {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int d = 1 << i;
-                cd t = mk(__shfl_up(s.re, d), __shfl_up(s.im, d));
-                if (lane < d) t = mk(0.0, 0.0);
-                s = cfma(mk(ot->pstep[k][i][0], ot->pstep[k][i][1]), t, s);
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[b][k] = X[lane + 64 * b + k * (N / 4)];
+    };
+    auto stX = [&](int o, cd v) { X[o] = v; };
+    load_first();
+    radix4_pass<B, 1, INV>(x, tw, lane, stX);
+    ldX();
+    radix4_pass<B, 4, INV>(x, tw, lane, stX);
+    ldX();
+    radix4_pass<B, 16, INV>(x, tw, lane, stX);
+    ldX();
+    if constexpr (B == 1) {
+        radix4_pass<B, 64, INV>(x, tw, lane, store_last);
+    } else {
+        radix4_pass<B, 64, INV>(x, tw, lane, stX);
+        if constexpr (B == 4) {
+            ldX();
+            radix4_pass<B, 256, INV>(x, tw, lane, store_last);
+        }
+        if constexpr (R2) {
+            // n = 2, s = N/2: y[q] = a + b, y[q + N/2] = a - b for q < N/2; 2B items per lane
+            cd u[2 * B][2];
+#pragma unroll
+            for (int c = 0; c < 2 * B; ++c) { u[c][0] = X[lane + 64 * c]; u[c][1] = X[lane + 64 * c + N / 2]; }
+#pragma unroll
+            for (int c = 0; c < 2 * B; ++c) {
+                store_last(lane + 64 * c, cadd(u[c][0], u[c][1]));
+                store_last(lane + 64 * c + N / 2, csub(u[c][0], u[c][1]));
             }
-            cd ex = mk(__shfl_up(s.re, 1), __shfl_up(s.im, 1));
-            if (lane == 0) ex = mk(0.0, 0.0);
-            sst[k] = ex;
         }
     }
-    const double Dd = ot->D;
-    for (int e = 0; e < E; ++e) {
-        if (t0 + e < m) {
-            const double x = zb[t0 + e];
-            double yv = Dd * x;
+}
+}  // namespace
+
+template <int B, int WPB>
+__global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
+    constexpr int N = 256 * B, M = 2 * N;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cd *tw = (cd *) smem;                                       // [N] exp(-2 pi i k/N)
+    cd *sh = tw + N;                                            // [N] half-sample shift / N
+    cd *X = sh + N + (size_t) wave * N;                         // [N] per wave
+    double *zb = (double *) (sh + N + (size_t) WPB * N) + (size_t) wave * M;   // [M] per wave
+    for (int i = tid; i < N; i += 64 * WPB) {
+        tw[i] = ((const cd *) a.fft_tw)[i];
+        sh[i] = ((const cd *) a.fft_shift)[i];
+    }
+    __syncthreads();
+    const OutTables *__restrict__ ot = a.otab;
+    // one item per wave and turn: every item's result is a function of that item alone, bit for bit (pairing two items
+    // into one complex transform would make the last bits of one depend on the other)
+    for (size_t item = (size_t) blockIdx.x * WPB + wave; item < a.items; item += (size_t) gridDim.x * WPB) {
+        const cd *y = (const cd *) a.y + item * (size_t) M;
+        cd x[B][4];
+        auto angles = [&]() {
 #pragma unroll
-            for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
-                if (k < nmodes) {
-                    const cd r = mk(ot->r[k][0], ot->r[k][1]), p = mk(ot->p[k][0], ot->p[k][1]);
-                    yv += r.re * sst[k].re - r.im * sst[k].im;
-                    sst[k] = cfma(p, sst[k], mk(x, 0.0));
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = lane + 64 * b + k * (N / 4);
+                    const cd p = y[2 * j], c = y[2 * j + 1];
+                    // angle(d[i] * conj(d[i+1])) (demodulation.py:25-32)
+                    const double an = atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);
+                    x[b][k] = mk(an, 0.0);
+                    zb[2 * j] = an;                             // even output samples are the input
                 }
-            }
-            out[t0 + e] = yv;
-        }
+        };
+        // forward transform -> X (natural order)
+        fft_wave<B, false>(x, X, tw, lane, angles, [&](int o, cd v) { X[o] = v; });
+        // spectrum * shift, inverse transform; its last pass leaves the odd output samples (the imaginary parts are rounding noise)
+        auto shifted = [&]() {
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int f = lane + 64 * b + k * (N / 4);
+                    x[b][k] = cmul(X[f], sh[f]);
+                }
+        };
+        fft_wave<B, true>(x, X, tw, lane, shifted, [&](int o, cd v) { zb[2 * o + 1] = v.re; });
+        modal_lowpass_wave(ot, zb, a.out + item * (size_t) M, M, lane);
     }
+}
+
+template <int B, int WPB>
+static hipError_t launch_post_fft(const PostArgs &a, hipStream_t s) {
+    constexpr int N = 256 * B;
+    const size_t lds = (size_t) (2 * N + WPB * N) * 16 + (size_t) WPB * 2 * N * 8;
+    hipError_t e = hipFuncSetAttribute((const void *) post_fft_kernel<B, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    if (e != hipSuccess) return e;
+    size_t wgs = (a.items + WPB - 1) / WPB;
+    const size_t cap = 256 * 8;                                  // a few workgroups per CU; waves walk over the rest
+    if (wgs > cap) wgs = cap;
+    hipLaunchKernelGGL((post_fft_kernel<B, WPB>), dim3((unsigned) wgs), dim3(64 * WPB), lds, s, a);
+    return hipGetLastError();
 }
 
 size_t post_lds_bytes(int m, int mode) {
@@ -120,6 +270,14 @@ size_t post_lds_bytes(int m, int mode) {
 }
 
 hipError_t launch_post(const PostArgs &a, hipStream_t s) {
+    // FFT form of the resampler where it applies: FM, N = m/2 in {256, 512, 1024}, output lowpass in modal form
+    if (a.mode == SDRT_FM && a.fft_tw && a.fft_shift && a.fft_ok) {
+        switch (a.m) {
+            case 512: return launch_post_fft<1, 4>(a, s);
+            case 1024: return launch_post_fft<2, 4>(a, s);
+            case 2048: return launch_post_fft<4, 2>(a, s);
+        }
+    }
     const size_t lds = post_lds_bytes(a.m, a.mode);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *) post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);

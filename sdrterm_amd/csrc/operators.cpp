@@ -317,6 +317,22 @@ extern "C" void sdrt_build_resample_odd(int N, double *h) {
     }
 }
 
+extern "C" void sdrt_build_fft_resample(int N, double *tw, double *shift) {
+    const long double pi = 3.141592653589793238462643383279502884L;
+    for (int k = 0; k < N; ++k) {
+        // exp(-2 pi i k/N) with the angle reduced to the first octant by symmetry would be tighter still; cosl/sinl of an
+        // argument < 2 pi in long double is good to ~1e-19
+        const long double ang = -2.0L * pi * (long double) k / (long double) N;
+        tw[2 * k] = (double) cosl(ang);
+        tw[2 * k + 1] = (double) sinl(ang);
+        const int fs = k < N / 2 ? k : k - N;
+        if (2 * k == N) { shift[2 * k] = 0.0; shift[2 * k + 1] = 0.0; continue; }
+        const long double a2 = pi * (long double) fs / (long double) N;
+        shift[2 * k] = (double) (cosl(a2) / (long double) N);
+        shift[2 * k + 1] = (double) (sinl(a2) / (long double) N);
+    }
+}
+
 namespace {
 
 // quantise rows x cols reals (row-major, leading dimension ld) to S balanced base-256 digits against one power-of-two

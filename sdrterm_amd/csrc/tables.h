@@ -83,6 +83,11 @@ void sdrt_build_nco(double f, double fs, int tile_len, int n_tiles, double *tile
 // Odd-sample kernel of scipy.signal.resample(a, 2N) for real a of length N: y[2j+1] = sum_k a[k] h[(j-k) mod N].
 void sdrt_build_resample_odd(int N, double *h /*[N]*/);
 
+// Tables of the FFT form of scipy.signal.resample(a, 2N) for real a of length N (power of two): tw[k] = exp(-2 pi i k/N),
+// shift[f] = exp(+i pi fs/N)/N with fs the signed frequency of DFT bin f (0 at the Nyquist bin): the odd output samples are
+// IDFT(DFT(a) * shift) without further scaling, the even ones are a itself.
+void sdrt_build_fft_resample(int N, double *tw /*[N][2]*/, double *shift /*[N][2]*/);
+
 // Stage-A weights for the int8 matrix-core path.  A column is LC = G*L samples.  Main matrix: the 16 complex-mode rows
 // (column aggregates) with the within-column NCO phasor folded in, as a real 32 x 2LC matrix (rows: part + 2*stream +
 // 4*(mode>>1) + 8*(kind + 2*(mode&1)); columns: (sample, re/im)).  Mid matrix (G > 1): for every internal block boundary
