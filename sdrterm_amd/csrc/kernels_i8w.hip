@@ -236,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
 #pragma unroll
                 for (int e = 0; e < OPL; ++e) yb[j][e] = ybias[((wave + 8 * j) * SDRT_TB + nb) * NOUT + g + 4 * e];
             // ---- P2(it-2): tile carries, one wave per real stream; DPP rows = modes, lanes of a row = tiles ------------------
-            if (have_p2 && (wave >> 1) == (it & 3)) {
+            if (have_p2 && (wave >> 1) == (it & 1)) {     // waves 0-3 win the issue arbitration on their SIMDs and have the slack
                 const int st = wave & 1, o = g * 2 + st, t = nb;
                 cd *cf = carF(bP2), *cg = carG(bP2);
                 const cd m1 = tpwL[1 * 4 + g], m2 = tpwL[2 * 4 + g], m4 = tpwL[4 * 4 + g], m8 = tpwL[8 * 4 + g];
@@ -410,6 +410,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                             // the next item's first k-steps follow in the same ring (in the last iteration: this item's again, unused)
                             else issue(next_raw, std::integral_constant<int, stg + PF - NSTEP>{});
                         }
+                        __builtin_amdgcn_s_setprio(1);           // matrix instructions first: the other wave's vector work fills the gaps
                         static_for<0, S>([&](auto dc) {
                             constexpr int d = decltype(dc)::value;
                             __builtin_amdgcn_sched_barrier(0);
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                             if constexpr (i + 1 < KS * 3) F[d] = frag(std::integral_constant<int, i + 1>{}, dc);
                         });
                         __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_setprio(0);
                     }
                     piece(jc, ic);
                     __builtin_amdgcn_sched_barrier(0);
