@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SDRT_ABI_VERSION 1
+#define SDRT_ABI_VERSION 2
 
 /* Input encodings: src/misc/file_util.py:44-56 (DataType b,B,h,H,i,I,f,d). */
 enum sdrt_dtype {
@@ -106,6 +106,17 @@ int sdrt_process_host(sdrt_ctx *ctx, const void *raw_host, size_t n_chunks, doub
  * dsp_processor.py:147) as interleaved float64 (re, im), layout [row][chunk][m][2].  For parity tests. */
 int sdrt_process_device_debug(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, double *out_dev,
                               double *ydec_dev, void *stream);
+
+/*
+ * --smooth-output: scipy.signal.savgol_filter(z, window, 3) on every chunk's output samples before they are written
+ * (DspProcessor._transformData, dsp_processor.py:159-160; single-VFO processors only, VfoProcessor never smooths).
+ * The filter is linear; the caller designs it with scipy where the reference does and passes the operator:
+ *   interior outputs  i in [n_edge, m - n_edge):  out[i] = sum_k taps[k] * z[i + tap_first + k]   (samples outside the chunk count 0)
+ *   first n_edge outputs:  out[i] = sum_k left[i][k] * z[k],  last n_edge:  out[m-n_edge+i] = sum_k right[i][k] * z[m-window+k]
+ * (mode='interp': polynomial fits over the first / last `window` samples).  window == 0 switches smoothing off.
+ */
+int sdrt_set_smoothing(sdrt_ctx *ctx, int window, int ntaps, int tap_first, const double *taps, int n_edge,
+                       const double *left /*[n_edge][window]*/, const double *right /*[n_edge][window]*/);
 
 /* The carried IQ-correction offset (read_file.py:53): get/set as (re, im). */
 int sdrt_get_iq_offset(sdrt_ctx *ctx, double *re, double *im);

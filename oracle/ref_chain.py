@@ -119,8 +119,10 @@ def am_demod(y: np.ndarray) -> np.ndarray:
 
 
 def process_chunk(z: np.ndarray, q: int, mode: str, shift, out_sos, return_decimated: bool = False,
-                  faithful_dtype: bool = True):
+                  faithful_dtype: bool = True, smooth: int = 0):
     """dsp_processor.py:140-149: shift -> decimate -> demod -> output sosfilt, one chunk, all rows.
+
+    ``smooth``: window length of --smooth-output (0 = off), applied after the output lowpass (_transformData).
 
     ``faithful_dtype``: the reference allocates x and y with the dtype of the first Queue item
     (dsp_processor.py:172-177).  ``re + 1j*im`` is complex64 for float32 input (numpy promotion,
@@ -142,6 +144,9 @@ def process_chunk(z: np.ndarray, q: int, mode: str, shift, out_sos, return_decim
     else:
         raise ValueError(mode)
     out = signal.sosfilt(out_sos, d)
+    if smooth:
+        # --smooth-output, dsp_processor.py:159-160: savgol_filter(z, smooth, 3) on what is about to be written
+        out = signal.savgol_filter(out, smooth, 3)
     return (out, y) if return_decimated else out
 
 

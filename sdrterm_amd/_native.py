@@ -16,13 +16,14 @@ ITEM_SIZE = {'b': 1, 'B': 1, 'h': 2, 'H': 2, 'i': 4, 'I': 4, 'f': 4, 'd': 8}
 MODES = {'fm': 0, 'am': 1}
 OK, EINVAL, EHIP, ENOMEM, ENODEVICE = 0, 1, 2, 3, 4
 
+ABI_VERSION = 2
 EXPORTS = (
     'sdrt_abi_version', 'sdrt_config_size', 'sdrt_device_count', 'sdrt_last_error', 'sdrt_create', 'sdrt_destroy',
     'sdrt_out_per_chunk', 'sdrt_rows', 'sdrt_process_device', 'sdrt_process_host',
     'sdrt_process_device_debug', 'sdrt_get_iq_offset', 'sdrt_set_iq_offset', 'sdrt_profile_enable',
     'sdrt_kernel_time', 'sdrt_profile_reset', 'sdrt_kernel_name', 'sdrt_malloc', 'sdrt_free',
     'sdrt_memcpy_h2d', 'sdrt_memcpy_d2h', 'sdrt_memcpy_d2d', 'sdrt_device_synchronize', 'sdrt_set_device',
-    'sdrt_selftest_mfma', 'sdrt_selftest_mfma_i8', 'sdrt_stage_a_kind', 'sdrt_debug_stamps', 'sdrt_demodulate_host',
+    'sdrt_selftest_mfma', 'sdrt_selftest_mfma_i8', 'sdrt_set_smoothing', 'sdrt_stage_a_kind', 'sdrt_debug_stamps', 'sdrt_demodulate_host',
 )
 
 
@@ -93,10 +94,11 @@ def lib():
     l.sdrt_selftest_mfma.argtypes = [C.POINTER(C.c_double)]
     l.sdrt_selftest_mfma_i8.argtypes = [C.POINTER(C.c_int)]
     l.sdrt_stage_a_kind.argtypes = [C.c_void_p]
+    l.sdrt_set_smoothing.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     l.sdrt_demodulate_host.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     l.sdrt_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     l.sdrt_config_size.restype = C.c_size_t
-    if l.sdrt_abi_version() != 1 or l.sdrt_config_size() != C.sizeof(Config):
+    if l.sdrt_abi_version() != ABI_VERSION or l.sdrt_config_size() != C.sizeof(Config):
         raise NativeLibraryError('libsdrterm_hip.so ABI mismatch (version or sdrt_config layout)')
     _lib = l
     return l

@@ -49,6 +49,8 @@ struct sdrt_ctx {
     OutTables *d_otab = nullptr;
     double *d_nco_tile = nullptr, *d_nco_phase = nullptr, *d_resample = nullptr, *d_out_sos = nullptr;
     double *d_fft_tw = nullptr, *d_fft_shift = nullptr;
+    double *d_smooth = nullptr;       // taps | left | right of --smooth-output (sdrt_set_smoothing)
+    int sm_window = 0, sm_ntaps = 0, sm_first = 0, sm_edge = 0;
     bool fft_ok = false, out_modal = false;
     double *d_y = nullptr;            // [row][chunk][m][2] decimated samples between the two kernels
     size_t y_cap_chunks = 0;
@@ -458,6 +460,7 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_nco_tile);
     (void) hipFree(c->d_nco_phase);
     (void) hipFree(c->d_resample);
+    (void) hipFree(c->d_smooth);
     (void) hipFree(c->d_fft_tw);
     (void) hipFree(c->d_fft_shift);
     (void) hipFree(c->d_out_sos);
@@ -478,6 +481,36 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_raw);
     (void) hipFree(c->d_out);
     delete c;
+}
+
+int sdrt_set_smoothing(sdrt_ctx *c, int window, int ntaps, int tap_first, const double *taps, int n_edge, const double *left,
+                       const double *right) {
+    if (!c) return fail(SDRT_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    (void) hipFree(c->d_smooth);
+    c->d_smooth = nullptr;
+    c->sm_window = 0;
+    if (window == 0) return SDRT_OK;
+    if (window < 0 || ntaps < 1 || n_edge < 0 || !taps || (n_edge > 0 && (!left || !right)))
+        return fail(SDRT_EINVAL, "bad smoothing operator");
+    // scipy: "If mode is 'interp', window_length must be less than or equal to the size of x."
+    if (window > c->m || 2 * n_edge > c->m)
+        return fail(SDRT_EINVAL, "If mode is 'interp', window_length must be less than or equal to the size of x.");
+    const size_t cnt = (size_t) ntaps + 2 * (size_t) n_edge * window;
+    std::vector<double> all(cnt);
+    memcpy(all.data(), taps, sizeof(double) * ntaps);
+    if (n_edge) {
+        memcpy(all.data() + ntaps, left, sizeof(double) * n_edge * window);
+        memcpy(all.data() + ntaps + (size_t) n_edge * window, right, sizeof(double) * n_edge * window);
+    }
+    int rc = upload(&c->d_smooth, all.data(), cnt * sizeof(double));
+    if (rc != SDRT_OK) return rc;
+    c->sm_window = window;
+    c->sm_ntaps = ntaps;
+    c->sm_first = tap_first;
+    c->sm_edge = n_edge;
+    return SDRT_OK;
 }
 
 int sdrt_out_per_chunk(const sdrt_ctx *c) { return c ? c->m : -1; }
@@ -602,6 +635,20 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     {
         Timed t(c, s, 1);
         HIP_TRY(launch_post(pa, s));
+        if (c->sm_window > 0) {
+            SmoothArgs sa;
+            sa.out = out_dev;
+            sa.items = pa.items;
+            sa.m = c->m;
+            sa.window = c->sm_window;
+            sa.ntaps = c->sm_ntaps;
+            sa.tap_first = c->sm_first;
+            sa.n_edge = c->sm_edge;
+            sa.taps = c->d_smooth;
+            sa.left = c->d_smooth + c->sm_ntaps;
+            sa.right = sa.left + (size_t) c->sm_edge * c->sm_window;
+            HIP_TRY(launch_smooth(sa, s));
+        }
     }
     return SDRT_OK;
 }

@@ -66,6 +66,13 @@ struct PostArgs {
     int m, mode, out_sections;
     int fft_ok;                 // host check: modal lowpass available (OutTables.nmodes >= 0) and not disabled
 };
+struct SmoothArgs {
+    double *out;                // [items][m], smoothed in place
+    size_t items;
+    int m, window, ntaps, tap_first, n_edge;
+    const double *taps, *left, *right;
+};
+hipError_t launch_smooth(const SmoothArgs &a, hipStream_t s);
 size_t post_lds_bytes(int m, int mode);
 hipError_t launch_post(const PostArgs &a, hipStream_t s);
 hipError_t launch_chain(const DecimArgs &a, int L, int dt, bool nco, bool iq, size_t n_chunks, hipStream_t s);

@@ -286,3 +286,40 @@ hipError_t launch_post(const PostArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(post_kernel, dim3((unsigned) ((a.items + 3) / 4)), dim3(256), lds, s, a);
     return hipGetLastError();
 }
+
+// ---- --smooth-output: Savitzky-Golay operator on the written samples (dsp_processor.py:159-160), one wave per item -------
+__global__ __launch_bounds__(256) void smooth_kernel(SmoothArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int m = a.m, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *z = (double *) smem + (size_t) wave * m;
+    const size_t item = (size_t) blockIdx.x * 4 + wave;
+    if (item >= a.items) return;
+    double *out = a.out + item * (size_t) m;
+    for (int i = lane; i < m; i += 64) z[i] = out[i];
+    for (int i = lane; i < m; i += 64) {
+        double acc = 0.0;
+        if (i < a.n_edge) {
+            const double *row = a.left + (size_t) i * a.window;
+            for (int k = 0; k < a.window; ++k) acc = fma(row[k], z[k], acc);
+        } else if (i >= m - a.n_edge) {
+            const double *row = a.right + (size_t) (i - (m - a.n_edge)) * a.window;
+            for (int k = 0; k < a.window; ++k) acc = fma(row[k], z[m - a.window + k], acc);
+        } else {
+            for (int k = 0; k < a.ntaps; ++k) {
+                const int j = i + a.tap_first + k;
+                if (j >= 0 && j < m) acc = fma(a.taps[k], z[j], acc);
+            }
+        }
+        out[i] = acc;
+    }
+}
+
+hipError_t launch_smooth(const SmoothArgs &a, hipStream_t s) {
+    const size_t lds = (size_t) 4 * a.m * sizeof(double);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *) smooth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(smooth_kernel, dim3((unsigned) ((a.items + 3) / 4)), dim3(256), lds, s, a);
+    return hipGetLastError();
+}

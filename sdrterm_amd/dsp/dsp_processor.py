@@ -142,9 +142,12 @@ class DspProcessor(DataProcessor):
             return 'f'
         raise TypeError(f'chunks must be complex64 or complex128 arrays, not {chunk.dtype}')
 
-    def _getEngine(self, n: int, code: str):
+    def _getEngine(self, n: int, code: str, smoothed: bool = True):
+        """The GPU context for chunks of n samples of this encoding.  ``smoothed``: with --smooth-output applied
+        (_transformData, dsp_processor.py:159-160); _processChunk itself never smooths in the reference."""
+        window = self._smoothing() if smoothed else 0
         eng = self._engine
-        if eng is not None and eng.n == n and eng.code == code:
+        if eng is not None and eng.n == n and eng.code == code and eng.smooth == window:
             return eng
         mode = getattr(self.demod, 'mode', None)
         if mode not in ('fm', 'am', 're', 'im'):
@@ -156,24 +159,27 @@ class DspProcessor(DataProcessor):
         from ..engine import Engine
         sos = np.asarray(self._outputFilters, dtype=np.float64).reshape(-1, 6)
         self._engine = Engine(self._fs, self._decimationFactor, mode, code, n_samples=n, row_freqs=self._rowFreqs(),
-                              apply_shift=self._applyShift(), out_sos=sos, device=self._device)
+                              apply_shift=self._applyShift(), out_sos=sos, device=self._device, smooth=window)
         return self._engine
 
-    def _requireNoSmoothing(self):
-        if self.smooth:
-            raise NotImplementedError('--smooth-output (Savitzky-Golay, dsp_processor.py:159-160) is not in the GPU build yet')
+    def _smoothing(self) -> int:
+        """--smooth-output window (savgol_filter(z, smooth, 3) in _transformData, dsp_processor.py:159-160); 0 = off."""
+        return int(self.smooth) if self.smooth else 0
 
     # ---- per-chunk API kept for callers/tests written against the reference -----------------------------------
     def _processChunk(self, x: np.ndarray, y: np.ndarray, z: np.ndarray) -> None:
         """x (nFreq, n) complex with the chunk in row 0; fills y (nFreq, n/q) decimated samples and z (nFreq, n/q) output."""
-        self._requireNoSmoothing()
-        eng = self._getEngine(x.shape[1], self._encodingOf(x))
+        eng = self._getEngine(x.shape[1], self._encodingOf(x), smoothed=False)
         out, dec = eng.process_debug(np.ascontiguousarray(x[0]), 1)
         y[:] = dec
         z[:] = out
 
     def _transformData(self, x, y, z, file) -> None:
         self._processChunk(x, y, z)
+        if self._smoothing():
+            # same operator the batched path applies on the GPU (Engine(smooth=...)), here on one chunk
+            eng = self._getEngine(x.shape[1], self._encodingOf(x), smoothed=True)
+            z[:] = eng.process(np.ascontiguousarray(x[0]), 1).reshape(z.shape)
         file.write(np.ascontiguousarray(z, dtype='=f8').tobytes())     # == pack('@Nd', *z.flat), dsp_processor.py:162
 
     # ---- consumer loop ----------------------------------------------------------------------------------------
@@ -190,7 +196,6 @@ class DspProcessor(DataProcessor):
         return (got[:-1] if eof else got), eof
 
     def _runBatch(self, chunks) -> np.ndarray:
-        self._requireNoSmoothing()
         eng = self._getEngine(chunks[0].size, self._encodingOf(chunks[0]))
         raw = np.ascontiguousarray(np.stack(chunks) if len(chunks) > 1 else chunks[0])
         return eng.process(raw, len(chunks)).reshape(self._nFreq, len(chunks), eng.m)

@@ -38,6 +38,22 @@ def output_sos(fs_dec: int, omega_out, degree: int = 3) -> np.ndarray:
         ellip(degree, 1, 30, omega_out, btype='lowpass', analog=False, output='sos', fs=fs_dec), dtype=np.float64)
 
 
+def savgol_operator(window: int, polyorder: int = 3):
+    """The linear operator of ``scipy.signal.savgol_filter(z, window, polyorder)`` (mode='interp'), which is what
+    --smooth-output applies (src/dsp/dsp_processor.py:159-160), read off scipy's own result on unit impulses:
+    (taps, tap_first, n_edge, left, right) as include/sdrterm_hip.h:sdrt_set_smoothing takes them."""
+    from scipy.signal import savgol_filter
+    size = 4 * window + 5
+    op = savgol_filter(np.eye(size), window, polyorder, axis=0)     # op[i, j] = d out[i] / d in[j]
+    n_edge = window // 2                                            # scipy _fit_edges_polyfit: halflen outputs per side
+    left = np.ascontiguousarray(op[:n_edge, :window])
+    right = np.ascontiguousarray(op[size - n_edge:, size - window:])
+    mid = size // 2
+    nz = np.nonzero(op[mid])[0]
+    taps = np.ascontiguousarray(op[mid, nz[0]:nz[-1] + 1])
+    return taps, int(nz[0] - mid), n_edge, left, right
+
+
 _DEMOD_MODES = {'fm': 0, 'am': 1, 're': 2, 'im': 3}
 
 
@@ -55,7 +71,7 @@ class Engine:
 
     def __init__(self, fs, decimation, mode, code='h', n_samples=None, row_freqs=None, apply_shift=None,
                  out_sos=None, omega_out=12500, normalize=False, correct_iq=False, impedance=50,
-                 big_endian=False, device=0):
+                 big_endian=False, device=0, smooth=0):
         if mode not in nat.MODES:
             raise ValueError(f'unsupported demodulation mode {mode!r}')
         if code not in nat.DTYPES:
@@ -102,6 +118,11 @@ class Engine:
         self.m = nat.lib().sdrt_out_per_chunk(self._ctx)
         self.stage_a = {0: 'f64', 1: 'i8x32', 2: 'i8t', 3: 'i8w'}[nat.lib().sdrt_stage_a_kind(self._ctx)]   # which stage-A kernel runs
         self.chunk_bytes = self.n * 2 * nat.ITEM_SIZE[code]
+        self.smooth = int(smooth) if smooth else 0
+        if smooth:
+            taps, first, n_edge, left, right = savgol_operator(int(smooth))
+            nat.check(nat.lib().sdrt_set_smoothing(self._ctx, int(smooth), taps.size, first, taps.ctypes.data, n_edge,
+                                                   left.ctypes.data, right.ctypes.data))
 
     # -- processing ---------------------------------------------------------------------------------
     def process(self, raw, n_chunks=None) -> np.ndarray:

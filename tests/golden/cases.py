@@ -3,7 +3,7 @@
 Field meanings follow the reference CLI (src/sdrterm.py:54-107): ``code`` is the --encoding name
 (misc/file_util.py:44-56), ``q`` is --decimation, ``center`` is --center-frequency, ``vfos`` is the
 --vfos csv (rows = csv entries + center, then center last, vfo_processor.py:43-47), ``omega_out`` is
---omega-out, ``normalize`` / ``correct_iq`` are --normalize-input / --correct-iq.
+--omega-out, ``normalize`` / ``correct_iq`` are --normalize-input / --correct-iq, ``smooth`` is --smooth-output.
 """
 READ_SIZE = 131072  # bytes per chunk, misc/read_file.py:38
 
@@ -40,6 +40,9 @@ CASES = [
     _c('b_q128_fm_c0', 'b', 128, 'fm', omega_out=2500, amp=100, seed=27),
     _c('H_q64_am_norm_c', 'H', 64, 'am', center=15700, normalize=True, seed=28),
     _c('h_q256_fm_c', 'h', 256, 'fm', center=15700, omega_out=1500, seed=29),
+    # --smooth-output (Savitzky-Golay on the written samples, dsp_processor.py:159-160): odd and even window lengths
+    _c('h_q64_fm_c_smooth11', 'h', 64, 'fm', center=15700, smooth=11, seed=30),
+    _c('h_q32_am_norm_c0_smooth8', 'h', 32, 'am', normalize=True, smooth=8, seed=31),
 ]
 
 BY_NAME = {c['name']: c for c in CASES}

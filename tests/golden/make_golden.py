@@ -94,7 +94,7 @@ def run_reader(case):
 
 
 def make_processor(case):
-    kw = dict(center=case['center'], omegaOut=case['omega_out'], dec=case['q'],
+    kw = dict(center=case['center'], omegaOut=case['omega_out'], dec=case['q'], smooth=case.get('smooth', False),
               fileInfo={'bitsPerSample': case['code']})
     if case.get('vfos'):
         p = VfoProcessor(case['fs'], vfoHost='localhost:1', vfos=case['vfos'], **kw)
@@ -189,7 +189,15 @@ def known_answer():
 def main():
     out = {}
     meta = {}
+    path = os.path.join(HERE, 'reference_vectors.npz')
+    only = sys.argv[1:]                  # names: (re)generate just these cases and keep the rest of the file as it is
+    if only:
+        old = np.load(path)
+        out.update({k: old[k] for k in old.files})
+        meta.update(json.loads(bytes(old['meta_json']).decode()))
     for case in CASES:
+        if only and case['name'] not in only:
+            continue
         res = run_case(case)
         for k, v in res.items():
             out[f"{case['name']}/{k}"] = v

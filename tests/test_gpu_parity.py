@@ -16,7 +16,7 @@ def _engine(case):
     return Engine(case['fs'], case['q'], case['mode'], case['code'], row_freqs=rows,
                   apply_shift=bool(case.get('vfos') or case['center']), omega_out=case['omega_out'],
                   normalize=bool(case.get('normalize')), correct_iq=bool(case.get('correct_iq')),
-                  big_endian=bool(case.get('big_endian')))
+                  big_endian=bool(case.get('big_endian')), smooth=case.get('smooth', 0))
 
 
 def test_mfma_layout_selftest():

@@ -101,8 +101,9 @@ def test_unsupported_selections_fail_like_the_reference():
         p._getEngine(32768, 'd')
     p.selectOutputFm()
     p.smooth = 5
-    with pytest.raises(NotImplementedError):
-        p._runBatch([np.zeros(32768, complex)])
+    assert p._smoothing() == 5                                          # --smooth-output reaches the engine as its window
+    p.smooth = False
+    assert p._smoothing() == 0
 
 
 def test_shared_library_exports_every_declared_symbol():
@@ -115,7 +116,7 @@ def test_shared_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(lib, n), f'{n} declared in the header but not exported'
     assert set(_native.EXPORTS) <= names
-    assert _native.lib().sdrt_abi_version() == 1
+    assert _native.lib().sdrt_abi_version() == _native.ABI_VERSION == 2
     assert ctypes.sizeof(_native.Config) == _native.lib().sdrt_config_size()
 
 
@@ -186,3 +187,25 @@ def test_split_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_savgol_operator_reproduces_scipy():
+    """The operator handed to sdrt_set_smoothing is scipy's savgol_filter(z, w, 3) for odd and even windows."""
+    from scipy.signal import savgol_filter
+    from sdrterm_amd.engine import savgol_operator
+    rng = np.random.default_rng(3)
+    for w, m in ((5, 64), (11, 512), (8, 1024), (51, 512), (4, 16)):
+        taps, first, n_edge, left, right = savgol_operator(w)
+        z = rng.normal(size=m)
+        out = np.zeros(m)
+        for i in range(m):
+            if i < n_edge:
+                out[i] = left[i] @ z[:w]
+            elif i >= m - n_edge:
+                out[i] = right[i - (m - n_edge)] @ z[m - w:]
+            else:
+                for k in range(taps.size):
+                    j = i + first + k
+                    if 0 <= j < m:
+                        out[i] += taps[k] * z[j]
+        assert np.abs(out - savgol_filter(z, w, 3)).max() < 1e-12

@@ -27,7 +27,7 @@ def test_numpy_oracle_matches_reference(case, golden):
         zin = ch.read(rawc)
         np.testing.assert_allclose(zin[::case.get('zsub', 251)], z[f'{name}/reader_sub'][c], rtol=1e-12, atol=1e-9)
         assert abs(zin[-1] - z[f'{name}/reader_last'][c]) <= 1e-9 * max(1.0, abs(zin[-1]))
-        out, y = ref_chain.process_chunk(zin, case['q'], case['mode'], ch.shift, ch.out_sos, True)
+        out, y = ref_chain.process_chunk(zin, case['q'], case['mode'], ch.shift, ch.out_sos, True, smooth=case.get('smooth', 0))
         assert np.abs(out - exp[c]).max() <= tol_for(exp[c]) * 1e-3   # same scipy -> essentially exact
         if c == 0:
             y0 = z[f'{name}/y0']
@@ -38,6 +38,8 @@ def test_numpy_oracle_matches_reference(case, golden):
 
 @pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
 def test_c_oracle_matches_reference(case, golden):
+    if case.get('smooth'):
+        pytest.skip('--smooth-output is restated in the numpy oracle only')
     z, _ = golden
     name = case['name']
     raw = case_raw(case)
