@@ -61,6 +61,7 @@ struct sdrt_ctx {
     bool use_i8t = false;             //   ... in the 16x16x64 form; otherwise the 32x32x32 form
     bool use_i8w = false;             //   ... wide columns, persistent workgroups (default where supported)
     WideTables *d_wtab = nullptr;
+    double *d_edge_ab = nullptr, *d_edge_pq = nullptr, *d_gvec = nullptr;
     int n_cus = 256;
     signed char *d_w8 = nullptr, *d_w8mid = nullptr;
     DecimTables *d_tab8 = nullptr;    // tables for columns of SDRT_I8_G blocks
@@ -297,11 +298,11 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         const bool want_i8 = !(force && strcmp(force, "f64") == 0);
         const bool want_x32 = force && strcmp(force, "i8x32") == 0;   // diagnostics: the 32x32x32 int8 kernel
         const bool want_t = force && strcmp(force, "i8t") == 0;       // diagnostics: the one-block-per-column 16x16x64 kernel
-        c->use_i8w = want_i8 && !want_x32 && !want_t && !c->iq && chain_i8w_supported(q, cfg->dtype, n) &&
+        c->use_i8w = want_i8 && !want_x32 && !want_t && chain_i8w_supported(q, cfg->dtype, n) &&
                      chain_i8w_lds_bytes(q, n) <= 160 * 1024;
         c->use_i8t = !c->use_i8w && want_i8 && !want_x32 && !c->iq && chain_i8t_supported(L, cfg->dtype, n) &&
                      chain_i8t_lds_bytes(n, L, m) <= 160 * 1024;
-        c->use_i8 = c->use_i8w || c->use_i8t || (want_i8 && !c->iq && chain_i8_supported(L, cfg->dtype, n) &&
+        c->use_i8 = c->use_i8w || c->use_i8t || (want_i8 && !c->iq && !c->use_i8w && chain_i8_supported(L, cfg->dtype, n) &&
                                                  chain_i8_lds_bytes(n, L, m) <= 160 * 1024);
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->n_cus = cus;
@@ -316,13 +317,18 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         const size_t per_row = (size_t) 2 * S * KS * 64 * 16, per_row_loc = (size_t) S * KS * 4 * NR * 16;
         std::vector<signed char> w8(per_row * c->rows), w8l(per_row_loc * c->rows);
         std::vector<double> samp((size_t) c->rows * LC * 2), blk((size_t) c->rows * (n / LC) * 2);
+        std::vector<double> eab((size_t) c->rows * 16 * 32 * 4), epq((size_t) c->rows * 16 * 4), gv((size_t) c->rows * 48 * 2);
+        const double lam = c->iq ? cfg->iq_inductance : 0.0;
         for (int r = 0; r < c->rows && rc == SDRT_OK; ++r) {
             double comb = 0.0, combl = 0.0;
             double *sp = &samp[(size_t) r * LC * 2], *bp = &blk[(size_t) r * (n / LC) * 2];
             if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, LC, n / LC, sp, bp);
-            if (sdrt_build_i8_weights_wide(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, c->nco ? sp : nullptr, S,
-                                           w8.data() + per_row * r, &comb, w8l.data() + per_row_loc * r, &combl) != 0)
+            if (sdrt_build_i8_weights_wide(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, c->nco ? sp : nullptr, S, lam,
+                                           w8.data() + per_row * r, &comb, w8l.data() + per_row_loc * r, &combl,
+                                           &gv[(size_t) r * 96]) != 0)
                 rc = fail(SDRT_EINVAL, "int8 weight quantisation failed");
+            sdrt_build_wide_edge(&wtab, c->nco ? sp : nullptr, c->nco ? bp : nullptr, n, lam, &eab[(size_t) r * 2048],
+                                 &epq[(size_t) r * 64]);
             // one power-of-two scale per context (rows differ by a rotation of the weights only); otherwise the other form
             if (r == 0) { c->w8_combine = comb; c->w8mid_combine = combl; }
             else if (comb != c->w8_combine || combl != c->w8mid_combine) { c->use_i8w = false; break; }
@@ -333,9 +339,17 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         }
         if (rc == SDRT_OK && c->use_i8w) rc = upload(&c->d_w8, w8.data(), w8.size());
         if (rc == SDRT_OK && c->use_i8w) rc = upload(&c->d_w8mid, w8l.data(), w8l.size());
+        if (rc == SDRT_OK && c->use_i8w) rc = upload(&c->d_edge_ab, eab.data(), eab.size() * sizeof(double));
+        if (rc == SDRT_OK && c->use_i8w) rc = upload(&c->d_edge_pq, epq.data(), epq.size() * sizeof(double));
+        if (rc == SDRT_OK && c->use_i8w) rc = upload(&c->d_gvec, gv.data(), gv.size() * sizeof(double));
+        if (c->use_i8w && c->iq && c->w8_combine == 0.0) c->use_i8w = false;
         if (!c->use_i8w) {
-            (void) hipFree(c->d_wtab); c->d_wtab = nullptr;
-            c->use_i8t = want_i8_fallback_t(L, cfg->dtype, n, m);
+            (void) hipFree(c->d_wtab);
+    (void) hipFree(c->d_edge_ab);
+    (void) hipFree(c->d_edge_pq);
+    (void) hipFree(c->d_gvec); c->d_wtab = nullptr;
+            c->use_i8t = !c->iq && want_i8_fallback_t(L, cfg->dtype, n, m);
+            c->use_i8 = c->use_i8t;
         }
     }
     if (rc == SDRT_OK && c->use_i8t) {
@@ -407,7 +421,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     if (rc == SDRT_OK && c->use_i8) {
         static const double kOff[8] = {0.0, 128.0, 128.0, 32896.0, 0, 0, 0, 0};
         c->x_offset = kOff[cfg->dtype];
-        if (rc == SDRT_OK && c->use_i8 && (c->x_offset != 0.0 || c->norm_bias != 0.0)) {
+        if (rc == SDRT_OK && c->use_i8 && !c->iq && (c->x_offset != 0.0 || c->norm_bias != 0.0)) {
             // response of the (linear) decimator to the constant the slices leave out: run the f64 kernel once on a
             // constant chunk and keep its decimated samples
             const double cre = c->x_offset + c->norm_bias, cim = c->x_offset;
@@ -470,6 +484,9 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_w8mid);
     (void) hipFree(c->d_tab8);
     (void) hipFree(c->d_wtab);
+    (void) hipFree(c->d_edge_ab);
+    (void) hipFree(c->d_edge_pq);
+    (void) hipFree(c->d_gvec);
     (void) hipFree(c->d_nco_tile8);
     (void) hipFree(c->d_nco_phase8);
     (void) hipFree(c->d_ybias);
@@ -600,6 +617,14 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     da.w8mid_combine = c->w8mid_combine;
     da.x_offset = c->x_offset;
     da.wtab = c->d_wtab;
+    da.edge_ab = c->d_edge_ab;
+    da.edge_pq = c->d_edge_pq;
+    da.gvec = c->d_gvec;
+    da.e_off_re = c->iq ? -c->norm_bias : c->x_offset;      // IQ: the edge operators see the true samples
+    da.e_off_im = c->iq ? 0.0 : c->x_offset;
+    da.c_re = c->x_offset + c->norm_bias;
+    da.c_im = c->x_offset;
+    da.iq_gs = c->L / 4;
     if (c->use_i8) {
         da.tab = c->d_tab8;
         da.n_tiles = c->n_tiles8;

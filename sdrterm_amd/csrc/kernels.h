@@ -35,6 +35,12 @@ struct DecimArgs {
     double w8_combine;          // scale * 2^-(8S-1)
     double x_offset;            // what the slices leave out of every component: x = x' + x_offset
     const WideTables *wtab;     // wide-column kernel (kernels_i8w.hip) only; there w8mid holds the local-row planes
+    const double *edge_ab;      //   [rows][16][32][4] edge operators as per-sample coefficients (sdrt_build_wide_edge)
+    const double *edge_pq;      //   [rows][16][4]     their IQ-offset terms
+    const double *gvec;         //   [rows][48][2]     IQ rank-one vectors (sdrt_build_i8_weights_wide)
+    double e_off_re, e_off_im;  //   what the edge operators subtract from the decoded components
+    double c_re, c_im;          //   IQ: the constant the slices leave out of (re, im)
+    int iq_gs;                  //   IQ: samples per prefix group
 };
 
 struct IqArgs {

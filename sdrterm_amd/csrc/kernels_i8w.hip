@@ -45,7 +45,7 @@ __device__ __forceinline__ double swap16_add(double x, double y) {
 }
 
 struct WideLds {        // byte offsets
-    int wmain, wloc, cF, cG, bp, mup, tpw, tailF, tailFc, psi, buf, buf_stride, total;
+    int wmain, wloc, cF, cG, bp, mup, tpw, tailF, tailFc, psi, gv, pq, cpow, buf, buf_stride, total;
     // per buffer (offsets in 16-byte units from its start): carF [(NT+1)*8], carG [(NT+1)*8], F0 [8], Gu [8]
 };
 __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt) {
@@ -61,6 +61,9 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt) {
     l.tailF = p; p += 16 * 16;
     l.tailFc = p; p += 16 * 16;
     l.psi = p; p += nt * SDRT_TB * 16;              // column phasors of the row
+    l.gv = p; p += 48 * 16;                         // IQ: rank-one vectors {g_re, g_im} per matrix row
+    l.pq = p; p += 16 * 2 * 16;                     // IQ: offset terms of the edge operators
+    l.cpow = p; p += nt * SDRT_TB * 8;              // IQ: (1-lambda)^(column start)
     l.buf = p;
     l.buf_stride = (2 * (nt + 1) * 8 + 16) * 16;
     p += 3 * l.buf_stride;
@@ -69,7 +72,7 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt) {
 }
 }  // namespace
 
-template <int DT, int NOUT, int NT, int S>
+template <int DT, int NOUT, int NT, int S, bool IQ>
 __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     constexpr int LC = SDRT_WIDE_LC, KS = LC / 32;
     constexpr int NSL = W8Enc<DT>::slices;
@@ -97,6 +100,8 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     const v4i *wlocL = (const v4i *) (smem + lo.wloc);
     cd *cFL = (cd *) (smem + lo.cF), *cGL = (cd *) (smem + lo.cG), *bpL = (cd *) (smem + lo.bp), *mupL = (cd *) (smem + lo.mup), *tpwL = (cd *) (smem + lo.tpw);
     cd *tailFL = (cd *) (smem + lo.tailF), *tailFcL = (cd *) (smem + lo.tailFc), *psiL = (cd *) (smem + lo.psi);
+    cd *gvL = (cd *) (smem + lo.gv), *pqL = (cd *) (smem + lo.pq);
+    double *cpowL = (double *) (smem + lo.cpow);
     auto carF = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride); };
     auto carG = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + (NT + 1) * 8; };
     auto F0L = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + 2 * (NT + 1) * 8; };
@@ -139,13 +144,11 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     }
     if (tid >= 32 && tid < 48) mupL[tid - 32] = mk(wt->mu_pow[(tid - 32) >> 2][tid & 3][0], wt->mu_pow[(tid - 32) >> 2][tid & 3][1]);
     // edge operator of this thread: output o16 = tid >> 5 (kind: 0 head -> F0, 1 tail -> Gu; chain o = mode*2 + stream), sample l
-    const int e_o16 = tid >> 5, e_l = tid & 31, e_kind = e_o16 >> 3, e_o = e_o16 & 7, e_mode = e_o >> 1, e_st = e_o & 1;
-    const int e_lc = e_l <= SDRT_EDGE ? e_l : SDRT_EDGE;            // lanes 28..31 carry weight 0
-    const long e_idx = e_kind ? (long) n - (SDRT_EDGE + 1) + e_lc : (long) e_lc;
-    cd e_tab = mk(0.0, 0.0);
-    if (e_l <= SDRT_EDGE)
-        e_tab = e_kind ? mk(wt->tailU[e_mode][e_l][0], wt->tailU[e_mode][e_l][1]) : mk(wt->head[e_mode][e_l][0], wt->head[e_mode][e_l][1]);
-    const double xoff = a.x_offset;
+    const int e_o16 = tid >> 5, e_l = tid & 31, e_kind = e_o16 >> 3, e_o = e_o16 & 7;
+    // sample l of the 32-sample window of the output: the chunk's first / last 32 samples (the operator spans 28 of them)
+    const long e_idx = e_kind ? (long) n - 32 + e_l : (long) e_l;
+    const double e_off_re = a.e_off_re, e_off_im = a.e_off_im;   // what the edge operators subtract from the decoded components
+    const int cgs = LC / (IQ ? a.iq_gs : LC);                    // IQ prefix groups per column
     const double cs_main = a.w8_combine * (NSL == 2 ? 256.0 : 1.0), cs_loc = a.w8mid_combine * (NSL == 2 ? 256.0 : 1.0);
     const size_t chunk_bytes = (size_t) n * 2 * ITEM;
     // this lane's bytes of k-step s of a tile: column nb, samples 32 s + 8 g .. + 7
@@ -163,10 +166,15 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             for (int i = tid; i < S * KS * 64; i += 512)
                 dl[i] = (i & 15) < NR ? wl[(i >> 4) * NR + (i & 15)] : (v4i) {0, 0, 0, 0};
         }
-        const cd *nco_samp_g = nco ? (const cd *) a.nco_tile + (size_t) row * LC : nullptr;                // exp(i theta j), j < LC
         const cd *nco_blk_g = nco ? (const cd *) a.nco_phase + (size_t) row * (size_t) (n / LC) : nullptr;  // exp(i theta LC c)
-        cd e_rot = mk(1.0, 0.0);
-        if (nco) e_rot = cmul(nco_samp_g[e_idx % LC], nco_blk_g[e_idx / LC]);
+        // coefficients of this thread's sample in its edge operator (NCO phasor and IQ correction of the window folded in)
+        const cd e_A = ((const cd *) a.edge_ab)[(((size_t) row * 16 + e_o16) * 32 + e_l) * 2];
+        const cd e_B = ((const cd *) a.edge_ab)[(((size_t) row * 16 + e_o16) * 32 + e_l) * 2 + 1];
+        if constexpr (IQ) {
+            if (tid < 48) gvL[tid] = ((const cd *) a.gvec)[(size_t) row * 48 + tid];
+            if (tid >= 64 && tid < 96) pqL[tid - 64] = ((const cd *) a.edge_pq)[(size_t) row * 32 + (tid - 64)];
+            for (int i = tid; i < NT * SDRT_TB; i += 512) cpowL[i] = a.iq_pow[i * cgs];
+        }
         for (int i = tid; i < NT * SDRT_TB; i += 512) psiL[i] = nco ? nco_blk_g[i] : mk(1.0, 0.0);
         const cd *ybias = (const cd *) a.ybias + (size_t) row * m;      // always present for this kernel (zeros if there is no offset)
         __syncthreads();
@@ -234,7 +242,33 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
 #pragma unroll
             for (int j = 0; j < TPW; ++j)
 #pragma unroll
-                for (int e = 0; e < OPL; ++e) yb[j][e] = ybias[((wave + 8 * j) * SDRT_TB + nb) * NOUT + g + 4 * e];
+                for (int e = 0; e < OPL; ++e) {
+                    if constexpr (IQ) yb[j][e] = mk(0.0, 0.0);          // no constant response: the offset term carries it
+                    else yb[j][e] = ybias[((wave + 8 * j) * SDRT_TB + nb) * NOUT + g + 4 * e];
+                }
+            // IQ offsets (prefix kernels): at the chunk start, at the tail window and at this lane's columns of item it-1
+            cd off_head = mk(0.0, 0.0), off_tail = mk(0.0, 0.0), off_q = mk(0.0, 0.0), gq[TPW];
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) gq[j] = mk(0.0, 0.0);
+            if constexpr (IQ) {
+                const long ck = chunk_of(HAVE_K ? it : 0), cq = chunk_of(have_q ? it - 1 : 0);
+                const int ngrp = n / a.iq_gs, gt = (n - 32) / a.iq_gs;
+                off_head = ((const cd *) a.iq_chunk_off)[ck];
+                const cd gtl = ((const cd *) a.iq_group_off)[(size_t) ck * ngrp + gt];
+                const double ptl = a.iq_pow[gt];
+                off_tail = mk(fma(ptl, off_head.re, gtl.re), fma(ptl, off_head.im, gtl.im));
+                off_q = ((const cd *) a.iq_chunk_off)[cq];
+                // the same value in every lane: keep them in scalar registers
+                auto uni = [](double v) {
+                    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+                };
+                off_head = mk(uni(off_head.re), uni(off_head.im));
+                off_tail = mk(uni(off_tail.re), uni(off_tail.im));
+                off_q = mk(uni(off_q.re), uni(off_q.im));
+#pragma unroll
+                for (int j = 0; j < TPW; ++j)
+                    gq[j] = ((const cd *) a.iq_group_off)[(size_t) cq * ngrp + (size_t) ((wave + 8 * j) * SDRT_TB + nb) * cgs];
+            }
             // ---- P2(it-2): tile carries, one wave per real stream; DPP rows = modes, lanes of a row = tiles ------------------
             if (have_p2 && (wave >> 1) == (it & 1)) {     // waves 0-3 win the issue arbitration on their SIMDs and have the slack
                 const int st = wave & 1, o = g * 2 + st, t = nb;
@@ -274,7 +308,23 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                 constexpr int j = decltype(jc)::value, i = decltype(ic)::value;
                 const int tile = wave + 8 * j;
                 if (have_q) {
-                    if constexpr (i == 1) {
+                    if constexpr (IQ && i == 0) {
+                        // IQ correction, the part that is linear in the offset at the column's first sample:
+                        // row value += (c - off).re g_re[row] + (c - off).im g_im[row]
+                        const double cp = cpowL[tile * SDRT_TB + nb];
+                        const double dr = a.c_re - fma(cp, off_q.re, gq[j].re), di = a.c_im - fma(cp, off_q.im, gq[j].im);
+                        const cd g0 = gvL[4 * g + 0], g1 = gvL[4 * g + 1], g2 = gvL[4 * g + 2], g3 = gvL[4 * g + 3];
+                        dC[j][0] = mk(fma(dr, g0.re, fma(di, g0.im, dC[j][0].re)), fma(dr, g1.re, fma(di, g1.im, dC[j][0].im)));
+                        dC[j][1] = mk(fma(dr, g2.re, fma(di, g2.im, dC[j][1].re)), fma(dr, g3.re, fma(di, g3.im, dC[j][1].im)));
+                        const cd h0 = gvL[16 + 4 * g + 0], h1 = gvL[16 + 4 * g + 1], h2 = gvL[16 + 4 * g + 2], h3 = gvL[16 + 4 * g + 3];
+                        dA[j][0] = mk(fma(dr, h0.re, fma(di, h0.im, dA[j][0].re)), fma(dr, h1.re, fma(di, h1.im, dA[j][0].im)));
+                        dA[j][1] = mk(fma(dr, h2.re, fma(di, h2.im, dA[j][1].re)), fma(dr, h3.re, fma(di, h3.im, dA[j][1].im)));
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const cd l0 = gvL[32 + 4 * g + v];
+                            dl[j][v] = fma(dr, l0.re, fma(di, l0.im, dl[j][v]));
+                        }
+                    } else if constexpr (i == 1) {
                         const cd ps = psiL[tile * SDRT_TB + nb];      // the column's common phasor multiplies the complex DATA
                         cd t;
                         t = mk(ps.re * dC[j][0].re - ps.im * dC[j][1].re, ps.re * dC[j][0].im - ps.im * dC[j][1].im);
@@ -358,10 +408,15 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                 if constexpr (HAVE_K && j == 0 && i == P3_0 + 5) {
                     // E(it): this thread's term of its edge operator, summed over the 32 lanes of the output: inside the DPP
                     // rows, then across the two rows of each half
-                    const double xr = decode<DT>(e_re, swap) - xoff, xi = decode<DT>(e_im, swap) - xoff;
-                    const cd u = cmul(mk(xr, xi), e_rot);
-                    const double us = e_st ? u.im : u.re;
-                    cd f = mk(e_tab.re * us, e_tab.im * us);
+                    const double xr = decode<DT>(e_re, swap) - e_off_re, xi = decode<DT>(e_im, swap) - e_off_im;
+                    cd f = mk(fma(e_A.re, xr, e_B.re * xi), fma(e_A.im, xr, e_B.im * xi));
+                    if constexpr (IQ) {
+                        if (e_l == 0) {                          // the offset at the window's first sample, once per output
+                            const cd ow = e_kind ? off_tail : off_head, P = pqL[2 * e_o16], Q = pqL[2 * e_o16 + 1];
+                            f.re -= P.re * ow.re + Q.re * ow.im;
+                            f.im -= P.im * ow.re + Q.im * ow.im;
+                        }
+                    }
                     f = cadd(f, dpp_row<0x111>(f));
                     f = cadd(f, dpp_row<0x112>(f));
                     f = cadd(f, dpp_row<0x114>(f));
@@ -487,13 +542,17 @@ size_t chain_i8w_lds_bytes(int q, int n) {
     return (size_t) wide_lds(SDRT_I8_DIGITS, SDRT_WIDE_LC / q, n / (SDRT_TB * SDRT_WIDE_LC)).total;
 }
 
-template <int DT, int NOUT, int NT>
-static hipError_t launch_i8w_k(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute((const void *) chain_i8w_kernel<DT, NOUT, NT, SDRT_I8_DIGITS>,
+template <int DT, int NOUT, int NT, bool IQ>
+static hipError_t launch_i8w_q(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute((const void *) chain_i8w_kernel<DT, NOUT, NT, SDRT_I8_DIGITS, IQ>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((chain_i8w_kernel<DT, NOUT, NT, SDRT_I8_DIGITS>), grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((chain_i8w_kernel<DT, NOUT, NT, SDRT_I8_DIGITS, IQ>), grid, dim3(512), lds, s, a);
     return hipGetLastError();
+}
+template <int DT, int NOUT, int NT>
+static hipError_t launch_i8w_k(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    return a.iq_group_off ? launch_i8w_q<DT, NOUT, NT, true>(a, grid, lds, s) : launch_i8w_q<DT, NOUT, NT, false>(a, grid, lds, s);
 }
 
 template <int DT>

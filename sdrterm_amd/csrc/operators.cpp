@@ -551,9 +551,27 @@ extern "C" int sdrt_build_wide_tables(const double *sos, int sections, int q, do
     return 0;
 }
 
+namespace {
+// row (coefficients of x_re at even, of x_im at odd positions, LC samples) -> row of W (I - T); g-sums of the ORIGINAL row
+void fold_iq(double *row, int LC, double lambda, double *g2) {
+    const R lam = (R) lambda, om = (R) 1 - lam;
+    for (int comp = 0; comp < 2; ++comp) {
+        R gsum = 0, gp = 1;
+        for (int t = 0; t < LC; ++t) { gsum = gsum + (R) row[2 * t + comp] * gp; gp = gp * om; }
+        g2[comp] = (double) gsum;
+        R Sacc = 0;                                   // S_j = sum_{i>j} c[i] lambda (1-lambda)^(i-1-j)
+        for (int j = LC - 1; j >= 0; --j) {
+            const R c = (R) row[2 * j + comp];
+            row[2 * j + comp] = (double) (c - Sacc);
+            Sacc = lam * c + om * Sacc;
+        }
+    }
+}
+}  // namespace
+
 extern "C" int sdrt_build_i8_weights_wide(const double *sos, int sections, int q, double data_scale, const double *nco_samp,
-                                          int S, signed char *main_out, double *main_combine, signed char *loc_out,
-                                          double *loc_combine) {
+                                          int S, double iq_lambda, signed char *main_out, double *main_combine,
+                                          signed char *loc_out, double *loc_combine, double *gvec) {
     Modal m;
     const char *err = nullptr;
     if (!build_modal(sos, sections, m, &err)) return -2;
@@ -587,6 +605,8 @@ extern "C" int sdrt_build_i8_weights_wide(const double *sos, int sections, int q
                         Wf[(size_t) r * cols + 2 * t + 1] = cxi[stream][part];
                     }
             }
+    if (iq_lambda > 0.0)
+        for (int r = 0; r < 32; ++r) fold_iq(&Wf[(size_t) r * cols], LC, iq_lambda, gvec + 2 * r);
     *main_combine = quantise_planes(Wf.data(), 32, cols, cols, S, [&](int d, int r, int c, signed char dig) {
         int ks, kg, j;
         kpos(c, ks, kg, j);
@@ -613,6 +633,10 @@ extern "C" int sdrt_build_i8_weights_wide(const double *sos, int sections, int q
             Wl[(size_t) (2 * b + 1) * cols + 2 * t] = mt * ti(t);        // stream im: mt (xr ti + xi tr)
             Wl[(size_t) (2 * b + 1) * cols + 2 * t + 1] = mt * tr(t);
         }
+    if (iq_lambda > 0.0) {
+        for (int r = 0; r < 16; ++r) gvec[2 * (32 + r)] = gvec[2 * (32 + r) + 1] = 0.0;
+        for (int r = 0; r < NR; ++r) fold_iq(&Wl[(size_t) r * cols], LC, iq_lambda, gvec + 2 * (32 + r));
+    }
     *loc_combine = quantise_planes(Wl.data(), NR, cols, cols, S, [&](int d, int r, int c, signed char dig) {
         int ks, kg, j;
         kpos(c, ks, kg, j);
@@ -620,4 +644,57 @@ extern "C" int sdrt_build_i8_weights_wide(const double *sos, int sections, int q
     });
     if (*loc_combine == 0.0) return -1;
     return 0;
+}
+
+extern "C" void sdrt_build_wide_edge(const WideTables *wt, const double *nco_samp, const double *nco_blk, int n, double iq_lambda,
+                                     double *ab, double *pq) {
+    const int LC = SDRT_WIDE_LC, WN = 32;
+    const R lam = (R) iq_lambda, om = (R) 1 - lam;
+    R g[WN];                                           // (1-lambda)^l
+    g[0] = 1;
+    for (int l = 1; l < WN; ++l) g[l] = g[l - 1] * om;
+    for (int o16 = 0; o16 < 16; ++o16) {
+        const int kind = o16 >> 3, o = o16 & 7, mode = o >> 1, st = o & 1;
+        C hc1[WN], hc2[WN];                            // h_l c1_l, h_l c2_l: coefficient of z_re[l], z_im[l]
+        for (int l = 0; l < WN; ++l) {
+            C h(0);
+            long idx;
+            if (kind == 0) {
+                idx = l;
+                if (l <= SDRT_EDGE) h = C((R) wt->head[mode][l][0], (R) wt->head[mode][l][1]);
+            } else {
+                idx = (long) n - WN + l;
+                if (l >= WN - 1 - SDRT_EDGE) h = C((R) wt->tailU[mode][l - (WN - 1 - SDRT_EDGE)][0], (R) wt->tailU[mode][l - (WN - 1 - SDRT_EDGE)][1]);
+            }
+            C rot(1);
+            if (nco_samp) {
+                const C a((R) nco_samp[2 * (idx % LC)], (R) nco_samp[2 * (idx % LC) + 1]);
+                const C b((R) nco_blk[2 * (idx / LC)], (R) nco_blk[2 * (idx / LC) + 1]);
+                rot = a * b;
+            }
+            // stream st of rot * (zr + i zi): st 0: rot.re zr - rot.im zi; st 1: rot.im zr + rot.re zi
+            const R c1 = st ? rot.im : rot.re, c2 = st ? rot.re : -rot.im;
+            hc1[l] = h * C(c1);
+            hc2[l] = h * C(c2);
+        }
+        C P(0), Q(0);
+        for (int j = 0; j < WN; ++j) {
+            // column j of (I - T): 1 at l = j, -lambda (1-lambda)^(l-1-j) for l > j
+            C A = hc1[j], B = hc2[j];
+            if (iq_lambda > 0.0) {
+                R t = lam;
+                for (int l = j + 1; l < WN; ++l) {
+                    A = A - hc1[l] * C(t);
+                    B = B - hc2[l] * C(t);
+                    t = t * om;
+                }
+                P = P + hc1[j] * C(g[j]);
+                Q = Q + hc2[j] * C(g[j]);
+            }
+            double *dst = ab + ((size_t) o16 * WN + j) * 4;
+            dst[0] = (double) A.re; dst[1] = (double) A.im; dst[2] = (double) B.re; dst[3] = (double) B.im;
+        }
+        pq[o16 * 4 + 0] = (double) P.re; pq[o16 * 4 + 1] = (double) P.im;
+        pq[o16 * 4 + 2] = (double) Q.re; pq[o16 * 4 + 3] = (double) Q.im;
+    }
 }

@@ -125,8 +125,23 @@ int sdrt_build_wide_tables(const double *sos, int sections, int q, double data_s
 // 4*mode + 2*stream + part) go to  main[(((tile*S + digit)*KS + kstep)*64 + row + 16*kg)*16 + j];  the local tile (row =
 // 2*b + stream: the part of output b of the column that depends on this column's samples only, direct term included,
 // NR = 2*nout rows) goes to  loc[((((digit*KS + kstep)*4 + kg)*NR) + row)*16 + j].  One power-of-two scale each.
+// With IQ correction (iq_lambda > 0; read_file.py:64-77: z[i] -= off; off += z[i]*lambda) the correction inside a column is
+// linear in the column's samples and in the offset at its first sample: z = (I - T) x - g off, T[i][j] = lambda
+// (1-lambda)^(i-1-j) (j < i), g[i] = (1-lambda)^i.  The planes then hold W (I - T), and gvec[row] = {sum_t w_re[t] g[t],
+// sum_t w_im[t] g[t]} (rows 0..31 main, 32..32+NR-1 local; w_re / w_im = the row's coefficients of the real / imaginary
+// sample components) gives the rank-one rest: row value += (c - off).re * gvec[row][0] + (c - off).im * gvec[row][1], c =
+// the constant the int8 slices leave out.  gvec may be NULL when iq_lambda == 0.
 int sdrt_build_i8_weights_wide(const double *sos, int sections, int q, double data_scale, const double *nco_samp, int S,
-                               signed char *main_out, double *main_combine, signed char *loc_out, double *loc_combine);
+                               double iq_lambda, signed char *main_out, double *main_combine, signed char *loc_out,
+                               double *loc_combine, double *gvec /*[48][2]*/);
+
+// Edge operators of the wide-column kernel as per-sample coefficients: output o16 = 8*kind + 2*mode + stream (kind 0: causal
+// state F0 at the chunk start from samples 0..31, kind 1: the sample part Gu of the anticausal state at the chunk end from
+// samples n-32..n-1) is  sum_l ab[o16][l][0..1] * x_re[l] + ab[o16][l][2..3] * x_im[l]  -  pq[o16][0..1] * off_re -
+// pq[o16][2..3] * off_im, all complex {re, im}, x the true samples of the window, off the IQ offset at its first sample
+// (lambda == 0: no correction, pq = 0).  NCO phasors as for the planes (NULL = no shift).
+void sdrt_build_wide_edge(const struct WideTables *wt, const double *nco_samp, const double *nco_blk, int n, double iq_lambda,
+                          double *ab /*[16][32][4]*/, double *pq /*[16][4]*/);
 
 // IQ-correction geometric weights: pw[j] = (1-lambda)^j, j <= count.
 void sdrt_build_iq_pow(double lambda, int count, double *pw);

@@ -6,6 +6,7 @@ import numpy as np
 from scipy.signal import cheby1, decimate
 
 lib = C.CDLL(sys.argv[1] if len(sys.argv) > 1 else '/tmp/t/libop.so')
+lib.sdrt_build_wide_edge.restype = None
 LC, TB, NM, EDGE = 256, 16, 4, 27
 
 
@@ -22,7 +23,7 @@ def cplx(a, shape):
     return v[..., 0] + 1j * v[..., 1]
 
 
-def run(q, n, theta, seed=1, S=5):
+def run(q, n, theta, seed=1, S=5, lam=0.0, off0=0j):
     rng = np.random.default_rng(seed)
     sos = np.ascontiguousarray(cheby1(8, 0.05, 0.8 / q, output='sos'))
     wt = WideTables()
@@ -38,9 +39,11 @@ def run(q, n, theta, seed=1, S=5):
     main = np.zeros(2 * S * KS * 64 * 16, np.int8)
     loc = np.zeros(S * KS * 4 * NR * 16, np.int8)
     cm, cl = C.c_double(), C.c_double()
+    gvec = np.zeros((48, 2))
     rc = lib.sdrt_build_i8_weights_wide(sos.ctypes.data_as(C.c_void_p), 4, q, C.c_double(1.0),
-                                        samp_ri.ctypes.data_as(C.c_void_p) if theta else None, S,
-                                        main.ctypes.data_as(C.c_void_p), C.byref(cm), loc.ctypes.data_as(C.c_void_p), C.byref(cl))
+                                        samp_ri.ctypes.data_as(C.c_void_p) if theta else None, S, C.c_double(lam),
+                                        main.ctypes.data_as(C.c_void_p), C.byref(cm), loc.ctypes.data_as(C.c_void_p), C.byref(cl),
+                                        gvec.ctypes.data_as(C.c_void_p))
     assert rc == 0
     # de-quantise into float weight matrices W[row][2*LC] by K position
     main = main.reshape(2, S, KS, 4, 16, 16)      # tile, digit, kstep, kg, row, j
@@ -62,9 +65,23 @@ def run(q, n, theta, seed=1, S=5):
     nt = ncol // TB
     X = x.reshape(ncol, LC)
     blk = np.exp(1j * theta * LC * np.arange(ncol))
+    # IQ correction reference: z[i] = x[i] - off; off += z[i]*lam  (read_file.py:64-77), offsets at column starts
+    offs = np.zeros(n + 1, complex)
+    zc = x.copy()
+    if lam:
+        off = off0
+        for i in range(n):
+            offs[i] = off
+            zc[i] = x[i] - off
+            off += zc[i] * lam
+        offs[n] = off
     # stage A
     A = np.einsum('rt,ct->cr', Wm[:, :, 0], X.real) + np.einsum('rt,ct->cr', Wm[:, :, 1], X.imag)     # [col][32]
     Lv = np.einsum('rt,ct->cr', Wl[:, :, 0], X.real) + np.einsum('rt,ct->cr', Wl[:, :, 1], X.imag)    # [col][NR]
+    if lam:
+        d = -offs[np.arange(ncol) * LC]                # (c - off) with c = 0 here
+        A += d.real[:, None] * gvec[None, :32, 0] + d.imag[:, None] * gvec[None, :32, 1]
+        Lv += d.real[:, None] * gvec[None, 32:32 + NR, 0] + d.imag[:, None] * gvec[None, 32:32 + NR, 1]
     # rows: 16*kind + 4*mode + 2*stream + part
     A = A.reshape(ncol, 2, 4, 2, 2)
     st = A[..., 0] + 1j * A[..., 1]                # [col][kind][mode][stream] complex states
@@ -101,11 +118,26 @@ def run(q, n, theta, seed=1, S=5):
     for b in range(nout):
         yl[:, :, b, :] = Lv.reshape(nt, TB, nout, 2)[:, :, b, :] + \
             (bp2[b][None, None, :, None] * Cx + bp2[nout - b][None, None, :, None] * Ax).real.sum(axis=2)
-    # edge operators: the decimator sees u = x e^{i theta t}
-    u = x * np.exp(1j * theta * np.arange(n))
-    us = np.stack([u.real, u.imag], -1)            # [t][stream]
-    F0 = np.einsum('ml,ls->ms', head, us[:28])
-    Gu = np.einsum('ml,ls->ms', tailU, us[n - 28:])
+    # edge operators: the decimator sees u = z e^{i theta t}
+    u = zc * np.exp(1j * theta * np.arange(n))
+    blk_ri = np.ascontiguousarray(np.stack([blk.real, blk.imag], -1))
+    ab = np.zeros((16, 32, 4))
+    pq = np.zeros((16, 4))
+    lib.sdrt_build_wide_edge(C.byref(wt), samp_ri.ctypes.data_as(C.c_void_p) if theta else None,
+                             blk_ri.ctypes.data_as(C.c_void_p), n, C.c_double(lam), ab.ctypes.data_as(C.c_void_p),
+                             pq.ctypes.data_as(C.c_void_p))
+    Aj = ab[..., 0] + 1j * ab[..., 1]
+    Bj = ab[..., 2] + 1j * ab[..., 3]
+    Pq = pq[:, 0] + 1j * pq[:, 1]
+    Qq = pq[:, 2] + 1j * pq[:, 3]
+    F0 = np.zeros((4, 2), complex)
+    Gu = np.zeros((4, 2), complex)
+    for o16 in range(16):
+        kind, o = o16 >> 3, o16 & 7
+        win = x[:32] if kind == 0 else x[n - 32:]
+        ow = offs[0] if kind == 0 else offs[n - 32]
+        val = (Aj[o16] * win.real).sum() + (Bj[o16] * win.imag).sum() - (Pq[o16] * ow.real + Qq[o16] * ow.imag)
+        (F0 if kind == 0 else Gu)[o >> 1, o & 1] = val
     F = np.zeros((nt + 1, 4, 2), complex)
     F[0] = F0
     for t_ in range(nt):
@@ -130,5 +162,8 @@ def run(q, n, theta, seed=1, S=5):
 if __name__ == '__main__':
     ok = True
     for q, n, th in [(64, 32768, 0.0), (64, 32768, 0.37), (32, 32768, 0.1), (64, 65536, -1.1), (128, 32768, 0.2), (256, 32768, 0.0)]:
-        ok &= run(q, n, th) < 1e-11
+        ok &= run(q, n, th) < 2e-11
+    for q, n, th in [(64, 32768, 0.37), (32, 32768, -0.2)]:
+        ok &= run(q, n, th, lam=50 / 1024000, off0=300 - 200j) < 2e-11
+        ok &= run(q, n, th, lam=0.01, off0=-1000 + 50j) < 2e-11
     print('OK' if ok else 'FAIL')
