@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsdrterm_hip.so')
+# SDRTERM_HIP_LIB: another build of the same library (A/B measurements of kernel variants); default: the in-tree build
+LIB_PATH = os.environ.get('SDRTERM_HIP_LIB') or os.path.join(_HERE, 'libsdrterm_hip.so')
 
 # enum sdrt_dtype, keyed by the reference's DataType names (src/misc/file_util.py:44-56)
 DTYPES = {'b': 0, 'B': 1, 'h': 2, 'H': 3, 'i': 4, 'I': 5, 'f': 6, 'd': 7}

@@ -86,7 +86,7 @@ __device__ __forceinline__ void resample_wave(const double *a, const double *hr,
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) zodd[2 * (j0 + r) + 1] = acc[r];
+    for (int r = 0; r < R; ++r) { const int i = 2 * (j0 + r) + 1; zodd[i + (i >> 3)] = acc[r]; }   // padded layout of the post kernels (zpos)
 }
 
 // ---- input decoding (read_file.py:51,100-101; file_util.py:44-56) -------------------------------------------------

@@ -6,48 +6,58 @@
 
 // Output lowpass of one item in modal form, one wave: y[t] = D x[t] + sum_k Re(r_k s_k(t)), s_k(t+1) = p_k s_k(t) + x[t].
 // Lane l owns samples [l*E, l*E+E): local end state, inclusive scan along the wave, exclusive shift = state at the lane's
-// first sample.  zb: [m] demodulated samples (LDS), out: [m] (global).
-__device__ __forceinline__ void modal_lowpass_wave(const OutTables *__restrict__ ot, const double *zb, double *out, const int m, const int lane) {
-    const int nmodes = ot->nmodes;
+// first sample.  zb: [m] demodulated samples in LDS at positions zpos(i) (one pad double per 8 samples: the lanes' strided
+// runs then fall on different banks); the results overwrite zb and leave with coalesced stores.  out: [m] (global).
+__device__ __forceinline__ int zpos(int i) { return i + (i >> 3); }
+__device__ __forceinline__ int zlen(int m) { return m + (m >> 3) + 1; }
+
+template <int NM>
+__device__ __forceinline__ void modal_lowpass_body(const OutTables *__restrict__ ot, double *zb, double *out, const int m, const int lane) {
     const int E = ot->E, t0 = lane * E;
-    cd sst[SDRT_OUT_MAXMODES];
+    cd sst[NM > 0 ? NM : 1], pk[NM > 0 ? NM : 1], rk[NM > 0 ? NM : 1];
 #pragma unroll
-    for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
-        sst[k] = mk(0.0, 0.0);
-        if (k < nmodes) {
-            const cd p = mk(ot->p[k][0], ot->p[k][1]);
-            cd s = mk(0.0, 0.0);
-            for (int e = 0; e < E; ++e) {
-                const double x = (t0 + e < m) ? zb[t0 + e] : 0.0;
-                s = cfma(p, s, mk(x, 0.0));
-            }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int d = 1 << i;
-                cd t = mk(__shfl_up(s.re, d), __shfl_up(s.im, d));
-                if (lane < d) t = mk(0.0, 0.0);
-                s = cfma(mk(ot->pstep[k][i][0], ot->pstep[k][i][1]), t, s);
-            }
-            cd ex = mk(__shfl_up(s.re, 1), __shfl_up(s.im, 1));
-            if (lane == 0) ex = mk(0.0, 0.0);
-            sst[k] = ex;
+    for (int k = 0; k < NM; ++k) {
+        pk[k] = mk(ot->p[k][0], ot->p[k][1]);
+        rk[k] = mk(ot->r[k][0], ot->r[k][1]);
+        cd s = mk(0.0, 0.0);
+        for (int e = 0; e < E; ++e) {
+            const double x = (t0 + e < m) ? zb[zpos(t0 + e)] : 0.0;
+            s = cfma(pk[k], s, mk(x, 0.0));
         }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int d = 1 << i;
+            cd t = mk(__shfl_up(s.re, d), __shfl_up(s.im, d));
+            if (lane < d) t = mk(0.0, 0.0);
+            s = cfma(mk(ot->pstep[k][i][0], ot->pstep[k][i][1]), t, s);
+        }
+        cd ex = mk(__shfl_up(s.re, 1), __shfl_up(s.im, 1));
+        if (lane == 0) ex = mk(0.0, 0.0);
+        sst[k] = ex;
     }
     const double Dd = ot->D;
     for (int e = 0; e < E; ++e) {
         if (t0 + e < m) {
-            const double x = zb[t0 + e];
+            const double x = zb[zpos(t0 + e)];
             double yv = Dd * x;
 #pragma unroll
-            for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
-                if (k < nmodes) {
-                    const cd r = mk(ot->r[k][0], ot->r[k][1]), p = mk(ot->p[k][0], ot->p[k][1]);
-                    yv += r.re * sst[k].re - r.im * sst[k].im;
-                    sst[k] = cfma(p, sst[k], mk(x, 0.0));
-                }
+            for (int k = 0; k < NM; ++k) {
+                yv += rk[k].re * sst[k].re - rk[k].im * sst[k].im;
+                sst[k] = cfma(pk[k], sst[k], mk(x, 0.0));
             }
-            out[t0 + e] = yv;
+            zb[zpos(t0 + e)] = yv;
         }
+    }
+    for (int i = lane; i < m; i += 64) out[i] = zb[zpos(i)];
+}
+
+__device__ __forceinline__ void modal_lowpass_wave(const OutTables *__restrict__ ot, double *zb, double *out, const int m, const int lane) {
+    switch (ot->nmodes) {
+        case 0: modal_lowpass_body<0>(ot, zb, out, m, lane); break;
+        case 1: modal_lowpass_body<1>(ot, zb, out, m, lane); break;
+        case 2: modal_lowpass_body<2>(ot, zb, out, m, lane); break;
+        case 3: modal_lowpass_body<3>(ot, zb, out, m, lane); break;
+        default: modal_lowpass_body<4>(ot, zb, out, m, lane); break;
     }
 }
 
@@ -57,7 +67,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
     const bool fm = a.mode == SDRT_FM;
     const int N = m >> 1;
     double *hr = (double *) smem;                              // [N] (FM): hr[i] = h[(-i) mod N]
-    double *wbase = hr + (fm ? N : 0) + (size_t) wave * (size_t) (fm ? m + N : m);
+    double *wbase = hr + (fm ? N : 0) + (size_t) wave * (size_t) (fm ? zlen(m) + N : zlen(m));
     double *av = wbase;                                        // [N] pair angles (FM)
     double *zb = wbase + (fm ? N : 0);                         // [m] demodulated samples at the decimated rate
     if (fm) {
@@ -74,7 +84,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
             av[j] = atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);    // angle(d[i] * conj(d[i+1]))
         }
         // even samples are the input, odd samples the circulant product with the half-sample Dirichlet kernel
-        for (int j = lane; j < N; j += 64) zb[2 * j] = av[j];
+        for (int j = lane; j < N; j += 64) zb[zpos(2 * j)] = av[j];
         switch (N >> 6) {
             case 1: resample_wave<1>(av, hr, zb, N, lane); break;
             case 2: resample_wave<2>(av, hr, zb, N, lane); break;
@@ -85,13 +95,13 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
                 for (int j = lane; j < N; j += 64) {
                     double s0 = 0.0;
                     for (int k = 0; k < N; ++k) s0 = fma(av[k], hr[(k - j + N) % N], s0);
-                    zb[2 * j + 1] = s0;
+                    zb[zpos(2 * j + 1)] = s0;
                 }
         }
     } else {
         for (int k = lane; k < m; k += 64) {
             const cd v = y[k];
-            zb[k] = v.re * v.re + v.im * v.im;
+            zb[zpos(k)] = v.re * v.re + v.im * v.im;
         }
     }
 
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
             double st[2 * SDRT_MAX_OUT_SECTIONS];
             for (int s = 0; s < 2 * SDRT_MAX_OUT_SECTIONS; ++s) st[s] = 0.0;
             for (int i = 0; i < m; ++i) {
-                double xc = zb[i];
+                double xc = zb[zpos(i)];
                 for (int s = 0; s < a.out_sections; ++s) {
                     const double *c = a.out_sos + 6 * s;
                     const double xn = fma(c[0], xc, st[2 * s]);
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
     cd *tw = (cd *) smem;                                       // [N] exp(-2 pi i k/N)
     cd *sh = tw + N;                                            // [N] half-sample shift / N
     cd *X = sh + N + (size_t) wave * N;                         // [N] per wave
-    double *zb = (double *) (sh + N + (size_t) WPB * N) + (size_t) wave * M;   // [M] per wave
+    double *zb = (double *) (sh + N + (size_t) WPB * N) + (size_t) wave * (M + (M >> 3) + 1);   // [zlen(M)] per wave
     for (int i = tid; i < N; i += 64 * WPB) {
         tw[i] = ((const cd *) a.fft_tw)[i];
         sh[i] = ((const cd *) a.fft_shift)[i];
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
                     // angle(d[i] * conj(d[i+1])) (demodulation.py:25-32)
                     const double an = atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);
                     x[b][k] = mk(an, 0.0);
-                    zb[2 * j] = an;                             // even output samples are the input
+                    zb[zpos(2 * j)] = an;                       // even output samples are the input
                 }
         };
         // forward transform -> X (natural order)
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
                     x[b][k] = cmul(X[f], sh[f]);
                 }
         };
-        fft_wave<B, true>(x, X, tw, lane, shifted, [&](int o, cd v) { zb[2 * o + 1] = v.re; });
+        fft_wave<B, true>(x, X, tw, lane, shifted, [&](int o, cd v) { zb[zpos(2 * o + 1)] = v.re; });
         modal_lowpass_wave(ot, zb, a.out + item * (size_t) M, M, lane);
     }
 }
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
 template <int B, int WPB>
 static hipError_t launch_post_fft(const PostArgs &a, hipStream_t s) {
     constexpr int N = 256 * B;
-    const size_t lds = (size_t) (2 * N + WPB * N) * 16 + (size_t) WPB * 2 * N * 8;
+    const size_t lds = (size_t) (2 * N + WPB * N) * 16 + (size_t) WPB * (2 * N + (2 * N >> 3) + 1) * 8;
     hipError_t e = hipFuncSetAttribute((const void *) post_fft_kernel<B, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     if (e != hipSuccess) return e;
     size_t wgs = (a.items + WPB - 1) / WPB;
@@ -265,8 +275,8 @@ static hipError_t launch_post_fft(const PostArgs &a, hipStream_t s) {
 }
 
 size_t post_lds_bytes(int m, int mode) {
-    const size_t N = (size_t) m / 2;
-    return (mode == SDRT_FM ? N + 4 * ((size_t) m + N) : 4 * (size_t) m) * sizeof(double);
+    const size_t N = (size_t) m / 2, zl = (size_t) m + (size_t) (m >> 3) + 1;
+    return (mode == SDRT_FM ? N + 4 * (zl + N) : 4 * zl) * sizeof(double);
 }
 
 hipError_t launch_post(const PostArgs &a, hipStream_t s) {
