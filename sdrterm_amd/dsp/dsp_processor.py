@@ -62,6 +62,7 @@ class DspProcessor(DataProcessor):
         self._outputFilters = []
         self._nFreq = 1
         self._engine = None
+        self._engineReader = {}
         self._device = int(kwargs.get('device') or 0)
 
     # ---- rates ----------------------------------------------------------------------------------------
@@ -134,20 +135,33 @@ class DspProcessor(DataProcessor):
         return bool(self.centerFreq)
 
     @staticmethod
-    def _encodingOf(chunk: np.ndarray) -> str:
-        """Queue items are what the reader's ``re + 1j*im`` produced: complex128, or complex64 for float32 input."""
+    def _encodingOf(chunk) -> str:
+        """Queue items are what the reference reader's ``re + 1j*im`` produced (complex128, or complex64 for float32 input),
+        or the raw reads of this package's reader (misc/read_file.py: RawChunk), whose per-sample steps the GPU does."""
+        from ..misc.read_file import RawChunk
+        if isinstance(chunk, RawChunk):
+            return chunk.code
         if chunk.dtype == np.complex128:
             return 'd'
         if chunk.dtype == np.complex64:
             return 'f'
         raise TypeError(f'chunks must be complex64 or complex128 arrays, not {chunk.dtype}')
 
-    def _getEngine(self, n: int, code: str, smoothed: bool = True):
+    @staticmethod
+    def _readerSteps(chunk) -> dict:
+        """Engine options for the reader's per-sample steps (read_file.py:100-103) when the chunk is raw."""
+        from ..misc.read_file import RawChunk
+        if not isinstance(chunk, RawChunk):
+            return {}
+        return dict(normalize=chunk.normalize, correct_iq=chunk.correctIq, impedance=chunk.impedance, big_endian=chunk.bigEndian)
+
+    def _getEngine(self, n: int, code: str, smoothed: bool = True, **reader):
         """The GPU context for chunks of n samples of this encoding.  ``smoothed``: with --smooth-output applied
-        (_transformData, dsp_processor.py:159-160); _processChunk itself never smooths in the reference."""
+        (_transformData, dsp_processor.py:159-160); _processChunk itself never smooths in the reference.  ``reader``: the
+        reader's per-sample steps for raw chunks (_readerSteps)."""
         window = self._smoothing() if smoothed else 0
         eng = self._engine
-        if eng is not None and eng.n == n and eng.code == code and eng.smooth == window:
+        if eng is not None and eng.n == n and eng.code == code and eng.smooth == window and self._engineReader == reader:
             return eng
         mode = getattr(self.demod, 'mode', None)
         if mode not in ('fm', 'am', 're', 'im'):
@@ -159,7 +173,8 @@ class DspProcessor(DataProcessor):
         from ..engine import Engine
         sos = np.asarray(self._outputFilters, dtype=np.float64).reshape(-1, 6)
         self._engine = Engine(self._fs, self._decimationFactor, mode, code, n_samples=n, row_freqs=self._rowFreqs(),
-                              apply_shift=self._applyShift(), out_sos=sos, device=self._device, smooth=window)
+                              apply_shift=self._applyShift(), out_sos=sos, device=self._device, smooth=window, **reader)
+        self._engineReader = reader
         return self._engine
 
     def _smoothing(self) -> int:
@@ -187,17 +202,24 @@ class DspProcessor(DataProcessor):
         """One blocking get, then whatever is already queued (at most MAX_BATCH).  Returns (chunks, saw_eof).
         The reader signals EOF with b'' (read_file.py:169-171)."""
         got = [buffer.get()]
-        while isinstance(got[-1], np.ndarray) and len(got) < self.MAX_BATCH:
+        while self._isChunk(got[-1]) and len(got) < self.MAX_BATCH:
             try:
                 got.append(buffer.get_nowait())
             except (Empty, ValueError, OSError):
                 break
-        eof = not isinstance(got[-1], np.ndarray)
+        eof = not self._isChunk(got[-1])
         return (got[:-1] if eof else got), eof
 
+    @staticmethod
+    def _isChunk(item) -> bool:
+        return isinstance(item, np.ndarray) or type(item).__name__ == 'RawChunk'
+
     def _runBatch(self, chunks) -> np.ndarray:
-        eng = self._getEngine(chunks[0].size, self._encodingOf(chunks[0]))
-        raw = np.ascontiguousarray(np.stack(chunks) if len(chunks) > 1 else chunks[0])
+        eng = self._getEngine(chunks[0].size, self._encodingOf(chunks[0]), **self._readerSteps(chunks[0]))
+        if self._readerSteps(chunks[0]):
+            raw = b''.join(c.data for c in chunks)
+        else:
+            raw = np.ascontiguousarray(np.stack(chunks) if len(chunks) > 1 else chunks[0])
         return eng.process(raw, len(chunks)).reshape(self._nFreq, len(chunks), eng.m)
 
     def _emit(self, z: np.ndarray, file) -> None:

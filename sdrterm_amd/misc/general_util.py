@@ -34,6 +34,14 @@ def tprint(*args, **kwargs) -> None:
         eprint(*args, **kwargs)
 
 
+def applyIgnoreException(func, *args):
+    """Calls ``func(*args)``; an exception is returned instead of raised (general_util.py:63-67)."""
+    try:
+        return func(*args)
+    except Exception as e:      # noqa: BLE001 -- that is the contract
+        return e
+
+
 def findPort(host='localhost') -> int:
     """Ask the OS for a free TCP port on ``host`` (general_util.py:93-101)."""
     with closing(socket(AF_INET, SOCK_STREAM)) as s:

@@ -242,3 +242,41 @@ def test_linearity_of_the_decimator():
     _, y2 = eng.process_debug((x2).astype('<i2').tobytes())
     _, y3 = eng.process_debug((3 * x1 + x2).astype('<i2').tobytes())
     assert np.abs(y3 - (3 * y1 + y2)).max() <= 1e-9 * np.abs(y3).max()
+
+
+@pytest.mark.parametrize('name', ['h_q64_fm_iq', 'H_q64_am_norm_c', 'h_be_q64_fm_c', 'B_q64_fm_c', 'f_q64_fm_c'])
+def test_raw_reader_feeds_the_gpu_processor(golden, name):
+    """File -> this package's readFile (raw bytes on the Queue) -> DspProcessor: unpack / --normalize-input / --correct-iq
+    run on the GPU (read_file.py:100-103), outputs equal the reference's for the same file."""
+    import queue
+    from sdrterm_amd.dsp import DspProcessor
+    from sdrterm_amd.misc.file_util import DataType
+    from sdrterm_amd.misc.read_file import readFile
+    z, _ = golden
+    case = BY_NAME[name]
+    sample = DataType[case['code']].value
+    if case.get('big_endian'):
+        sample = sample.newbyteorder('>')
+
+    class Q(_ListQueue):
+        def put_nowait(self, x):
+            self.q.put(x)
+
+    class P:
+        exitcode, name = None, 'writer'
+
+    with tempfile.TemporaryDirectory() as d:
+        src, dst = os.path.join(d, 'in.raw'), os.path.join(d, 'out.bin')
+        with open(src, 'wb') as f:
+            f.write(case_raw(case))
+        buf = Q([])
+        readFile(bitsPerSample=sample, fs=case['fs'], buffers=[buf], processes=[P()], isDead=_Flag(), inFile=src,
+                 correctIq=bool(case.get('correct_iq')), normalize=bool(case.get('normalize')))
+        p = DspProcessor(case['fs'], center=case['center'], omegaOut=case['omega_out'], dec=case['q'],
+                         fileInfo={'bitsPerSample': str(sample)})
+        {'fm': p.selectOutputFm, 'am': p.selectOutputAm}[case['mode']]()
+        p.processData(_Flag(), buf, dst)
+        got = np.fromfile(dst, dtype='=f8')
+    exp = z[f'{name}/z']
+    assert got.size == exp.size
+    assert np.abs(got.reshape(exp.shape) - exp).max() <= ref_tol(case, exp)
