@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     constexpr int WPK = 4 * ITEM;                    // 32-bit words per lane and k-step (8 complex samples)
     constexpr int TILE = SDRT_TB * LC;               // samples per tile
     constexpr int NSTEP = KS * TPW;                  // k-steps per wave and item
-    constexpr int PF = 2;                            // k-steps of raw samples in flight
+    constexpr int PF = NOUT == 8 ? 1 : 2;            // k-steps of raw samples in flight (registers are scarcer with 8 outputs per column)
     static_assert(NOUT == 4 || NOUT == 8, "4 or 8 outputs per column");
     static_assert(NT == 8 || NT == 16, "8 or 16 tiles per chunk");
     typedef typename Enc<DT>::raw raw_t;

@@ -217,13 +217,10 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     cd *tw = (cd *) smem;                                       // [N] exp(-2 pi i k/N)
-    cd *sh = tw + N;                                            // [N] half-sample shift / N
-    cd *X = sh + N + (size_t) wave * N;                         // [N] per wave
-    double *zb = (double *) (sh + N + (size_t) WPB * N) + (size_t) wave * (M + (M >> 3) + 1);   // [zlen(M)] per wave
-    for (int i = tid; i < N; i += 64 * WPB) {
-        tw[i] = ((const cd *) a.fft_tw)[i];
-        sh[i] = ((const cd *) a.fft_shift)[i];
-    }
+    const cd *__restrict__ sh = (const cd *) a.fft_shift;       // [N] half-sample shift / N: read once per item, from L2
+    cd *X = tw + N + (size_t) wave * N;                         // [N] per wave
+    double *zb = (double *) (tw + N + (size_t) WPB * N) + (size_t) wave * (M + (M >> 3) + 1);   // [zlen(M)] per wave
+    for (int i = tid; i < N; i += 64 * WPB) tw[i] = ((const cd *) a.fft_tw)[i];
     __syncthreads();
     const OutTables *__restrict__ ot = a.otab;
     // one item per wave and turn: every item's result is a function of that item alone, bit for bit (pairing two items
@@ -264,7 +261,7 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
 template <int B, int WPB>
 static hipError_t launch_post_fft(const PostArgs &a, hipStream_t s) {
     constexpr int N = 256 * B;
-    const size_t lds = (size_t) (2 * N + WPB * N) * 16 + (size_t) WPB * (2 * N + (2 * N >> 3) + 1) * 8;
+    const size_t lds = (size_t) (N + WPB * N) * 16 + (size_t) WPB * (2 * N + (2 * N >> 3) + 1) * 8;
     hipError_t e = hipFuncSetAttribute((const void *) post_fft_kernel<B, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     if (e != hipSuccess) return e;
     size_t wgs = (a.items + WPB - 1) / WPB;
