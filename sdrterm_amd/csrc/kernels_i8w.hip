@@ -518,7 +518,11 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
 #undef SDRT_STAMP
             bcur = bcur == 2 ? 0 : bcur + 1;
         };
+        // diagnostic: core-clock and 100 MHz real-time stamps around the steady-state iterations -> in-kernel clock
+        unsigned long long *clk = (a.stamps && (int) bid * 2 < a.stamp_wgs && lane == 0) ? a.stamps + ((size_t) bid * 8 + wave) * 16 : nullptr;
+        if (clk) { clk[10] = __builtin_amdgcn_s_memtime(); clk[11] = __builtin_amdgcn_s_memrealtime(); }
         for (int it = 0; it < cnt; ++it) iteration(std::true_type{}, it);
+        if (clk) { clk[12] = __builtin_amdgcn_s_memtime(); clk[13] = __builtin_amdgcn_s_memrealtime(); clk[14] = (unsigned long long) cnt; }
         for (int it = cnt; it < cnt + 3; ++it) iteration(std::false_type{}, it);
     }
 }

@@ -44,6 +44,11 @@ def main():
     show('iteration', 0, 4)
     k = (s[:, :, 2] - s[:, :, 1])
     print('K by wave (median):', np.median(k, axis=0))
+    core = (s[:, :, 12] - s[:, :, 10])[valid]
+    real = (s[:, :, 13] - s[:, :, 11])[valid]
+    cnt = s[:, :, 14][valid]
+    print(f'in-kernel clock: {np.median(core / real) * 100:.0f} MHz (core cycles per 100 MHz real-time tick x 100), '
+          f'{np.median(core / cnt):.0f} core cycles and {np.median(real / cnt) * 10:.0f} ns per item and workgroup')
 
 
 if __name__ == '__main__':
