@@ -51,7 +51,67 @@ __device__ __forceinline__ void modal_lowpass_body(const OutTables *__restrict__
     for (int i = lane; i < m; i += 64) out[i] = zb[zpos(i)];
 }
 
+// The same for the usual case -- one complex pole pair + one real pole (ellip(3, ...), dsp_processor.py:39-45), E = m/64
+// samples per lane known at compile time: the lane's samples stay in registers between the two passes, the real pole runs
+// in real arithmetic, the first four scan steps are DPP row shifts.
+template <int EE>
+__device__ __forceinline__ void modal_lowpass_c1r1(const OutTables *__restrict__ ot, double *zb, double *out, const int lane) {
+    constexpr int m = 64 * EE;
+    const int t0 = lane * EE;
+    double xs[EE];
+#pragma unroll
+    for (int e = 0; e < EE; ++e) xs[e] = zb[zpos(t0 + e)];
+    const cd pc = mk(ot->p[0][0], ot->p[0][1]), rc = mk(ot->r[0][0], ot->r[0][1]);
+    const double pr = ot->p[1][0], rr = ot->r[1][0];
+    cd sc = mk(0.0, 0.0);
+    double sr = 0.0;
+#pragma unroll
+    for (int e = 0; e < EE; ++e) {
+        sc = cfma(pc, sc, mk(xs[e], 0.0));
+        sr = fma(pr, sr, xs[e]);
+    }
+    // inclusive scan of the lanes' end states along the wave: inside the 16-lane rows with DPP shifts (multipliers
+    // p^(E 2^i)), then the carry of the rows before (their end states chained in scalar registers) into every lane
+    static_for<0, 4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        sc = cfma(mk(ot->pstep[0][i][0], ot->pstep[0][i][1]), dpp_row<0x110 + (1 << i)>(sc), sc);
+        sr = fma(ot->pstep[1][i][0], dpp_row<0x110 + (1 << i)>(sr), sr);
+    });
+    {
+        auto at = [](double v, int l) {
+            return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+        };
+        const cd P16 = mk(ot->pstep[0][4][0], ot->pstep[0][4][1]);
+        const double Q16 = ot->pstep[1][4][0];
+        const cd c1 = mk(at(sc.re, 15), at(sc.im, 15));
+        const cd c2 = cfma(P16, c1, mk(at(sc.re, 31), at(sc.im, 31)));
+        const cd c3 = cfma(P16, c2, mk(at(sc.re, 47), at(sc.im, 47)));
+        const double d1 = at(sr, 15), d2 = fma(Q16, d1, at(sr, 31)), d3 = fma(Q16, d2, at(sr, 47));
+        const int row = lane >> 4;
+        const cd cin = row == 0 ? mk(0.0, 0.0) : (row == 1 ? c1 : (row == 2 ? c2 : c3));
+        const double din = row == 0 ? 0.0 : (row == 1 ? d1 : (row == 2 ? d2 : d3));
+        sc = cfma(mk(ot->prow[0][lane & 15][0], ot->prow[0][lane & 15][1]), cin, sc);
+        sr = fma(ot->prow[1][lane & 15][0], din, sr);
+    }
+    sc = mk(__shfl_up(sc.re, 1), __shfl_up(sc.im, 1));      // exclusive: the state at the lane's first sample
+    sr = __shfl_up(sr, 1);
+    if (lane == 0) { sc = mk(0.0, 0.0); sr = 0.0; }
+    const double Dd = ot->D;
+#pragma unroll
+    for (int e = 0; e < EE; ++e) {
+        const double x = xs[e];
+        zb[zpos(t0 + e)] = fma(Dd, x, fma(rc.re, sc.re, fma(-rc.im, sc.im, rr * sr)));
+        sc = cfma(pc, sc, mk(x, 0.0));
+        sr = fma(pr, sr, x);
+    }
+    for (int i = lane; i < m; i += 64) out[i] = zb[zpos(i)];
+}
+
 __device__ __forceinline__ void modal_lowpass_wave(const OutTables *__restrict__ ot, double *zb, double *out, const int m, const int lane) {
+    if (ot->nmodes == 2 && ot->ncomplex == 1) {
+        if (m == 512) { modal_lowpass_c1r1<8>(ot, zb, out, lane); return; }
+        if (m == 1024) { modal_lowpass_c1r1<16>(ot, zb, out, lane); return; }
+    }
     switch (ot->nmodes) {
         case 0: modal_lowpass_body<0>(ot, zb, out, m, lane); break;
         case 1: modal_lowpass_body<1>(ot, zb, out, m, lane); break;
@@ -138,6 +198,9 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
 // its stores.  N = 256 B.  O(N log N) instead of the O(N^2) circulant product of post_kernel.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
+// position of element i in the per-wave transform buffer: one pad element per four, so that the stride-4 stores of the
+// first pass fall on different banks
+__device__ __forceinline__ int xpos(int i) { return i + (i >> 2); }
 __device__ __forceinline__ cd csub(cd a, cd b) { return mk(a.re - b.re, a.im - b.im); }
 template <bool INV> __device__ __forceinline__ cd cmul_tw(cd v, cd w) {      // v * w (forward) or v * conj(w) (inverse)
     if constexpr (INV) return mk(v.re * w.re + v.im * w.im, v.im * w.re - v.re * w.im);
@@ -178,9 +241,9 @@ __device__ __forceinline__ void fft_wave(cd (&x)[B][4], cd *X, const cd *tw, con
 #pragma unroll
         for (int b = 0; b < B; ++b)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) x[b][k] = X[lane + 64 * b + k * (N / 4)];
+            for (int k = 0; k < 4; ++k) x[b][k] = X[xpos(lane + 64 * b + k * (N / 4))];
     };
-    auto stX = [&](int o, cd v) { X[o] = v; };
+    auto stX = [&](int o, cd v) { X[xpos(o)] = v; };
     load_first();
     radix4_pass<B, 1, INV>(x, tw, lane, stX);
     ldX();
@@ -200,7 +263,7 @@ __device__ __forceinline__ void fft_wave(cd (&x)[B][4], cd *X, const cd *tw, con
             // n = 2, s = N/2: y[q] = a + b, y[q + N/2] = a - b for q < N/2; 2B items per lane
             cd u[2 * B][2];
 #pragma unroll
-            for (int c = 0; c < 2 * B; ++c) { u[c][0] = X[lane + 64 * c]; u[c][1] = X[lane + 64 * c + N / 2]; }
+            for (int c = 0; c < 2 * B; ++c) { u[c][0] = X[xpos(lane + 64 * c)]; u[c][1] = X[xpos(lane + 64 * c + N / 2)]; }
 #pragma unroll
             for (int c = 0; c < 2 * B; ++c) {
                 store_last(lane + 64 * c, cadd(u[c][0], u[c][1]));
@@ -218,8 +281,12 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     cd *tw = (cd *) smem;                                       // [N] exp(-2 pi i k/N)
     const cd *__restrict__ sh = (const cd *) a.fft_shift;       // [N] half-sample shift / N: read once per item, from L2
-    cd *X = tw + N + (size_t) wave * N;                         // [N] per wave
-    double *zb = (double *) (tw + N + (size_t) WPB * N) + (size_t) wave * (M + (M >> 3) + 1);   // [zlen(M)] per wave
+    // per wave: the padded transform buffer (xpos) and, in the same bytes, the demodulated samples for the lowpass (zpos):
+    // the last inverse pass has loaded all of X before it stores into zb
+    constexpr int XL = N + N / 4 + 1;                           // 16-byte elements; covers zlen(M) doubles as well
+    static_assert((size_t) XL * 16 >= (size_t) (M + (M >> 3) + 1) * 8, "zb must fit the transform buffer");
+    cd *X = tw + N + (size_t) wave * XL;
+    double *zb = (double *) X;
     for (int i = tid; i < N; i += 64 * WPB) tw[i] = ((const cd *) a.fft_tw)[i];
     __syncthreads();
     const OutTables *__restrict__ ot = a.otab;
@@ -228,6 +295,7 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
     for (size_t item = (size_t) blockIdx.x * WPB + wave; item < a.items; item += (size_t) gridDim.x * WPB) {
         const cd *y = (const cd *) a.y + item * (size_t) M;
         cd x[B][4];
+        double ev[B][4];
         auto angles = [&]() {
 #pragma unroll
             for (int b = 0; b < B; ++b)
@@ -238,11 +306,11 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
                     // angle(d[i] * conj(d[i+1])) (demodulation.py:25-32)
                     const double an = atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);
                     x[b][k] = mk(an, 0.0);
-                    zb[zpos(2 * j)] = an;                       // even output samples are the input
+                    ev[b][k] = an;                              // even output samples are the input
                 }
         };
         // forward transform -> X (natural order)
-        fft_wave<B, false>(x, X, tw, lane, angles, [&](int o, cd v) { X[o] = v; });
+        fft_wave<B, false>(x, X, tw, lane, angles, [&](int o, cd v) { X[xpos(o)] = v; });
         // spectrum * shift, inverse transform; its last pass leaves the odd output samples (the imaginary parts are rounding noise)
         auto shifted = [&]() {
 #pragma unroll
@@ -250,10 +318,14 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int f = lane + 64 * b + k * (N / 4);
-                    x[b][k] = cmul(X[f], sh[f]);
+                    x[b][k] = cmul(X[xpos(f)], sh[f]);
                 }
         };
         fft_wave<B, true>(x, X, tw, lane, shifted, [&](int o, cd v) { zb[zpos(2 * o + 1)] = v.re; });
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) zb[zpos(2 * (lane + 64 * b + k * (N / 4)))] = ev[b][k];
         modal_lowpass_wave(ot, zb, a.out + item * (size_t) M, M, lane);
     }
 }
@@ -261,7 +333,7 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
 template <int B, int WPB>
 static hipError_t launch_post_fft(const PostArgs &a, hipStream_t s) {
     constexpr int N = 256 * B;
-    const size_t lds = (size_t) (N + WPB * N) * 16 + (size_t) WPB * (2 * N + (2 * N >> 3) + 1) * 8;
+    const size_t lds = (size_t) (N + WPB * (N + N / 4 + 1)) * 16;
     hipError_t e = hipFuncSetAttribute((const void *) post_fft_kernel<B, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     if (e != hipSuccess) return e;
     size_t wgs = (a.items + WPB - 1) / WPB;

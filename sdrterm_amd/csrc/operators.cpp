@@ -275,11 +275,23 @@ extern "C" int sdrt_build_out_tables(const double *sos, int sections, int m, Out
         ++nm;
     }
     if (nm > SDRT_OUT_MAXMODES) return 0;
+    // complex modes first, real ones after (the kernels handle the two kinds separately)
+    {
+        C tp[16], tr[16];
+        int w = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int k = 0; k < nm; ++k)
+                if ((rp[k].im != 0) == (pass == 0)) { tp[w] = rp[k]; tr[w] = rr[k]; ++w; }
+        for (int k = 0; k < nm; ++k) { rp[k] = tp[k]; rr[k] = tr[k]; }
+        out->ncomplex = 0;
+        for (int k = 0; k < nm; ++k) if (rp[k].im != 0) out->ncomplex++;
+    }
     out->D = (double) D;
     for (int k = 0; k < nm; ++k) {
         put(out->r[k], rr[k]);
         put(out->p[k], rp[k]);
         for (int i = 0; i < 6; ++i) put(out->pstep[k][i], cpow(rp[k], out->E * (1 << i)));
+        for (int j = 0; j < 16; ++j) put(out->prow[k][j], cpow(rp[k], out->E * (j + 1)));
     }
     out->nmodes = nm;
     return 0;

@@ -59,10 +59,13 @@ struct WideTables {
 struct OutTables {
     int32_t nmodes;          // 0..SDRT_OUT_MAXMODES; -1: not representable -> kernel uses the sequential SOS form
     int32_t E;               // consecutive samples per lane: max(1, m / 64)
+    int32_t ncomplex;        // modes [0, ncomplex) are complex poles (each standing for its conjugate too), the rest real
+    int32_t reserved;
     double D;
     double r[SDRT_OUT_MAXMODES][2];
     double p[SDRT_OUT_MAXMODES][2];
     double pstep[SDRT_OUT_MAXMODES][6][2];   // p^(E * 2^i): wave scan multipliers
+    double prow[SDRT_OUT_MAXMODES][16][2];   // p^(E * (j+1)), j < 16: from the end of the previous 16-lane row to lane j of a row
 };
 
 #ifdef __cplusplus
