@@ -548,9 +548,16 @@ size_t chain_i8w_lds_bytes(int q, int n) {
 
 template <int DT, int NOUT, int NT, bool IQ>
 static hipError_t launch_i8w_q(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute((const void *) chain_i8w_kernel<DT, NOUT, NT, SDRT_I8_DIGITS, IQ>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    if (e != hipSuccess) return e;
+    // once per device and instantiation (a driver call per launch costs more than the gap between two kernels)
+    static thread_local int done_dev = -1;
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    if (done_dev != dev) {
+        hipError_t e = hipFuncSetAttribute((const void *) chain_i8w_kernel<DT, NOUT, NT, SDRT_I8_DIGITS, IQ>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+        done_dev = dev;
+    }
     hipLaunchKernelGGL((chain_i8w_kernel<DT, NOUT, NT, SDRT_I8_DIGITS, IQ>), grid, dim3(512), lds, s, a);
     return hipGetLastError();
 }

@@ -334,8 +334,14 @@ template <int B, int WPB>
 static hipError_t launch_post_fft(const PostArgs &a, hipStream_t s) {
     constexpr int N = 256 * B;
     const size_t lds = (size_t) (N + WPB * (N + N / 4 + 1)) * 16;
-    hipError_t e = hipFuncSetAttribute((const void *) post_fft_kernel<B, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    if (e != hipSuccess) return e;
+    static thread_local int done_dev = -1;                      // once per device and instantiation
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    if (done_dev != dev) {
+        hipError_t e = hipFuncSetAttribute((const void *) post_fft_kernel<B, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+        done_dev = dev;
+    }
     size_t wgs = (a.items + WPB - 1) / WPB;
     const size_t cap = 256 * 8;                                  // a few workgroups per CU; waves walk over the rest
     if (wgs > cap) wgs = cap;
