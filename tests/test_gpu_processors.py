@@ -280,3 +280,46 @@ def test_raw_reader_feeds_the_gpu_processor(golden, name):
     exp = z[f'{name}/z']
     assert got.size == exp.size
     assert np.abs(got.reshape(exp.shape) - exp).max() <= ref_tol(case, exp)
+
+
+def test_full_size_workload_properties(monkeypatch):
+    """BASELINE.json configs[1] at bench size (2^30 samples = 32768 chunks, synthesised on the device like bench.py does):
+    size-independent properties instead of an oracle run -- (1) two independently written kernels (wide-column persistent
+    int8 kernel vs the one-block-per-column int8 kernel) agree on every output, (2) splitting the call does not change a
+    bit, (3) a sample of chunks equals the C oracle."""
+    import torch
+    import bench
+    from oracle import c_chain, ref_chain
+    from sdrterm_amd.engine import Engine
+    dev = torch.device('cuda', 0)
+    n_chunks, n, q = 32768, bench.N, bench.Q
+    raw = bench.synth_iq_torch(n_chunks * n, seed=99, device=dev)
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    wide = Engine(bench.FS, q, 'fm', 'h', row_freqs=[bench.CENTER], omega_out=bench.OMEGA_OUT)
+    assert wide.stage_a == 'i8w'
+    out_w = torch.empty(n_chunks * wide.m, dtype=torch.float64, device=dev)
+    wide.process_device(raw.data_ptr(), n_chunks, out_w.data_ptr())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out_w).all())
+    # (2) two calls of half the size
+    out_h = torch.empty_like(out_w)
+    half = n_chunks // 2
+    wide.process_device(raw.data_ptr(), half, out_h.data_ptr())
+    wide.process_device(raw.data_ptr() + half * wide.chunk_bytes, n_chunks - half, out_h.data_ptr() + half * wide.m * 8)
+    torch.cuda.synchronize()
+    assert bool(torch.equal(out_w, out_h))
+    # (1) the other int8 kernel
+    monkeypatch.setenv('SDRTERM_STAGE_A', 'i8t')
+    narrow = Engine(bench.FS, q, 'fm', 'h', row_freqs=[bench.CENTER], omega_out=bench.OMEGA_OUT)
+    assert narrow.stage_a == 'i8t'
+    narrow.process_device(raw.data_ptr(), n_chunks, out_h.data_ptr())
+    torch.cuda.synchronize()
+    assert float((out_w - out_h).abs().max()) < 1e-8
+    # (3) oracle on a few chunks spread over the stream
+    pick = [0, 1, 4095, 16384, 32766, 32767]
+    sub = b''.join(raw[c * n:(c + 1) * n].cpu().numpy().tobytes() for c in pick)
+    shift = c_chain.shift_table([bench.CENTER], bench.FS, n)
+    exp, _ = c_chain.process_stream(sub, 'h', n, q, 'fm', shift, ref_chain.cheby_sos(q), ref_chain.ellip_sos(bench.FS // q, bench.OMEGA_OUT),
+                                    threads=4)
+    got = out_w.reshape(n_chunks, wide.m)[pick].cpu().numpy()
+    assert np.abs(got - exp[:, 0, :]).max() < 1e-6
