@@ -163,8 +163,12 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             const v4i *wl = (const v4i *) (a.w8mid + (size_t) row * (size_t) (S * KS * 4 * NR * 16));
             v4i *dl = (v4i *) (smem + lo.wloc);
             // global layout is compact ([digit][kstep][kg][NR rows]); in LDS every (digit, kstep, kg) group has 16 rows
-            for (int i = tid; i < S * KS * 64; i += 512)
-                dl[i] = (i & 15) < NR ? wl[(i >> 4) * NR + (i & 15)] : (v4i) {0, 0, 0, 0};
+            // and the rows are placed so that the matrix result lands in the lane that finishes the output: output b = g + 4e,
+            // stream st <-> row 4g + 2e + st (lane g holds rows 4g .. 4g+3)
+            for (int i = tid; i < S * KS * 64; i += 512) {
+                const int pr = i & 15, b = (pr >> 2) + 4 * ((pr >> 1) & 1), st = pr & 1;
+                dl[i] = b < NOUT ? wl[(i >> 4) * NR + 2 * b + st] : (v4i) {0, 0, 0, 0};
+            }
         }
         const cd *nco_blk_g = nco ? (const cd *) a.nco_phase + (size_t) row * (size_t) (n / LC) : nullptr;  // exp(i theta LC c)
         // coefficients of this thread's sample in its edge operator (NCO phasor and IQ correction of the window folded in)
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         // sharing the SIMD finds the matrix pipe free meanwhile (and vice versa).  LDS carry buffers: item k uses k % 3.
         cd yq[2][TPW][OPL], ynew[TPW][OPL];          // column-local outputs: [0] two iterations old (P3 finishes them now)
         cd dC[TPW][2], dA[TPW][2];                   // [stream]: causal / anticausal states of (mode g, column nb) of the tile
-        double dl[TPW][4];                           // local rows of this lane: outputs 2g, 2g+1 x streams
+        double dl[TPW][4];                           // local rows of this lane: its own outputs g + 4e, [2e + stream]
         cd pv[TPW][OPL];                             // P3 accumulators
         double part[4][2];
 #pragma unroll
@@ -320,25 +324,27 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         dA[j][0] = mk(fma(dr, h0.re, fma(di, h0.im, dA[j][0].re)), fma(dr, h1.re, fma(di, h1.im, dA[j][0].im)));
                         dA[j][1] = mk(fma(dr, h2.re, fma(di, h2.im, dA[j][1].re)), fma(dr, h3.re, fma(di, h3.im, dA[j][1].im)));
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const cd l0 = gvL[32 + 4 * g + v];
+                        for (int v = 0; v < 2 * OPL; ++v) {       // local rows of this lane: output g + 4 (v >> 1), stream v & 1
+                            const cd l0 = gvL[32 + 2 * (g + 4 * (v >> 1)) + (v & 1)];
                             dl[j][v] = fma(dr, l0.re, fma(di, l0.im, dl[j][v]));
                         }
                     } else if constexpr (i == 1) {
                         const cd ps = psiL[tile * SDRT_TB + nb];      // the column's common phasor multiplies the complex DATA
+                        // (explicit fma everywhere in the pieces: they exist in two compiled copies, steady state and drain,
+                        // and both must round identically -- an item's bits must not depend on the batch it arrived in)
                         cd t;
-                        t = mk(ps.re * dC[j][0].re - ps.im * dC[j][1].re, ps.re * dC[j][0].im - ps.im * dC[j][1].im);
-                        dC[j][1] = mk(ps.im * dC[j][0].re + ps.re * dC[j][1].re, ps.im * dC[j][0].im + ps.re * dC[j][1].im);
+                        t = mk(fma(ps.re, dC[j][0].re, -(ps.im * dC[j][1].re)), fma(ps.re, dC[j][0].im, -(ps.im * dC[j][1].im)));
+                        dC[j][1] = mk(fma(ps.im, dC[j][0].re, ps.re * dC[j][1].re), fma(ps.im, dC[j][0].im, ps.re * dC[j][1].im));
                         dC[j][0] = t;
-                        t = mk(ps.re * dA[j][0].re - ps.im * dA[j][1].re, ps.re * dA[j][0].im - ps.im * dA[j][1].im);
-                        dA[j][1] = mk(ps.im * dA[j][0].re + ps.re * dA[j][1].re, ps.im * dA[j][0].im + ps.re * dA[j][1].im);
+                        t = mk(fma(ps.re, dA[j][0].re, -(ps.im * dA[j][1].re)), fma(ps.re, dA[j][0].im, -(ps.im * dA[j][1].im)));
+                        dA[j][1] = mk(fma(ps.im, dA[j][0].re, ps.re * dA[j][1].re), fma(ps.im, dA[j][0].im, ps.re * dA[j][1].im));
                         dA[j][0] = t;
                     } else if constexpr (i == 2) {
                         const cd ps = psiL[tile * SDRT_TB + nb];
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const double t2 = ps.re * dl[j][2 * h] - ps.im * dl[j][2 * h + 1];
-                            dl[j][2 * h + 1] = ps.im * dl[j][2 * h] + ps.re * dl[j][2 * h + 1];
+                        for (int h = 0; h < OPL; ++h) {
+                            const double t2 = fma(ps.re, dl[j][2 * h], -(ps.im * dl[j][2 * h + 1]));
+                            dl[j][2 * h + 1] = fma(ps.im, dl[j][2 * h], ps.re * dl[j][2 * h + 1]);
                             dl[j][2 * h] = t2;
                         }
                     } else if constexpr (i >= 3 && i <= 10) {
@@ -365,22 +371,20 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     } else if constexpr (i >= 12 && i < P3_0) {
                         constexpr int e = (i - 12) / 3, sub = (i - 12) % 3;
                         if constexpr (sub < 2) {
-                            // this mode's share of outputs b of the column, plus the local rows where this lane holds them
+                            // this mode's share of outputs b of the column
 #pragma unroll
                             for (int bb = 2 * sub; bb < 2 * sub + 2; ++bb) {
                                 const int b = 4 * e + bb;
                                 const cd bc = bpL[b * 4 + g], ba = bpL[(NOUT - b) * 4 + g];
-                                part[bb][0] = bc.re * dC[j][0].re - bc.im * dC[j][0].im + ba.re * dA[j][0].re - ba.im * dA[j][0].im;
-                                part[bb][1] = bc.re * dC[j][1].re - bc.im * dC[j][1].im + ba.re * dA[j][1].re - ba.im * dA[j][1].im;
-                                const double mine = (g == (b >> 1)) ? 1.0 : 0.0;
-                                part[bb][0] = fma(mine, dl[j][2 * (b & 1)], part[bb][0]);
-                                part[bb][1] = fma(mine, dl[j][2 * (b & 1) + 1], part[bb][1]);
+                                part[bb][0] = fma(bc.re, dC[j][0].re, fma(-bc.im, dC[j][0].im, fma(ba.re, dA[j][0].re, -(ba.im * dA[j][0].im))));
+                                part[bb][1] = fma(bc.re, dC[j][1].re, fma(-bc.im, dC[j][1].im, fma(ba.re, dA[j][1].re, -(ba.im * dA[j][1].im))));
                             }
                         } else {
                             // sum over the four modes (lanes 16 apart) as a reduce-scatter: lane g ends up with output g + 4e
                             const double r0 = swap32_add(part[0][0], part[2][0]), i0 = swap32_add(part[0][1], part[2][1]);
                             const double r1 = swap32_add(part[1][0], part[3][0]), i1 = swap32_add(part[1][1], part[3][1]);
-                            ynew[j][e] = mk(swap16_add(r0, r1), swap16_add(i0, i1));
+                            // ... plus the column-local part, which the matrix cores left in this very lane
+                            ynew[j][e] = mk(swap16_add(r0, r1) + dl[j][2 * e], swap16_add(i0, i1) + dl[j][2 * e + 1]);
                         }
                     }
                 }
@@ -394,8 +398,8 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         for (int e = 0; e < OPL; ++e) {
                             const cd f = cFL[(e * 4 + mode) * 64 + lane], gq = cGL[(e * 4 + mode) * 64 + lane];
                             if constexpr (mode == 0) pv[j][e] = mk(yq[0][j][e].re + yb[j][e].re, yq[0][j][e].im + yb[j][e].im);
-                            pv[j][e].re += f.re * Fa.re - f.im * Fa.im + (gq.re * Ga.re - gq.im * Ga.im);
-                            pv[j][e].im += f.re * Fb.re - f.im * Fb.im + (gq.re * Gb.re - gq.im * Gb.im);
+                            pv[j][e].re = fma(f.re, Fa.re, fma(-f.im, Fa.im, fma(gq.re, Ga.re, fma(-gq.im, Ga.im, pv[j][e].re))));
+                            pv[j][e].im = fma(f.re, Fb.re, fma(-f.im, Fb.im, fma(gq.re, Gb.re, fma(-gq.im, Gb.im, pv[j][e].im))));
                         }
                     }
                 } else if constexpr (i == P3_0 + 4) {
@@ -413,8 +417,8 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     if constexpr (IQ) {
                         if (e_l == 0) {                          // the offset at the window's first sample, once per output
                             const cd ow = e_kind ? off_tail : off_head, P = pqL[2 * e_o16], Q = pqL[2 * e_o16 + 1];
-                            f.re -= P.re * ow.re + Q.re * ow.im;
-                            f.im -= P.im * ow.re + Q.im * ow.im;
+                            f.re = fma(-P.re, ow.re, fma(-Q.re, ow.im, f.re));
+                            f.im = fma(-P.im, ow.re, fma(-Q.im, ow.im, f.im));
                         }
                     }
                     f = cadd(f, dpp_row<0x111>(f));
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     static_for<0, 3>([&](auto rc) {
                         constexpr int rt = decltype(rc)::value;
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
+                        for (int v = 0; v < (rt < 2 ? 4 : 2 * OPL); ++v) {
                             double dsum = (double) acc[rt][S - 1][v];
 #pragma unroll
                             for (int q = S - 2; q >= 0; --q) dsum = fma(dsum, 256.0, (double) acc[rt][q][v]);

@@ -283,43 +283,54 @@ def test_raw_reader_feeds_the_gpu_processor(golden, name):
 
 
 def test_full_size_workload_properties(monkeypatch):
-    """BASELINE.json configs[1] at bench size (2^30 samples = 32768 chunks, synthesised on the device like bench.py does):
-    size-independent properties instead of an oracle run -- (1) two independently written kernels (wide-column persistent
-    int8 kernel vs the one-block-per-column int8 kernel) agree on every output, (2) splitting the call does not change a
-    bit, (3) a sample of chunks equals the C oracle."""
-    import torch
-    import bench
+    """BASELINE.json configs[1] at bench size (2^30 samples = 32768 chunks resident on the device): size-independent
+    properties instead of an oracle run -- (1) two independently written kernels (wide-column persistent int8 kernel vs
+    the one-block-per-column int8 kernel) agree on every output, (2) splitting the call does not change a bit, (3) a
+    sample of chunks equals the C oracle.  (No torch here: its bundled HIP runtime and the system one this library links
+    do not initialise in either order inside one process.)"""
     from oracle import c_chain, ref_chain
+    from sdrterm_amd import _native as nat
     from sdrterm_amd.engine import Engine
-    dev = torch.device('cuda', 0)
-    n_chunks, n, q = 32768, bench.N, bench.Q
-    raw = bench.synth_iq_torch(n_chunks * n, seed=99, device=dev)
+    from tests.golden import prng
+    fs, q, n, center, omega = 256_000_000, 64, 32768, 15000, 12500
+    n_chunks, base = 32768, 256
     monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
-    wide = Engine(bench.FS, q, 'fm', 'h', row_freqs=[bench.CENTER], omega_out=bench.OMEGA_OUT)
+    wide = Engine(fs, q, 'fm', 'h', row_freqs=[center], omega_out=omega)
     assert wide.stage_a == 'i8w'
-    out_w = torch.empty(n_chunks * wide.m, dtype=torch.float64, device=dev)
-    wide.process_device(raw.data_ptr(), n_chunks, out_w.data_ptr())
-    torch.cuda.synchronize()
-    assert bool(torch.isfinite(out_w).all())
-    # (2) two calls of half the size
-    out_h = torch.empty_like(out_w)
-    half = n_chunks // 2
-    wide.process_device(raw.data_ptr(), half, out_h.data_ptr())
-    wide.process_device(raw.data_ptr() + half * wide.chunk_bytes, n_chunks - half, out_h.data_ptr() + half * wide.m * 8)
-    torch.cuda.synchronize()
-    assert bool(torch.equal(out_w, out_h))
+    block = np.frombuffer(prng.raw_bytes('h', n * base, seed=99, amp=8000), dtype=np.uint8)      # 256 distinct chunks
+    d_raw = nat.DeviceBuffer(n_chunks * wide.chunk_bytes)
+    for i in range(0, n_chunks, base):
+        nat.check(nat.lib().sdrt_memcpy_h2d(d_raw.ptr + i * wide.chunk_bytes, block.ctypes.data, block.size))
+    d_a = nat.DeviceBuffer(n_chunks * wide.m * 8)
+    d_b = nat.DeviceBuffer(n_chunks * wide.m * 8)
+
+    def fetch(buf):
+        nat.check(nat.lib().sdrt_device_synchronize())
+        return buf.download(np.empty(n_chunks * wide.m, dtype=np.float64))
+
+    wide.process_device(d_raw.ptr, n_chunks, d_a.ptr)
+    out_w = fetch(d_a)
+    assert np.isfinite(out_w).all()
+    # (2) two calls of unequal size
+    cut = 12345
+    wide.process_device(d_raw.ptr, cut, d_b.ptr)
+    wide.process_device(d_raw.ptr + cut * wide.chunk_bytes, n_chunks - cut, d_b.ptr + cut * wide.m * 8)
+    assert np.array_equal(out_w, fetch(d_b))
+    # the stream repeats every 256 chunks, so must the output, bit for bit (every workgroup / pipeline slot agrees)
+    rep = out_w.reshape(n_chunks // base, base * wide.m)
+    assert np.array_equal(rep, np.broadcast_to(rep[0], rep.shape))
     # (1) the other int8 kernel
     monkeypatch.setenv('SDRTERM_STAGE_A', 'i8t')
-    narrow = Engine(bench.FS, q, 'fm', 'h', row_freqs=[bench.CENTER], omega_out=bench.OMEGA_OUT)
+    narrow = Engine(fs, q, 'fm', 'h', row_freqs=[center], omega_out=omega)
     assert narrow.stage_a == 'i8t'
-    narrow.process_device(raw.data_ptr(), n_chunks, out_h.data_ptr())
-    torch.cuda.synchronize()
-    assert float((out_w - out_h).abs().max()) < 1e-8
-    # (3) oracle on a few chunks spread over the stream
-    pick = [0, 1, 4095, 16384, 32766, 32767]
-    sub = b''.join(raw[c * n:(c + 1) * n].cpu().numpy().tobytes() for c in pick)
-    shift = c_chain.shift_table([bench.CENTER], bench.FS, n)
-    exp, _ = c_chain.process_stream(sub, 'h', n, q, 'fm', shift, ref_chain.cheby_sos(q), ref_chain.ellip_sos(bench.FS // q, bench.OMEGA_OUT),
-                                    threads=4)
-    got = out_w.reshape(n_chunks, wide.m)[pick].cpu().numpy()
+    narrow.process_device(d_raw.ptr, n_chunks, d_b.ptr)
+    assert np.abs(out_w - fetch(d_b)).max() < 1e-8
+    # (3) oracle on a few chunks
+    pick = [0, 1, 100, 255]
+    sub = b''.join(block[c * wide.chunk_bytes:(c + 1) * wide.chunk_bytes].tobytes() for c in pick)
+    shift = c_chain.shift_table([center], fs, n)
+    exp, _ = c_chain.process_stream(sub, 'h', n, q, 'fm', shift, ref_chain.cheby_sos(q), ref_chain.ellip_sos(fs // q, omega), threads=4)
+    got = out_w.reshape(n_chunks, wide.m)[[c + 256 * 77 for c in pick]]
     assert np.abs(got - exp[:, 0, :]).max() < 1e-6
+    for b in (d_raw, d_a, d_b):
+        b.free()
