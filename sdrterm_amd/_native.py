@@ -6,6 +6,7 @@ fallback.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` 
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SDRTERM_HIP_LIB: another build of the same library (A/B measurements of kernel variants); default: the in-tree build
@@ -54,6 +55,29 @@ class Config(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  A PyTorch-ROCm wheel bundles its own libamdhip64 and insists on it when it is imported;
+    if this library had pulled in the system one first, torch would then find "no ROCm-capable device".  So when torch
+    is installed (not necessarily imported), its runtime is loaded first and this library binds to it through the common
+    SONAME; without torch the system runtime is used.  (Plumbing only: nothing of torch runs.)"""
+    if 'torch' in sys.modules or os.environ.get('SDRTERM_SYSTEM_HIP'):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        return
+    for root in (spec.submodule_search_locations if spec and spec.submodule_search_locations else ()):
+        for name in ('libamdhip64.so', 'libamdhip64.so.7', 'libamdhip64.so.6'):
+            path = os.path.join(root, 'lib', name)
+            if os.path.exists(path):
+                try:
+                    C.CDLL(path, mode=C.RTLD_GLOBAL)
+                except OSError:
+                    pass
+                return
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -62,6 +86,7 @@ def lib():
         raise NativeLibraryError(
             f'{LIB_PATH} is missing: the HIP extension has not been built and there is no CPU path. '
             'Run `make -C sdrterm_amd/csrc` (needs hipcc, targets gfx950).')
+    _share_hip_runtime_with_torch()
     try:
         l = C.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64 not found
