@@ -334,3 +334,33 @@ def test_full_size_workload_properties(monkeypatch):
     assert np.abs(got - exp[:, 0, :]).max() < 1e-6
     for b in (d_raw, d_a, d_b):
         b.free()
+
+
+def test_edge_cases_empty_ragged_and_small_batches(golden):
+    """Empty input, input that is not a whole number of chunks, a stream that ends at once, and every batch size around
+    the depth of the wide kernel's software pipeline (1..5 chunks, then odd sizes): same outputs as one call."""
+    from sdrterm_amd.dsp import DspProcessor
+    from sdrterm_amd.engine import Engine
+    from tests.golden import prng
+    eng = Engine(1024000, 64, 'fm', 'h', row_freqs=[15700], omega_out=5000)
+    assert eng.stage_a == 'i8w'
+    assert eng.process(b'', 0).shape == (1, 0)                            # nothing in, nothing out
+    with pytest.raises(ValueError):
+        eng.process(b'\x00' * (eng.chunk_bytes + 6))                      # ragged: the caller must pad, as the reader does
+    nch = 23
+    raw = prng.raw_bytes('h', eng.n * nch, seed=5, amp=6000)
+    full = eng.process(raw).reshape(nch, eng.m)
+    cb = eng.chunk_bytes
+    pos, sizes = 0, [1, 2, 3, 4, 5, 7, 1]
+    for k in sizes:
+        part = eng.process(raw[pos * cb:(pos + k) * cb]).reshape(k, eng.m)
+        assert np.array_equal(part, full[pos:pos + k])
+        pos += k
+    assert pos == nch
+    # a stream that is only EOF: the writer produces an empty file and returns
+    p = DspProcessor(1024000, center=15700, omegaOut=5000, dec=64, fileInfo={'bitsPerSample': 'int16'})
+    p.selectOutputFm()
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, 'out.bin')
+        p.processData(_Flag(), _ListQueue([b'']), path)
+        assert os.path.getsize(path) == 0
