@@ -83,6 +83,9 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     constexpr int WPK = 4 * ITEM;                    // 32-bit words per lane and k-step (8 complex samples)
     constexpr int TILE = SDRT_TB * LC;               // samples per tile
     constexpr int NSTEP = KS * TPW;                  // k-steps per wave and item
+    // NOUT == 4: the local tile has 8 rows; two digit planes share one matrix instruction (rows 0-7 / 8-15), see below
+    constexpr bool PACK = NOUT == 4;
+    constexpr int NLF = PACK ? (NSL == 2 ? 5 : 3) : S;   // local-tile fragments per k-step
     constexpr int PF = NOUT == 8 ? 1 : 2;            // k-steps of raw samples in flight (registers are scarcer with 8 outputs per column)
     static_assert(NOUT == 4 || NOUT == 8, "4 or 8 outputs per column");
     static_assert(NT == 8 || NT == 16, "8 or 16 tiles per chunk");
@@ -162,12 +165,26 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             for (int i = tid; i < 2 * S * KS * 64; i += 512) dst[i] = wg[i];
             const v4i *wl = (const v4i *) (a.w8mid + (size_t) row * (size_t) (S * KS * 4 * NR * 16));
             v4i *dl = (v4i *) (smem + lo.wloc);
-            // global layout is compact ([digit][kstep][kg][NR rows]); in LDS every (digit, kstep, kg) group has 16 rows
-            // and the rows are placed so that the matrix result lands in the lane that finishes the output: output b = g + 4e,
-            // stream st <-> row 4g + 2e + st (lane g holds rows 4g .. 4g+3)
-            for (int i = tid; i < S * KS * 64; i += 512) {
-                const int pr = i & 15, b = (pr >> 2) + 4 * ((pr >> 1) & 1), st = pr & 1;
-                dl[i] = b < NOUT ? wl[(i >> 4) * NR + 2 * b + st] : (v4i) {0, 0, 0, 0};
+            // global layout is compact ([digit][kstep][kg][NR rows]); in LDS every (fragment, kstep, kg) group has 16 rows
+            if constexpr (PACK) {
+                // 8 local rows (row 2b + stream): one fragment carries TWO digit planes, the lower one in rows 0-7 and the
+                // higher one in rows 8-15, so that one matrix instruction does both products with the same slice.  Fragments
+                // 0..2 = planes (0|1), (2|3), (4|-) for the high slice (16-bit) or the only slice (8-bit); 3, 4 = planes
+                // (1|2), (3|4) for the low slice.  Accumulator a = fragment a (+ fragment 3+a): rows 0-7 hold level 2a(+1),
+                // rows 8-15 the level above it.
+                for (int i = tid; i < NLF * KS * 64; i += 512) {
+                    const int f = i / (KS * 64), s_ = (i / 64) % KS, ln = i & 63, kg = ln >> 4, row = ln & 15;
+                    const int lo_pl = f < 3 ? 2 * f : 2 * (f - 3) + 1;
+                    const int d = row < 8 ? lo_pl : lo_pl + 1;
+                    dl[i] = d < S ? wl[((d * KS + s_) * 4 + kg) * NR + (row & 7)] : (v4i) {0, 0, 0, 0};
+                }
+            } else {
+                // 16 local rows, placed so that the matrix result lands in the lane that finishes the output: output
+                // b = g + 4e, stream st <-> row 4g + 2e + st (lane g holds rows 4g .. 4g+3)
+                for (int i = tid; i < S * KS * 64; i += 512) {
+                    const int pr = i & 15, b = (pr >> 2) + 4 * ((pr >> 1) & 1), st = pr & 1;
+                    dl[i] = b < NOUT ? wl[(i >> 4) * NR + 2 * b + st] : (v4i) {0, 0, 0, 0};
+                }
             }
         }
         const cd *nco_blk_g = nco ? (const cd *) a.nco_phase + (size_t) row * (size_t) (n / LC) : nullptr;  // exp(i theta LC c)
@@ -205,7 +222,9 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         // sharing the SIMD finds the matrix pipe free meanwhile (and vice versa).  LDS carry buffers: item k uses k % 3.
         cd yq[2][TPW][OPL], ynew[TPW][OPL];          // column-local outputs: [0] two iterations old (P3 finishes them now)
         cd dC[TPW][2], dA[TPW][2];                   // [stream]: causal / anticausal states of (mode g, column nb) of the tile
-        double dl[TPW][4];                           // local rows of this lane: its own outputs g + 4e, [2e + stream]
+        double dl[TPW][4];                           // local rows of this lane: 8 outputs per column: its own outputs g + 4e,
+                                                     // [2e + stream]; 4 per column: outputs 2 (g & 1) + (v >> 1), stream v & 1,
+                                                     // lower levels in lanes g < 2, higher levels in lanes g >= 2
         cd pv[TPW][OPL];                             // P3 accumulators
         double part[4][2];
 #pragma unroll
@@ -323,10 +342,20 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         const cd h0 = gvL[16 + 4 * g + 0], h1 = gvL[16 + 4 * g + 1], h2 = gvL[16 + 4 * g + 2], h3 = gvL[16 + 4 * g + 3];
                         dA[j][0] = mk(fma(dr, h0.re, fma(di, h0.im, dA[j][0].re)), fma(dr, h1.re, fma(di, h1.im, dA[j][0].im)));
                         dA[j][1] = mk(fma(dr, h2.re, fma(di, h2.im, dA[j][1].re)), fma(dr, h3.re, fma(di, h3.im, dA[j][1].im)));
+                        if constexpr (PACK) {
+                            // local values of output 2 (g & 1) + (v >> 1), stream v & 1, split over the lanes g and g + 2: once
+                            const double lowhalf = g < 2 ? 1.0 : 0.0, dr2 = dr * lowhalf, di2 = di * lowhalf;
 #pragma unroll
-                        for (int v = 0; v < 2 * OPL; ++v) {       // local rows of this lane: output g + 4 (v >> 1), stream v & 1
-                            const cd l0 = gvL[32 + 2 * (g + 4 * (v >> 1)) + (v & 1)];
-                            dl[j][v] = fma(dr, l0.re, fma(di, l0.im, dl[j][v]));
+                            for (int v = 0; v < 4; ++v) {
+                                const cd l0 = gvL[32 + 4 * (g & 1) + v];
+                                dl[j][v] = fma(dr2, l0.re, fma(di2, l0.im, dl[j][v]));
+                            }
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {             // local rows of this lane: output g + 4 (v >> 1), stream v & 1
+                                const cd l0 = gvL[32 + 2 * (g + 4 * (v >> 1)) + (v & 1)];
+                                dl[j][v] = fma(dr, l0.re, fma(di, l0.im, dl[j][v]));
+                            }
                         }
                     } else if constexpr (i == 1) {
                         const cd ps = psiL[tile * SDRT_TB + nb];      // the column's common phasor multiplies the complex DATA
@@ -342,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     } else if constexpr (i == 2) {
                         const cd ps = psiL[tile * SDRT_TB + nb];
 #pragma unroll
-                        for (int h = 0; h < OPL; ++h) {
+                        for (int h = 0; h < 2; ++h) {
                             const double t2 = fma(ps.re, dl[j][2 * h], -(ps.im * dl[j][2 * h + 1]));
                             dl[j][2 * h + 1] = fma(ps.im, dl[j][2 * h], ps.re * dl[j][2 * h + 1]);
                             dl[j][2 * h] = t2;
@@ -378,13 +407,21 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                 const cd bc = bpL[b * 4 + g], ba = bpL[(NOUT - b) * 4 + g];
                                 part[bb][0] = fma(bc.re, dC[j][0].re, fma(-bc.im, dC[j][0].im, fma(ba.re, dA[j][0].re, -(ba.im * dA[j][0].im))));
                                 part[bb][1] = fma(bc.re, dC[j][1].re, fma(-bc.im, dC[j][1].im, fma(ba.re, dA[j][1].re, -(ba.im * dA[j][1].im))));
+                                if constexpr (PACK) {
+                                    // the column-local part: lanes g and g + 2 hold its lower and higher levels for outputs
+                                    // 2 (g & 1), 2 (g & 1) + 1; the sum over the mode lanes below adds them up
+                                    const double mine = ((g & 1) == (b >> 1)) ? 1.0 : 0.0;
+                                    part[bb][0] = fma(mine, dl[j][2 * (b & 1)], part[bb][0]);
+                                    part[bb][1] = fma(mine, dl[j][2 * (b & 1) + 1], part[bb][1]);
+                                }
                             }
                         } else {
                             // sum over the four modes (lanes 16 apart) as a reduce-scatter: lane g ends up with output g + 4e
                             const double r0 = swap32_add(part[0][0], part[2][0]), i0 = swap32_add(part[0][1], part[2][1]);
                             const double r1 = swap32_add(part[1][0], part[3][0]), i1 = swap32_add(part[1][1], part[3][1]);
+                            if constexpr (PACK) ynew[j][e] = mk(swap16_add(r0, r1), swap16_add(i0, i1));
                             // ... plus the column-local part, which the matrix cores left in this very lane
-                            ynew[j][e] = mk(swap16_add(r0, r1) + dl[j][2 * e], swap16_add(i0, i1) + dl[j][2 * e + 1]);
+                            else ynew[j][e] = mk(swap16_add(r0, r1) + dl[j][2 * e], swap16_add(i0, i1) + dl[j][2 * e + 1]);
                         }
                     }
                 }
@@ -474,7 +511,16 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                             constexpr int d = decltype(dc)::value;
                             __builtin_amdgcn_sched_barrier(0);
                             const v4i A = F[d];
-                            if constexpr (NSL == 2) {
+                            if constexpr (PACK && rt == 2) {
+                                // packed local tile: fragment d < 3 with the high (or only) slice starts accumulator d,
+                                // fragment 3 + a with the low slice adds to accumulator a
+                                if constexpr (d < 3) {
+                                    if constexpr (s == 0) acc[2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, NSL == 2 ? bhi : blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                    else acc[2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, NSL == 2 ? bhi : blo, acc[2][d], 0, 0, 0);
+                                } else if constexpr (d < NLF) {
+                                    acc[2][d - 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[2][d - 3], 0, 0, 0);
+                                }
+                            } else if constexpr (NSL == 2) {
                                 // digit d x high slice -> level d+1 (accumulator d); digit d x low slice -> level d (accumulator d-1)
                                 if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, (v4i) {0, 0, 0, 0}, 0, 0, 0);
                                 else acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, acc[rt][d], 0, 0, 0);
@@ -483,7 +529,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                 if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
                                 else acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[rt][d], 0, 0, 0);
                             }
-                            if constexpr (i + 1 < KS * 3) F[d] = frag(std::integral_constant<int, i + 1>{}, dc);
+                            // the fragment's register takes the next group's fragment (none for the unused slots of a packed tile)
+                            if constexpr (i + 1 < KS * 3) {
+                                if constexpr (!(PACK && (i + 1) % 3 == 2 && d >= NLF)) F[d] = frag(std::integral_constant<int, i + 1>{}, dc);
+                            }
                         });
                         __builtin_amdgcn_sched_barrier(0);
                         __builtin_amdgcn_s_setprio(0);
@@ -497,12 +546,24 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     double val[8];
                     static_for<0, 3>([&](auto rc) {
                         constexpr int rt = decltype(rc)::value;
+                        if constexpr (PACK && rt == 2) {
+                            // accumulator a: rows 0-7 level 2a (+1), rows 8-15 one level up: lanes g >= 2 scale by 256
+                            const double csl = g >= 2 ? cs_loc * 256.0 : cs_loc;
 #pragma unroll
-                        for (int v = 0; v < (rt < 2 ? 4 : 2 * OPL); ++v) {
-                            double dsum = (double) acc[rt][S - 1][v];
+                            for (int v = 0; v < 4; ++v) {
+                                double dsum = (double) acc[2][2][v];
+                                dsum = fma(dsum, 65536.0, (double) acc[2][1][v]);
+                                dsum = fma(dsum, 65536.0, (double) acc[2][0][v]);
+                                dl[j][v] = dsum * csl;
+                            }
+                        } else {
 #pragma unroll
-                            for (int q = S - 2; q >= 0; --q) dsum = fma(dsum, 256.0, (double) acc[rt][q][v]);
-                            if constexpr (rt < 2) val[4 * rt + v] = dsum * cs_main; else dl[j][v] = dsum * cs_loc;
+                            for (int v = 0; v < 4; ++v) {
+                                double dsum = (double) acc[rt][S - 1][v];
+#pragma unroll
+                                for (int q = S - 2; q >= 0; --q) dsum = fma(dsum, 256.0, (double) acc[rt][q][v]);
+                                if constexpr (rt < 2) val[4 * rt + v] = dsum * cs_main; else dl[j][v] = dsum * cs_loc;
+                            }
                         }
                     });
                     dC[j][0] = mk(val[0], val[1]);
