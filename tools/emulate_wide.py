@@ -5,7 +5,9 @@ import sys
 import numpy as np
 from scipy.signal import cheby1, decimate
 
-lib = C.CDLL(sys.argv[1] if len(sys.argv) > 1 else '/tmp/t/libop.so')
+import os
+_DEFAULT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'sdrterm_amd', 'libsdrterm_hip.so')
+lib = C.CDLL(sys.argv[1] if __name__ == '__main__' and len(sys.argv) > 1 else _DEFAULT)     # host-side table builders only
 lib.sdrt_build_wide_edge.restype = None
 LC, TB, NM, EDGE = 256, 16, 4, 27
 
