@@ -64,3 +64,23 @@ def test_golden_parity(case, golden, stage_a):
     print(f'{name} [{eng.stage_a}]: decimated rel err {yerr:.3e}, output max abs err {err:.3e} (tol {ref_tol(case, exp):.1e})')
     assert yerr <= (1e-3 if case['code'] == 'f' else 1e-9)
     assert err <= ref_tol(case, exp)
+
+
+@pytest.mark.parametrize('rows,nch', [(64, 3), (300, 2), (33, 17), (5, 100)])
+def test_item_distribution_of_the_persistent_kernel(rows, nch, monkeypatch):
+    """Many rows x few chunks and few rows x many chunks (rows above and below the number of workgroup slots, chunk counts
+    that are not multiples of 8): the wide-column persistent kernel must cover every (chunk, row) item exactly once --
+    checked against the independently written one-block-per-column kernel."""
+    from sdrterm_amd.engine import Engine
+    from tests.golden import prng
+    fs, q = 1024000, 64
+    freqs = [1000.0 * (i - rows // 2) for i in range(rows)]
+    raw = prng.raw_bytes('h', 32768 * nch, seed=rows, amp=5000)
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    a = Engine(fs, q, 'fm', 'h', row_freqs=freqs, omega_out=5000)
+    out_a = a.process(raw)
+    monkeypatch.setenv('SDRTERM_STAGE_A', 'i8t')
+    b = Engine(fs, q, 'fm', 'h', row_freqs=freqs, omega_out=5000)
+    out_b = b.process(raw)
+    assert (a.stage_a, b.stage_a) == ('i8w', 'i8t')
+    assert np.isfinite(out_a).all() and np.abs(out_a - out_b).max() < 1e-8
