@@ -14,10 +14,11 @@ VFOS8 = [-40e6 + 15000, -30e6 + 15000, -20e6 + 15000, -10e6 + 15000, 10e6 + 1500
 
 def run(name, n_chunks, steps=5, **kw):
     eng = Engine(FS, **kw)
-    one = np.frombuffer(prng.raw_bytes(kw.get('code', 'h'), eng.n * 32, 9, 100 if kw.get('code', 'h') in 'bB' else 8000), dtype=np.uint8)
+    BLK = 512        # distinct chunks before the stream repeats (a short period keeps every workgroup on the same few L2 lines)
+    one = np.frombuffer(prng.raw_bytes(kw.get('code', 'h'), eng.n * BLK, 9, 100 if kw.get('code', 'h') in 'bB' else 8000), dtype=np.uint8)
     d_raw = nat.DeviceBuffer(n_chunks * eng.chunk_bytes)
-    for i in range(0, n_chunks, 32):
-        k = min(32, n_chunks - i)
+    for i in range(0, n_chunks, BLK):
+        k = min(BLK, n_chunks - i)
         nat.check(nat.lib().sdrt_memcpy_h2d(d_raw.ptr + i * eng.chunk_bytes, one.ctypes.data, k * eng.chunk_bytes))
     d_out = nat.DeviceBuffer(eng.rows * n_chunks * eng.m * 8)
     for _ in range(2):
@@ -42,6 +43,7 @@ def run(name, n_chunks, steps=5, **kw):
 
 if __name__ == '__main__':
     run('configs[1] single VFO FM dec=64 int16', 16384, decimation=64, mode='fm', code='h', row_freqs=[15000], omega_out=12500)
+    run('configs[1] variant center=0 (no shift)', 16384, decimation=64, mode='fm', code='h', row_freqs=[0], apply_shift=False, omega_out=12500)
     run('configs[2]-like 8 VFOs FM dec=32 int16', 4096, decimation=32, mode='fm', code='h', row_freqs=VFOS8, omega_out=12500)
     run('configs[2] 8 VFOs FM dec=32 int16 --correct-iq', 4096, decimation=32, mode='fm', code='h', row_freqs=VFOS8, omega_out=12500, correct_iq=True)
     run('configs[2] 8 VFOs AM dec=32 int16 --correct-iq --normalize', 4096, decimation=32, mode='am', code='h', row_freqs=VFOS8, omega_out=12500, correct_iq=True, normalize=True)
