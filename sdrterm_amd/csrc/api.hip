@@ -62,6 +62,7 @@ struct sdrt_ctx {
     bool use_i8w = false;             //   ... wide columns, persistent workgroups (default where supported)
     WideTables *d_wtab = nullptr;
     double *d_edge_ab = nullptr, *d_edge_pq = nullptr, *d_gvec = nullptr;
+    bool wide_rs = false;             // wide kernel in its real-stream form (no shift, no IQ correction)
     int n_cus = 256;
     signed char *d_w8 = nullptr, *d_w8mid = nullptr;
     DecimTables *d_tab8 = nullptr;    // tables for columns of SDRT_I8_G blocks
@@ -314,7 +315,10 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         if (sdrt_build_wide_tables(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, &wtab, &msg) != 0)
             rc = fail(SDRT_EINVAL, "wide-column tables: %s", msg ? msg : "failed");
         if (rc == SDRT_OK) rc = upload(&c->d_wtab, &wtab, sizeof(wtab));
-        const size_t per_row = (size_t) 2 * S * KS * 64 * 16, per_row_loc = (size_t) S * KS * 4 * NR * 16;
+        const char *rsenv = getenv("SDRTERM_WIDE_RS");               // diagnostics: "0" keeps the general form
+        c->wide_rs = !c->nco && !c->iq && chain_i8w_rs_supported(cfg->dtype, n) && !(rsenv && strcmp(rsenv, "0") == 0);
+        const size_t per_row = c->wide_rs ? (size_t) S * (LC / 64) * 64 * 16 : (size_t) 2 * S * KS * 64 * 16;
+        const size_t per_row_loc = c->wide_rs ? (size_t) S * (LC / 64) * 4 * (NR / 2) * 16 : (size_t) S * KS * 4 * NR * 16;
         std::vector<signed char> w8(per_row * c->rows), w8l(per_row_loc * c->rows);
         std::vector<double> samp((size_t) c->rows * LC * 2), blk((size_t) c->rows * (n / LC) * 2);
         std::vector<double> eab((size_t) c->rows * 16 * 32 * 4), epq((size_t) c->rows * 16 * 4), gv((size_t) c->rows * 48 * 2);
@@ -323,10 +327,13 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
             double comb = 0.0, combl = 0.0;
             double *sp = &samp[(size_t) r * LC * 2], *bp = &blk[(size_t) r * (n / LC) * 2];
             if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, LC, n / LC, sp, bp);
-            if (sdrt_build_i8_weights_wide(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, c->nco ? sp : nullptr, S, lam,
-                                           w8.data() + per_row * r, &comb, w8l.data() + per_row_loc * r, &combl,
-                                           &gv[(size_t) r * 96]) != 0)
-                rc = fail(SDRT_EINVAL, "int8 weight quantisation failed");
+            const int brc = c->wide_rs
+                ? sdrt_build_i8_weights_wide_rs(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, S, w8.data() + per_row * r, &comb,
+                                                w8l.data() + per_row_loc * r, &combl)
+                : sdrt_build_i8_weights_wide(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, c->nco ? sp : nullptr, S, lam,
+                                             w8.data() + per_row * r, &comb, w8l.data() + per_row_loc * r, &combl,
+                                             &gv[(size_t) r * 96]);
+            if (brc != 0) rc = fail(SDRT_EINVAL, "int8 weight quantisation failed");
             sdrt_build_wide_edge(&wtab, c->nco ? sp : nullptr, c->nco ? bp : nullptr, n, lam, &eab[(size_t) r * 2048],
                                  &epq[(size_t) r * 64]);
             // one power-of-two scale per context (rows differ by a rotation of the weights only); otherwise the other form
@@ -625,6 +632,7 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     da.c_re = c->x_offset + c->norm_bias;
     da.c_im = c->x_offset;
     da.iq_gs = c->L / 4;
+    da.rs = c->use_i8w && c->wide_rs;
     if (c->use_i8) {
         da.tab = c->d_tab8;
         da.n_tiles = c->n_tiles8;

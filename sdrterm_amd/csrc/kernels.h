@@ -41,6 +41,7 @@ struct DecimArgs {
     double e_off_re, e_off_im;  //   what the edge operators subtract from the decoded components
     double c_re, c_im;          //   IQ: the constant the slices leave out of (re, im)
     int iq_gs;                  //   IQ: samples per prefix group
+    int rs;                     //   real-stream form (no shift, no IQ correction): w8 / w8mid hold sdrt_build_i8_weights_wide_rs planes
 };
 
 struct IqArgs {
@@ -97,6 +98,7 @@ hipError_t launch_chain_i8t(const DecimArgs &a, int L, int dt, size_t n_chunks, 
 hipError_t launch_i8t_selftest(const int *A, const int *B, int *D, hipStream_t s);
 // wide-column persistent int8 kernel (kernels_i8w.hip): q in {32, 64}, 8/16-bit integer encodings, 8 or 16 tiles per chunk
 bool chain_i8w_supported(int q, int dt, int n);
+bool chain_i8w_rs_supported(int dt, int n);       // its real-stream form (no shift, no IQ correction)
 size_t chain_i8w_lds_bytes(int q, int n);
 hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, int n_cus, hipStream_t s);
 hipError_t launch_swap_selftest(const double *x, const double *y, double *out, hipStream_t s);

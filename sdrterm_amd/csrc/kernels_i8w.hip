@@ -72,21 +72,29 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt) {
 }
 }  // namespace
 
-template <int DT, int NOUT, int NT, int S, bool IQ>
+// RS ("real streams"): no frequency shift and no IQ correction.  The real and the imaginary sample stream are then filtered by
+// the same real-coefficient operator: ONE 16-row aggregate tile applied to the re bytes and to the im bytes separately, 64
+// samples per k-step, and a local tile of NOUT rows per stream in which 16 / NOUT digit planes share one instruction: 96
+// (NOUT = 4) or 112 (NOUT = 8) matrix instructions per tile instead of 184 / 216.
+template <int DT, int NOUT, int NT, int S, bool IQ, bool RS>
 __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
-    constexpr int LC = SDRT_WIDE_LC, KS = LC / 32;
+    static_assert(!(RS && IQ), "the real-stream form has no IQ correction");
+    constexpr int LC = SDRT_WIDE_LC, KS = RS ? LC / 64 : LC / 32, SPK = LC / KS;   // k-steps per column, samples per k-step
     constexpr int NSL = W8Enc<DT>::slices;
     constexpr int ITEM = Enc<DT>::size;
     constexpr int NR = 2 * NOUT;                     // rows of the local tile
     constexpr int OPL = NOUT / 4;                    // outputs a lane finishes per tile
     constexpr int TPW = NT / 8;                      // tiles per wave and item
-    constexpr int WPK = 4 * ITEM;                    // 32-bit words per lane and k-step (8 complex samples)
+    constexpr int WPK = (RS ? 8 : 4) * ITEM;         // 32-bit words per lane and k-step (8 complex samples; RS: 16)
     constexpr int TILE = SDRT_TB * LC;               // samples per tile
     constexpr int NSTEP = KS * TPW;                  // k-steps per wave and item
     // NOUT == 4: the local tile has 8 rows; two digit planes share one matrix instruction (rows 0-7 / 8-15), see below
-    constexpr bool PACK = NOUT == 4;
-    constexpr int NLF = PACK ? (NSL == 2 ? 5 : 3) : S;   // local-tile fragments per k-step
-    constexpr int PF = NOUT == 8 ? 1 : 2;            // k-steps of raw samples in flight (registers are scarcer with 8 outputs per column)
+    constexpr bool PACK = NOUT == 4 && !RS;
+    constexpr int PPF = RS ? 16 / NOUT : (PACK ? 2 : 1);         // digit planes per local-tile fragment
+    constexpr int NHF = (S + PPF - 1) / PPF;                      // fragments used with the high (or only) slice
+    constexpr int NLF = (PACK || RS) ? NHF + (NSL == 2 ? (S - 1 + PPF - 1) / PPF : 0) : S;   // local-tile fragments per k-step
+    constexpr int NSLOT = RS ? 1 : 4;                             // raw-sample register ring (RS: reloaded in place once sliced)
+    constexpr int PF = (NOUT == 8 || RS) ? 1 : 2;            // k-steps of raw samples in flight (registers are scarcer with 8 outputs per column)
     static_assert(NOUT == 4 || NOUT == 8, "4 or 8 outputs per column");
     static_assert(NT == 8 || NT == 16, "8 or 16 tiles per chunk");
     typedef typename Enc<DT>::raw raw_t;
@@ -154,19 +162,29 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     const int cgs = LC / (IQ ? a.iq_gs : LC);                    // IQ prefix groups per column
     const double cs_main = a.w8_combine * (NSL == 2 ? 256.0 : 1.0), cs_loc = a.w8mid_combine * (NSL == 2 ? 256.0 : 1.0);
     const size_t chunk_bytes = (size_t) n * 2 * ITEM;
-    // this lane's bytes of k-step s of a tile: column nb, samples 32 s + 8 g .. + 7
-    const size_t lane_off = ((size_t) nb * LC + (size_t) g * 8) * 2 * ITEM;
+    // this lane's bytes of k-step s of a tile: column nb, samples SPK s + (SPK/4) g .. + SPK/4 - 1
+    const size_t lane_off = ((size_t) nb * LC + (size_t) g * (SPK / 4)) * 2 * ITEM;
 
     for (unsigned row = row0; row < (unsigned) a.rows; row += rstep) {
         __syncthreads();                             // nobody still reads the previous row's planes
         {
-            const v4i *wg = (const v4i *) (a.w8 + (size_t) row * (size_t) (2 * S * KS * 1024));
+            constexpr int MT = RS ? 1 : 2, LR = RS ? NOUT : NR;       // aggregate tiles, rows of the compact local planes
+            const v4i *wg = (const v4i *) (a.w8 + (size_t) row * (size_t) (MT * S * KS * 1024));
             v4i *dst = (v4i *) (smem + lo.wmain);
-            for (int i = tid; i < 2 * S * KS * 64; i += 512) dst[i] = wg[i];
-            const v4i *wl = (const v4i *) (a.w8mid + (size_t) row * (size_t) (S * KS * 4 * NR * 16));
+            for (int i = tid; i < MT * S * KS * 64; i += 512) dst[i] = wg[i];
+            const v4i *wl = (const v4i *) (a.w8mid + (size_t) row * (size_t) (S * KS * 4 * LR * 16));
             v4i *dl = (v4i *) (smem + lo.wloc);
-            // global layout is compact ([digit][kstep][kg][NR rows]); in LDS every (fragment, kstep, kg) group has 16 rows
-            if constexpr (PACK) {
+            // global layout is compact ([digit][kstep][kg][rows]); in LDS every (fragment, kstep, kg) group has 16 rows
+            if constexpr (RS) {
+                // NOUT rows (row b, the same for both streams): PPF = 16 / NOUT digit planes per fragment, row group rg holds
+                // plane base + rg; fragments f < NHF (high / only slice): base = f PPF, the others (low slice): 1 + (f - NHF) PPF.
+                // Accumulator a = fragment a (+ fragment NHF + a): row group rg at level a PPF + rg (+1).
+                for (int i = tid; i < NLF * KS * 64; i += 512) {
+                    const int f = i / (KS * 64), s_ = (i / 64) % KS, ln = i & 63, kg = ln >> 4, rowp = ln & 15;
+                    const int d = (f < NHF ? f * PPF : 1 + (f - NHF) * PPF) + rowp / NOUT;
+                    dl[i] = d < S ? wl[((d * KS + s_) * 4 + kg) * LR + rowp % NOUT] : (v4i) {0, 0, 0, 0};
+                }
+            } else if constexpr (PACK) {
                 // 8 local rows (row 2b + stream): one fragment carries TWO digit planes, the lower one in rows 0-7 and the
                 // higher one in rows 8-15, so that one matrix instruction does both products with the same slice.  Fragments
                 // 0..2 = planes (0|1), (2|3), (4|-) for the high slice (16-bit) or the only slice (8-bit); 3, 4 = planes
@@ -200,12 +218,12 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         const cd *ybias = (const cd *) a.ybias + (size_t) row * m;      // always present for this kernel (zeros if there is no offset)
         __syncthreads();
 
-        uint32_t raw[4][WPK];
+        uint32_t raw[NSLOT][WPK];
         auto issue = [&](const unsigned char *chunk_raw, auto sc) {
             // k-step st (0 .. NSTEP-1) of the item: tile wave + 8 (st / KS), k-step st % KS
             constexpr int st = decltype(sc)::value;
-            const unsigned char *p = chunk_raw + ((size_t) (wave + 8 * (st / KS)) * TILE + (size_t) (st % KS) * 32) * 2 * ITEM + lane_off;
-            load_words<WPK * 4>(p, raw[st & 3]);
+            const unsigned char *p = chunk_raw + ((size_t) (wave + 8 * (st / KS)) * TILE + (size_t) (st % KS) * SPK) * 2 * ITEM + lane_off;
+            load_words<WPK * 4>(p, raw[st % NSLOT]);
         };
         {
             const unsigned char *c0 = (const unsigned char *) a.raw + (size_t) chunk_of(0) * chunk_bytes;
@@ -222,6 +240,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         // sharing the SIMD finds the matrix pipe free meanwhile (and vice versa).  LDS carry buffers: item k uses k % 3.
         cd yq[2][TPW][OPL], ynew[TPW][OPL];          // column-local outputs: [0] two iterations old (P3 finishes them now)
         cd dC[TPW][2], dA[TPW][2];                   // [stream]: causal / anticausal states of (mode g, column nb) of the tile
+        double dli[RS ? TPW : 1][4];                 // RS: local rows of the imaginary stream (dl: of the real stream)
         double dl[TPW][4];                           // local rows of this lane: 8 outputs per column: its own outputs g + 4e,
                                                      // [2e + stream]; 4 per column: outputs 2 (g & 1) + (v >> 1), stream v & 1,
                                                      // lower levels in lanes g < 2, higher levels in lanes g >= 2
@@ -235,6 +254,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) dl[j][v] = 0.0;
         }
+#pragma unroll
+        for (int j = 0; j < (RS ? TPW : 1); ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dli[j][v] = 0.0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) part[b][0] = part[b][1] = 0.0;
 
@@ -357,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                 dl[j][v] = fma(dr, l0.re, fma(di, l0.im, dl[j][v]));
                             }
                         }
-                    } else if constexpr (i == 1) {
+                    } else if constexpr (i == 1 && !RS) {
                         const cd ps = psiL[tile * SDRT_TB + nb];      // the column's common phasor multiplies the complex DATA
                         // (explicit fma everywhere in the pieces: they exist in two compiled copies, steady state and drain,
                         // and both must round identically -- an item's bits must not depend on the batch it arrived in)
@@ -368,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         t = mk(fma(ps.re, dA[j][0].re, -(ps.im * dA[j][1].re)), fma(ps.re, dA[j][0].im, -(ps.im * dA[j][1].im)));
                         dA[j][1] = mk(fma(ps.im, dA[j][0].re, ps.re * dA[j][1].re), fma(ps.im, dA[j][0].im, ps.re * dA[j][1].im));
                         dA[j][0] = t;
-                    } else if constexpr (i == 2) {
+                    } else if constexpr (i == 2 && !RS) {
                         const cd ps = psiL[tile * SDRT_TB + nb];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
@@ -413,13 +436,22 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                     const double mine = ((g & 1) == (b >> 1)) ? 1.0 : 0.0;
                                     part[bb][0] = fma(mine, dl[j][2 * (b & 1)], part[bb][0]);
                                     part[bb][1] = fma(mine, dl[j][2 * (b & 1) + 1], part[bb][1]);
+                                } else if constexpr (RS && NOUT == 4) {
+                                    // every lane holds one level group of all four outputs (dl: real stream, dli: imaginary)
+                                    part[bb][0] += dl[j][bb];
+                                    part[bb][1] += dli[j][bb];
+                                } else if constexpr (RS) {
+                                    // lanes g hold outputs 4 (g & 1) .. + 3, level groups g >> 1
+                                    const double mine = ((g & 1) == e) ? 1.0 : 0.0;
+                                    part[bb][0] = fma(mine, dl[j][bb], part[bb][0]);
+                                    part[bb][1] = fma(mine, dli[j][bb], part[bb][1]);
                                 }
                             }
                         } else {
                             // sum over the four modes (lanes 16 apart) as a reduce-scatter: lane g ends up with output g + 4e
                             const double r0 = swap32_add(part[0][0], part[2][0]), i0 = swap32_add(part[0][1], part[2][1]);
                             const double r1 = swap32_add(part[1][0], part[3][0]), i1 = swap32_add(part[1][1], part[3][1]);
-                            if constexpr (PACK) ynew[j][e] = mk(swap16_add(r0, r1), swap16_add(i0, i1));
+                            if constexpr (PACK || RS) ynew[j][e] = mk(swap16_add(r0, r1), swap16_add(i0, i1));
                             // ... plus the column-local part, which the matrix cores left in this very lane
                             else ynew[j][e] = mk(swap16_add(r0, r1) + dl[j][2 * e], swap16_add(i0, i1) + dl[j][2 * e + 1]);
                         }
@@ -475,101 +507,251 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             const unsigned char *next_raw = (const unsigned char *) a.raw + (size_t) chunk_of(more ? it + 1 : it) * chunk_bytes;
             static_for<0, TPW>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                v4i acc[3][S];
-                v4i F[S];                            // digit-plane fragments of the current group; each is reloaded for the next
-                                                     // group as soon as its last matrix instruction has been issued
-                auto frag = [&](auto ic, auto dc) -> v4i {
-                    constexpr int i = decltype(ic)::value, d = decltype(dc)::value, s = i / 3, rt = i % 3;
-                    if constexpr (rt < 2) return wmainL[((rt * S + d) * KS + s) * 64 + lane];
-                    else return wlocL[(d * KS + s) * 64 + lane];
-                };
-                if constexpr (HAVE_K) static_for<0, S>([&](auto dc) { F[decltype(dc)::value] = frag(std::integral_constant<int, 0>{}, dc); });
-                v4i blo, bhi;
-                static_for<0, KS * 3>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value, s = i / 3, rt = i % 3, stg = j * KS + s;
+                if constexpr (RS) {
+                    v4i accR[S], accI[S], accLR[NHF], accLI[NHF];
+                    v4i A[S], L[NLF];
+                    auto fragA = [&](auto sc, auto dc) -> v4i {
+                        return wmainL[(decltype(dc)::value * KS + decltype(sc)::value) * 64 + lane];
+                    };
+                    auto fragL = [&](auto sc, auto fc) -> v4i {
+                        return wlocL[(decltype(fc)::value * KS + decltype(sc)::value) * 64 + lane];
+                    };
                     if constexpr (HAVE_K) {
-                        if constexpr (rt == 0) {
-                            // slices of this k-step's 8 complex samples; then its raw registers take the k-step PF ahead
-                            const uint32_t *cur = raw[stg & 3];
+                        static_for<0, S>([&](auto dc) { A[decltype(dc)::value] = fragA(std::integral_constant<int, 0>{}, dc); });
+                    }
+                    v4i br_lo, br_hi, bi_lo, bi_hi;
+                    static_for<0, KS>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value, stg = j * KS + s;
+                        if constexpr (HAVE_K) {
+                            // slices of this k-step's 16 complex samples, de-interleaved: re bytes and im bytes
+                            const uint32_t *cur = raw[stg % NSLOT];
                             if constexpr (ITEM == 2) {
                                 const unsigned sel_lo = swap ? 0x07050301u : 0x06040200u, sel_hi = swap ? 0x06040200u : 0x07050301u;
 #pragma unroll
-                                for (int w = 0; w < 4; ++w) {
-                                    blo[w] = (int) (__builtin_amdgcn_perm(cur[2 * w + 1], cur[2 * w], sel_lo) ^ W8Enc<DT>::xlo);
-                                    bhi[w] = (int) (__builtin_amdgcn_perm(cur[2 * w + 1], cur[2 * w], sel_hi) ^ W8Enc<DT>::xhi);
+                                for (int w = 0; w < 4; ++w) {      // 4 samples -> one dword per (component, slice)
+                                    const unsigned xl = __builtin_amdgcn_perm(cur[4 * w + 1], cur[4 * w], sel_lo);      // [re0 im0 re1 im1] low bytes
+                                    const unsigned yl = __builtin_amdgcn_perm(cur[4 * w + 3], cur[4 * w + 2], sel_lo);
+                                    const unsigned xh = __builtin_amdgcn_perm(cur[4 * w + 1], cur[4 * w], sel_hi);
+                                    const unsigned yh = __builtin_amdgcn_perm(cur[4 * w + 3], cur[4 * w + 2], sel_hi);
+                                    br_lo[w] = (int) (__builtin_amdgcn_perm(yl, xl, 0x06040200u) ^ W8Enc<DT>::xlo);
+                                    bi_lo[w] = (int) (__builtin_amdgcn_perm(yl, xl, 0x07050301u) ^ W8Enc<DT>::xlo);
+                                    br_hi[w] = (int) (__builtin_amdgcn_perm(yh, xh, 0x06040200u) ^ W8Enc<DT>::xhi);
+                                    bi_hi[w] = (int) (__builtin_amdgcn_perm(yh, xh, 0x07050301u) ^ W8Enc<DT>::xhi);
                                 }
                             } else {
 #pragma unroll
-                                for (int w = 0; w < 4; ++w) { blo[w] = (int) (cur[w] ^ W8Enc<DT>::xlo); bhi[w] = 0; }
+                                for (int w = 0; w < 4; ++w) {      // a word holds [re0 im0 re1 im1]
+                                    br_lo[w] = (int) (__builtin_amdgcn_perm(cur[2 * w + 1], cur[2 * w], 0x06040200u) ^ W8Enc<DT>::xlo);
+                                    bi_lo[w] = (int) (__builtin_amdgcn_perm(cur[2 * w + 1], cur[2 * w], 0x07050301u) ^ W8Enc<DT>::xlo);
+                                    br_hi[w] = 0;
+                                    bi_hi[w] = 0;
+                                }
                             }
                             if constexpr (stg + PF < NSTEP) issue(chunk_raw, std::integral_constant<int, stg + PF>{});
-                            // the next item's first k-steps follow in the same ring (in the last iteration: this item's again, unused)
                             else issue(next_raw, std::integral_constant<int, stg + PF - NSTEP>{});
-                        }
-                        __builtin_amdgcn_s_setprio(1);           // matrix instructions first: the other wave's vector work fills the gaps
-                        static_for<0, S>([&](auto dc) {
-                            constexpr int d = decltype(dc)::value;
-                            __builtin_amdgcn_sched_barrier(0);
-                            const v4i A = F[d];
-                            if constexpr (PACK && rt == 2) {
-                                // packed local tile: fragment d < 3 with the high (or only) slice starts accumulator d,
-                                // fragment 3 + a with the low slice adds to accumulator a
-                                if constexpr (d < 3) {
-                                    if constexpr (s == 0) acc[2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, NSL == 2 ? bhi : blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
-                                    else acc[2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, NSL == 2 ? bhi : blo, acc[2][d], 0, 0, 0);
-                                } else if constexpr (d < NLF) {
-                                    acc[2][d - 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[2][d - 3], 0, 0, 0);
+                            // group 0: aggregates of the real stream
+                            __builtin_amdgcn_s_setprio(1);
+                            static_for<0, S>([&](auto dc) {
+                                constexpr int d = decltype(dc)::value;
+                                __builtin_amdgcn_sched_barrier(0);
+                                if constexpr (NSL == 2) {
+                                    if constexpr (s == 0) accR[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[d], br_hi, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                    else accR[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[d], br_hi, accR[d], 0, 0, 0);
+                                    if constexpr (d >= 1) accR[d - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[d], br_lo, accR[d - 1], 0, 0, 0);
+                                } else {
+                                    if constexpr (s == 0) accR[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[d], br_lo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                    else accR[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[d], br_lo, accR[d], 0, 0, 0);
                                 }
-                            } else if constexpr (NSL == 2) {
-                                // digit d x high slice -> level d+1 (accumulator d); digit d x low slice -> level d (accumulator d-1)
-                                if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, (v4i) {0, 0, 0, 0}, 0, 0, 0);
-                                else acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, acc[rt][d], 0, 0, 0);
-                                if constexpr (d >= 1) acc[rt][d - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[rt][d - 1], 0, 0, 0);
-                            } else {
-                                if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
-                                else acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[rt][d], 0, 0, 0);
+                            });
+                            __builtin_amdgcn_sched_barrier(0);
+                            __builtin_amdgcn_s_setprio(0);
+                        }
+                        piece(jc, std::integral_constant<int, 6 * s + 0>{});
+                        piece(jc, std::integral_constant<int, 6 * s + 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (HAVE_K) {
+                            // group 1: the same planes on the imaginary stream; each fragment register then takes the next k-step's
+                            __builtin_amdgcn_s_setprio(1);
+                            static_for<0, S>([&](auto dc) {
+                                constexpr int d = decltype(dc)::value;
+                                __builtin_amdgcn_sched_barrier(0);
+                                if constexpr (NSL == 2) {
+                                    if constexpr (s == 0) accI[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[d], bi_hi, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                    else accI[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[d], bi_hi, accI[d], 0, 0, 0);
+                                    if constexpr (d >= 1) accI[d - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[d], bi_lo, accI[d - 1], 0, 0, 0);
+                                } else {
+                                    if constexpr (s == 0) accI[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[d], bi_lo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                    else accI[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[d], bi_lo, accI[d], 0, 0, 0);
+                                }
+                                if constexpr (s + 1 < KS) A[d] = fragA(std::integral_constant<int, s + 1>{}, dc);
+                            });
+                            __builtin_amdgcn_sched_barrier(0);
+                            __builtin_amdgcn_s_setprio(0);
+                        }
+                        piece(jc, std::integral_constant<int, 6 * s + 2>{});
+                        piece(jc, std::integral_constant<int, 6 * s + 3>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (HAVE_K) {
+                            // group 2: the local tile, both streams (its fragments are fetched only now: registers are scarce and
+                            // the other wave of the SIMD covers the LDS latency)
+                            static_for<0, NLF>([&](auto fc) { L[decltype(fc)::value] = fragL(sc, fc); });
+                            __builtin_amdgcn_sched_barrier(0);
+                            __builtin_amdgcn_s_setprio(1);
+                            static_for<0, NLF>([&](auto fc) {
+                                constexpr int f = decltype(fc)::value;
+                                __builtin_amdgcn_sched_barrier(0);
+                                if constexpr (f < NHF) {
+                                    if constexpr (s == 0) {
+                                        accLR[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(L[f], NSL == 2 ? br_hi : br_lo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                        accLI[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(L[f], NSL == 2 ? bi_hi : bi_lo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                    } else {
+                                        accLR[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(L[f], NSL == 2 ? br_hi : br_lo, accLR[f], 0, 0, 0);
+                                        accLI[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(L[f], NSL == 2 ? bi_hi : bi_lo, accLI[f], 0, 0, 0);
+                                    }
+                                } else {
+                                    accLR[f - NHF] = __builtin_amdgcn_mfma_i32_16x16x64_i8(L[f], br_lo, accLR[f - NHF], 0, 0, 0);
+                                    accLI[f - NHF] = __builtin_amdgcn_mfma_i32_16x16x64_i8(L[f], bi_lo, accLI[f - NHF], 0, 0, 0);
+                                }
+                            });
+                            __builtin_amdgcn_sched_barrier(0);
+                            __builtin_amdgcn_s_setprio(0);
+                        }
+                        piece(jc, std::integral_constant<int, 6 * s + 4>{});
+                        piece(jc, std::integral_constant<int, 6 * s + 5>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    if constexpr (j == 0) SDRT_STAMP(2);
+                    if constexpr (HAVE_K) {
+                        // int32 levels -> fp64.  Aggregates: lane (g, nb) = mode g of column nb, rows v = 2*kind + part, per stream.
+                        double vr[4], vi[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            double sr_ = (double) accR[S - 1][v], si_ = (double) accI[S - 1][v];
+#pragma unroll
+                            for (int q = S - 2; q >= 0; --q) {
+                                sr_ = fma(sr_, 256.0, (double) accR[q][v]);
+                                si_ = fma(si_, 256.0, (double) accI[q][v]);
                             }
-                            // the fragment's register takes the next group's fragment (none for the unused slots of a packed tile)
-                            if constexpr (i + 1 < KS * 3) {
-                                if constexpr (!(PACK && (i + 1) % 3 == 2 && d >= NLF)) F[d] = frag(std::integral_constant<int, i + 1>{}, dc);
+                            vr[v] = sr_ * cs_main;
+                            vi[v] = si_ * cs_main;
+                        }
+                        dC[j][0] = mk(vr[0], vr[1]);
+                        dA[j][0] = mk(vr[2], vr[3]);
+                        dC[j][1] = mk(vi[0], vi[1]);
+                        dA[j][1] = mk(vi[2], vi[3]);
+                        // local tile: this lane holds level group rg of outputs (NOUT == 4: b = v; 8: b = 4 (g & 1) + v)
+                        const int rg = PPF == 4 ? g : (g >> 1);
+                        const double csl = cs_loc * (rg == 0 ? 1.0 : (rg == 1 ? 256.0 : (rg == 2 ? 65536.0 : 16777216.0)));
+                        constexpr double STEP = PPF == 4 ? 4294967296.0 : 65536.0;      // 256^PPF between accumulators
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            double sr_ = (double) accLR[NHF - 1][v], si_ = (double) accLI[NHF - 1][v];
+#pragma unroll
+                            for (int q = NHF - 2; q >= 0; --q) {
+                                sr_ = fma(sr_, STEP, (double) accLR[q][v]);
+                                si_ = fma(si_, STEP, (double) accLI[q][v]);
+                            }
+                            dl[j][v] = sr_ * csl;
+                            dli[j][v] = si_ * csl;
+                        }
+                    }
+                } else {
+                    v4i acc[3][S];
+                    v4i F[S];                            // digit-plane fragments of the current group; each is reloaded for the next
+                                                         // group as soon as its last matrix instruction has been issued
+                    auto frag = [&](auto ic, auto dc) -> v4i {
+                        constexpr int i = decltype(ic)::value, d = decltype(dc)::value, s = i / 3, rt = i % 3;
+                        if constexpr (rt < 2) return wmainL[((rt * S + d) * KS + s) * 64 + lane];
+                        else return wlocL[(d * KS + s) * 64 + lane];
+                    };
+                    if constexpr (HAVE_K) static_for<0, S>([&](auto dc) { F[decltype(dc)::value] = frag(std::integral_constant<int, 0>{}, dc); });
+                    v4i blo, bhi;
+                    static_for<0, KS * 3>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, s = i / 3, rt = i % 3, stg = j * KS + s;
+                        if constexpr (HAVE_K) {
+                            if constexpr (rt == 0) {
+                                // slices of this k-step's 8 complex samples; then its raw registers take the k-step PF ahead
+                                const uint32_t *cur = raw[stg & 3];
+                                if constexpr (ITEM == 2) {
+                                    const unsigned sel_lo = swap ? 0x07050301u : 0x06040200u, sel_hi = swap ? 0x06040200u : 0x07050301u;
+    #pragma unroll
+                                    for (int w = 0; w < 4; ++w) {
+                                        blo[w] = (int) (__builtin_amdgcn_perm(cur[2 * w + 1], cur[2 * w], sel_lo) ^ W8Enc<DT>::xlo);
+                                        bhi[w] = (int) (__builtin_amdgcn_perm(cur[2 * w + 1], cur[2 * w], sel_hi) ^ W8Enc<DT>::xhi);
+                                    }
+                                } else {
+    #pragma unroll
+                                    for (int w = 0; w < 4; ++w) { blo[w] = (int) (cur[w] ^ W8Enc<DT>::xlo); bhi[w] = 0; }
+                                }
+                                if constexpr (stg + PF < NSTEP) issue(chunk_raw, std::integral_constant<int, stg + PF>{});
+                                // the next item's first k-steps follow in the same ring (in the last iteration: this item's again, unused)
+                                else issue(next_raw, std::integral_constant<int, stg + PF - NSTEP>{});
+                            }
+                            __builtin_amdgcn_s_setprio(1);           // matrix instructions first: the other wave's vector work fills the gaps
+                            static_for<0, S>([&](auto dc) {
+                                constexpr int d = decltype(dc)::value;
+                                __builtin_amdgcn_sched_barrier(0);
+                                const v4i A = F[d];
+                                if constexpr (PACK && rt == 2) {
+                                    // packed local tile: fragment d < 3 with the high (or only) slice starts accumulator d,
+                                    // fragment 3 + a with the low slice adds to accumulator a
+                                    if constexpr (d < 3) {
+                                        if constexpr (s == 0) acc[2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, NSL == 2 ? bhi : blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                        else acc[2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, NSL == 2 ? bhi : blo, acc[2][d], 0, 0, 0);
+                                    } else if constexpr (d < NLF) {
+                                        acc[2][d - 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[2][d - 3], 0, 0, 0);
+                                    }
+                                } else if constexpr (NSL == 2) {
+                                    // digit d x high slice -> level d+1 (accumulator d); digit d x low slice -> level d (accumulator d-1)
+                                    if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                    else acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, acc[rt][d], 0, 0, 0);
+                                    if constexpr (d >= 1) acc[rt][d - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[rt][d - 1], 0, 0, 0);
+                                } else {
+                                    if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                    else acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[rt][d], 0, 0, 0);
+                                }
+                                // the fragment's register takes the next group's fragment (none for the unused slots of a packed tile)
+                                if constexpr (i + 1 < KS * 3) {
+                                    if constexpr (!(PACK && (i + 1) % 3 == 2 && d >= NLF)) F[d] = frag(std::integral_constant<int, i + 1>{}, dc);
+                                }
+                            });
+                            __builtin_amdgcn_sched_barrier(0);
+                            __builtin_amdgcn_s_setprio(0);
+                        }
+                        piece(jc, ic);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    if constexpr (j == 0) SDRT_STAMP(2);
+                    if constexpr (HAVE_K) {
+                        // int32 levels -> fp64: value = cs * sum_q 256^q acc[q]; lane (g, nb): rows 4g+v of column nb (v = 2*stream + part)
+                        double val[8];
+                        static_for<0, 3>([&](auto rc) {
+                            constexpr int rt = decltype(rc)::value;
+                            if constexpr (PACK && rt == 2) {
+                                // accumulator a: rows 0-7 level 2a (+1), rows 8-15 one level up: lanes g >= 2 scale by 256
+                                const double csl = g >= 2 ? cs_loc * 256.0 : cs_loc;
+    #pragma unroll
+                                for (int v = 0; v < 4; ++v) {
+                                    double dsum = (double) acc[2][2][v];
+                                    dsum = fma(dsum, 65536.0, (double) acc[2][1][v]);
+                                    dsum = fma(dsum, 65536.0, (double) acc[2][0][v]);
+                                    dl[j][v] = dsum * csl;
+                                }
+                            } else {
+    #pragma unroll
+                                for (int v = 0; v < 4; ++v) {
+                                    double dsum = (double) acc[rt][S - 1][v];
+    #pragma unroll
+                                    for (int q = S - 2; q >= 0; --q) dsum = fma(dsum, 256.0, (double) acc[rt][q][v]);
+                                    if constexpr (rt < 2) val[4 * rt + v] = dsum * cs_main; else dl[j][v] = dsum * cs_loc;
+                                }
                             }
                         });
-                        __builtin_amdgcn_sched_barrier(0);
-                        __builtin_amdgcn_s_setprio(0);
+                        dC[j][0] = mk(val[0], val[1]);
+                        dC[j][1] = mk(val[2], val[3]);
+                        dA[j][0] = mk(val[4], val[5]);
+                        dA[j][1] = mk(val[6], val[7]);
                     }
-                    piece(jc, ic);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                if constexpr (j == 0) SDRT_STAMP(2);
-                if constexpr (HAVE_K) {
-                    // int32 levels -> fp64: value = cs * sum_q 256^q acc[q]; lane (g, nb): rows 4g+v of column nb (v = 2*stream + part)
-                    double val[8];
-                    static_for<0, 3>([&](auto rc) {
-                        constexpr int rt = decltype(rc)::value;
-                        if constexpr (PACK && rt == 2) {
-                            // accumulator a: rows 0-7 level 2a (+1), rows 8-15 one level up: lanes g >= 2 scale by 256
-                            const double csl = g >= 2 ? cs_loc * 256.0 : cs_loc;
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) {
-                                double dsum = (double) acc[2][2][v];
-                                dsum = fma(dsum, 65536.0, (double) acc[2][1][v]);
-                                dsum = fma(dsum, 65536.0, (double) acc[2][0][v]);
-                                dl[j][v] = dsum * csl;
-                            }
-                        } else {
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) {
-                                double dsum = (double) acc[rt][S - 1][v];
-#pragma unroll
-                                for (int q = S - 2; q >= 0; --q) dsum = fma(dsum, 256.0, (double) acc[rt][q][v]);
-                                if constexpr (rt < 2) val[4 * rt + v] = dsum * cs_main; else dl[j][v] = dsum * cs_loc;
-                            }
-                        }
-                    });
-                    dC[j][0] = mk(val[0], val[1]);
-                    dC[j][1] = mk(val[2], val[3]);
-                    dA[j][0] = mk(val[4], val[5]);
-                    dA[j][1] = mk(val[6], val[7]);
                 }
             });
             // the queue of column-local outputs moves on
@@ -592,43 +774,32 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     }
 }
 
-// permlane swap self-test: out[0][l] = swap32_add(x[l], y[l]), out[1][l] = swap16_add(x[l], y[l])
-__global__ void swap_selftest_kernel(const double *x, const double *y, double *out) {
-    const int l = threadIdx.x & 63;
-    out[l] = swap32_add(x[l], y[l]);
-    out[64 + l] = swap16_add(x[l], y[l]);
-}
+// The 8-bit encodings are instantiated in a second translation unit (kernels_i8w_b.hip includes this file with
+// SDRT_I8W_BYTES defined) so that the two halves compile in parallel.
+hipError_t launch_chain_i8w_bytes(const DecimArgs &a, int nout, int nt, int dt, dim3 grid, size_t lds, hipStream_t s);
 
-// ---- launch helpers -----------------------------------------------------------------------------------------------
-bool chain_i8w_supported(int q, int dt, int n) {
-    if (!(q == 32 || q == 64)) return false;
-    if (!(dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16)) return false;
-    const int nt = n / (SDRT_TB * SDRT_WIDE_LC);
-    return n % (SDRT_TB * SDRT_WIDE_LC) == 0 && (nt == 8 || nt == 16);
-}
-
-size_t chain_i8w_lds_bytes(int q, int n) {
-    return (size_t) wide_lds(SDRT_I8_DIGITS, SDRT_WIDE_LC / q, n / (SDRT_TB * SDRT_WIDE_LC)).total;
-}
-
-template <int DT, int NOUT, int NT, bool IQ>
+template <int DT, int NOUT, int NT, bool IQ, bool RS>
 static hipError_t launch_i8w_q(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     // once per device and instantiation (a driver call per launch costs more than the gap between two kernels)
     static thread_local int done_dev = -1;
     int dev = 0;
     (void) hipGetDevice(&dev);
     if (done_dev != dev) {
-        hipError_t e = hipFuncSetAttribute((const void *) chain_i8w_kernel<DT, NOUT, NT, SDRT_I8_DIGITS, IQ>,
+        hipError_t e = hipFuncSetAttribute((const void *) chain_i8w_kernel<DT, NOUT, NT, SDRT_I8_DIGITS, IQ, RS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
         done_dev = dev;
     }
-    hipLaunchKernelGGL((chain_i8w_kernel<DT, NOUT, NT, SDRT_I8_DIGITS, IQ>), grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((chain_i8w_kernel<DT, NOUT, NT, SDRT_I8_DIGITS, IQ, RS>), grid, dim3(512), lds, s, a);
     return hipGetLastError();
 }
 template <int DT, int NOUT, int NT>
 static hipError_t launch_i8w_k(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
-    return a.iq_group_off ? launch_i8w_q<DT, NOUT, NT, true>(a, grid, lds, s) : launch_i8w_q<DT, NOUT, NT, false>(a, grid, lds, s);
+    // no shift, no IQ correction: real streams (instantiated for the 16-bit encodings at 8 tiles per chunk only)
+    if constexpr (Enc<DT>::size == 2 && NT == 8) {
+        if (a.rs) return launch_i8w_q<DT, NOUT, NT, false, true>(a, grid, lds, s);
+    } else if (a.rs) return hipErrorInvalidValue;
+    return a.iq_group_off ? launch_i8w_q<DT, NOUT, NT, true, false>(a, grid, lds, s) : launch_i8w_q<DT, NOUT, NT, false, false>(a, grid, lds, s);
 }
 
 template <int DT>
@@ -638,6 +809,34 @@ static hipError_t launch_i8w_d(const DecimArgs &a, int nout, int nt, dim3 grid, 
     if (nout == 8 && nt == 8) return launch_i8w_k<DT, 8, 8>(a, grid, lds, s);
     if (nout == 8 && nt == 16) return launch_i8w_k<DT, 8, 16>(a, grid, lds, s);
     return hipErrorInvalidValue;
+}
+
+#ifdef SDRT_I8W_BYTES
+hipError_t launch_chain_i8w_bytes(const DecimArgs &a, int nout, int nt, int dt, dim3 grid, size_t lds, hipStream_t s) {
+    return dt == SDRT_S8 ? launch_i8w_d<SDRT_S8>(a, nout, nt, grid, lds, s) : launch_i8w_d<SDRT_U8>(a, nout, nt, grid, lds, s);
+}
+#else
+// permlane swap self-test: out[0][l] = swap32_add(x[l], y[l]), out[1][l] = swap16_add(x[l], y[l])
+__global__ void swap_selftest_kernel(const double *x, const double *y, double *out) {
+    const int l = threadIdx.x & 63;
+    out[l] = swap32_add(x[l], y[l]);
+    out[64 + l] = swap16_add(x[l], y[l]);
+}
+
+// ---- launch helpers -----------------------------------------------------------------------------------------------
+bool chain_i8w_rs_supported(int dt, int n) {
+    return (dt == SDRT_S16 || dt == SDRT_U16) && n == 8 * SDRT_TB * SDRT_WIDE_LC;
+}
+
+bool chain_i8w_supported(int q, int dt, int n) {
+    if (!(q == 32 || q == 64)) return false;
+    if (!(dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16)) return false;
+    const int nt = n / (SDRT_TB * SDRT_WIDE_LC);
+    return n % (SDRT_TB * SDRT_WIDE_LC) == 0 && (nt == 8 || nt == 16);
+}
+
+size_t chain_i8w_lds_bytes(int q, int n) {
+    return (size_t) wide_lds(SDRT_I8_DIGITS, SDRT_WIDE_LC / q, n / (SDRT_TB * SDRT_WIDE_LC)).total;
 }
 
 hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, int n_cus, hipStream_t s) {
@@ -650,8 +849,7 @@ hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, 
     const dim3 grid((unsigned) wgs);
     const size_t lds = chain_i8w_lds_bytes(q, a.n);
     switch (dt) {
-        case SDRT_S8: return launch_i8w_d<SDRT_S8>(a, nout, nt, grid, lds, s);
-        case SDRT_U8: return launch_i8w_d<SDRT_U8>(a, nout, nt, grid, lds, s);
+        case SDRT_S8: case SDRT_U8: return launch_chain_i8w_bytes(a, nout, nt, dt, grid, lds, s);     // kernels_i8w_b.hip
         case SDRT_S16: return launch_i8w_d<SDRT_S16>(a, nout, nt, grid, lds, s);
         case SDRT_U16: return launch_i8w_d<SDRT_U16>(a, nout, nt, grid, lds, s);
     }
@@ -662,3 +860,4 @@ hipError_t launch_swap_selftest(const double *x, const double *y, double *out, h
     hipLaunchKernelGGL(swap_selftest_kernel, dim3(1), dim3(64), 0, s, x, y, out);
     return hipGetLastError();
 }
+#endif

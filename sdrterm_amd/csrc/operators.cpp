@@ -658,6 +658,51 @@ extern "C" int sdrt_build_i8_weights_wide(const double *sos, int sections, int q
     return 0;
 }
 
+extern "C" int sdrt_build_i8_weights_wide_rs(const double *sos, int sections, int q, double data_scale, int S,
+                                             signed char *main_out, double *main_combine, signed char *loc_out,
+                                             double *loc_combine) {
+    Modal m;
+    const char *err = nullptr;
+    if (!build_modal(sos, sections, m, &err)) return -2;
+    const int LC = SDRT_WIDE_LC, KS = LC / 64;
+    if (q < LC / SDRT_WIDE_MAXOUT || q > LC || (q & (q - 1))) return -3;
+    const int nout = LC / q;
+    C P[4], ac[4], aa[4];
+    for (int i = 0; i < 4; ++i) { P[i] = m.p[2 * i]; ac[i] = m.alpha[2 * i]; aa[i] = m.alpha[2 * i] / P[i]; }
+    std::vector<double> Wf((size_t) 16 * LC, 0.0);
+    for (int mode = 0; mode < 4; ++mode)
+        for (int kind = 0; kind < 2; ++kind)
+            for (int t = 0; t < LC; ++t) {
+                const C w = kind == 0 ? ac[mode] * cpow(P[mode], LC - 1 - t) : aa[mode] * cpow(P[mode], t);
+                Wf[(size_t) (4 * mode + 2 * kind + 0) * LC + t] = (double) w.re * data_scale;
+                Wf[(size_t) (4 * mode + 2 * kind + 1) * LC + t] = (double) w.im * data_scale;
+            }
+    *main_combine = quantise_planes(Wf.data(), 16, LC, LC, S, [&](int d, int r, int c, signed char dig) {
+        const int ks = c / 64, kg = (c % 64) / 16, j = c % 16;
+        main_out[((((size_t) d * KS + ks) * 64) + (r + 16 * kg)) * 16 + j] = dig;
+    });
+    if (*main_combine == 0.0) return -1;
+    C sum_a_over_p(0);
+    for (int i = 0; i < 8; ++i) sum_a_over_p = sum_a_over_p + m.alpha[i] / m.p[i];
+    const double d0p = (double) (m.d0 - sum_a_over_p.re) * data_scale;
+    std::vector<double> Wl((size_t) nout * LC, 0.0);
+    for (int b = 0; b < nout; ++b)
+        for (int t = 0; t < LC; ++t) {
+            R acc = 0;
+            for (int i = 0; i < 4; ++i) {
+                const C w = t < b * q ? ac[i] * cpow(P[i], b * q - 1 - t) : aa[i] * cpow(P[i], t - b * q);
+                acc = acc + 2 * w.re;
+            }
+            Wl[(size_t) b * LC + t] = (double) acc * data_scale + (t == b * q ? d0p : 0.0);
+        }
+    *loc_combine = quantise_planes(Wl.data(), nout, LC, LC, S, [&](int d, int r, int c, signed char dig) {
+        const int ks = c / 64, kg = (c % 64) / 16, j = c % 16;
+        loc_out[(((((size_t) d * KS + ks) * 4 + kg) * nout) + r) * 16 + j] = dig;
+    });
+    if (*loc_combine == 0.0) return -1;
+    return 0;
+}
+
 extern "C" void sdrt_build_wide_edge(const WideTables *wt, const double *nco_samp, const double *nco_blk, int n, double iq_lambda,
                                      double *ab, double *pq) {
     const int LC = SDRT_WIDE_LC, WN = 32;

@@ -138,6 +138,15 @@ int sdrt_build_i8_weights_wide(const double *sos, int sections, int q, double da
                                double iq_lambda, signed char *main_out, double *main_combine, signed char *loc_out,
                                double *loc_combine, double *gvec /*[48][2]*/);
 
+// Digit planes of the wide-column kernel WITHOUT frequency shift ("real streams"): the real and the imaginary sample stream
+// are then filtered by the same real-coefficient operator, so one 16-row tile (row = 4*mode + 2*kind + part, kind 0 causal /
+// 1 anticausal column aggregate) serves both, applied to the re bytes and to the im bytes separately, 64 samples per
+// k-step: KS = 4, K position (kstep, kg, j) <-> sample 64*kstep + 16*kg + j.
+//   main[((digit*KS + kstep)*64 + row + 16*kg)*16 + j]
+//   loc [((((digit*KS + kstep)*4 + kg)*nout) + b)*16 + j]      row b: the column-local part of output b (per stream)
+int sdrt_build_i8_weights_wide_rs(const double *sos, int sections, int q, double data_scale, int S, signed char *main_out,
+                                  double *main_combine, signed char *loc_out, double *loc_combine);
+
 // Edge operators of the wide-column kernel as per-sample coefficients: output o16 = 8*kind + 2*mode + stream (kind 0: causal
 // state F0 at the chunk start from samples 0..31, kind 1: the sample part Gu of the anticausal state at the chunk end from
 // samples n-32..n-1) is  sum_l ab[o16][l][0..1] * x_re[l] + ab[o16][l][2..3] * x_im[l]  -  pq[o16][0..1] * off_re -
