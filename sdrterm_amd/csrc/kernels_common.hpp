@@ -1,15 +1,19 @@
 #pragma once
 // Shared device helpers of the MI355X-native sdrterm DSP hot path (gfx950 only).  Included by kernels*.hip.
 //
-// chain_kernel   one workgroup per (chunk, row), everything fused:
-//                 unpack -> normalise -> [IQ correction] -> NCO -> zero-phase order-8 decimator in modal block form
-//                 (stage A on the f64 matrix cores, in-tile scans with DPP row shifts, tile carries through LDS)
-//                 -> FM pair-angle + resample m/2 -> m, or AM -> output lowpass as a 256-thread modal scan -> store.
+// Kernels (DESIGN.md sections 3, 4):
+//   kernels_i8w.hip   chain_i8w_kernel   unpack .. decimate on the int8 matrix cores, 256-sample columns, persistent and
+//                                        software-pipelined (the default for 8/16-bit integer input, q = 32 / 64)
+//   kernels_i8t.hip   chain_i8t_kernel   the same arithmetic with one block of <= 64 samples per column (other q / chunk sizes)
+//   kernels_i8.hip    chain_i8_kernel    ... on v_mfma_i32_32x32x32_i8 (diagnostic)
+//   kernels.hip       chain_kernel       stage A on the f64 matrix cores (float / 32-bit input, IQ correction off the wide path),
+//                                        IQ prefix kernels, stand-alone discriminators
+//   kernels_post.hip  post_fft_kernel / post_kernel / smooth_kernel   FM/AM discriminator, resampler, output lowpass, --smooth-output
 //
 // Reference steps replaced (peads/sdrterm, paths relative to its root):
 //   read_file.py:100-103 (unpack/_normalize/_correctIq), demodulation.py:71-79 (shiftFreq),
 //   dsp_processor.py:147 (scipy decimate), demodulation.py:25-48 (fmDemod/amDemod), dsp_processor.py:32-36,149
-//   (applyFilters/sosfilt).
+//   (applyFilters/sosfilt), dsp_processor.py:159-160 (savgol_filter).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -17,7 +21,6 @@
 
 #include "kernels.h"
 
-// Shared device code of the chain kernels (kernels.hip: f64 stage A; kernels_i8.hip: int8-sliced stage A).
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
