@@ -85,7 +85,7 @@ def shift_table(freqs, fs: float, n: int) -> np.ndarray:
 
 
 def process_stream(raw: bytes, code: str, n: int, q: int, mode: str, shift, dec_sos, out_sos, *,
-                   big_endian=False, norm=None, iq_inductance=None, off=0j, threads=1):
+                   big_endian=False, norm=None, iq_inductance=None, off=0j, threads=1, smooth=0):
     """Returns (out[chunks, rows, m], carried offset).  ``norm`` = (xmin, 1/(xmax-xmin)) or None."""
     import sys
     item = np.dtype({'b': 'i1', 'B': 'u1', 'h': 'i2', 'H': 'u2', 'i': 'i4', 'I': 'u4', 'f': 'f4', 'd': 'f8'}[code]).itemsize
@@ -110,4 +110,13 @@ def process_stream(raw: bytes, code: str, n: int, q: int, mode: str, shift, dec_
         C.c_int(threads))
     if rc:
         raise ValueError(f'orc_process_stream rc={rc}')
+    if smooth:
+        # --smooth-output, dsp_processor.py:159-160: savgol_filter(z, smooth, 3) on every chunk's samples (single VFO)
+        for c in range(n_chunks):
+            for r in range(rows):
+                row = np.ascontiguousarray(out[c, r])
+                rc = lib().orc_savgol(_p(row), C.c_size_t(m), C.c_int(int(smooth)), C.c_int(3))
+                if rc:
+                    raise ValueError(f'orc_savgol rc={rc}')
+                out[c, r] = row
     return out, complex(offv[0])

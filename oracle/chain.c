@@ -388,3 +388,92 @@ int orc_max_threads(void) {
     return 1;
 #endif
 }
+
+/* ---- --smooth-output: scipy.signal.savgol_filter(z, window, polyorder), mode='interp' (dsp_processor.py:159-160) ------------
+ * Restated from scipy's published algorithm (scipy/signal/_savitzky_golay.py): interior = correlation with the least-squares
+ * smoothing coefficients (minimum-norm solution of A c = e0, A[k][j] = x_j^k, x = pos .. pos-window+1, pos = window/2 or
+ * window/2 - 1/2 for even windows); the first / last window/2 outputs = a degree-`polyorder` polynomial fitted to the first /
+ * last `window` samples, evaluated at their positions.  Small dense systems, solved in long double. */
+static int orc_solve(int k, long double *M /* k x k */, long double *rhs) {
+    for (int c = 0; c < k; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < k; ++r) if (fabsl(M[r * k + c]) > fabsl(M[piv * k + c])) piv = r;
+        if (M[piv * k + c] == 0.0L) return -1;
+        if (piv != c) {
+            for (int j = 0; j < k; ++j) { long double t = M[c * k + j]; M[c * k + j] = M[piv * k + j]; M[piv * k + j] = t; }
+            long double t = rhs[c]; rhs[c] = rhs[piv]; rhs[piv] = t;
+        }
+        for (int r = c + 1; r < k; ++r) {
+            const long double f = M[r * k + c] / M[c * k + c];
+            for (int j = c; j < k; ++j) M[r * k + j] -= f * M[c * k + j];
+            rhs[r] -= f * rhs[c];
+        }
+    }
+    for (int c = k - 1; c >= 0; --c) {
+        long double s = rhs[c];
+        for (int j = c + 1; j < k; ++j) s -= M[c * k + j] * rhs[j];
+        rhs[c] = s / M[c * k + c];
+    }
+    return 0;
+}
+
+int orc_savgol(double *z, size_t m, int window, int polyorder) {
+    const int k = polyorder + 1, half = window / 2;
+    if (window < 1 || polyorder < 0 || polyorder >= window || (size_t) window > m || k > 8) return -1;
+    double *out = (double *) malloc(m * sizeof(double));
+    long double *coef = (long double *) malloc((size_t) window * sizeof(long double));
+    if (!out || !coef) { free(out); free(coef); return -2; }
+    /* interior coefficients: c = A^T (A A^T)^-1 e0 with x_j = pos - j (the 'conv' ordering of savgol_coeffs) */
+    const long double pos = (window % 2) ? (long double) half : (long double) half - 0.5L;
+    long double G[64], lam[8];
+    for (int a = 0; a < k; ++a)
+        for (int b = 0; b < k; ++b) {
+            long double s = 0;
+            for (int j = 0; j < window; ++j) s += powl(pos - j, a) * powl(pos - j, b);
+            G[a * k + b] = s;
+        }
+    for (int a = 0; a < k; ++a) lam[a] = a == 0 ? 1.0L : 0.0L;
+    if (orc_solve(k, G, lam)) { free(out); free(coef); return -3; }
+    for (int j = 0; j < window; ++j) {
+        long double s = 0;
+        for (int a = 0; a < k; ++a) s += lam[a] * powl(pos - j, a);
+        coef[j] = s;
+    }
+    /* scipy.ndimage.convolve1d(z, coef, mode='constant') with the (symmetric) coefficients: samples i - first .. i - first +
+     * window - 1, first = window/2 for odd windows and window/2 - 1 for even ones (convolve1d's origin rule); zeros outside */
+    const int first = (window % 2) ? half : half - 1;
+    for (size_t i = 0; i < m; ++i) {
+        long double s = 0;
+        for (int j = 0; j < window; ++j) {
+            const long long t = (long long) i + j - first;
+            if (t >= 0 && t < (long long) m) s += coef[j] * z[t];
+        }
+        out[i] = (double) s;
+    }
+    /* edges: least-squares polynomial over the first / last `window` samples (normal equations on x = 0 .. window-1) */
+    for (int side = 0; side < 2; ++side) {
+        const size_t w0 = side ? m - (size_t) window : 0;
+        long double N[64], rhs[8];
+        for (int a = 0; a < k; ++a) {
+            for (int b = 0; b < k; ++b) {
+                long double s = 0;
+                for (int j = 0; j < window; ++j) s += powl(j, a + b);
+                N[a * k + b] = s;
+            }
+            long double s = 0;
+            for (int j = 0; j < window; ++j) s += powl(j, a) * z[w0 + j];
+            rhs[a] = s;
+        }
+        if (orc_solve(k, N, rhs)) { free(out); free(coef); return -3; }
+        for (int i = 0; i < half; ++i) {
+            const int x = side ? window - half + i : i;
+            long double s = 0;
+            for (int a = k - 1; a >= 0; --a) s = s * x + rhs[a];
+            out[w0 + x] = (double) s;
+        }
+    }
+    memcpy(z, out, m * sizeof(double));
+    free(out);
+    free(coef);
+    return 0;
+}

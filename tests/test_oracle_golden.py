@@ -38,8 +38,6 @@ def test_numpy_oracle_matches_reference(case, golden):
 
 @pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
 def test_c_oracle_matches_reference(case, golden):
-    if case.get('smooth'):
-        pytest.skip('--smooth-output is restated in the numpy oracle only')
     z, _ = golden
     name = case['name']
     raw = case_raw(case)
@@ -53,7 +51,7 @@ def test_c_oracle_matches_reference(case, golden):
     out, off = c_chain.process_stream(raw, case['code'], n, case['q'], case['mode'], shift,
                                       z[f'{name}/cheby_sos'], z[f'{name}/ellip_sos'],
                                       big_endian=bool(case.get('big_endian')), norm=norm, iq_inductance=L,
-                                      threads=2)
+                                      threads=2, smooth=case.get('smooth', 0))
     exp = z[f'{name}/z']
     assert out.shape == exp.shape
     assert np.abs(out - exp).max() <= ref_tol(case, exp)
