@@ -4,7 +4,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from tests.util import CASES, case_raw, ref_tol, samples_per_chunk, tol_for
+from tests.util import BY_NAME, CASES, case_raw, ref_tol, samples_per_chunk, tol_for
 
 pytestmark = pytest.mark.gpu
 
@@ -84,3 +84,24 @@ def test_item_distribution_of_the_persistent_kernel(rows, nch, monkeypatch):
     out_b = b.process(raw)
     assert (a.stage_a, b.stage_a) == ('i8w', 'i8t')
     assert np.isfinite(out_a).all() and np.abs(out_a - out_b).max() < 1e-8
+
+
+@pytest.mark.parametrize('name', ['h_q64_fm_c', 'h_q32_fm_c', 'h_q64_fm_c0'])
+def test_resampler_forms_agree(name, golden, monkeypatch):
+    """scipy.signal.resample of the FM discriminator (demodulation.py:35-38) in its two GPU forms -- in-wave FFT (default)
+    and the circulant product with the half-sample Dirichlet kernel -- and the general vs real-stream form of the wide kernel:
+    every combination meets the reference's vectors."""
+    z, _ = golden
+    case = BY_NAME[name]
+    exp = z[f'{name}/z']
+    nch, rows, m = exp.shape
+    outs = []
+    for resample, rs in (('fft', '1'), ('direct', '1'), ('fft', '0')):
+        monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+        monkeypatch.setenv('SDRTERM_RESAMPLE', resample)
+        monkeypatch.setenv('SDRTERM_WIDE_RS', rs)
+        out, _ = _engine(case).process_debug(case_raw(case))
+        got = out.reshape(rows, nch, m).transpose(1, 0, 2)
+        assert np.abs(got - exp).max() <= ref_tol(case, exp)
+        outs.append(got)
+    assert np.abs(outs[0] - outs[1]).max() < 1e-9 and np.abs(outs[0] - outs[2]).max() < 1e-9
