@@ -307,6 +307,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
                                                  chain_i8_lds_bytes(n, L, m) <= 160 * 1024);
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->n_cus = cus;
+        if (const char *e = getenv("SDRTERM_WIDE_CUS")) { const int v = atoi(e); if (v >= 8 && v <= c->n_cus) c->n_cus = v / 8 * 8; }   // diagnostics: fewer persistent workgroups
     }
     if (rc == SDRT_OK && c->use_i8w) {
         // wide columns (256 samples): tables, NCO phasors per column, digit planes per row (NCO folded in)
