@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SDRT_ABI_VERSION 2
+#define SDRT_ABI_VERSION 3
 
 /* Input encodings: src/misc/file_util.py:44-56 (DataType b,B,h,H,i,I,f,d). */
 enum sdrt_dtype {
@@ -143,6 +143,39 @@ int sdrt_device_synchronize(void);
 int sdrt_set_device(int device);
 
 /*
+ * Streams and pinned host memory, for hosts that overlap transfers with computation themselves (the multi-GPU --simo
+ * driver, sdrterm_amd/parallel.py: broadcast of block k+1 beside the kernels of block k).
+ */
+int sdrt_stream_create(void **stream);
+int sdrt_stream_destroy(void *stream);
+int sdrt_stream_synchronize(void *stream);
+int sdrt_host_alloc(void **host_ptr, size_t bytes);      /* page-locked: async copies, full PCIe rate */
+int sdrt_host_free(void *host_ptr);
+int sdrt_memcpy_h2d_async(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int sdrt_memcpy_d2h_async(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+/* `waiter` waits (on the device) for everything submitted to `signaller` so far. */
+int sdrt_stream_wait_stream(void *waiter, void *signaller);
+
+/*
+ * Multi-GPU --simo: one process per GPU runs VfoProcessor (vfo_processor.py:38-57,80-126) on its
+ * contiguous share of the rows; the process that holds the reader's Queue hands every raw block to the others.  That is
+ * the only exchange on the path, and it runs over RCCL (librccl, loaded on first use) between device buffers:
+ *   sdrt_comm_unique_id   one rank creates the 128-byte id, the host side passes it to the others (pipe, socket, file)
+ *   sdrt_comm_init        every rank, collectively; binds the calling process to `device`
+ *   sdrt_comm_bcast       the raw block from `root` to every rank, in place, asynchronous on `stream`
+ *   sdrt_comm_allgather   alternative when every rank already holds 1/world of the block (each host link fed one shard):
+ *                         all seven xGMI links of every GPU carry one shard each way instead of the root's links carrying all
+ */
+typedef struct sdrt_comm sdrt_comm;
+int sdrt_comm_unique_id(void *id128);
+int sdrt_comm_init(const void *id128, int world, int rank, int device, sdrt_comm **out);
+int sdrt_comm_bcast(sdrt_comm *comm, void *dev_buf, size_t bytes, int root, void *stream);
+int sdrt_comm_allgather(sdrt_comm *comm, const void *send_dev, void *recv_dev, size_t bytes_per_rank, void *stream);
+int sdrt_comm_world(const sdrt_comm *comm);
+int sdrt_comm_rank(const sdrt_comm *comm);
+void sdrt_comm_destroy(sdrt_comm *comm);
+
+/*
  * Stand-alone discriminators on already-decimated samples: fmDemod / amDemod / realOutput / imagOutput of
  * src/dsp/demodulation.py:25-68 (mode 0 FM: pair angle + FFT-equivalent resample m/2 -> m; 1 AM: re^2+im^2; 2 re; 3 im).
  *   y_host : rows * m interleaved (re, im) float64;  out_host : rows * m float64.  Host buffers, synchronous.
@@ -154,13 +187,14 @@ int sdrt_demodulate_host(int mode, const double *y_host, int rows, int m, double
 int sdrt_debug_stamps(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, double *out_dev,
                       unsigned long long *stamps_host, int n_wgs);
 
-/* Self-tests of the matrix-core operand layouts the decimator relies on (one 16x16x4 f64 / 32x32x32 int8 product). */
+/* Self-tests of the matrix-core operand layouts the decimator relies on (one 16x16x4 f64 / 16x16x64 int8 product, the lane swaps). */
 int sdrt_selftest_mfma(double *max_abs_err);
 int sdrt_selftest_mfma_i8(int *mismatches);
 
-/* Which stage-A kernel the context uses: 0 = fp64 matrix cores; 2 = int8 matrix cores (16x16x64 form) with exact integer
- * slicing, the default for 8/16-bit integer encodings without --correct-iq; 1 = the 32x32x32 int8 form.  All meet the
- * same tolerance.  Environment SDRTERM_STAGE_A=f64 or =i8x32 forces 0 or 1 (diagnostics). */
+/* Which stage-A kernel the context uses: 0 = fp64 matrix cores; 2 = int8 matrix cores with exact integer slicing, one
+ * block per column (16x16x64); 3 = the same arithmetic in the wide-column persistent kernel (default for 8/16-bit integer
+ * encodings at decimation 32 / 64).  All meet the same tolerance.  Environment SDRTERM_STAGE_A=f64 or =i8t forces 0 or 2
+ * (diagnostics). */
 int sdrt_stage_a_kind(const sdrt_ctx *ctx);
 
 #ifdef __cplusplus

@@ -18,7 +18,7 @@ ITEM_SIZE = {'b': 1, 'B': 1, 'h': 2, 'H': 2, 'i': 4, 'I': 4, 'f': 4, 'd': 8}
 MODES = {'fm': 0, 'am': 1}
 OK, EINVAL, EHIP, ENOMEM, ENODEVICE = 0, 1, 2, 3, 4
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 EXPORTS = (
     'sdrt_abi_version', 'sdrt_config_size', 'sdrt_device_count', 'sdrt_last_error', 'sdrt_create', 'sdrt_destroy',
     'sdrt_out_per_chunk', 'sdrt_rows', 'sdrt_process_device', 'sdrt_process_host',
@@ -26,6 +26,10 @@ EXPORTS = (
     'sdrt_kernel_time', 'sdrt_profile_reset', 'sdrt_kernel_name', 'sdrt_malloc', 'sdrt_free',
     'sdrt_memcpy_h2d', 'sdrt_memcpy_d2h', 'sdrt_memcpy_d2d', 'sdrt_device_synchronize', 'sdrt_set_device',
     'sdrt_selftest_mfma', 'sdrt_selftest_mfma_i8', 'sdrt_set_smoothing', 'sdrt_stage_a_kind', 'sdrt_debug_stamps', 'sdrt_demodulate_host',
+    'sdrt_stream_create', 'sdrt_stream_destroy', 'sdrt_stream_synchronize', 'sdrt_host_alloc', 'sdrt_host_free',
+    'sdrt_memcpy_h2d_async', 'sdrt_memcpy_d2h_async', 'sdrt_stream_wait_stream',
+    'sdrt_comm_unique_id', 'sdrt_comm_init', 'sdrt_comm_bcast', 'sdrt_comm_allgather', 'sdrt_comm_world', 'sdrt_comm_rank',
+    'sdrt_comm_destroy',
 )
 
 
@@ -124,6 +128,22 @@ def lib():
     l.sdrt_demodulate_host.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     l.sdrt_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     l.sdrt_config_size.restype = C.c_size_t
+    l.sdrt_stream_create.argtypes = [C.POINTER(C.c_void_p)]
+    l.sdrt_stream_destroy.argtypes = [C.c_void_p]
+    l.sdrt_stream_synchronize.argtypes = [C.c_void_p]
+    l.sdrt_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    l.sdrt_host_free.argtypes = [C.c_void_p]
+    l.sdrt_memcpy_h2d_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    l.sdrt_memcpy_d2h_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    l.sdrt_stream_wait_stream.argtypes = [C.c_void_p, C.c_void_p]
+    l.sdrt_comm_unique_id.argtypes = [C.c_void_p]
+    l.sdrt_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    l.sdrt_comm_bcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    l.sdrt_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    l.sdrt_comm_world.argtypes = [C.c_void_p]
+    l.sdrt_comm_rank.argtypes = [C.c_void_p]
+    l.sdrt_comm_destroy.argtypes = [C.c_void_p]
+    l.sdrt_comm_destroy.restype = None
     if l.sdrt_abi_version() != ABI_VERSION or l.sdrt_config_size() != C.sizeof(Config):
         raise NativeLibraryError('libsdrterm_hip.so ABI mismatch (version or sdrt_config layout)')
     _lib = l

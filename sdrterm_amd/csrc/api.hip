@@ -25,6 +25,19 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+}  // namespace
+
+// used by the other translation units of the library (comm.hip)
+int sdrt_set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+namespace {
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
@@ -57,15 +70,15 @@ struct sdrt_ctx {
     void *d_raw = nullptr;
     double *d_out = nullptr;
     size_t stage_cap_chunks = 0;
-    bool use_i8 = false;              // stage A on the int8 matrix cores (integer encodings, no IQ correction)
-    bool use_i8t = false;             //   ... in the 16x16x64 form; otherwise the 32x32x32 form
+    bool use_i8 = false;              // stage A on the int8 matrix cores (8/16-bit integer encodings): use_i8w || use_i8t
+    bool use_i8t = false;             //   ... one block per column (16x16x64), no IQ correction
     bool use_i8w = false;             //   ... wide columns, persistent workgroups (default where supported)
     WideTables *d_wtab = nullptr;
     double *d_edge_ab = nullptr, *d_edge_pq = nullptr, *d_gvec = nullptr;
     bool wide_rs = false;             // wide kernel in its real-stream form (no shift, no IQ correction)
     int n_cus = 256;
     signed char *d_w8 = nullptr, *d_w8mid = nullptr;
-    DecimTables *d_tab8 = nullptr;    // tables for columns of SDRT_I8_G blocks
+    DecimTables *d_tab8 = nullptr;    // tables for columns of SDRT_I8T_G blocks
     double *d_nco_tile8 = nullptr, *d_nco_phase8 = nullptr;
     double *d_ybias = nullptr;
     double w8_combine = 0.0, w8mid_combine = 0.0, x_offset = 0.0;
@@ -143,6 +156,147 @@ int upload(T **dst, const void *src, size_t bytes) {
     return SDRT_OK;
 }
 
+
+// ---- stage A on the int8 matrix cores: table construction per form ----------------------------------------------------
+void free_stage_a(sdrt_ctx *c) {
+    auto drop = [](auto *&p) { if (p) (void) hipFree(p); p = nullptr; };
+    drop(c->d_wtab); drop(c->d_edge_ab); drop(c->d_edge_pq); drop(c->d_gvec);
+    drop(c->d_w8); drop(c->d_w8mid); drop(c->d_tab8); drop(c->d_nco_tile8); drop(c->d_nco_phase8);
+    c->use_i8w = c->use_i8t = c->wide_rs = false;
+    c->w8_combine = c->w8mid_combine = 0.0;
+}
+
+// wide columns (256 samples, chain_i8w_kernel): tables, NCO phasors per column, digit planes per row (NCO folded in).
+// Leaves c->use_i8w set on success; returns SDRT_OK with use_i8w clear when this form does not apply.
+template <class ScaleFn>
+int setup_wide(sdrt_ctx *c, const sdrt_config *cfg, ScaleFn &) {
+    const int q = cfg->decimation, n = cfg->n_samples;
+    const int S = SDRT_I8_DIGITS, LC = SDRT_WIDE_LC, KS = LC / 32, NR = 2 * (LC / q);
+    const char *msg = nullptr;
+    WideTables wtab;
+    if (sdrt_build_wide_tables(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, &wtab, &msg) != 0)
+        return fail(SDRT_EINVAL, "wide-column tables: %s", msg ? msg : "failed");
+    const char *rsenv = getenv("SDRTERM_WIDE_RS");               // diagnostics: "0" keeps the general form
+    c->wide_rs = !c->nco && !c->iq && chain_i8w_rs_supported(cfg->dtype, n) && !(rsenv && strcmp(rsenv, "0") == 0);
+    const size_t per_row = c->wide_rs ? (size_t) S * (LC / 64) * 64 * 16 : (size_t) 2 * S * KS * 64 * 16;
+    const size_t per_row_loc = c->wide_rs ? (size_t) S * (LC / 64) * 4 * (NR / 2) * 16 : (size_t) S * KS * 4 * NR * 16;
+    std::vector<signed char> w8(per_row * c->rows), w8l(per_row_loc * c->rows);
+    std::vector<double> samp((size_t) c->rows * LC * 2), blk((size_t) c->rows * (n / LC) * 2);
+    std::vector<double> eab((size_t) c->rows * 16 * 32 * 4), epq((size_t) c->rows * 16 * 4), gv((size_t) c->rows * 48 * 2);
+    const double lam = c->iq ? cfg->iq_inductance : 0.0;
+    bool ok = true;
+    for (int r = 0; r < c->rows && ok; ++r) {
+        double comb = 0.0, combl = 0.0;
+        double *sp = &samp[(size_t) r * LC * 2], *bp = &blk[(size_t) r * (n / LC) * 2];
+        if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, LC, n / LC, sp, bp);
+        const int brc = c->wide_rs
+            ? sdrt_build_i8_weights_wide_rs(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, S, w8.data() + per_row * r, &comb,
+                                            w8l.data() + per_row_loc * r, &combl)
+            : sdrt_build_i8_weights_wide(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, c->nco ? sp : nullptr, S, lam,
+                                         w8.data() + per_row * r, &comb, w8l.data() + per_row_loc * r, &combl,
+                                         &gv[(size_t) r * 96]);
+        sdrt_build_wide_edge(&wtab, c->nco ? sp : nullptr, c->nco ? bp : nullptr, n, lam, &eab[(size_t) r * 2048],
+                             &epq[(size_t) r * 64]);
+        // one power-of-two scale per context (rows differ by a rotation of the weights only); a digit overflow or unequal
+        // scales: this form does not apply
+        if (brc != 0 || comb == 0.0 || combl == 0.0) ok = false;
+        else if (r == 0) { c->w8_combine = comb; c->w8mid_combine = combl; }
+        else if (comb != c->w8_combine || combl != c->w8mid_combine) ok = false;
+    }
+    if (!ok) { free_stage_a(c); return SDRT_OK; }
+    int rc = upload(&c->d_wtab, &wtab, sizeof(wtab));
+    if (rc == SDRT_OK && c->nco) {
+        rc = upload(&c->d_nco_tile8, samp.data(), samp.size() * sizeof(double));
+        if (rc == SDRT_OK) rc = upload(&c->d_nco_phase8, blk.data(), blk.size() * sizeof(double));
+    }
+    if (rc == SDRT_OK) rc = upload(&c->d_w8, w8.data(), w8.size());
+    if (rc == SDRT_OK) rc = upload(&c->d_w8mid, w8l.data(), w8l.size());
+    if (rc == SDRT_OK) rc = upload(&c->d_edge_ab, eab.data(), eab.size() * sizeof(double));
+    if (rc == SDRT_OK) rc = upload(&c->d_edge_pq, epq.data(), epq.size() * sizeof(double));
+    if (rc == SDRT_OK) rc = upload(&c->d_gvec, gv.data(), gv.size() * sizeof(double));
+    c->use_i8w = rc == SDRT_OK;
+    return rc;
+}
+
+// one block of L <= 64 samples per column (chain_i8t_kernel): tables for columns of G blocks, digit planes per row
+template <class ScaleFn>
+int setup_i8t(sdrt_ctx *c, const sdrt_config *cfg, ScaleFn &scale_tables) {
+    const int q = cfg->decimation, n = cfg->n_samples, L = c->L;
+    const int S = SDRT_I8_DIGITS, G = SDRT_I8T_G, LC = L * G, KS = LC / 32, NR = 2 * (G - 1);
+    const char *msg = nullptr;
+    DecimTables tab8;
+    if (sdrt_build_decim_tables(cfg->dec_sos, cfg->dec_sections, q, G, &tab8, &msg) != 0)
+        return fail(SDRT_EINVAL, "decimator tables: %s", msg ? msg : "failed");
+    scale_tables(tab8);
+    c->n_tiles8 = n / (SDRT_TB * LC);
+    const size_t per_row = (size_t) 2 * S * KS * 64 * 16, per_row_mid = (size_t) S * KS * 4 * NR * 16;
+    std::vector<signed char> w8(per_row * c->rows), w8m(per_row_mid * c->rows + 16);
+    std::vector<double> samp((size_t) c->rows * LC * 2), blk((size_t) c->rows * (n / LC) * 2);
+    bool ok = true;
+    for (int r = 0; r < c->rows && ok; ++r) {
+        double comb = 0.0, combm = 0.0;
+        double *sp = &samp[(size_t) r * LC * 2], *bp = &blk[(size_t) r * (n / LC) * 2];
+        if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, LC, n / LC, sp, bp);
+        const int brc = sdrt_build_i8_weights16(cfg->dec_sos, cfg->dec_sections, &tab8, c->norm_scale, c->nco ? sp : nullptr, S,
+                                                w8.data() + per_row * r, &comb, w8m.data() + per_row_mid * r, &combm);
+        if (brc != 0 || comb == 0.0) ok = false;
+        else if (r == 0) { c->w8_combine = comb; c->w8mid_combine = combm; }
+        else if (comb != c->w8_combine || combm != c->w8mid_combine) ok = false;
+    }
+    if (!ok) { free_stage_a(c); return SDRT_OK; }          // the fp64 kernel takes over
+    int rc = upload(&c->d_tab8, &tab8, sizeof(tab8));
+    if (rc == SDRT_OK && c->nco) {
+        rc = upload(&c->d_nco_tile8, samp.data(), samp.size() * sizeof(double));
+        if (rc == SDRT_OK) rc = upload(&c->d_nco_phase8, blk.data(), blk.size() * sizeof(double));
+    }
+    if (rc == SDRT_OK) rc = upload(&c->d_w8, w8.data(), w8.size());
+    if (rc == SDRT_OK && per_row_mid) rc = upload(&c->d_w8mid, w8m.data(), per_row_mid * c->rows);
+    c->use_i8t = rc == SDRT_OK;
+    return rc;
+}
+
+// The int8 kernels filter x - x_offset (the slices' range); the decimator is linear, so its response to the constant the
+// slices leave out (plus the normalisation bias) is one vector per row: run the fp64 kernel once on a constant chunk.
+int setup_ybias(sdrt_ctx *c, const sdrt_config *cfg) {
+    static const double kOff[8] = {0.0, 128.0, 128.0, 32896.0, 0, 0, 0, 0};
+    const int n = cfg->n_samples, m = c->m;
+    c->x_offset = kOff[cfg->dtype];
+    const size_t bytes = (size_t) c->rows * m * 2 * sizeof(double);
+    if (!c->iq && (c->x_offset != 0.0 || c->norm_bias != 0.0)) {
+        const double cre = c->x_offset + c->norm_bias, cim = c->x_offset;
+        std::vector<double> cz((size_t) n * 2);
+        for (int i = 0; i < n; ++i) { cz[2 * i] = cre; cz[2 * i + 1] = cim; }
+        double *d_cz = nullptr;
+        int rc = upload(&d_cz, cz.data(), cz.size() * sizeof(double));
+        if (rc == SDRT_OK && hipMalloc((void **) &c->d_ybias, bytes) != hipSuccess) rc = fail(SDRT_ENOMEM, "hipMalloc failed");
+        if (rc == SDRT_OK) {
+            DecimArgs da;
+            memset(&da, 0, sizeof(da));
+            da.raw = d_cz;
+            da.tab = c->d_tab;
+            da.nco_tile = c->d_nco_tile;
+            da.nco_phase = c->d_nco_phase;
+            da.ydec = c->d_ybias;
+            da.n_chunks = 1;
+            da.n = n;
+            da.m = m;
+            da.n_tiles = c->n_tiles;
+            da.rows = c->rows;
+            hipError_t e = launch_chain(da, c->L, SDRT_F64, c->nco, false, 1, nullptr);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e != hipSuccess) rc = fail(SDRT_EHIP, "ybias kernel failed: %s", hipGetErrorString(e));
+        }
+        (void) hipFree(d_cz);
+        return rc;
+    }
+    if (c->use_i8w) {
+        // the wide-column kernel always adds its ybias operand (no branch in its inner loop): zeros here
+        if (hipMalloc((void **) &c->d_ybias, bytes) != hipSuccess) return fail(SDRT_ENOMEM, "hipMalloc failed");
+        if (hipMemset(c->d_ybias, 0, bytes) != hipSuccess) return fail(SDRT_EHIP, "hipMemset failed");
+    }
+    return SDRT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -192,6 +346,13 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     if (n % q) return fail(SDRT_EINVAL, "decimation must divide n_samples");   // dsp_processor.py:147,173
     const int m = n / q;
     if (cfg->mode == SDRT_FM && (m < 2 || (m & 1))) return fail(SDRT_EINVAL, "FM needs an even number of outputs per chunk");
+    // the post stage keeps one (chunk, row) item per wave in LDS: FFT resampler for m/2 in {256 .. 2048}, else the direct forms
+    {
+        const int Nh = m / 2;
+        const bool fft_fm = cfg->mode == SDRT_FM && (Nh == 256 || Nh == 512 || Nh == 1024 || Nh == 2048);
+        if (!fft_fm && post_waves_per_block(m, cfg->mode) == 0)
+            return fail(SDRT_EINVAL, "%d outputs per chunk (n_samples / decimation) exceed what the demodulation stage holds in LDS", m);
+    }
     if (cfg->correct_iq && n / (L / 4) < 256)
         return fail(SDRT_EINVAL, "correct_iq needs at least %d samples per chunk", 256 * (L / 4));
 
@@ -286,7 +447,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         rc = upload(&c->d_resample, h.data(), h.size() * sizeof(double));
         const int N = m / 2;
         const char *pf = getenv("SDRTERM_RESAMPLE");             // diagnostics: "direct" forces the circulant product
-        if (rc == SDRT_OK && (N == 256 || N == 512 || N == 1024) && !(pf && strcmp(pf, "direct") == 0)) {
+        if (rc == SDRT_OK && (N == 256 || N == 512 || N == 1024 || N == 2048) && !(pf && strcmp(pf, "direct") == 0)) {
             std::vector<double> tw((size_t) N * 2), sh((size_t) N * 2);
             sdrt_build_fft_resample(N, tw.data(), sh.data());
             rc = upload(&c->d_fft_tw, tw.data(), tw.size() * sizeof(double));
@@ -295,175 +456,22 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         }
     }
     if (rc == SDRT_OK) {
-        const char *force = getenv("SDRTERM_STAGE_A");      // diagnostics: "f64" forces the fp64 matrix-core kernel
+        const char *force = getenv("SDRTERM_STAGE_A");      // diagnostics: "f64" forces the fp64 matrix-core kernel,
         const bool want_i8 = !(force && strcmp(force, "f64") == 0);
-        const bool want_x32 = force && strcmp(force, "i8x32") == 0;   // diagnostics: the 32x32x32 int8 kernel
-        const bool want_t = force && strcmp(force, "i8t") == 0;       // diagnostics: the one-block-per-column 16x16x64 kernel
-        c->use_i8w = want_i8 && !want_x32 && !want_t && chain_i8w_supported(q, cfg->dtype, n) &&
-                     chain_i8w_lds_bytes(q, n) <= 160 * 1024;
-        c->use_i8t = !c->use_i8w && want_i8 && !want_x32 && !c->iq && chain_i8t_supported(L, cfg->dtype, n) &&
-                     chain_i8t_lds_bytes(n, L, m) <= 160 * 1024;
-        c->use_i8 = c->use_i8w || c->use_i8t || (want_i8 && !c->iq && !c->use_i8w && chain_i8_supported(L, cfg->dtype, n) &&
-                                                 chain_i8_lds_bytes(n, L, m) <= 160 * 1024);
+        const bool want_t = force && strcmp(force, "i8t") == 0;       // "i8t" the one-block-per-column 16x16x64 kernel
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->n_cus = cus;
         if (const char *e = getenv("SDRTERM_WIDE_CUS")) { const int v = atoi(e); if (v >= 8 && v <= c->n_cus) c->n_cus = v / 8 * 8; }   // diagnostics: fewer persistent workgroups
+        // int8 matrix-core forms in order of preference; a form that cannot represent this configuration (unequal
+        // power-of-two scales between rows, a digit overflow) releases what it uploaded and the next one is tried; the
+        // fp64 matrix-core kernel takes whatever is left
+        if (want_i8 && !want_t && chain_i8w_supported(q, cfg->dtype, n) && chain_i8w_lds_bytes(q, n) <= 160 * 1024)
+            rc = setup_wide(c, cfg, scale_tables);
+        if (rc == SDRT_OK && !c->use_i8w && want_i8 && !c->iq && want_i8_fallback_t(L, cfg->dtype, n, m))
+            rc = setup_i8t(c, cfg, scale_tables);
+        c->use_i8 = c->use_i8w || c->use_i8t;
     }
-    if (rc == SDRT_OK && c->use_i8w) {
-        // wide columns (256 samples): tables, NCO phasors per column, digit planes per row (NCO folded in)
-        const int S = SDRT_I8_DIGITS, LC = SDRT_WIDE_LC, KS = LC / 32, NR = 2 * (LC / q);
-        WideTables wtab;
-        if (sdrt_build_wide_tables(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, &wtab, &msg) != 0)
-            rc = fail(SDRT_EINVAL, "wide-column tables: %s", msg ? msg : "failed");
-        if (rc == SDRT_OK) rc = upload(&c->d_wtab, &wtab, sizeof(wtab));
-        const char *rsenv = getenv("SDRTERM_WIDE_RS");               // diagnostics: "0" keeps the general form
-        c->wide_rs = !c->nco && !c->iq && chain_i8w_rs_supported(cfg->dtype, n) && !(rsenv && strcmp(rsenv, "0") == 0);
-        const size_t per_row = c->wide_rs ? (size_t) S * (LC / 64) * 64 * 16 : (size_t) 2 * S * KS * 64 * 16;
-        const size_t per_row_loc = c->wide_rs ? (size_t) S * (LC / 64) * 4 * (NR / 2) * 16 : (size_t) S * KS * 4 * NR * 16;
-        std::vector<signed char> w8(per_row * c->rows), w8l(per_row_loc * c->rows);
-        std::vector<double> samp((size_t) c->rows * LC * 2), blk((size_t) c->rows * (n / LC) * 2);
-        std::vector<double> eab((size_t) c->rows * 16 * 32 * 4), epq((size_t) c->rows * 16 * 4), gv((size_t) c->rows * 48 * 2);
-        const double lam = c->iq ? cfg->iq_inductance : 0.0;
-        for (int r = 0; r < c->rows && rc == SDRT_OK; ++r) {
-            double comb = 0.0, combl = 0.0;
-            double *sp = &samp[(size_t) r * LC * 2], *bp = &blk[(size_t) r * (n / LC) * 2];
-            if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, LC, n / LC, sp, bp);
-            const int brc = c->wide_rs
-                ? sdrt_build_i8_weights_wide_rs(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, S, w8.data() + per_row * r, &comb,
-                                                w8l.data() + per_row_loc * r, &combl)
-                : sdrt_build_i8_weights_wide(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, c->nco ? sp : nullptr, S, lam,
-                                             w8.data() + per_row * r, &comb, w8l.data() + per_row_loc * r, &combl,
-                                             &gv[(size_t) r * 96]);
-            if (brc != 0) rc = fail(SDRT_EINVAL, "int8 weight quantisation failed");
-            sdrt_build_wide_edge(&wtab, c->nco ? sp : nullptr, c->nco ? bp : nullptr, n, lam, &eab[(size_t) r * 2048],
-                                 &epq[(size_t) r * 64]);
-            // one power-of-two scale per context (rows differ by a rotation of the weights only); otherwise the other form
-            if (r == 0) { c->w8_combine = comb; c->w8mid_combine = combl; }
-            else if (comb != c->w8_combine || combl != c->w8mid_combine) { c->use_i8w = false; break; }
-        }
-        if (rc == SDRT_OK && c->use_i8w && c->nco) {
-            rc = upload(&c->d_nco_tile8, samp.data(), samp.size() * sizeof(double));
-            if (rc == SDRT_OK) rc = upload(&c->d_nco_phase8, blk.data(), blk.size() * sizeof(double));
-        }
-        if (rc == SDRT_OK && c->use_i8w) rc = upload(&c->d_w8, w8.data(), w8.size());
-        if (rc == SDRT_OK && c->use_i8w) rc = upload(&c->d_w8mid, w8l.data(), w8l.size());
-        if (rc == SDRT_OK && c->use_i8w) rc = upload(&c->d_edge_ab, eab.data(), eab.size() * sizeof(double));
-        if (rc == SDRT_OK && c->use_i8w) rc = upload(&c->d_edge_pq, epq.data(), epq.size() * sizeof(double));
-        if (rc == SDRT_OK && c->use_i8w) rc = upload(&c->d_gvec, gv.data(), gv.size() * sizeof(double));
-        if (c->use_i8w && c->iq && c->w8_combine == 0.0) c->use_i8w = false;
-        if (!c->use_i8w) {
-            (void) hipFree(c->d_wtab);
-    (void) hipFree(c->d_edge_ab);
-    (void) hipFree(c->d_edge_pq);
-    (void) hipFree(c->d_gvec); c->d_wtab = nullptr;
-            c->use_i8t = !c->iq && want_i8_fallback_t(L, cfg->dtype, n, m);
-            c->use_i8 = c->use_i8t;
-        }
-    }
-    if (rc == SDRT_OK && c->use_i8t) {
-        // columns of G blocks: tables, NCO phasors per column, digit planes per row (NCO folded in, so they differ per row)
-        const int S = SDRT_I8_DIGITS, G = SDRT_I8T_G, LC = L * G, KS = LC / 32, NR = 2 * (G - 1);
-        DecimTables tab8;
-        if (sdrt_build_decim_tables(cfg->dec_sos, cfg->dec_sections, q, G, &tab8, &msg) != 0)
-            rc = fail(SDRT_EINVAL, "decimator tables: %s", msg ? msg : "failed");
-        scale_tables(tab8);
-        c->n_tiles8 = n / (SDRT_TB * LC);
-        if (rc == SDRT_OK) rc = upload(&c->d_tab8, &tab8, sizeof(tab8));
-        const size_t per_row = (size_t) 2 * S * KS * 64 * 16, per_row_mid = (size_t) S * KS * 4 * NR * 16;
-        std::vector<signed char> w8(per_row * c->rows), w8m(per_row_mid * c->rows + 16);
-        std::vector<double> samp((size_t) c->rows * LC * 2), blk((size_t) c->rows * (n / LC) * 2);
-        for (int r = 0; r < c->rows && rc == SDRT_OK; ++r) {
-            double comb = 0.0, combm = 0.0;
-            double *sp = &samp[(size_t) r * LC * 2], *bp = &blk[(size_t) r * (n / LC) * 2];
-            if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, LC, n / LC, sp, bp);
-            if (sdrt_build_i8_weights16(cfg->dec_sos, cfg->dec_sections, &tab8, c->norm_scale, c->nco ? sp : nullptr, S,
-                                        w8.data() + per_row * r, &comb, w8m.data() + per_row_mid * r, &combm) != 0)
-                rc = fail(SDRT_EINVAL, "int8 weight quantisation failed");
-            if (r == 0) { c->w8_combine = comb; c->w8mid_combine = combm; }
-            else if (comb != c->w8_combine || combm != c->w8mid_combine) { c->use_i8t = false; break; }   // other int8 form
-        }
-        if (rc == SDRT_OK && c->use_i8t && c->nco) {
-            rc = upload(&c->d_nco_tile8, samp.data(), samp.size() * sizeof(double));
-            if (rc == SDRT_OK) rc = upload(&c->d_nco_phase8, blk.data(), blk.size() * sizeof(double));
-        }
-        if (rc == SDRT_OK && c->use_i8t) rc = upload(&c->d_w8, w8.data(), w8.size());
-        if (rc == SDRT_OK && c->use_i8t && per_row_mid) rc = upload(&c->d_w8mid, w8m.data(), per_row_mid * c->rows);
-        if (!c->use_i8t) {      // clean up for the fallback form, which builds its own tables
-            (void) hipFree(c->d_tab8); c->d_tab8 = nullptr;
-            (void) hipFree(c->d_nco_tile8); c->d_nco_tile8 = nullptr;
-            (void) hipFree(c->d_nco_phase8); c->d_nco_phase8 = nullptr;
-        }
-    }
-    if (rc == SDRT_OK && c->use_i8 && !c->use_i8t && !c->use_i8w) {
-        // tables for columns of G blocks, digit planes per row (the NCO's within-column phasor is folded into the weights,
-        // so they differ per row)
-        const int S = SDRT_I8_DIGITS, G = SDRT_I8_G, LC = L * G, KS = LC / 16, NR = 2 * (G - 1);
-        DecimTables tab8;
-        if (sdrt_build_decim_tables(cfg->dec_sos, cfg->dec_sections, q, G, &tab8, &msg) != 0)
-            rc = fail(SDRT_EINVAL, "decimator tables: %s", msg ? msg : "failed");
-        scale_tables(tab8);
-        c->n_tiles8 = n / (SDRT_TB * LC);
-        if (rc == SDRT_OK) rc = upload(&c->d_tab8, &tab8, sizeof(tab8));
-        const size_t per_row = (size_t) S * KS * 64 * 16, per_row_mid = (size_t) S * KS * 2 * NR * 16;
-        std::vector<signed char> w8(per_row * c->rows), w8m(per_row_mid * c->rows + 16);
-        std::vector<double> samp((size_t) c->rows * LC * 2), blk((size_t) c->rows * (n / LC) * 2);
-        for (int r = 0; r < c->rows && rc == SDRT_OK; ++r) {
-            double comb = 0.0, combm = 0.0;
-            double *sp = &samp[(size_t) r * LC * 2], *bp = &blk[(size_t) r * (n / LC) * 2];
-            if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, LC, n / LC, sp, bp);
-            if (sdrt_build_i8_weights(cfg->dec_sos, cfg->dec_sections, &tab8, c->norm_scale, c->nco ? sp : nullptr, S,
-                                      w8.data() + per_row * r, &comb, w8m.data() + per_row_mid * r, &combm) != 0)
-                rc = fail(SDRT_EINVAL, "int8 weight quantisation failed");
-            // one power-of-two scale per context keeps the kernel's recombination uniform: rows only differ by a
-            // rotation of the weights, so their maxima agree to within a factor < 2; take the first and verify
-            if (r == 0) { c->w8_combine = comb; c->w8mid_combine = combm; }
-            else if (comb != c->w8_combine || combm != c->w8mid_combine) { c->use_i8 = false; break; }
-        }
-        if (rc == SDRT_OK && c->use_i8 && c->nco) {
-            rc = upload(&c->d_nco_tile8, samp.data(), samp.size() * sizeof(double));
-            if (rc == SDRT_OK) rc = upload(&c->d_nco_phase8, blk.data(), blk.size() * sizeof(double));
-        }
-        if (rc == SDRT_OK && c->use_i8 && per_row_mid) rc = upload(&c->d_w8mid, w8m.data(), per_row_mid * c->rows);
-        if (rc == SDRT_OK && c->use_i8) rc = upload(&c->d_w8, w8.data(), w8.size());
-    }
-    if (rc == SDRT_OK && c->use_i8) {
-        static const double kOff[8] = {0.0, 128.0, 128.0, 32896.0, 0, 0, 0, 0};
-        c->x_offset = kOff[cfg->dtype];
-        if (rc == SDRT_OK && c->use_i8 && !c->iq && (c->x_offset != 0.0 || c->norm_bias != 0.0)) {
-            // response of the (linear) decimator to the constant the slices leave out: run the f64 kernel once on a
-            // constant chunk and keep its decimated samples
-            const double cre = c->x_offset + c->norm_bias, cim = c->x_offset;
-            std::vector<double> cz((size_t) n * 2);
-            for (int i = 0; i < n; ++i) { cz[2 * i] = cre; cz[2 * i + 1] = cim; }
-            double *d_cz = nullptr;
-            rc = upload(&d_cz, cz.data(), cz.size() * sizeof(double));
-            if (rc == SDRT_OK && hipMalloc((void **) &c->d_ybias, (size_t) c->rows * m * 2 * sizeof(double)) != hipSuccess)
-                rc = fail(SDRT_ENOMEM, "hipMalloc failed");
-            if (rc == SDRT_OK) {
-                DecimArgs da;
-                memset(&da, 0, sizeof(da));
-                da.raw = d_cz;
-                da.tab = c->d_tab;
-                da.nco_tile = c->d_nco_tile;
-                da.nco_phase = c->d_nco_phase;
-                da.ydec = c->d_ybias;
-                da.n_chunks = 1;
-                da.n = n;
-                da.m = m;
-                da.n_tiles = c->n_tiles;
-                da.rows = c->rows;
-                hipError_t e = launch_chain(da, L, SDRT_F64, c->nco, false, 1, nullptr);
-                if (e == hipSuccess) e = hipDeviceSynchronize();
-                if (e != hipSuccess) rc = fail(SDRT_EHIP, "ybias kernel failed: %s", hipGetErrorString(e));
-            }
-            (void) hipFree(d_cz);
-        } else if (rc == SDRT_OK && c->use_i8w) {
-            // the wide-column kernel always adds its ybias operand (no branch in its inner loop): zeros here
-            const size_t bytes = (size_t) c->rows * m * 2 * sizeof(double);
-            if (hipMalloc((void **) &c->d_ybias, bytes) != hipSuccess) rc = fail(SDRT_ENOMEM, "hipMalloc failed");
-            else if (hipMemset(c->d_ybias, 0, bytes) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemset failed");
-        }
-    }
+    if (rc == SDRT_OK && c->use_i8) rc = setup_ybias(c, cfg);
     if (rc != SDRT_OK) {
         sdrt_destroy(c);
         return rc;
@@ -522,6 +530,8 @@ int sdrt_set_smoothing(sdrt_ctx *c, int window, int ntaps, int tap_first, const 
     // scipy: "If mode is 'interp', window_length must be less than or equal to the size of x."
     if (window > c->m || 2 * n_edge > c->m)
         return fail(SDRT_EINVAL, "If mode is 'interp', window_length must be less than or equal to the size of x.");
+    if (smooth_waves_per_block(c->m) == 0)
+        return fail(SDRT_EINVAL, "--smooth-output: %d outputs per chunk exceed what the smoothing stage holds in LDS", c->m);
     const size_t cnt = (size_t) ntaps + 2 * (size_t) n_edge * window;
     std::vector<double> all(cnt);
     memcpy(all.data(), taps, sizeof(double) * ntaps);
@@ -647,8 +657,6 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
         } else if (c->use_i8t) {
             // the int8 kernels feed x - x_offset to the matrix cores; normalisation bias and offset come back via ybias
             HIP_TRY(launch_chain_i8t(da, c->L, c->cfg.dtype, n_chunks, s));
-        } else if (c->use_i8) {
-            HIP_TRY(launch_chain_i8(da, c->L, c->cfg.dtype, c->nco, n_chunks, s));
         } else {
             HIP_TRY(launch_chain(da, c->L, c->cfg.dtype, c->nco, c->iq, n_chunks, s));
         }
@@ -793,6 +801,48 @@ int sdrt_device_synchronize(void) {
     return SDRT_OK;
 }
 
+int sdrt_stream_create(void **stream) {
+    if (!stream) return fail(SDRT_EINVAL, "null argument");
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *) s;
+    return SDRT_OK;
+}
+int sdrt_stream_destroy(void *stream) {
+    HIP_TRY(hipStreamDestroy((hipStream_t) stream));
+    return SDRT_OK;
+}
+int sdrt_stream_synchronize(void *stream) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
+    return SDRT_OK;
+}
+int sdrt_host_alloc(void **p, size_t bytes) {
+    if (!p) return fail(SDRT_EINVAL, "null argument");
+    HIP_TRY(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+    return SDRT_OK;
+}
+int sdrt_host_free(void *p) {
+    HIP_TRY(hipHostFree(p));
+    return SDRT_OK;
+}
+int sdrt_memcpy_h2d_async(void *d, const void *s, size_t b, void *stream) {
+    HIP_TRY(hipMemcpyAsync(d, s, b, hipMemcpyHostToDevice, (hipStream_t) stream));
+    return SDRT_OK;
+}
+int sdrt_memcpy_d2h_async(void *d, const void *s, size_t b, void *stream) {
+    HIP_TRY(hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, (hipStream_t) stream));
+    return SDRT_OK;
+}
+int sdrt_stream_wait_stream(void *waiter, void *signaller) {
+    hipEvent_t e = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipError_t r = hipEventRecord(e, (hipStream_t) signaller);
+    if (r == hipSuccess) r = hipStreamWaitEvent((hipStream_t) waiter, e, 0);
+    (void) hipEventDestroy(e);          // released once the recorded work has completed
+    if (r != hipSuccess) return fail(SDRT_EHIP, "stream dependency failed: %s", hipGetErrorString(r));
+    return SDRT_OK;
+}
+
 int sdrt_demodulate_host(int mode, const double *y_host, int rows, int m, double *out_host) {
     if (!y_host || !out_host || rows < 1 || m < 1 || mode < 0 || mode > 3) return fail(SDRT_EINVAL, "bad argument");
     if (mode == 0 && (m & 1)) return fail(SDRT_EINVAL, "FM needs an even number of samples per row");
@@ -839,29 +889,7 @@ int sdrt_debug_stamps(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double 
 int sdrt_stage_a_kind(const sdrt_ctx *c) { return c ? (c->use_i8w ? 3 : (c->use_i8t ? 2 : (c->use_i8 ? 1 : 0))) : -1; }
 
 int sdrt_selftest_mfma_i8(int *mismatches) {
-    int A[1024], B[1024], D[1024], *dA = nullptr, *dB = nullptr, *dD = nullptr;
-    for (int i = 0; i < 32; ++i)
-        for (int k = 0; k < 32; ++k) {
-            A[i * 32 + k] = ((i * 7 + k * 3) % 23) - 11;          // asymmetric small integers, both signs
-            B[k * 32 + i] = ((k * 5 - i * 2 + 64) % 19) - 9;
-        }
-    HIP_TRY(hipMalloc((void **) &dA, sizeof(A)));
-    HIP_TRY(hipMalloc((void **) &dB, sizeof(B)));
-    HIP_TRY(hipMalloc((void **) &dD, sizeof(D)));
-    HIP_TRY(hipMemcpy(dA, A, sizeof(A), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dB, B, sizeof(B), hipMemcpyHostToDevice));
-    HIP_TRY(launch_i8_selftest(dA, dB, dD, nullptr));
-    HIP_TRY(hipMemcpy(D, dD, sizeof(D), hipMemcpyDeviceToHost));
-    (void) hipFree(dA);
-    (void) hipFree(dB);
-    (void) hipFree(dD);
     int bad = 0;
-    for (int i = 0; i < 32; ++i)
-        for (int j = 0; j < 32; ++j) {
-            int ref = 0;
-            for (int k = 0; k < 32; ++k) ref += A[i * 32 + k] * B[k * 32 + j];
-            if (ref != D[i * 32 + j]) ++bad;
-        }
     // 16x16x64 form
     {
         static int A2[16 * 64], B2[64 * 16], D2[256];

@@ -27,7 +27,7 @@ struct DecimArgs {
     const double *iq_chunk_off; // [chunk+1][2]     true offset at the start of every chunk
     const double *iq_pow;       // [n/GS + 1]       (1-lambda)^(GS*k)
     double iq_lambda;
-    // int8-sliced stage A (kernels_i8.hip) only:
+    // int8-sliced stage A (kernels_i8t.hip, kernels_i8w.hip) only:
     const signed char *w8;      // [rows][S][LC/16][64][16] main digit planes in MFMA A-operand order (LC = G*L)
     const signed char *w8mid;   // [rows][S][LC/16][2][NR][16] mid-boundary digit planes (G > 1)
     double w8mid_combine;
@@ -80,16 +80,13 @@ struct SmoothArgs {
     const double *taps, *left, *right;
 };
 hipError_t launch_smooth(const SmoothArgs &a, hipStream_t s);
+int smooth_waves_per_block(int m);                // 0: one item does not fit LDS
 size_t post_lds_bytes(int m, int mode);
+int post_waves_per_block(int m, int mode);       // 0: the post stage cannot hold one item in LDS
 hipError_t launch_post(const PostArgs &a, hipStream_t s);
 hipError_t launch_chain(const DecimArgs &a, int L, int dt, bool nco, bool iq, size_t n_chunks, hipStream_t s);
 #define SDRT_I8_DIGITS 5
-#define SDRT_I8_G 1             // blocks per matrix-core column in the 32x32x32 int8 kernel (diagnostic variant)
 #define SDRT_I8T_G 1            // blocks per matrix-core column in the 16x16x64 int8 kernel (the default path)
-bool chain_i8_supported(int L, int dt, int n);
-size_t chain_i8_lds_bytes(int n, int L, int m);
-hipError_t launch_chain_i8(const DecimArgs &a, int L, int dt, bool nco, size_t n_chunks, hipStream_t s);
-hipError_t launch_i8_selftest(const int *A, const int *B, int *D, hipStream_t s);
 hipError_t launch_mfma_selftest(const double *A, const double *B, double *D, hipStream_t s);
 hipError_t launch_demod(const double *y, double *out, const double *resample_odd, int rows, int m, int mode, hipStream_t s);
 bool chain_i8t_supported(int L, int dt, int n);

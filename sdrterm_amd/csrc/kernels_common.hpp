@@ -5,7 +5,6 @@
 //   kernels_i8w.hip   chain_i8w_kernel   unpack .. decimate on the int8 matrix cores, 256-sample columns, persistent and
 //                                        software-pipelined (the default for 8/16-bit integer input, q = 32 / 64)
 //   kernels_i8t.hip   chain_i8t_kernel   the same arithmetic with one block of <= 64 samples per column (other q / chunk sizes)
-//   kernels_i8.hip    chain_i8_kernel    ... on v_mfma_i32_32x32x32_i8 (diagnostic)
 //   kernels.hip       chain_kernel       stage A on the f64 matrix cores (float / 32-bit input, IQ correction off the wide path),
 //                                        IQ prefix kernels, stand-alone discriminators
 //   kernels_post.hip  post_fft_kernel / post_kernel / smooth_kernel   FM/AM discriminator, resampler, output lowpass, --smooth-output

@@ -2,7 +2,7 @@
 // Same lane mapping, scans and tail as the f64 kernel (kernels.hip): lane (g, nb) = (sample quarter / mode, block of
 // the tile).  Only the stage-A product differs: the lane's L/4 samples are split into int8 slices (x = 256 hi + lo' +
 // offset) and multiplied with S signed base-256 digit planes of the weights (NCO phasor folded in) -- exact int32
-// accumulation, one fp64 recombination per output (see kernels_i8.hip for the scheme).
+// accumulation, one fp64 recombination per output.
 #include "kernels_common.hpp"
 
 typedef int v4i __attribute__((ext_vector_type(4)));

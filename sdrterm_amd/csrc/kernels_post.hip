@@ -111,6 +111,7 @@ __device__ __forceinline__ void modal_lowpass_wave(const OutTables *__restrict__
     if (ot->nmodes == 2 && ot->ncomplex == 1) {
         if (m == 512) { modal_lowpass_c1r1<8>(ot, zb, out, lane); return; }
         if (m == 1024) { modal_lowpass_c1r1<16>(ot, zb, out, lane); return; }
+        if (m == 2048) { modal_lowpass_c1r1<32>(ot, zb, out, lane); return; }
     }
     switch (ot->nmodes) {
         case 0: modal_lowpass_body<0>(ot, zb, out, m, lane); break;
@@ -121,9 +122,10 @@ __device__ __forceinline__ void modal_lowpass_wave(const OutTables *__restrict__
     }
 }
 
+// blockDim.x / 64 items per workgroup (launch_post picks as many waves as fit LDS)
 __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int m = a.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = a.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wpb = blockDim.x >> 6;
     const bool fm = a.mode == SDRT_FM;
     const int N = m >> 1;
     double *hr = (double *) smem;                              // [N] (FM): hr[i] = h[(-i) mod N]
@@ -131,10 +133,10 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
     double *av = wbase;                                        // [N] pair angles (FM)
     double *zb = wbase + (fm ? N : 0);                         // [m] demodulated samples at the decimated rate
     if (fm) {
-        for (int i = tid; i < N; i += 256) hr[i] = a.resample_odd[i == 0 ? 0 : N - i];
+        for (int i = tid; i < N; i += blockDim.x) hr[i] = a.resample_odd[i == 0 ? 0 : N - i];
         __syncthreads();
     }
-    const size_t item = (size_t) blockIdx.x * 4 + wave;
+    const size_t item = (size_t) blockIdx.x * wpb + wave;
     if (item >= a.items) return;
     const cd *y = (const cd *) a.y + item * (size_t) m;
 
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
             case 4: resample_wave<4>(av, hr, zb, N, lane); break;
             case 8: resample_wave<8>(av, hr, zb, N, lane); break;
             case 16: resample_wave<16>(av, hr, zb, N, lane); break;
+            case 32: resample_wave<32>(av, hr, zb, N, lane); break;
             default:
                 for (int j = lane; j < N; j += 64) {
                     double s0 = 0.0;
@@ -236,7 +239,8 @@ __device__ __forceinline__ void radix4_pass(cd (&x)[B][4], const cd *tw, const i
 template <int B, bool INV, class Load, class Store>
 __device__ __forceinline__ void fft_wave(cd (&x)[B][4], cd *X, const cd *tw, const int lane, Load load_first, Store store_last) {
     constexpr int N = 256 * B;
-    constexpr bool R2 = (B == 2);                    // 512 = 2 * 4^4: a final radix-2 pass
+    constexpr bool R2 = (B == 2 || B == 8);          // 512 = 2 * 4^4, 2048 = 2 * 4^5: a final radix-2 pass
+    static_assert(B == 1 || B == 2 || B == 4 || B == 8, "N = 256, 512, 1024 or 2048");
     auto ldX = [&]() {
 #pragma unroll
         for (int b = 0; b < B; ++b)
@@ -258,6 +262,10 @@ __device__ __forceinline__ void fft_wave(cd (&x)[B][4], cd *X, const cd *tw, con
         if constexpr (B == 4) {
             ldX();
             radix4_pass<B, 256, INV>(x, tw, lane, store_last);
+        }
+        if constexpr (B == 8) {
+            ldX();
+            radix4_pass<B, 256, INV>(x, tw, lane, stX);
         }
         if constexpr (R2) {
             // n = 2, s = N/2: y[q] = a + b, y[q + N/2] = a - b for q < N/2; 2B items per lane
@@ -349,9 +357,19 @@ static hipError_t launch_post_fft(const PostArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-size_t post_lds_bytes(int m, int mode) {
+static size_t post_lds_bytes_w(int m, int mode, int wpb) {
     const size_t N = (size_t) m / 2, zl = (size_t) m + (size_t) (m >> 3) + 1;
-    return (mode == SDRT_FM ? N + 4 * (zl + N) : 4 * zl) * sizeof(double);
+    return (mode == SDRT_FM ? N + wpb * (zl + N) : wpb * zl) * sizeof(double);
+}
+// waves (= items) per workgroup of post_kernel: as many of 4, 2, 1 as fit the 160 KiB of LDS; 0: not even one
+int post_waves_per_block(int m, int mode) {
+    for (int w = 4; w >= 1; w >>= 1)
+        if (post_lds_bytes_w(m, mode, w) <= 160 * 1024) return w;
+    return 0;
+}
+size_t post_lds_bytes(int m, int mode) {
+    const int w = post_waves_per_block(m, mode);
+    return post_lds_bytes_w(m, mode, w ? w : 1);
 }
 
 hipError_t launch_post(const PostArgs &a, hipStream_t s) {
@@ -361,14 +379,17 @@ hipError_t launch_post(const PostArgs &a, hipStream_t s) {
             case 512: return launch_post_fft<1, 4>(a, s);
             case 1024: return launch_post_fft<2, 4>(a, s);
             case 2048: return launch_post_fft<4, 2>(a, s);
+            case 4096: return launch_post_fft<8, 1>(a, s);
         }
     }
-    const size_t lds = post_lds_bytes(a.m, a.mode);
+    const int wpb = post_waves_per_block(a.m, a.mode);
+    if (wpb == 0) return hipErrorInvalidValue;                      // sdrt_create refuses such a configuration
+    const size_t lds = post_lds_bytes_w(a.m, a.mode, wpb);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *) post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(post_kernel, dim3((unsigned) ((a.items + 3) / 4)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(post_kernel, dim3((unsigned) ((a.items + wpb - 1) / wpb)), dim3(64 * wpb), lds, s, a);
     return hipGetLastError();
 }
 
@@ -377,7 +398,7 @@ __global__ __launch_bounds__(256) void smooth_kernel(SmoothArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int m = a.m, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *z = (double *) smem + (size_t) wave * m;
-    const size_t item = (size_t) blockIdx.x * 4 + wave;
+    const size_t item = (size_t) blockIdx.x * (blockDim.x >> 6) + wave;
     if (item >= a.items) return;
     double *out = a.out + item * (size_t) m;
     for (int i = lane; i < m; i += 64) z[i] = out[i];
@@ -399,12 +420,20 @@ __global__ __launch_bounds__(256) void smooth_kernel(SmoothArgs a) {
     }
 }
 
+int smooth_waves_per_block(int m) {
+    for (int w = 4; w >= 1; w >>= 1)
+        if ((size_t) w * m * sizeof(double) <= 160 * 1024) return w;
+    return 0;
+}
+
 hipError_t launch_smooth(const SmoothArgs &a, hipStream_t s) {
-    const size_t lds = (size_t) 4 * a.m * sizeof(double);
+    const int wpb = smooth_waves_per_block(a.m);
+    if (wpb == 0) return hipErrorInvalidValue;                      // sdrt_set_smoothing refuses such a configuration
+    const size_t lds = (size_t) wpb * a.m * sizeof(double);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *) smooth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(smooth_kernel, dim3((unsigned) ((a.items + 3) / 4)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(smooth_kernel, dim3((unsigned) ((a.items + wpb - 1) / wpb)), dim3(64 * wpb), lds, s, a);
     return hipGetLastError();
 }

@@ -374,80 +374,6 @@ double quantise_planes(const double *W, int rows, int cols, int ld, int S, Emit 
 
 }  // namespace
 
-extern "C" int sdrt_build_i8_weights(const double *sos, int sections, const DecimTables *tab, double data_scale,
-                                     const double *nco_samp, int S, signed char *main_out, double *main_combine,
-                                     signed char *mid_out, double *mid_combine) {
-    Modal m;
-    const char *err = nullptr;
-    if (!build_modal(sos, sections, m, &err)) return -2;
-    const int L = tab->L, G = tab->G, LC = L * G, cols = 2 * LC, KS = LC / 16;
-    std::vector<double> Wf((size_t) 32 * cols, 0.0);
-    C P[4], ac[4], aa[4];
-    C sum_a_over_p(0);
-    for (int i = 0; i < 8; ++i) sum_a_over_p = sum_a_over_p + m.alpha[i] / m.p[i];
-    const double d0p = (double) (m.d0 - sum_a_over_p.re) * data_scale;
-    for (int i = 0; i < 4; ++i) { P[i] = m.p[2 * i]; ac[i] = m.alpha[2 * i]; aa[i] = m.alpha[2 * i] / P[i]; }
-    auto tr = [&](int t) { return nco_samp ? nco_samp[2 * t] : 1.0; };
-    auto ti = [&](int t) { return nco_samp ? nco_samp[2 * t + 1] : 0.0; };
-    // main rows: column aggregates.  causal: alpha p^(LC-1-t), anticausal: (alpha/p) p^t  (scaled with the data)
-    for (int mode = 0; mode < 4; ++mode)
-        for (int kind = 0; kind < 2; ++kind)
-            for (int t = 0; t < LC; ++t) {
-                const C w = kind == 0 ? ac[mode] * cpow(P[mode], LC - 1 - t) : aa[mode] * cpow(P[mode], t);
-                const double wr = (double) w.re * data_scale, wi = (double) w.im * data_scale;
-                // u = x e^{i theta t}: u_re = xr tr - xi ti, u_im = xr ti + xi tr; state(stream) = sum_t w[t] u_stream[t]
-                const double cxr[2][2] = {{wr * tr(t), wi * tr(t)}, {wr * ti(t), wi * ti(t)}};      // [stream][part], coefficient of xr
-                const double cxi[2][2] = {{-wr * ti(t), -wi * ti(t)}, {wr * tr(t), wi * tr(t)}};    // coefficient of xi
-                for (int stream = 0; stream < 2; ++stream)
-                    for (int part = 0; part < 2; ++part) {
-                        const int r = part + 2 * stream + 4 * (mode >> 1) + 8 * (kind + 2 * (mode & 1));
-                        Wf[(size_t) r * cols + 2 * t] = cxr[stream][part];
-                        Wf[(size_t) r * cols + 2 * t + 1] = cxi[stream][part];
-                    }
-            }
-    auto col_pos = [&](int c, int &ks, int &h, int &j) {
-        const int sample = c >> 1, comp = c & 1;
-        h = sample / (LC / 2);
-        const int within = sample % (LC / 2);
-        ks = within / 8;
-        j = 2 * (within % 8) + comp;
-    };
-    *main_combine = quantise_planes(Wf.data(), 32, cols, cols, S, [&](int d, int r, int c, signed char dig) {
-        int ks, h, j;
-        col_pos(c, ks, h, j);
-        main_out[((((size_t) d * KS + ks) * 64) + (r + 32 * h)) * 16 + j] = dig;
-    });
-    if (*main_combine == 0.0) return -1;
-    if (G > 1) {
-        // mid rows: output at the start of block g of the column, column-local part:
-        //   d0' u[L g] + sum_i 2 Re( alpha_i sum_{t < L g} p_i^(L g - 1 - t) u[t] + (alpha_i/p_i) sum_{t >= L g} p_i^(t - L g) u[t] )
-        const int NR = 2 * (G - 1);
-        std::vector<double> Wm((size_t) NR * cols, 0.0);
-        for (int g = 1; g < G; ++g)
-            for (int t = 0; t < LC; ++t) {
-                R acc = 0;
-                for (int i = 0; i < 4; ++i) {
-                    const C w = t < L * g ? ac[i] * cpow(P[i], L * g - 1 - t) : aa[i] * cpow(P[i], t - L * g);
-                    acc = acc + 2 * w.re;
-                }
-                double mt = (double) acc * data_scale;
-                if (t == L * g) mt += d0p;
-                // stream re: mt (xr tr - xi ti);  stream im: mt (xr ti + xi tr)
-                Wm[(size_t) (0 + 2 * (g - 1)) * cols + 2 * t] = mt * tr(t);
-                Wm[(size_t) (0 + 2 * (g - 1)) * cols + 2 * t + 1] = -mt * ti(t);
-                Wm[(size_t) (1 + 2 * (g - 1)) * cols + 2 * t] = mt * ti(t);
-                Wm[(size_t) (1 + 2 * (g - 1)) * cols + 2 * t + 1] = mt * tr(t);
-            }
-        *mid_combine = quantise_planes(Wm.data(), NR, cols, cols, S, [&](int d, int r, int c, signed char dig) {
-            int ks, h, j;
-            col_pos(c, ks, h, j);
-            mid_out[(((((size_t) d * KS + ks) * 2 + h) * NR) + r) * 16 + j] = dig;
-        });
-        if (*mid_combine == 0.0) return -1;
-    }
-    return 0;
-}
-
 extern "C" int sdrt_build_i8_weights16(const double *sos, int sections, const DecimTables *tab, double data_scale,
                                        const double *nco_samp, int S, signed char *out, double *combine,
                                        signed char *mid_out, double *mid_combine) {

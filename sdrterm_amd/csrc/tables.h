@@ -91,21 +91,6 @@ void sdrt_build_resample_odd(int N, double *h /*[N]*/);
 // IDFT(DFT(a) * shift) without further scaling, the even ones are a itself.
 void sdrt_build_fft_resample(int N, double *tw /*[N][2]*/, double *shift /*[N][2]*/);
 
-// Stage-A weights for the int8 matrix-core path.  A column is LC = G*L samples.  Main matrix: the 16 complex-mode rows
-// (column aggregates) with the within-column NCO phasor folded in, as a real 32 x 2LC matrix (rows: part + 2*stream +
-// 4*(mode>>1) + 8*(kind + 2*(mode&1)); columns: (sample, re/im)).  Mid matrix (G > 1): for every internal block boundary
-// g = 1..G-1 and stream one real row, the part of that boundary's output that depends on this column only (row
-// stream + 2*(g-1)).  Both are quantised to S signed base-256 digits against one power-of-two scale each.
-// Layouts (MFMA A-operand order, KS = LC/16 k-steps):
-//   main[((digit*KS + kstep)*64 + lane)*16 + j],  lane = row + 32*h,  column = sample h*LC/2 + 8*kstep + (j>>1), comp j&1
-//   mid [(((digit*KS + kstep)*2 + h)*NR + row)*16 + j],  NR = 2*(G-1)
-// *combine = scale * 2^-(8S-1): value = combine * sum_d 256^d * (integer dot product of digit d).
-// `tab` must have been built with the same G.  nco_samp: [LC][2] within-column phasors, or NULL (no shift).
-// Returns 0, or -1 if a digit overflowed.
-int sdrt_build_i8_weights(const double *sos, int sections, const struct DecimTables *tab, double data_scale,
-                          const double *nco_samp, int S, signed char *main_out, double *main_combine,
-                          signed char *mid_out, double *mid_combine);
-
 // Digit planes for the 16x16x64 int8 matrix-core kernel (chain_i8t_kernel).  A column is LC = G*L samples.  Two row tiles
 // of 16 rows: tile 0 = causal, tile 1 = anticausal aggregates of the column; row = 4*mode + 2*stream + part.  For G > 1 a
 // third, compact tile holds per internal block boundary g and stream the column-local part of that boundary's output

@@ -116,7 +116,7 @@ class Engine:
         self._ctx = C.c_void_p()
         nat.check(nat.lib().sdrt_create(C.byref(cfg), C.byref(self._ctx)))
         self.m = nat.lib().sdrt_out_per_chunk(self._ctx)
-        self.stage_a = {0: 'f64', 1: 'i8x32', 2: 'i8t', 3: 'i8w'}[nat.lib().sdrt_stage_a_kind(self._ctx)]   # which stage-A kernel runs
+        self.stage_a = {0: 'f64', 2: 'i8t', 3: 'i8w'}[nat.lib().sdrt_stage_a_kind(self._ctx)]   # which stage-A kernel runs
         self.chunk_bytes = self.n * 2 * nat.ITEM_SIZE[code]
         self.smooth = int(smooth) if smooth else 0
         if smooth:
@@ -133,12 +133,15 @@ class Engine:
             if buf.size % self.chunk_bytes:
                 raise ValueError(f'input is not a whole number of {self.chunk_bytes}-byte chunks')
             n_chunks = buf.size // self.chunk_bytes
+        elif buf.size < n_chunks * self.chunk_bytes:
+            raise ValueError(f'{n_chunks} chunks need {n_chunks * self.chunk_bytes} bytes, got {buf.size}')
         out = np.empty((self.rows, n_chunks * self.m), dtype=np.float64)
         nat.check(nat.lib().sdrt_process_host(self._ctx, buf.ctypes.data, n_chunks, out.ctypes.data))
         return out
 
     def process_device(self, raw_ptr: int, n_chunks: int, out_ptr: int, stream: int = 0, ydec_ptr: int = 0):
-        """Device pointers in/out, asynchronous on ``stream`` (hipStream_t handle, 0 = default)."""
+        """Device pointers in/out, asynchronous on ``stream`` (hipStream_t handle, 0 = default).  One stream per context:
+        the decimated samples and the IQ prefix tables of a call live in per-context scratch buffers."""
         if ydec_ptr:
             nat.check(nat.lib().sdrt_process_device_debug(self._ctx, raw_ptr, n_chunks, out_ptr, ydec_ptr, stream or None))
         else:
@@ -150,6 +153,8 @@ class Engine:
             np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
         if n_chunks is None:
             n_chunks = buf.size // self.chunk_bytes
+        elif buf.size < n_chunks * self.chunk_bytes:
+            raise ValueError(f'{n_chunks} chunks need {n_chunks * self.chunk_bytes} bytes, got {buf.size}')
         d_raw = nat.DeviceBuffer(n_chunks * self.chunk_bytes).upload(buf[:n_chunks * self.chunk_bytes])
         d_out = nat.DeviceBuffer(self.rows * n_chunks * self.m * 8)
         d_y = nat.DeviceBuffer(self.rows * n_chunks * self.m * 16)

@@ -1,15 +1,29 @@
-"""Multi-GPU partitioning of the hot path: one process per GPU, no data-path reduction.
+"""Multi-GPU operation of the hot path: one process per GPU, no reduction anywhere.
 
-* single VFO: chunks are independent (dsp_processor.py:140-149 keeps no state between them), so a stream of
-  chunks is split into contiguous ranges, one per rank, with no collective at all;
-* ``--simo``: rows (VFO channels) are independent given the raw block, so rows are split contiguously across
-  ranks and the raw IQ block is broadcast from the rank that holds it (the only collective; RCCL over xGMI when
-  the process group's backend is "nccl", gloo in the CPU tests).
+* single VFO: chunks are independent (dsp_processor.py:140-149 keeps no state between them), so a stream of chunks is
+  split into contiguous ranges, one per rank, with no collective at all (``shard_chunks``; bench.py's default workload);
+* ``--simo``: rows (VFO channels) are independent given the raw block (vfo_processor.py:80-84), so the rows are split
+  contiguously across the ranks (``shard_rows``) and the rank that owns the reader's Queue hands every raw block to the
+  others -- the only exchange on the path.  ``BlockChannel`` is that exchange: a fixed-size header (chunks in the block,
+  end-of-stream flag) followed by the block's bytes, over one of two transports:
 
-These helpers are pure index arithmetic plus one ``torch.distributed.broadcast``; torch is imported lazily so the
-single-GPU product path (ctypes only) never needs it.
+    ``RcclTransport``   device buffers, RCCL broadcast over xGMI through the C ABI (``sdrt_comm_*``, include/sdrterm_hip.h);
+                        the 128-byte unique id travels over a TCP socket at MASTER_ADDR:MASTER_PORT
+    ``TorchTransport``  a ``torch.distributed`` process group the caller initialised ("nccl" is RCCL on ROCm; "gloo" on
+                        CPU is what the tests use); torch is imported lazily, the single-GPU product path never needs it
+
+``SimoShard`` is what ``VfoProcessor`` uses: which rows this rank serves, which TCP port, and the channel.
 """
-from typing import List, Tuple
+import ctypes as C
+import os
+import socket
+import struct
+import time
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+HEADER = struct.Struct('<qq')        # chunks in the block, end-of-stream flag
 
 
 def split_range(total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -31,13 +45,187 @@ def shard_chunks(n_chunks: int, world: int, rank: int) -> Tuple[int, int]:
     return split_range(n_chunks, world, rank)
 
 
-def broadcast_block(tensor, src: int = 0, group=None):
-    """Broadcast the raw IQ block (a uint8/int16 tensor, device or host) from ``src`` to every rank, in place."""
-    import torch
-    import torch.distributed as dist
-    # the block is opaque bytes to the collective: a uint8 view works for every backend (gloo has no int16)
-    dist.broadcast(tensor.contiguous().view(torch.uint8) if tensor.dtype != torch.uint8 else tensor, src=src, group=group)
-    return tensor
+def env_rank_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world) as torch.distributed.run and ``spawn_ranks`` export them; (0, 0, 1) when unset."""
+    return (int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0'))),
+            int(os.environ.get('WORLD_SIZE', '1')))
+
+
+# ---- transports ------------------------------------------------------------------------------------------------------
+class TorchTransport:
+    """Broadcast through an initialised ``torch.distributed`` group.  Blocks are host (gloo) or device (nccl) uint8 tensors."""
+
+    def __init__(self, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised')
+        self._torch, self._dist, self._group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.device = device if device is not None else torch.device('cpu')
+        self.on_device = self.device.type != 'cpu'
+
+    def bcast_bytes(self, data: Optional[bytes], nbytes: int, root: int = 0) -> bytes:
+        t = self._torch.empty(nbytes, dtype=self._torch.uint8, device=self.device)
+        if self.rank == root:
+            t.copy_(self._torch.frombuffer(bytearray(data), dtype=self._torch.uint8))
+        self._dist.broadcast(t, src=root, group=self._group)
+        return t.cpu().numpy().tobytes()
+
+    def bcast_block(self, data: Optional[bytes], nbytes: int, root: int = 0):
+        """('host', bytes): the block as every rank's engine takes it from host memory."""
+        return 'host', self.bcast_bytes(data, nbytes, root)
+
+    def close(self):
+        pass
+
+
+class RcclTransport:
+    """RCCL broadcast between device buffers through the C ABI; no torch.  ``uid``: the 128-byte id (rank 0 creates it with
+    ``RcclTransport.unique_id()`` and the launcher passes it on), or None to exchange it over TCP at MASTER_ADDR:MASTER_PORT."""
+
+    on_device = True
+
+    def __init__(self, rank: int, world: int, device: int, uid: Optional[bytes] = None):
+        from . import _native as nat
+        self._nat = nat
+        self.rank, self.world, self.device_index = rank, world, device
+        if uid is None:
+            uid = self._exchange_uid(rank, world)
+        self._comm = C.c_void_p()
+        buf = C.create_string_buffer(uid, 128)
+        nat.check(nat.lib().sdrt_comm_init(buf, world, rank, device, C.byref(self._comm)))
+        self._stage = None          # device staging buffer for bcast_bytes
+        self._stage_cap = 0
+        self._block = None          # device buffer of bcast_block
+        self._block_cap = 0
+
+    @staticmethod
+    def unique_id() -> bytes:
+        from . import _native as nat
+        buf = C.create_string_buffer(128)
+        nat.check(nat.lib().sdrt_comm_unique_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def _exchange_uid(rank: int, world: int) -> bytes:
+        addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+        port = int(os.environ.get('SDRTERM_UID_PORT', int(os.environ.get('MASTER_PORT', '29500')) + 17))
+        if rank == 0:
+            uid = RcclTransport.unique_id()
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind((addr, port))
+                srv.listen(world)
+                for _ in range(world - 1):
+                    conn, _peer = srv.accept()
+                    with conn:
+                        conn.sendall(uid)
+            return uid
+        deadline = time.time() + 120
+        while True:
+            try:
+                with socket.create_connection((addr, port), timeout=5) as s:
+                    uid = b''
+                    while len(uid) < 128:
+                        part = s.recv(128 - len(uid))
+                        if not part:
+                            raise ConnectionError('short unique id')
+                        uid += part
+                    return uid
+            except OSError:
+                if time.time() > deadline:
+                    raise
+                time.sleep(0.1)
+
+    def bcast_device(self, dev_ptr: int, nbytes: int, root: int = 0, stream: int = 0) -> None:
+        """In place on device memory, asynchronous on ``stream``."""
+        self._nat.check(self._nat.lib().sdrt_comm_bcast(self._comm, dev_ptr, nbytes, root, stream or None))
+
+    def allgather_device(self, send_ptr: int, recv_ptr: int, bytes_per_rank: int, stream: int = 0) -> None:
+        self._nat.check(self._nat.lib().sdrt_comm_allgather(self._comm, send_ptr, recv_ptr, bytes_per_rank, stream or None))
+
+    def bcast_bytes(self, data: Optional[bytes], nbytes: int, root: int = 0) -> bytes:
+        """Small host messages (the block header) through a device staging buffer."""
+        nat = self._nat
+        if nbytes > self._stage_cap:
+            if self._stage is not None:
+                self._stage.free()
+            self._stage, self._stage_cap = nat.DeviceBuffer(max(nbytes, 4096)), max(nbytes, 4096)
+        if self.rank == root:
+            self._stage.upload(np.frombuffer(data, dtype=np.uint8))
+        self.bcast_device(self._stage.ptr, nbytes, root)
+        nat.check(nat.lib().sdrt_device_synchronize())
+        return self._stage.download(np.empty(nbytes, dtype=np.uint8)).tobytes()
+
+    def bcast_block(self, data: Optional[bytes], nbytes: int, root: int = 0):
+        """('dev', pointer): the block stays in device memory on every rank (one upload on the root, RCCL broadcast,
+        sdrt_process_device on the spot).  The buffer is reused by the next call: consume the block first."""
+        nat = self._nat
+        if nbytes > self._block_cap:
+            if self._block is not None:
+                self._block.free()
+            self._block, self._block_cap = nat.DeviceBuffer(nbytes), nbytes
+        if self.rank == root:
+            self._block.upload(np.frombuffer(data, dtype=np.uint8))
+        self.bcast_device(self._block.ptr, nbytes, root)
+        nat.check(nat.lib().sdrt_device_synchronize())
+        return 'dev', self._block.ptr
+
+    def close(self):
+        if self._block is not None:
+            self._block.free()
+            self._block = None
+        if getattr(self, '_comm', None) is not None and self._comm.value:
+            self._nat.lib().sdrt_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+        if self._stage is not None:
+            self._stage.free()
+            self._stage = None
+
+
+class Block:
+    """One exchanged block: ``n`` chunks either in host memory (``host``: bytes) or in device memory (``dev_ptr``)."""
+    __slots__ = ('n', 'eof', 'host', 'dev_ptr', 'size')
+
+    def __init__(self, n, eof, host=None, dev_ptr=0, size=0):
+        self.n, self.eof, self.host, self.dev_ptr, self.size = n, eof, host, dev_ptr, size
+
+
+class BlockChannel:
+    """The reader-side rank sends (chunks in the block, end-of-stream flag, block bytes); ``exchange`` returns the same
+    ``Block`` on every rank."""
+
+    def __init__(self, transport, chunk_bytes: int, root: int = 0):
+        self.t, self.chunk_bytes, self.root = transport, chunk_bytes, root
+
+    def exchange(self, block: Optional[bytes], n_chunks: int = 0, eof: bool = False) -> Block:
+        hdr = HEADER.pack(n_chunks, int(eof)) if self.t.rank == self.root else None
+        n_chunks, eof = HEADER.unpack(self.t.bcast_bytes(hdr, HEADER.size, self.root))
+        out = Block(int(n_chunks), bool(eof))
+        if n_chunks:
+            where, what = self.t.bcast_block(block, n_chunks * self.chunk_bytes, self.root)
+            if where == 'dev':
+                out.dev_ptr = what
+            else:
+                out.host = what
+        return out
+
+
+class SimoShard:
+    """This rank's share of a --simo processor: rows [lo, hi) of the reference's row order (vfo_processor.py:43-47), served
+    on TCP port ``base_port + rank`` -- client k of that port receives row lo + k."""
+
+    def __init__(self, n_rows: int, rank: int, world: int):
+        self.rank, self.world = rank, world
+        self.lo, self.hi = split_range(n_rows, world, rank)
+
+    @property
+    def rows(self) -> int:
+        return self.hi - self.lo
+
+    def port(self, base_port: int) -> int:
+        return base_port + self.rank
 
 
 def max_over_ranks(value: float, device=None) -> float:

@@ -29,11 +29,11 @@ def test_mfma_layout_selftest():
     assert bad.value == 0
 
 
-@pytest.fixture(params=['auto', 'f64', 'i8x32', 'i8t'])
+@pytest.fixture(params=['auto', 'f64', 'i8t'])
 def stage_a(request, monkeypatch):
     """Every golden case runs with the kernel the library picks (int8 matrix cores: wide-column persistent kernel where it
     applies, else the one-block-per-column 16x16x64 form, for 8/16-bit integer encodings), with the fp64 matrix-core kernel
-    forced, and with the 32x32x32 and one-block 16x16x64 int8 forms forced."""
+    forced, and with the one-block 16x16x64 int8 form forced."""
     if request.param == 'auto':
         monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
     else:

@@ -116,7 +116,7 @@ def test_shared_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(lib, n), f'{n} declared in the header but not exported'
     assert set(_native.EXPORTS) <= names
-    assert _native.lib().sdrt_abi_version() == _native.ABI_VERSION == 2
+    assert _native.lib().sdrt_abi_version() == _native.ABI_VERSION == 3
     assert ctypes.sizeof(_native.Config) == _native.lib().sdrt_config_size()
 
 
@@ -150,8 +150,13 @@ def _gloo_worker(rank, world, port, q):
     rows = [float(100 * i) for i in range(9)]
     mine, (lo, hi) = parallel.shard_rows(rows, world, rank)
     c0, c1 = parallel.shard_chunks(37, world, rank)
-    block = torch.arange(4096, dtype=torch.int16) * (1 if rank == 0 else 0)     # only rank 0 holds the IQ block
-    parallel.broadcast_block(block, src=0)
+    # only rank 0 holds the IQ block; the channel hands every rank the same (chunks, eof, bytes)
+    ch = parallel.BlockChannel(parallel.TorchTransport(), chunk_bytes=2048)
+    src = torch.arange(4096, dtype=torch.int16).numpy().tobytes() if rank == 0 else None
+    blk = ch.exchange(src, 4, False)
+    end = ch.exchange(b'' if rank == 0 else None, 0, True)
+    assert (blk.n, blk.eof, end.n, end.eof) == (4, False, 0, True)
+    block = torch.frombuffer(bytearray(blk.host), dtype=torch.int16)
     gathered = [None] * world
     dist.all_gather_object(gathered, {'rows': (lo, hi), 'chunks': (c0, c1), 'sum': int(block.sum())})
     slow = parallel.max_over_ranks(1.0 + rank)

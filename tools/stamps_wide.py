@@ -19,7 +19,8 @@ def main():
     for i in range(0, n_chunks, 64):
         nat.check(nat.lib().sdrt_memcpy_h2d(d_raw.ptr + i * eng.chunk_bytes, one.ctypes.data, min(64, n_chunks - i) * eng.chunk_bytes))
     d_out = nat.DeviceBuffer(n_chunks * eng.m * 8)
-    for _ in range(3):
+    warm = int(sys.argv[3]) if len(sys.argv) > 3 else 3      # e.g. 1800 launches of 2^30 samples = 2 s of load before the stamped launch
+    for _ in range(warm):
         eng.process_device(d_raw.ptr, n_chunks, d_out.ptr)
     nat.check(nat.lib().sdrt_device_synchronize())
     nw = 512                                   # stamp slots: 4 waves x 16 each -> 256 workgroups of 8 waves
