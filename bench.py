@@ -1,21 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the sdrterm DSP hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload fm64|simo64]
 
-Workload (BASELINE.json configs[1]): 256 MS/s synthetic int16 IQ, FM demodulation, decimation 64, one VFO,
-processed in the reference's 131072-byte chunks (32768 complex samples).  One "step" is one pass of the whole
-hot path (unpack -> NCO -> zero-phase decimator -> FM discriminator -> resample -> output lowpass) over a batch
-of chunks that is already resident in HBM.  With N > 1 each rank owns its own batch (chunks are independent,
-SURVEY.md section 8e): weak scaling, no data-path collective.
+fm64 (default; BASELINE.json configs[1]): 256 MS/s synthetic int16 IQ, FM demodulation, decimation 64, one VFO, processed in
+the reference's 131072-byte chunks (32768 complex samples).  One "step" is one pass of the whole hot path (unpack -> NCO
+-> zero-phase decimator -> FM discriminator -> resample -> output lowpass) over a batch of chunks that is already resident
+in HBM.  With N > 1 each rank owns its own batch (chunks are independent): weak scaling, no
+data-path collective.
 
-torch is used here only as plumbing (device buffers, synthetic data, torch.distributed barrier / max); the
-product path is the C ABI of libsdrterm_hip.so called through ctypes.
+simo64 (configs[3]): 64 VFO rows, decimation 32, FM; the rows are sharded contiguously over the ranks and every step's raw
+block is broadcast from rank 0 over RCCL (sdrt_comm_bcast, the only collective), block k+1 beside the kernels of block k.
+Total work is fixed: strong scaling; value = input samples per second.
+
+Launch: under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this file is one rank.  Started
+plainly with --gpus N > 1 it starts the N ranks itself as child processes -- before anything touches a GPU -- and relays rank
+0's line.
+
+Timing: W warm-up steps, then back-to-back steps until --settle-seconds have passed (the chip lowers its clock under this
+load; a cold start would flatter the number), then EXACTLY K timed steps between barriers, maximum over ranks; after that
+a --long-seconds run without per-kernel events gives the steady-state figure next to it ("steady_state").
+
+torch is plumbing here (device buffers, synthetic data, barrier / max over ranks); the product path is the C ABI of
+libsdrterm_hip.so called through ctypes.
 """
 import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -23,14 +36,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FS = 256_000_000
-Q = 64
 CENTER = 15_000
 OMEGA_OUT = 12_500
 N = 32768                      # complex samples per chunk for int16 (131072 B)
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_PEAK_TFLOPS = 78.6        # MI355X vector/matrix fp64 peak (spec)
-ALG_BYTES_PER_SAMPLE = 4.0 + 8.0 / Q      # int16 IQ in + float64 out every q samples
-FP64_FLOP_PER_SAMPLE = 64.0    # stage A: 16 real rows x 2 streams x 2 flop per input sample
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+I8_PEAK_POPS = 5.0             # dense int8 matrix peak, Pop/s (2 x bf16 per clock: MI355X_MICROARCH.md, Matrix cores)
+FP64_PEAK_TFLOPS = 78.6
+
+WORKLOADS = {
+    # name: (decimation, total rows, default chunks per step, scaling)
+    'fm64': (64, 1, 32768, 'weak'),
+    'simo64': (32, 64, 512, 'strong'),
+}
+
+
+def simo_rows(n_rows):
+    """Row frequencies as VfoProcessor lays them out (vfo_processor.py:43-47): csv offsets + center, then center last."""
+    step = 3_000_000
+    offs = [(i - (n_rows - 1) // 2) * step for i in range(n_rows - 1)]
+    offs = [o if o < 0 else o + step for o in offs]                       # none of the csv rows sits on the center itself
+    return [float(o + CENTER) for o in offs] + [float(CENTER)]
 
 
 def synth_iq_torch(n_samples, seed, device):
@@ -53,52 +78,84 @@ def synth_iq_torch(n_samples, seed, device):
     return out
 
 
-def cpu_baseline(raw_bytes, budget_s=12.0):
-    """The plain-C oracle (oracle/chain.c) timed on this host's cores on a bounded sample of the same workload."""
-    import numpy as np
+def cpu_baseline(raw_bytes, q, freqs, budget_s=10.0):
+    """The plain-C oracle (oracle/chain.c) timed on this host's cores on a bounded sample of the same workload: all cores
+    (OpenMP over chunks) and one core."""
     from oracle import c_chain, ref_chain
-    threads = min(c_chain.max_threads(), os.cpu_count() or 1)
-    shift = c_chain.shift_table([CENTER], FS, N)
-    dec, outs = ref_chain.cheby_sos(Q), ref_chain.ellip_sos(FS // Q, OMEGA_OUT)
+    shift = c_chain.shift_table(freqs, FS, N)
+    dec, outs = ref_chain.cheby_sos(q), ref_chain.ellip_sos(FS // q, OMEGA_OUT)
     chunk_b = N * 4
     avail = len(raw_bytes) // chunk_b
-    want = max(threads, (avail // threads) * threads)
-    # warm (thread pool, page faults), then a timed probe pass to size the bounded sample to ~budget_s of CPU work
-    c_chain.process_stream(raw_bytes[:want * chunk_b], 'h', N, Q, 'fm', shift, dec, outs, threads=threads)
-    t0 = time.perf_counter()
-    c_chain.process_stream(raw_bytes[:want * chunk_b], 'h', N, Q, 'fm', shift, dec, outs, threads=threads)
-    dt1 = max(time.perf_counter() - t0, 1e-6)
-    reps = max(1, min(200, int(round(budget_s / dt1))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        c_chain.process_stream(raw_bytes[:want * chunk_b], 'h', N, Q, 'fm', shift, dec, outs, threads=threads)
-    dt = time.perf_counter() - t0
-    return {'value': round(reps * want * N / dt / 1e6, 3), 'unit': 'MSamples/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{reps} pass(es) over {want} chunks x {N} samples of the same int16 FM stream, oracle/chain.c '
-                      f'(fp64 C port of the reference chain), {threads} OpenMP threads, {dt:.1f} s'}
+
+    def timed(threads, budget):
+        want = max(threads, min(avail, (avail // threads) * threads))
+        if threads == 1:
+            want = min(avail, 8)
+        run = lambda: c_chain.process_stream(raw_bytes[:want * chunk_b], 'h', N, q, 'fm', shift, dec, outs, threads=threads)
+        run()                                                   # warm (thread pool, page faults)
+        t0 = time.perf_counter()
+        run()
+        dt1 = max(time.perf_counter() - t0, 1e-6)
+        reps = max(1, min(200, int(round(budget / dt1))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run()
+        dt = time.perf_counter() - t0
+        return reps * want * N / dt / 1e6, reps, want, dt
+
+    threads = min(c_chain.max_threads(), os.cpu_count() or 1)
+    v_all, reps, want, dt = timed(threads, budget_s)
+    v_one, reps1, want1, dt1 = timed(1, budget_s / 2)
+    return {'value': round(v_all, 3), 'unit': 'MSamples/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{reps} pass(es) over {want} chunks x {N} samples of the same int16 stream ({len(freqs)} row(s), dec={q}), '
+                      f'oracle/chain.c (fp64 C port of the reference chain), {threads} OpenMP threads, {dt:.1f} s',
+            'single_core': {'value': round(v_one, 3), 'unit': 'MSamples/s', 'cores': 1,
+                            'sample': f'{reps1} pass(es) over {want1} chunks, 1 thread, {dt1:.1f} s'}}
 
 
-def measured_traffic(kernel_name, n_chunks):
-    """HBM bytes per launch of the chain kernel from the rocprofv3 PMC passes (tools/pmc.sh; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE), if a measurement of this workload is committed."""
-    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+def committed_record(name):
     try:
-        rec = json.load(open(path))
+        return json.load(open(os.path.join(ROOT, 'profiles', name)))
     except (OSError, ValueError):
         return None
-    if rec.get('chunks_per_step_per_gpu') != n_chunks or rec.get('kernel') not in kernel_name:
-        return None
-    return rec.get('hbm_bytes_per_launch')
+
+
+def launch_ranks(args, argv):
+    """--gpus N without a launcher: start the N ranks as fresh child processes (nothing in this process has touched a GPU)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, p.wait())
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--chunks', type=int, default=32768, help='chunks per step per GPU (32768 = 2^30 samples)')
+    ap.add_argument('--steps', type=int, default=1500)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='fm64')
+    ap.add_argument('--chunks', type=int, default=0, help='chunks per step (fm64: per GPU, default 32768 = 2^30 samples; simo64: 512)')
+    ap.add_argument('--settle-seconds', type=float, default=2.0, help='untimed back-to-back steps before the timed region')
+    ap.add_argument('--long-seconds', type=float, default=2.0, help='steady-state run after the timed region (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true', help='diagnostic: no per-kernel HIP events in the timed region')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -115,73 +172,176 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
+    from sdrterm_amd import _native as nat, parallel
     from sdrterm_amd.engine import Engine
-    eng = Engine(FS, Q, 'fm', 'h', row_freqs=[CENTER], omega_out=OMEGA_OUT, device=local_rank)
-    n_chunks = args.chunks
+    q, rows_total, default_chunks, scaling = WORKLOADS[args.workload]
+    n_chunks = args.chunks or default_chunks
     n_samples = n_chunks * N
-    raw = synth_iq_torch(n_samples, seed=1234 + rank, device=device)
-    out = torch.empty((1, n_chunks * eng.m), dtype=torch.float64, device=device)
+    if args.workload == 'fm64':
+        freqs_all = [float(CENTER)]
+        freqs, (lo, hi) = freqs_all, (0, 1)
+        raw = synth_iq_torch(n_samples, seed=1234 + rank, device=device)
+        bufs = [raw]
+        comm = None
+    else:
+        freqs_all = simo_rows(rows_total)
+        freqs, (lo, hi) = parallel.shard_rows(freqs_all, world, rank)
+        # the stream lives on rank 0 (where the reader's Queue ends); two block buffers per rank: block k+1 arrives beside
+        # the kernels of block k
+        src = synth_iq_torch(2 * n_samples, seed=1234, device=device) if rank == 0 else None
+        bufs = [torch.empty((n_samples, 2), dtype=torch.int16, device=device) for _ in range(2)]
+        comm = None
+        if world > 1:
+            uid = [parallel.RcclTransport.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = parallel.RcclTransport(rank, world, local_rank, uid[0])
+    eng = Engine(FS, q, 'fm', 'h', row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_rank)
+    rows = len(freqs)
+    out = torch.empty((rows, n_chunks * eng.m), dtype=torch.float64, device=device)
+    lib = nat.lib()
+    s_comm = None
+    if comm is not None:
+        p = nat.C.c_void_p()
+        nat.check(lib.sdrt_stream_create(nat.C.byref(p)))
+        s_comm = p.value
     torch.cuda.synchronize()
 
+    block_bytes = n_samples * 4
+    state = {'k': 0}
+
+    def fetch(k):
+        """Block k of the stream into buffer k % 2 on every rank (simo64)."""
+        dst = bufs[k % 2]
+        if rank == 0:
+            dst.copy_(src[(k % 2) * n_samples:(k % 2 + 1) * n_samples], non_blocking=True)
+        if comm is not None:
+            nat.check(lib.sdrt_stream_wait_stream(s_comm, None))        # after the copy above / the kernels still reading dst
+            comm.bcast_device(dst.data_ptr(), block_bytes, 0, s_comm)
+
     def step():
-        eng.process_device(raw.data_ptr(), n_chunks, out.data_ptr(), 0)
+        k = state['k']
+        if args.workload == 'simo64':
+            fetch(k + 1)                                               # beside this step's kernels (other buffer)
+        eng.process_device(bufs[k % len(bufs)].data_ptr(), n_chunks, out.data_ptr(), 0)
+        if comm is not None:
+            nat.check(lib.sdrt_stream_wait_stream(None, s_comm))         # the next step's kernels need that block
+        state['k'] = k + 1
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    if args.workload == 'simo64':
+        fetch(0)
+        if comm is not None:
+            nat.check(lib.sdrt_stream_wait_stream(None, s_comm))
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    eng.profile(True)
+    t_settle = time.perf_counter()
+    settle_steps = 0
+    while time.perf_counter() - t_settle < args.settle_seconds:
+        for _ in range(16):
+            step()
+        torch.cuda.synchronize()
+        settle_steps += 16
+
+    # ---- the timed region: exactly K steps ---------------------------------------------------------------------------
+    eng.profile(not args.no_kernel_events)
     eng.profile_reset()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # default stream == the launch stream (0)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         step()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
     k_ms, k_n = eng.kernel_time(0)
     p_ms, p_n = eng.kernel_time(1)
     eng.profile(False)
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     assert bool(torch.isfinite(out).all()), 'non-finite output'
 
-    KERNEL_OF = {'i8w': 'chain_i8w_kernel', 'i8t': 'chain_i8t_kernel', 'i8x32': 'chain_i8_kernel', 'f64': 'chain_kernel'}
+    # ---- steady state: a longer run, no per-kernel events ---------------------------------------------------------------
+    steady = None
+    if args.long_seconds > 0:
+        per = max(elapsed / args.steps, 1e-6)
+        n_long = max(16, int(args.long_seconds / per))
+        barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_long):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        dt_long = parallel.max_over_ranks(time.perf_counter() - t1, device)
+        steady = {'steps': n_long, 'seconds': round(dt_long, 3), 'ms_per_step': round(dt_long / n_long * 1e3, 4)}
+
+    KERNEL_OF = {'i8w': 'chain_i8w_kernel', 'i8t': 'chain_i8t_kernel', 'f64': 'chain_kernel'}
     if rank == 0:
-        total_samples = float(n_samples) * args.steps * world
+        per_gpu = 1 if scaling == 'strong' else world
+        total_samples = float(n_samples) * args.steps * per_gpu
         value = total_samples / elapsed / 1e6
-        k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
-        achieved = ALG_BYTES_PER_SAMPLE * n_samples / k_avg_s / 1e9
+        ms_per_step = elapsed / args.steps * 1e3
+        # algorithmic bytes per input sample on ONE GPU (SURVEY.md section 8d): 4 B of int16 IQ in + 8 B per row and q samples out
+        alg_bps = 4.0 + 8.0 * rows / q
+        k_avg_ms = k_ms / max(k_n, 1) if k_n else None
+        p_avg_ms = p_ms / max(p_n, 1) if p_n else None
+        # the chain kernel's own algorithmic bytes: input + the decimated complex128 samples it hands to the post kernel
+        achieved = alg_bps * n_samples / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms else None
+        path_achieved = alg_bps * n_samples / (ms_per_step * 1e-3) / 1e9
+        # int8 matrix work of the dominant kernel: matrix instructions per 4096-sample tile x 16*16*64*2 operations
+        mfma_per_tile = {64: 184, 32: 216}[q] if eng.stage_a == 'i8w' else None
+        i8_ops = mfma_per_tile * 32768.0 * rows * n_samples / 4096 if mfma_per_tile else None
+        pmc = (committed_record('pmc_record.json') or committed_record('pmc_traffic.json')) if args.workload == 'fm64' else None
+        pmc_ok = bool(pmc) and pmc.get('chunks_per_step_per_gpu') == n_chunks and pmc.get('kernel', '') in KERNEL_OF[eng.stage_a]
+        roof = {'bound': 'hbm', 'kernel': KERNEL_OF[eng.stage_a],
+                'achieved': round(achieved, 1) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                'traffic': pmc.get('hbm_bytes_per_launch') if pmc_ok else None,
+                'avg_kernel_ms': round(k_avg_ms, 4) if k_avg_ms else None, 'launches': k_n,
+                'alg_bytes_per_sample': alg_bps,
+                # the whole step (chain + post + gaps) against the same bytes: what north_star's 50 % is asked of
+                'path_achieved': round(path_achieved, 1), 'path_frac': round(path_achieved / HBM_PEAK_GBS, 4),
+                'int8_pops': round(i8_ops / (k_avg_ms * 1e-3) / 1e15, 3) if (i8_ops and k_avg_ms) else None,
+                'int8_frac': round(i8_ops / (k_avg_ms * 1e-3) / 1e15 / I8_PEAK_POPS, 4) if (i8_ops and k_avg_ms) else None,
+                'mfma_i8_busy': pmc.get('mfma_busy') if pmc_ok else None}
         line = {
-            'metric': 'input MSamples/s IQ->FM demod, dec=64',
+            'metric': 'input MSamples/s IQ->FM demod, dec=64' if args.workload == 'fm64' else 'input MSamples/s 64-VFO --simo FM, dec=32',
             'value': round(value, 1), 'unit': 'MSamples/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'configs[1]: {FS // 1_000_000} MS/s synthetic int16 IQ (FM tone + noise), FM demod, '
-                                   f'dec={Q}, single VFO, center={CENTER} Hz, {n_chunks} chunks x {N} samples per GPU per step, '
-                                   'inputs resident in HBM',
-                       'chunks_per_step_per_gpu': n_chunks, 'samples_per_chunk': N, 'parallelism': f'chunk-sharded x{world}'},
-            'roofline': {'bound': 'hbm', 'kernel': KERNEL_OF[eng.stage_a], 'achieved': round(achieved, 1),
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': measured_traffic(KERNEL_OF[eng.stage_a], n_chunks),
-                         'avg_kernel_ms': round(k_avg_s * 1e3, 4), 'launches': k_n,
-                         'alg_bytes_per_sample': ALG_BYTES_PER_SAMPLE,
-                         'fp64_frac': round(FP64_FLOP_PER_SAMPLE * n_samples / k_avg_s / 1e12 / FP64_PEAK_TFLOPS, 4)},
-            'kernels_ms': {'chain_kernel': round(k_ms / max(k_n, 1), 4), 'post_kernel': round(p_ms / max(p_n, 1), 4)},
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+            'scaling': scaling, 'vs_baseline': None,
+            # what the arithmetic is: int8 x int8 -> int32 matrix products of 5 base-256 weight digits x 2 byte slices (exact),
+            # recombined and finished in fp64; 'f64' when the fp64 matrix-core kernel runs
+            'dtype': 'i8x5-split+f64' if eng.stage_a in ('i8w', 'i8t') else 'f64', 'data': 'synthetic',
+            'config': {'workload': (f'configs[1]: {FS // 1_000_000} MS/s synthetic int16 IQ (FM tone + noise), FM demod, dec={q}, single VFO, '
+                                    f'center={CENTER} Hz, {n_chunks} chunks x {N} samples per GPU per step, inputs resident in HBM')
+                       if args.workload == 'fm64' else
+                       (f'configs[3]: --simo {rows_total} VFO rows sharded {rows}/GPU, {FS // 1_000_000} MS/s synthetic int16 IQ, FM, dec={q}, '
+                        f'{n_chunks} chunks x {N} samples per step resident on rank 0, RCCL broadcast per step'),
+                       'chunks_per_step_per_gpu': n_chunks, 'samples_per_chunk': N, 'rows_per_gpu': rows,
+                       'parallelism': f'chunk-sharded x{world}' if args.workload == 'fm64' else f'rows-sharded x{world} + bcast',
+                       'settle_steps': settle_steps + args.warmup},
+            'step_ms': {'median': round(step_ms[len(step_ms) // 2], 4), 'min': round(step_ms[0], 4), 'max': round(step_ms[-1], 4),
+                        'timed_region_s': round(elapsed, 3)},
+            'steady_state': steady,
+            'roofline': roof,
+            'kernels_ms': {'chain_kernel': round(k_avg_ms, 4) if k_avg_ms else None,
+                           'post_kernel': round(p_avg_ms, 4) if p_avg_ms else None},
             'stage_a': eng.stage_a,
         }
         if not args.no_cpu_baseline and world == 1:
-            sample = raw[:min(n_samples, 4096 * N)].cpu().numpy().tobytes()
-            line['cpu_baseline'] = cpu_baseline(sample)
+            sample = (bufs[0] if args.workload == 'fm64' else src)[:min(n_samples, 2048 * N)].cpu().numpy().tobytes()
+            line['cpu_baseline'] = cpu_baseline(sample, q, freqs_all)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -43,6 +43,13 @@ CASES = [
     # --smooth-output (Savitzky-Golay on the written samples, dsp_processor.py:159-160): odd and even window lengths
     _c('h_q64_fm_c_smooth11', 'h', 64, 'fm', center=15700, smooth=11, seed=30),
     _c('h_q32_am_norm_c0_smooth8', 'h', 32, 'am', normalize=True, smooth=8, seed=31),
+    # small decimation factors (the CLI default is --decimation 2, src/sdrterm.py:80) and many outputs per chunk
+    _c('h_q2_fm_c', 'h', 2, 'fm', center=15700, omega_out=100000, seed=32),
+    _c('h_q4_am_c0', 'h', 4, 'am', omega_out=60000, seed=33),
+    _c('h_q2_am_norm_c', 'h', 2, 'am', center=-15700, normalize=True, omega_out=100000, seed=34),
+    _c('h_q8_fm_c', 'h', 8, 'fm', center=15700, omega_out=30000, seed=35),
+    _c('B_q16_fm_c', 'B', 16, 'fm', center=15700, omega_out=15000, amp=100, seed=36),
+    _c('f_q4_fm_c', 'f', 4, 'fm', center=15700, omega_out=60000, seed=37),
 ]
 
 BY_NAME = {c['name']: c for c in CASES}

@@ -364,3 +364,28 @@ def test_edge_cases_empty_ragged_and_small_batches(golden):
         path = os.path.join(d, 'out.bin')
         p.processData(_Flag(), _ListQueue([b'']), path)
         assert os.path.getsize(path) == 0
+
+
+def test_rccl_transport_single_rank_roundtrip():
+    """sdrt_comm_* through the C ABI with a world of one (what a 1-GPU box can run): librccl loads, the communicator
+    initialises on device 0, broadcast and all-gather of device buffers return the bytes, BlockChannel frames a block."""
+    from sdrterm_amd import _native as nat, parallel
+    t = parallel.RcclTransport(0, 1, 0, parallel.RcclTransport.unique_id())
+    try:
+        data = np.arange(4096, dtype=np.uint8).tobytes() * 3
+        assert t.bcast_bytes(data, len(data)) == data
+        ch = parallel.BlockChannel(t, chunk_bytes=4096)
+        blk = ch.exchange(data, 3, False)
+        assert (blk.n, blk.eof) == (3, False) and blk.dev_ptr
+        back = np.empty(len(data), dtype=np.uint8)
+        nat.check(nat.lib().sdrt_memcpy_d2h(back.ctypes.data, blk.dev_ptr, len(data)))
+        assert back.tobytes() == data
+        end = ch.exchange(b'', 0, True)
+        assert (end.n, end.eof) == (0, True)
+        src = nat.DeviceBuffer(1024).upload(np.full(1024, 7, dtype=np.uint8))
+        dst = nat.DeviceBuffer(1024)
+        t.allgather_device(src.ptr, dst.ptr, 1024)
+        nat.check(nat.lib().sdrt_device_synchronize())
+        assert (dst.download(np.empty(1024, dtype=np.uint8)) == 7).all()
+    finally:
+        t.close()

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc
 mkdir -p "$OUT"
 cd /tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
+ARGS="--steps 3 --warmup 1 --settle-seconds 0.5 --long-seconds 0 --no-cpu-baseline ${BENCH_ARGS:-}"
 pass() {
     name=$1; shift
     rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/$name.log" 2>&1
