@@ -193,7 +193,7 @@ int sdrt_selftest_mfma_i8(int *mismatches);
 
 /* Which stage-A kernel the context uses: 0 = fp64 matrix cores; 2 = int8 matrix cores with exact integer slicing, one
  * block per column (16x16x64); 3 = the same arithmetic in the wide-column persistent kernel (default for 8/16-bit integer
- * encodings at decimation 32 / 64).  All meet the same tolerance.  Environment SDRTERM_STAGE_A=f64 or =i8t forces 0 or 2
+ * encodings at decimation 32 / 64); 4 = the per-sample modal form in fp64 (decimation 2 and 4).  All meet the same tolerance.  Environment SDRTERM_STAGE_A=f64 or =i8t forces 0 or 2
  * (diagnostics). */
 int sdrt_stage_a_kind(const sdrt_ctx *ctx);
 

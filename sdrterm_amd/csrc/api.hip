@@ -73,6 +73,8 @@ struct sdrt_ctx {
     bool use_i8 = false;              // stage A on the int8 matrix cores (8/16-bit integer encodings): use_i8w || use_i8t
     bool use_i8t = false;             //   ... one block per column (16x16x64), no IQ correction
     bool use_i8w = false;             //   ... wide columns, persistent workgroups (default where supported)
+    bool use_seq = false;             // decimation < 8: per-sample modal form (chain_seq_kernel)
+    int iq_gs = 0;                    // samples per group of the IQ prefix tables
     WideTables *d_wtab = nullptr;
     double *d_edge_ab = nullptr, *d_edge_pq = nullptr, *d_gvec = nullptr;
     bool wide_rs = false;             // wide kernel in its real-stream form (no shift, no IQ correction)
@@ -338,11 +340,15 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     if (cfg->apply_shift && !cfg->row_freqs) return fail(SDRT_EINVAL, "row_freqs required when apply_shift is set");
     if (!(cfg->fs > 0)) return fail(SDRT_EINVAL, "fs must be positive");
     const int q = cfg->decimation, n = cfg->n_samples;
-    if (q < 8 || (q & (q - 1)))
-        return fail(SDRT_EINVAL, "this build supports decimation factors that are powers of two >= 8 (got %d)", q);
+    // the reference's chunks hold a power-of-two number of samples (131072 bytes / record size), so every decimation factor
+    // that divides them (dsp_processor.py:147,173) is a power of two
+    if (q & (q - 1)) return fail(SDRT_EINVAL, "this build supports decimation factors that are powers of two (got %d)", q);
     if (n <= SDRT_EDGE) return fail(SDRT_EINVAL, "n_samples must exceed the filter pad length %d", SDRT_EDGE);
+    const bool seq = q < 8;                                   // per-sample form; block forms from 8 up
     const int L = q < SDRT_MAXL ? q : SDRT_MAXL;
-    if (n % (SDRT_TB * L)) return fail(SDRT_EINVAL, "n_samples (%d) must be a multiple of %d", n, SDRT_TB * L);
+    if (seq && !chain_seq_supported(q, n))
+        return fail(SDRT_EINVAL, "decimation %d needs chunks of a multiple of %d samples (got %d)", q, 256 * (q > 16 ? q : 16), n);
+    if (!seq && n % (SDRT_TB * L)) return fail(SDRT_EINVAL, "n_samples (%d) must be a multiple of %d", n, SDRT_TB * L);
     if (n % q) return fail(SDRT_EINVAL, "decimation must divide n_samples");   // dsp_processor.py:147,173
     const int m = n / q;
     if (cfg->mode == SDRT_FM && (m < 2 || (m & 1))) return fail(SDRT_EINVAL, "FM needs an even number of outputs per chunk");
@@ -350,11 +356,12 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     {
         const int Nh = m / 2;
         const bool fft_fm = cfg->mode == SDRT_FM && (Nh == 256 || Nh == 512 || Nh == 1024 || Nh == 2048);
-        if (!fft_fm && post_waves_per_block(m, cfg->mode) == 0)
+        if (!fft_fm && post_waves_per_block(m, cfg->mode) == 0 && !(m >= 8192 && post_big_supported(m, cfg->mode)))
             return fail(SDRT_EINVAL, "%d outputs per chunk (n_samples / decimation) exceed what the demodulation stage holds in LDS", m);
     }
-    if (cfg->correct_iq && n / (L / 4) < 256)
-        return fail(SDRT_EINVAL, "correct_iq needs at least %d samples per chunk", 256 * (L / 4));
+    const int iq_gs = seq ? 16 : L / 4;                      // samples per group of the IQ prefix tables
+    if (cfg->correct_iq && n / iq_gs < 256)
+        return fail(SDRT_EINVAL, "correct_iq needs at least %d samples per chunk", 256 * iq_gs);
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -380,7 +387,9 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         c->norm_bias = -cfg->norm_xmin - 0.5 / cfg->norm_inv_range;
     }
     c->iq = cfg->correct_iq != 0;
-    const size_t lds = chain_lds_bytes(n, L, m);
+    c->use_seq = seq;
+    c->iq_gs = iq_gs;
+    const size_t lds = seq ? 0 : chain_lds_bytes(n, L, m);
     if (lds > 160 * 1024) {
         delete c;
         return fail(SDRT_EINVAL, "chunk needs %zu bytes of LDS (> 160 KiB): n_samples/decimation combination unsupported", lds);
@@ -409,7 +418,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         // with normalisation the reference corrects the NORMALISED samples (read_file.py:102-103): the offset lives in
         // normalised units, while the kernels work on x + bias (un-scaled) and scale at the end; off' = off / scale obeys
         // the same recurrence, so the device state is kept in un-scaled units and converted in get/set.
-        const int gs = L / 4, ng = n / gs;
+        const int gs = iq_gs, ng = n / gs;
         std::vector<double> pw((size_t) ng + 1);
         sdrt_build_iq_pow(cfg->iq_inductance, ng, pw.data());          // (1-lambda)^k, k <= ng
         std::vector<double> pwg((size_t) ng + 1);
@@ -433,10 +442,10 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     }
     if (rc == SDRT_OK && c->nco) {
         // exp(i theta t) is factored as (sample within block) x (block within chunk): L + n/L table entries per row
-        const int nblk = n / L;
-        std::vector<double> tile((size_t) c->rows * L * 2), phase((size_t) c->rows * nblk * 2);
+        const int Ln = seq ? 64 : L, nblk = n / Ln;           // chain_seq_kernel: 64 samples per table block
+        std::vector<double> tile((size_t) c->rows * Ln * 2), phase((size_t) c->rows * nblk * 2);
         for (int r = 0; r < c->rows; ++r)
-            sdrt_build_nco(cfg->row_freqs[r], cfg->fs, L, nblk, &tile[(size_t) r * L * 2],
+            sdrt_build_nco(cfg->row_freqs[r], cfg->fs, Ln, nblk, &tile[(size_t) r * Ln * 2],
                            &phase[(size_t) r * nblk * 2]);
         rc = upload(&c->d_nco_tile, tile.data(), tile.size() * sizeof(double));
         if (rc == SDRT_OK) rc = upload(&c->d_nco_phase, phase.data(), phase.size() * sizeof(double));
@@ -465,9 +474,11 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         // int8 matrix-core forms in order of preference; a form that cannot represent this configuration (unequal
         // power-of-two scales between rows, a digit overflow) releases what it uploaded and the next one is tried; the
         // fp64 matrix-core kernel takes whatever is left
-        if (want_i8 && !want_t && chain_i8w_supported(q, cfg->dtype, n) && chain_i8w_lds_bytes(q, n) <= 160 * 1024)
+        if (seq) {
+            // nothing to set up: the per-sample form reads DecimTables only
+        } else if (want_i8 && !want_t && chain_i8w_supported(q, cfg->dtype, n) && chain_i8w_lds_bytes(q, n) <= 160 * 1024)
             rc = setup_wide(c, cfg, scale_tables);
-        if (rc == SDRT_OK && !c->use_i8w && want_i8 && !c->iq && want_i8_fallback_t(L, cfg->dtype, n, m))
+        if (rc == SDRT_OK && !seq && !c->use_i8w && want_i8 && !c->iq && want_i8_fallback_t(L, cfg->dtype, n, m))
             rc = setup_i8t(c, cfg, scale_tables);
         c->use_i8 = c->use_i8w || c->use_i8t;
     }
@@ -592,7 +603,7 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     da.iq_pow = c->d_iq_pow;
     da.iq_lambda = c->cfg.iq_inductance;
     if (c->iq) {
-        const int gs = c->L / 4;
+        const int gs = c->iq_gs;
         if (n_chunks > c->iq_cap_chunks) {
             (void) hipFree(c->d_iq_group);
             (void) hipFree(c->d_iq_agg);
@@ -642,7 +653,7 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     da.e_off_im = c->iq ? 0.0 : c->x_offset;
     da.c_re = c->x_offset + c->norm_bias;
     da.c_im = c->x_offset;
-    da.iq_gs = c->L / 4;
+    da.iq_gs = c->iq_gs;
     da.rs = c->use_i8w && c->wide_rs;
     if (c->use_i8) {
         da.tab = c->d_tab8;
@@ -652,7 +663,9 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     }
     {
         Timed t(c, s, 0);
-        if (c->use_i8w) {
+        if (c->use_seq) {
+            HIP_TRY(launch_chain_seq(da, c->cfg.decimation, c->cfg.dtype, c->nco, c->iq, n_chunks, s));
+        } else if (c->use_i8w) {
             HIP_TRY(launch_chain_i8w(da, c->cfg.decimation, c->cfg.dtype, n_chunks, c->n_cus, s));
         } else if (c->use_i8t) {
             // the int8 kernels feed x - x_offset to the matrix cores; normalisation bias and offset come back via ybias
@@ -886,7 +899,7 @@ int sdrt_debug_stamps(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double 
     return SDRT_OK;
 }
 
-int sdrt_stage_a_kind(const sdrt_ctx *c) { return c ? (c->use_i8w ? 3 : (c->use_i8t ? 2 : (c->use_i8 ? 1 : 0))) : -1; }
+int sdrt_stage_a_kind(const sdrt_ctx *c) { return c ? (c->use_seq ? 4 : c->use_i8w ? 3 : (c->use_i8t ? 2 : (c->use_i8 ? 1 : 0))) : -1; }
 
 int sdrt_selftest_mfma_i8(int *mismatches) {
     int bad = 0;

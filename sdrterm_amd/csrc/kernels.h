@@ -98,4 +98,9 @@ bool chain_i8w_supported(int q, int dt, int n);
 bool chain_i8w_rs_supported(int dt, int n);       // its real-stream form (no shift, no IQ correction)
 size_t chain_i8w_lds_bytes(int q, int n);
 hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, int n_cus, hipStream_t s);
+// per-sample modal form for decimation < 8 and the workgroup-per-item demodulation stage for m > 4096 (kernels_seq.hip)
+bool chain_seq_supported(int q, int n);
+hipError_t launch_chain_seq(const DecimArgs &a, int q, int dt, bool nco, bool iq, size_t n_chunks, hipStream_t s);
+bool post_big_supported(int m, int mode);
+hipError_t launch_post_big(const PostArgs &a, hipStream_t s);
 hipError_t launch_swap_selftest(const double *x, const double *y, double *out, hipStream_t s);

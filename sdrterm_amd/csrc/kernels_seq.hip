@@ -1,0 +1,453 @@
+// Small decimation factors (q = 2, 4; the CLI default is --decimation 2, src/sdrterm.py:80) and chunks with many outputs.
+//
+// chain_seq_kernel: with an output every 2 or 4 samples there is nothing to gain from block aggregates on the matrix cores:
+// the zero-phase decimator (dsp_processor.py:147 -> scipy decimate) is evaluated in its per-sample modal form
+//     F_i(t+1) = p_i F_i(t) + ac_i u[t]        state before sample t (causal),       F_i(0) from the head operator
+//     G_i(t)   = p_i G_i(t+1) + aa_i u[t]      inclusive (anticausal),               G_i(n) from the tail operator
+//     y[t]     = d0p u[t] + 2 Re sum_i (F_i(t) + G_i(t))                              at t = q k
+// (tables.h: DecimTables; the same operator as every other chain kernel).  One workgroup per (chunk, row); every thread
+// owns a run of n/256 consecutive samples: pass 1 = the run's aggregates from zero states, a scan over the 256 threads
+// (wave shuffles + four wave totals), pass 2a = forward through the run with the true causal states (writes the direct
+// and causal part of its outputs), pass 2b = backward with the anticausal states (adds the rest).  The IQ correction
+// (read_file.py:64-77) runs forward in 2a and is unwound exactly in 2b: off_t = (off_{t+1} - lambda x_t) / (1 - lambda).
+//
+// post_big_kernel: the demodulation stage for chunks whose m outputs do not fit one wave's LDS share (m > 4096): one
+// workgroup per item, FM resampler as the circulant product with the half-sample kernel (O(N^2), LDS-tiled), output
+// lowpass as a modal scan over the workgroup.
+#include "kernels_common.hpp"
+
+namespace {
+
+constexpr int SEQ_NCO_L = 64;        // the NCO phasor is tabulated as exp(i theta j), j < 64, times exp(i theta 64 B)
+
+// suffix form of wave_scan_geometric: S_l = sum_{j >= l} mu^(j-l) x_j
+__device__ __forceinline__ cd wave_scan_geometric_rev(cd x, cd mu, int lane) {
+    cd mpow = mu;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int d = 1 << i;
+        cd t = mk(__shfl_down(x.re, d), __shfl_down(x.im, d));
+        if (lane + d > 63) t = mk(0.0, 0.0);
+        x = cfma(mpow, t, x);
+        mpow = cmul(mpow, mpow);
+    }
+    return x;
+}
+
+__device__ __forceinline__ cd cpow_u(cd b, unsigned e) {
+    cd r = mk(1.0, 0.0);
+    while (e) {
+        if (e & 1u) r = cmul(r, b);
+        b = cmul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+
+}  // namespace
+
+template <int DT, bool NCO, bool IQ>
+__global__ __launch_bounds__(256) void chain_seq_kernel(DecimArgs a, int qshift) {
+    constexpr int ITEM = Enc<DT>::size;
+    constexpr int SPG = ITEM >= 8 ? 1 : 8 / ITEM;          // samples per 16-byte load (f64: one 16-byte sample)
+    constexpr int GB = SPG * 2 * ITEM;                     // bytes per load
+    __shared__ cd wtot[16][4];
+    __shared__ cd tileL[SEQ_NCO_L];
+    __shared__ cd edgeL[16];                               // [0..7] F0, [8..15] sample part of G_end; index mode*2 + stream
+    const DecimTables *__restrict__ tab = a.tab;
+    const int n = a.n, T = n / 256;
+    const long qmask = (1L << qshift) - 1;
+    const unsigned bid = blockIdx.x, xcd = bid & 7u, slot = bid >> 3;
+    const long chunk = (long) (slot / (unsigned) a.rows) * 8 + xcd;
+    const int row = (int) (slot % (unsigned) a.rows);
+    if (chunk >= (long) a.n_chunks) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool swap = a.swap != 0;
+    const unsigned char *chunk_raw = (const unsigned char *) a.raw + (size_t) chunk * (size_t) n * 2 * ITEM;
+    const double nbias = a.norm_bias, lam = a.iq_lambda, om = 1.0 - lam, rom = 1.0 / om;
+    const cd *nco_blk = NCO ? (const cd *) a.nco_phase + (size_t) row * (size_t) (n / SEQ_NCO_L) : nullptr;
+    if (NCO && tid < SEQ_NCO_L) tileL[tid] = ((const cd *) a.nco_tile)[(size_t) row * SEQ_NCO_L + tid];
+    cd p[4], ac[4], aa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p[i] = mk(tab->pole[i][0], tab->pole[i][1]);
+        ac[i] = mk(tab->ac[i][0], tab->ac[i][1]);
+        aa[i] = mk(tab->aa[i][0], tab->aa[i][1]);
+    }
+    const double d0p = tab->d0p;
+    const long t0 = (long) tid * T;
+    // IQ offset at the run's first sample: group table (groups of 16 samples, from a zero offset at the chunk start) + the
+    // chunk's true starting offset
+    cd off0 = mk(0.0, 0.0);
+    if constexpr (IQ) {
+        const cd c0 = ((const cd *) a.iq_chunk_off)[chunk];
+        const long grp = t0 / a.iq_gs;
+        const cd go = ((const cd *) a.iq_group_off)[(size_t) chunk * (size_t) (n / a.iq_gs) + grp];
+        const double pw = a.iq_pow[grp];
+        off0 = mk(fma(pw, c0.re, go.re), fma(pw, c0.im, go.im));
+    }
+    __syncthreads();
+
+    // sample t as the decimator sees it; forward: `off` is the offset at t and becomes the offset at t + 1
+    auto shifted = [&](double xr, double xi, long t, double &ur, double &ui) {
+        if constexpr (NCO) {
+            const cd c = cmul(tileL[t & (SEQ_NCO_L - 1)], nco_blk[t / SEQ_NCO_L]);
+            ur = xr * c.re - xi * c.im;
+            ui = xr * c.im + xi * c.re;
+        } else {
+            ur = xr;
+            ui = xi;
+        }
+    };
+    // the run in load groups; fn(t, xr, xi) gets the decoded (biased) components in ascending or descending order of t
+    auto for_run = [&](auto dir, auto fn) {
+        constexpr bool FWD = decltype(dir)::value;
+        for (int g = 0; g < T / SPG; ++g) {
+            const long tg = t0 + (long) (FWD ? g : T / SPG - 1 - g) * SPG;
+            uint32_t wds[GB / 4];
+            load_words<GB>(chunk_raw + (size_t) tg * 2 * ITEM, wds);
+            static_for<0, SPG>([&](auto jc) {
+                constexpr int j = FWD ? decltype(jc)::value : SPG - 1 - decltype(jc)::value;
+                fn(tg + j, decode<DT>(get_item<DT, 2 * j>(wds), swap) + nbias, decode<DT>(get_item<DT, 2 * j + 1>(wds), swap));
+            });
+        }
+    };
+
+    // ---- pass 1: end states of the run from zero (causal: Horner; anticausal aggregate: running power) ------------------
+    cd F[4][2], A[4][2], pw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { F[i][0] = F[i][1] = A[i][0] = A[i][1] = mk(0.0, 0.0); pw[i] = aa[i]; }
+    {
+        cd off = off0;
+        for_run(std::true_type{}, [&](long t, double xr, double xi) {
+            if constexpr (IQ) {
+                xr -= off.re; xi -= off.im;
+                off.re = fma(xr, lam, off.re); off.im = fma(xi, lam, off.im);
+            }
+            double ur, ui;
+            shifted(xr, xi, t, ur, ui);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                F[i][0] = mk(fma(p[i].re, F[i][0].re, fma(-p[i].im, F[i][0].im, ac[i].re * ur)), fma(p[i].re, F[i][0].im, fma(p[i].im, F[i][0].re, ac[i].im * ur)));
+                F[i][1] = mk(fma(p[i].re, F[i][1].re, fma(-p[i].im, F[i][1].im, ac[i].re * ui)), fma(p[i].re, F[i][1].im, fma(p[i].im, F[i][1].re, ac[i].im * ui)));
+                A[i][0] = mk(fma(pw[i].re, ur, A[i][0].re), fma(pw[i].im, ur, A[i][0].im));
+                A[i][1] = mk(fma(pw[i].re, ui, A[i][1].re), fma(pw[i].im, ui, A[i][1].im));
+                pw[i] = cmul(pw[i], p[i]);
+            }
+        });
+    }
+    // ---- edge operators: F(0) from samples 0..27 (thread 0), the sample part of G(n) from samples n-28..n-1 (thread 255) ----
+    if (tid == 0 || tid == 255) {
+        cd acc[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[o] = mk(0.0, 0.0);
+        const long base = tid == 0 ? 0 : (long) n - (SDRT_EDGE + 1);
+        cd off = off0;
+        if constexpr (IQ) {
+            if (tid == 255) {               // walk from the run start to the window (the run is at least 32 samples long)
+                for (long t = t0; t < base; ++t) {
+                    const typename Enc<DT>::raw *rp = (const typename Enc<DT>::raw *) chunk_raw + 2 * t;
+                    const double zr = decode<DT>(rp[0], swap) + nbias - off.re, zi = decode<DT>(rp[1], swap) - off.im;
+                    off.re = fma(zr, lam, off.re); off.im = fma(zi, lam, off.im);
+                }
+            }
+        }
+        for (int l = 0; l <= SDRT_EDGE; ++l) {
+            const long t = base + l;
+            const typename Enc<DT>::raw *rp = (const typename Enc<DT>::raw *) chunk_raw + 2 * t;
+            double xr = decode<DT>(rp[0], swap) + nbias, xi = decode<DT>(rp[1], swap);
+            if constexpr (IQ) {
+                xr -= off.re; xi -= off.im;
+                off.re = fma(xr, lam, off.re); off.im = fma(xi, lam, off.im);
+            }
+            double ur, ui;
+            shifted(xr, xi, t, ur, ui);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double *c = tid == 0 ? tab->head[i][l] : tab->tailU[i][l];
+                acc[2 * i] = mk(fma(c[0], ur, acc[2 * i].re), fma(c[1], ur, acc[2 * i].im));
+                acc[2 * i + 1] = mk(fma(c[0], ui, acc[2 * i + 1].re), fma(c[1], ui, acc[2 * i + 1].im));
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 8; ++o) edgeL[(tid == 0 ? 0 : 8) + o] = acc[o];
+    }
+    // ---- causal scan over the threads: state at the run start ----------------------------------------------------------
+    cd MT[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) MT[i] = cpow_u(p[i], (unsigned) T);
+    cd S[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            S[i][st] = wave_scan_geometric(F[i][st], MT[i], lane);
+            if (lane == 63) wtot[i * 2 + st][wave] = S[i][st];
+        }
+    __syncthreads();
+    cd Fs[4][2], Fend[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const cd M64 = cpow_u(MT[i], 64u), Ml = cpow_u(MT[i], (unsigned) lane), Mt = cpow_u(MT[i], (unsigned) tid);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            cd wp = mk(0.0, 0.0);                          // inclusive sum of the waves before this one
+            for (int wv = 0; wv < wave; ++wv) wp = cfma(M64, wp, wtot[i * 2 + st][wv]);
+            cd ex = mk(__shfl_up(S[i][st].re, 1), __shfl_up(S[i][st].im, 1));
+            if (lane == 0) ex = mk(0.0, 0.0);
+            // exclusive value: previous lanes of this wave + earlier waves carried over `lane` runs + F(0) over `tid` runs
+            Fs[i][st] = cadd(ex, cadd(cmul(Ml, wp), cmul(Mt, edgeL[i * 2 + st])));
+            cd tot = mk(0.0, 0.0);
+            for (int wv = 0; wv < 4; ++wv) tot = cfma(M64, tot, wtot[i * 2 + st][wv]);
+            Fend[i][st] = cadd(tot, cmul(cpow_u(MT[i], 256u), edgeL[i * 2 + st]));      // F(n)
+        }
+    }
+    __syncthreads();
+    // ---- anticausal: G(n) from F(n) and the tail samples, then the suffix scan: state entering the run from the right ------
+    cd Gs[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const cd R = wave_scan_geometric_rev(A[i][st], MT[i], lane);
+            if (lane == 0) wtot[i * 2 + st][wave] = R;
+            S[i][st] = R;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const cd M64 = cpow_u(MT[i], 64u), Ml = cpow_u(MT[i], (unsigned) (63 - lane)), Mt = cpow_u(MT[i], (unsigned) (255 - tid));
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            cd Gn = edgeL[8 + i * 2 + st];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const cd Fj = Fend[j][st];
+                Gn = cfma(mk(tab->tailF[i][j][0], tab->tailF[i][j][1]), Fj, Gn);
+                Gn = cfma(mk(tab->tailFc[i][j][0], tab->tailFc[i][j][1]), mk(Fj.re, -Fj.im), Gn);
+            }
+            cd wp = mk(0.0, 0.0);                          // suffix sum of the waves after this one
+            for (int wv = 3; wv > wave; --wv) wp = cfma(M64, wp, wtot[i * 2 + st][wv]);
+            cd ex = mk(__shfl_down(S[i][st].re, 1), __shfl_down(S[i][st].im, 1));
+            if (lane == 63) ex = mk(0.0, 0.0);
+            Gs[i][st] = cadd(ex, cadd(cmul(Ml, wp), cmul(Mt, Gn)));                   // G(t0 + T)
+        }
+    }
+
+    // ---- pass 2a: forward with the causal states: direct + causal part of the run's outputs -----------------------------
+    double *yd = a.ydec + ((size_t) row * a.n_chunks + (size_t) chunk) * (size_t) a.m * 2;
+    cd off_end = off0;
+    {
+        cd off = off0;
+        for_run(std::true_type{}, [&](long t, double xr, double xi) {
+            if constexpr (IQ) {
+                xr -= off.re; xi -= off.im;
+                off.re = fma(xr, lam, off.re); off.im = fma(xi, lam, off.im);
+            }
+            double ur, ui;
+            shifted(xr, xi, t, ur, ui);
+            if ((t & qmask) == 0) {
+                double yr = d0p * ur, yi = d0p * ui;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { yr = fma(2.0, Fs[i][0].re, yr); yi = fma(2.0, Fs[i][1].re, yi); }
+                *(double2 *) (yd + 2 * (size_t) (t >> qshift)) = make_double2(yr, yi);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Fs[i][0] = mk(fma(p[i].re, Fs[i][0].re, fma(-p[i].im, Fs[i][0].im, ac[i].re * ur)), fma(p[i].re, Fs[i][0].im, fma(p[i].im, Fs[i][0].re, ac[i].im * ur)));
+                Fs[i][1] = mk(fma(p[i].re, Fs[i][1].re, fma(-p[i].im, Fs[i][1].im, ac[i].re * ui)), fma(p[i].re, Fs[i][1].im, fma(p[i].im, Fs[i][1].re, ac[i].im * ui)));
+            }
+        });
+        off_end = off;
+    }
+    // ---- pass 2b: backward with the anticausal states (inclusive), the IQ offset unwound ---------------------------------
+    {
+        cd off = off_end;                                   // offset at t0 + T
+        for_run(std::false_type{}, [&](long t, double xr, double xi) {
+            if constexpr (IQ) {
+                off.re = (off.re - lam * xr) * rom;          // offset at t
+                off.im = (off.im - lam * xi) * rom;
+                xr -= off.re; xi -= off.im;
+            }
+            double ur, ui;
+            shifted(xr, xi, t, ur, ui);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Gs[i][0] = mk(fma(p[i].re, Gs[i][0].re, fma(-p[i].im, Gs[i][0].im, aa[i].re * ur)), fma(p[i].re, Gs[i][0].im, fma(p[i].im, Gs[i][0].re, aa[i].im * ur)));
+                Gs[i][1] = mk(fma(p[i].re, Gs[i][1].re, fma(-p[i].im, Gs[i][1].im, aa[i].re * ui)), fma(p[i].re, Gs[i][1].im, fma(p[i].im, Gs[i][1].re, aa[i].im * ui)));
+            }
+            if ((t & qmask) == 0) {
+                double2 v = *(double2 *) (yd + 2 * (size_t) (t >> qshift));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v.x = fma(2.0, Gs[i][0].re, v.x); v.y = fma(2.0, Gs[i][1].re, v.y); }
+                *(double2 *) (yd + 2 * (size_t) (t >> qshift)) = v;
+            }
+        });
+    }
+}
+
+template <int DT>
+static hipError_t launch_seq_dt(const DecimArgs &a, int q, bool nco, bool iq, dim3 grid, hipStream_t s) {
+    int qs = 0;
+    while ((1 << qs) < q) ++qs;
+    if (nco) {
+        if (iq) hipLaunchKernelGGL((chain_seq_kernel<DT, true, true>), grid, dim3(256), 0, s, a, qs);
+        else hipLaunchKernelGGL((chain_seq_kernel<DT, true, false>), grid, dim3(256), 0, s, a, qs);
+    } else {
+        if (iq) hipLaunchKernelGGL((chain_seq_kernel<DT, false, true>), grid, dim3(256), 0, s, a, qs);
+        else hipLaunchKernelGGL((chain_seq_kernel<DT, false, false>), grid, dim3(256), 0, s, a, qs);
+    }
+    return hipGetLastError();
+}
+
+bool chain_seq_supported(int q, int n) {
+    // every thread's run: whole load groups, whole IQ groups (16 samples), at least the 28-sample edge windows, whole outputs
+    const int T = n / 256;
+    return n % 256 == 0 && T >= 32 && T % 16 == 0 && q >= 2 && (q & (q - 1)) == 0 && T % q == 0 && n % SEQ_NCO_L == 0;
+}
+
+hipError_t launch_chain_seq(const DecimArgs &a, int q, int dt, bool nco, bool iq, size_t n_chunks, hipStream_t s) {
+    const size_t groups = (n_chunks + 7) / 8;
+    const dim3 grid((unsigned) (groups * 8 * (size_t) a.rows));
+    switch (dt) {
+        case SDRT_S8: return launch_seq_dt<SDRT_S8>(a, q, nco, iq, grid, s);
+        case SDRT_U8: return launch_seq_dt<SDRT_U8>(a, q, nco, iq, grid, s);
+        case SDRT_S16: return launch_seq_dt<SDRT_S16>(a, q, nco, iq, grid, s);
+        case SDRT_U16: return launch_seq_dt<SDRT_U16>(a, q, nco, iq, grid, s);
+        case SDRT_S32: return launch_seq_dt<SDRT_S32>(a, q, nco, iq, grid, s);
+        case SDRT_U32: return launch_seq_dt<SDRT_U32>(a, q, nco, iq, grid, s);
+        case SDRT_F32: return launch_seq_dt<SDRT_F32>(a, q, nco, iq, grid, s);
+        case SDRT_F64: return launch_seq_dt<SDRT_F64>(a, q, nco, iq, grid, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// post_big_kernel: FM pair angle (demodulation.py:25-32) + resample m/2 -> m (demodulation.py:35-38: even outputs are the
+// angles, odd outputs the circulant product with the half-sample kernel) or AM (demodulation.py:41-48), then the output
+// lowpass (dsp_processor.py:32-36,149) as a modal scan.  One workgroup of 256 threads per (chunk, row) item; the item's m
+// samples live in the output buffer itself between the steps.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void post_big_kernel(PostArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ cd ptot[SDRT_OUT_MAXMODES][4];
+    const int m = a.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t item = blockIdx.x;
+    const cd *y = (const cd *) a.y + item * (size_t) m;
+    double *out = a.out + item * (size_t) m;
+    if (a.mode == SDRT_FM) {
+        const int N = m >> 1, msk = N - 1;
+        constexpr int AT = 2048, R = 16;                    // angles per LDS tile; outputs per thread and turn
+        double *hr = (double *) smem;                       // [N]: hr[i] = h[(-i) mod N]
+        double *at = hr + N;                                // [AT]
+        for (int i = tid; i < N; i += 256) hr[i] = a.resample_odd[i == 0 ? 0 : N - i];
+        for (int j = tid; j < N; j += 256) {
+            const cd pa = y[2 * j], c = y[2 * j + 1];
+            out[2 * j] = atan2(pa.im * c.re - pa.re * c.im, pa.re * c.re + pa.im * c.im);    // angle(d[i] * conj(d[i+1]))
+        }
+        __syncthreads();
+        // z_odd[j] = sum_k a[k] hr[(k - j) mod N]: thread owns R consecutive outputs per turn; a sliding register window
+        // feeds them from one new value of hr per k (as resample_wave does for one wave)
+        for (int j0 = R * tid; j0 < N; j0 += R * 256) {
+            double acc[R], B[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { acc[r] = 0.0; B[r] = 0.0; }
+            for (int k0 = 0; k0 < N; k0 += AT) {
+                __syncthreads();
+                for (int i = tid; i < AT; i += 256) at[i] = out[2 * (k0 + i)];
+                __syncthreads();
+#pragma unroll
+                for (int r = 1; r < R; ++r) B[r] = hr[(k0 - j0 - r) & msk];
+                for (int k = 0; k < AT; k += R) {
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        B[(R - u) % R] = hr[(k0 + k + u - j0) & msk];
+                        const double ak = at[k + u];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r] = fma(ak, B[(r - u + R) % R], acc[r]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) out[2 * (j0 + r) + 1] = acc[r];
+        }
+    } else {
+        for (int k = tid; k < m; k += 256) {
+            const cd v = y[k];
+            out[k] = v.re * v.re + v.im * v.im;
+        }
+    }
+    __syncthreads();
+    // ---- output lowpass: y[t] = D x[t] + sum_k Re(r_k s_k(t)), s_k(t+1) = p_k s_k(t) + x[t], s_k(0) = 0 --------------------
+    const OutTables *__restrict__ ot = a.otab;
+    const int nm = ot->nmodes;
+    if (nm < 0) {
+        // sequential transposed-direct-form-II cascade (any SOS); only when the modal form is not available
+        if (tid == 0) {
+            double st[2 * SDRT_MAX_OUT_SECTIONS];
+            for (int s = 0; s < 2 * SDRT_MAX_OUT_SECTIONS; ++s) st[s] = 0.0;
+            for (int i = 0; i < m; ++i) {
+                double xc = out[i];
+                for (int s = 0; s < a.out_sections; ++s) {
+                    const double *c = a.out_sos + 6 * s;
+                    const double xn = fma(c[0], xc, st[2 * s]);
+                    st[2 * s] = fma(c[1], xc, fma(-c[4], xn, st[2 * s + 1]));
+                    st[2 * s + 1] = fma(c[2], xc, -c[5] * xn);
+                    xc = xn;
+                }
+                out[i] = xc;
+            }
+        }
+        return;
+    }
+    const int E = m / 256, t0 = tid * E;
+    cd pk[SDRT_OUT_MAXMODES], rk[SDRT_OUT_MAXMODES], sst[SDRT_OUT_MAXMODES];
+#pragma unroll
+    for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
+        pk[k] = k < nm ? mk(ot->p[k][0], ot->p[k][1]) : mk(0.0, 0.0);
+        rk[k] = k < nm ? mk(ot->r[k][0], ot->r[k][1]) : mk(0.0, 0.0);
+        cd s = mk(0.0, 0.0);
+        if (k < nm)
+            for (int e = 0; e < E; ++e) s = cfma(pk[k], s, mk(out[t0 + e], 0.0));
+        const cd PE = cpow_u(pk[k], (unsigned) E);
+        const cd sc = wave_scan_geometric(s, PE, lane);
+        if (lane == 63) ptot[k][wave] = sc;
+        __syncthreads();
+        cd wp = mk(0.0, 0.0);
+        const cd P64 = cpow_u(PE, 64u);
+        for (int wv = 0; wv < wave; ++wv) wp = cfma(P64, wp, ptot[k][wv]);
+        cd ex = mk(__shfl_up(sc.re, 1), __shfl_up(sc.im, 1));
+        if (lane == 0) ex = mk(0.0, 0.0);
+        sst[k] = cadd(ex, cmul(cpow_u(PE, (unsigned) lane), wp));     // state at the run's first sample
+    }
+    const double Dd = ot->D;
+    for (int e = 0; e < E; ++e) {
+        const double x = out[t0 + e];
+        double yv = Dd * x;
+#pragma unroll
+        for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
+            if (k < nm) {
+                yv += rk[k].re * sst[k].re - rk[k].im * sst[k].im;
+                sst[k] = cfma(pk[k], sst[k], mk(x, 0.0));
+            }
+        }
+        out[t0 + e] = yv;
+    }
+}
+
+bool post_big_supported(int m, int mode) {
+    if (m % 256) return false;
+    if (mode != SDRT_FM) return true;
+    const int N = m / 2;
+    return (N & (N - 1)) == 0 && N >= 4096 && (size_t) (N + 2048) * sizeof(double) <= 160 * 1024;
+}
+
+hipError_t launch_post_big(const PostArgs &a, hipStream_t s) {
+    const size_t lds = a.mode == SDRT_FM ? (size_t) (a.m / 2 + 2048) * sizeof(double) : 0;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *) post_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(post_big_kernel, dim3((unsigned) a.items), dim3(256), lds, s, a);
+    return hipGetLastError();
+}

@@ -103,8 +103,8 @@ bool build_modal(const double *sos, int nsec, Modal &m, const char **err) {
 
 extern "C" int sdrt_build_decim_tables(const double *sos, int sections, int q, int G, DecimTables *out, const char **err) {
     if (G < 1 || G > SDRT_GMAX) { if (err) *err = "unsupported blocks-per-column"; return -3; }
-    static const char *kBadQ = "decimation must be a power of two >= 4 for the MFMA path";
-    if (q < 4 || (q & (q - 1))) { if (err) *err = kBadQ; return -1; }
+    static const char *kBadQ = "decimation must be a power of two >= 2";
+    if (q < 2 || (q & (q - 1))) { if (err) *err = kBadQ; return -1; }
     Modal m;
     if (!build_modal(sos, sections, m, err)) return -2;
     std::memset(out, 0, sizeof(*out));
@@ -124,6 +124,9 @@ extern "C" int sdrt_build_decim_tables(const double *sos, int sections, int q, i
         ac[i] = m.alpha[2 * i];
         aa[i] = m.alpha[2 * i] / P[i];
         mu[i] = cpow(P[i], L);
+        put(out->pole[i], P[i]);
+        put(out->ac[i], ac[i]);
+        put(out->aa[i], aa[i]);
     }
     for (int i = 0; i < 4; ++i) {
         for (int j = 0; j < L; ++j) {

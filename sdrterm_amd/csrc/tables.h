@@ -30,6 +30,9 @@ struct DecimTables {
     double tailF[SDRT_NMODE][SDRT_NMODE][2];     // G_end,i = sum_j tailF[i][j] F_j + tailFc[i][j] conj(F_j)
     double tailFc[SDRT_NMODE][SDRT_NMODE][2];    //          + sum_l tailU[i][l] * u[n-28+l]
     double tailU[SDRT_NMODE][SDRT_EDGE + 1][2];
+    // per-sample form (chain_seq_kernel, decimation < 8): F_i(t+1) = p_i F_i(t) + ac_i u[t] (state before sample t),
+    // G_i(t) = p_i G_i(t+1) + aa_i u[t] (inclusive), y[t] = d0p u[t] + 2 Re sum_i (F_i(t) + G_i(t))
+    double pole[SDRT_NMODE][2], ac[SDRT_NMODE][2], aa[SDRT_NMODE][2];
 };
 
 // Tables of the wide-column int8 kernel (chain_i8w_kernel, kernels_i8w.hip).  A matrix-core column is LC = 256 consecutive

@@ -47,7 +47,7 @@ def test_golden_parity(case, golden, stage_a):
     name = case['name']
     eng = _engine(case)
     if stage_a == 'f64':
-        assert eng.stage_a == 'f64'
+        assert eng.stage_a in ('f64', 'seq')         # decimation < 8 always takes the per-sample fp64 form
     elif stage_a == 'auto' and eng.stage_a not in ('i8w', 'i8t'):
         pytest.skip(f'auto: the library uses {eng.stage_a} for this case (covered by another run)')
     elif stage_a != 'auto' and eng.stage_a != stage_a:
