@@ -45,7 +45,7 @@ FP64_PEAK_TFLOPS = 78.6
 
 WORKLOADS = {
     # name: (decimation, total rows, default chunks per step, scaling)
-    'fm64': (64, 1, 32768, 'weak'),
+    'fm64': (64, 1, 131072, 'weak'),
     'simo64': (32, 64, 512, 'strong'),
 }
 
@@ -147,7 +147,7 @@ def main():
     ap.add_argument('--steps', type=int, default=1500)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='fm64')
-    ap.add_argument('--chunks', type=int, default=0, help='chunks per step (fm64: per GPU, default 32768 = 2^30 samples; simo64: 512)')
+    ap.add_argument('--chunks', type=int, default=0, help='chunks per step (fm64: per GPU, default 131072 = 2^32 samples = 16 s of the 256 MS/s stream; simo64: 512)')
     ap.add_argument('--settle-seconds', type=float, default=2.0, help='untimed back-to-back steps before the timed region')
     ap.add_argument('--long-seconds', type=float, default=2.0, help='steady-state run after the timed region (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')

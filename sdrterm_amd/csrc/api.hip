@@ -411,6 +411,8 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         for (int i = 0; i < SDRT_NMODE; ++i)
             for (int l = 0; l <= SDRT_EDGE; ++l)
                 for (int z = 0; z < 2; ++z) { t.head[i][l][z] *= k; t.tailU[i][l][z] *= k; }
+        for (int i = 0; i < SDRT_NMODE; ++i)
+            for (int z = 0; z < 2; ++z) { t.ac[i][z] *= k; t.aa[i][z] *= k; }
     };
     scale_tables(tab);
     rc = upload(&c->d_tab, &tab, sizeof(tab));

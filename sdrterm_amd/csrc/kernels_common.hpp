@@ -115,12 +115,21 @@ __device__ __forceinline__ double decode(typename Enc<DT>::raw v, bool swap) {
 }
 
 // BYTES contiguous bytes per lane (BYTES-aligned) into 32-bit words held in registers, widest loads available.
-template <int BYTES>
+// STREAM: once-read data (the raw sample stream of the persistent kernel): non-temporal loads keep it from displacing the
+// tables and digit planes that every workgroup re-reads from L2.
+template <int BYTES, bool STREAM = false>
 __device__ __forceinline__ void load_words(const unsigned char *p, uint32_t *dst) {
     if constexpr (BYTES % 16 == 0) {
 #pragma unroll
         for (int i = 0; i < BYTES / 16; ++i) {
-            const uint4 v = ((const uint4 *) p)[i];
+            typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+            uint4 v;
+            if constexpr (STREAM) {
+                const v4u_ t = __builtin_nontemporal_load((const v4u_ *) p + i);
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            } else {
+                v = ((const uint4 *) p)[i];
+            }
             dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
         }
     } else if constexpr (BYTES == 8) {

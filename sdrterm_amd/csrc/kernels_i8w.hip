@@ -21,6 +21,10 @@
 // is below the quantisation step of the planes.
 #include "kernels_common.hpp"
 
+#ifndef SDRT_RAW_NT
+#define SDRT_RAW_NT 0          // 1: non-temporal loads of the raw sample stream (measured: see DESIGN.md section 4)
+#endif
+
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             // k-step st (0 .. NSTEP-1) of the item: tile wave + 8 (st / KS), k-step st % KS
             constexpr int st = decltype(sc)::value;
             const unsigned char *p = chunk_raw + ((size_t) (wave + 8 * (st / KS)) * TILE + (size_t) (st % KS) * SPK) * 2 * ITEM + lane_off;
-            load_words<WPK * 4>(p, raw[st % NSLOT]);
+            load_words<WPK * 4, SDRT_RAW_NT != 0>(p, raw[st % NSLOT]);
         };
         {
             const unsigned char *c0 = (const unsigned char *) a.raw + (size_t) chunk_of(0) * chunk_bytes;
