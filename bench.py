@@ -151,7 +151,6 @@ def main():
     ap.add_argument('--settle-seconds', type=float, default=2.0, help='untimed back-to-back steps before the timed region')
     ap.add_argument('--long-seconds', type=float, default=2.0, help='steady-state run after the timed region (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-pipeline', action='store_true', help='demodulation stage after the chain kernel of the same step, not beside the next one')
     ap.add_argument('--no-kernel-events', action='store_true', help='diagnostic: no per-kernel HIP events in the timed region')
     args = ap.parse_args()
 
@@ -187,10 +186,10 @@ def main():
     else:
         freqs_all = simo_rows(rows_total)
         freqs, (lo, hi) = parallel.shard_rows(freqs_all, world, rank)
-        # the stream lives on rank 0 (where the reader's Queue ends); three block buffers per rank: block k+1 arrives beside
-        # the kernels of block k, and with the pipelined stages block k-1 may still be read when step k begins
+        # the stream lives on rank 0 (where the reader's Queue ends); two block buffers per rank: block k+1 arrives beside
+        # the kernels of block k
         src = synth_iq_torch(2 * n_samples, seed=1234, device=device) if rank == 0 else None
-        bufs = [torch.empty((n_samples, 2), dtype=torch.int16, device=device) for _ in range(3)]
+        bufs = [torch.empty((n_samples, 2), dtype=torch.int16, device=device) for _ in range(2)]
         comm = None
         if world > 1:
             uid = [parallel.RcclTransport.unique_id() if rank == 0 else None]
@@ -200,6 +199,10 @@ def main():
     rows = len(freqs)
     out = torch.empty((rows, n_chunks * eng.m), dtype=torch.float64, device=device)
     lib = nat.lib()
+    # everything is submitted to one non-blocking stream of this process (not the legacy default stream, which orders itself against
+    # every other stream)
+    st = torch.cuda.Stream(device=device)
+    S = st.cuda_stream
     s_comm = None
     if comm is not None:
         p = nat.C.c_void_p()
@@ -211,23 +214,24 @@ def main():
     state = {'k': 0}
 
     def fetch(k):
-        """Block k of the stream into buffer k % 3 on every rank (simo64)."""
-        dst = bufs[k % 3]
+        """Block k of the stream into buffer k % 2 on every rank (simo64)."""
+        dst = bufs[k % 2]
         if rank == 0:
-            dst.copy_(src[(k % 2) * n_samples:(k % 2 + 1) * n_samples], non_blocking=True)
+            with torch.cuda.stream(st):
+                dst.copy_(src[(k % 2) * n_samples:(k % 2 + 1) * n_samples], non_blocking=True)
         if comm is not None:
-            nat.check(lib.sdrt_stream_wait_stream(s_comm, None))        # after the copy above / the kernels still reading dst
+            nat.check(lib.sdrt_stream_wait_stream(s_comm, S))        # after the copy above / the kernels still reading dst
             comm.bcast_device(dst.data_ptr(), block_bytes, 0, s_comm)
 
-    run = eng.process_device if args.no_pipeline else eng.process_device_pipelined
+    run = eng.process_device
 
     def step():
         k = state['k']
         if args.workload == 'simo64':
             fetch(k + 1)                                               # beside this step's kernels (other buffer)
-        run(bufs[k % len(bufs)].data_ptr(), n_chunks, out.data_ptr(), 0)
+        run(bufs[k % len(bufs)].data_ptr(), n_chunks, out.data_ptr(), S)
         if comm is not None:
-            nat.check(lib.sdrt_stream_wait_stream(None, s_comm))         # the next step's kernels need that block
+            nat.check(lib.sdrt_stream_wait_stream(S, s_comm))         # the next step's kernels need that block
         state['k'] = k + 1
 
     def barrier():
@@ -237,32 +241,29 @@ def main():
     if args.workload == 'simo64':
         fetch(0)
         if comm is not None:
-            nat.check(lib.sdrt_stream_wait_stream(None, s_comm))
+            nat.check(lib.sdrt_stream_wait_stream(S, s_comm))
     for _ in range(args.warmup):
         step()
-    eng.flush(0)
     torch.cuda.synchronize()
     t_settle = time.perf_counter()
     settle_steps = 0
     while time.perf_counter() - t_settle < args.settle_seconds:
         for _ in range(16):
             step()
-        eng.flush(0)
         torch.cuda.synchronize()
         settle_steps += 16
 
     # ---- the timed region: exactly K steps ---------------------------------------------------------------------------
     eng.profile(not args.no_kernel_events)
     eng.profile_reset()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # default stream == the launch stream (0)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # recorded on the submission stream
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    evs[0].record()
+    evs[0].record(st)
     for i in range(args.steps):
         step()
-        evs[i + 1].record()
-    eng.flush(0)                  # every step's results are complete inside the timed region
+        evs[i + 1].record(st)
     torch.cuda.synchronize()
     barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
@@ -282,7 +283,6 @@ def main():
         t1 = time.perf_counter()
         for _ in range(n_long):
             step()
-        eng.flush(0)
         torch.cuda.synchronize()
         barrier()
         dt_long = parallel.max_over_ranks(time.perf_counter() - t1, device)
@@ -332,8 +332,7 @@ def main():
                         f'{n_chunks} chunks x {N} samples per step resident on rank 0, RCCL broadcast per step'),
                        'chunks_per_step_per_gpu': n_chunks, 'samples_per_chunk': N, 'rows_per_gpu': rows,
                        'parallelism': f'chunk-sharded x{world}' if args.workload == 'fm64' else f'rows-sharded x{world} + bcast',
-                       'settle_steps': settle_steps + args.warmup,
-                       'stages': 'in sequence' if args.no_pipeline else 'demodulation of step k beside the chain kernel of step k+1 (sdrt_process_device_pipelined)'},
+                       'settle_steps': settle_steps + args.warmup},
             'step_ms': {'median': round(step_ms[len(step_ms) // 2], 4), 'min': round(step_ms[0], 4), 'max': round(step_ms[-1], 4),
                         'timed_region_s': round(elapsed, 3)},
             'steady_state': steady,

@@ -102,17 +102,6 @@ int sdrt_rows(const sdrt_ctx *ctx);
 int sdrt_process_device(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, double *out_dev, void *stream);
 int sdrt_process_host(sdrt_ctx *ctx, const void *raw_host, size_t n_chunks, double *out_host);
 
-/*
- * Pipelined form for a host that streams batch after batch: the demodulation stage of call k (short dependent chains, far
- * from the chip's power limit) runs beside the matrix-core kernel of call k + 1 instead of after it -- the two stages go to
- * two internal streams confined to disjoint sets of compute units (7/8 and 1/8 of the chip).  Same arguments and results as
- * sdrt_process_device, with one difference in ordering: work submitted to `stream` after call k + 1 (or after sdrt_flush)
- * sees `out_dev` of call k; call k itself only orders `stream` behind the results of call k - 1.  `raw_dev` and `out_dev` of a
- * call must stay untouched until then.
- */
-int sdrt_process_device_pipelined(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, double *out_dev, void *stream);
-int sdrt_flush(sdrt_ctx *ctx, void *stream);      /* `stream` waits for every pipelined call made so far */
-
 /* Same as sdrt_process_device, additionally storing the decimated complex samples (the value of `y` after
  * dsp_processor.py:147) as interleaved float64 (re, im), layout [row][chunk][m][2].  For parity tests. */
 int sdrt_process_device_debug(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, double *out_dev,

@@ -65,12 +65,8 @@ struct sdrt_ctx {
     double *d_smooth = nullptr;       // taps | left | right of --smooth-output (sdrt_set_smoothing)
     int sm_window = 0, sm_ntaps = 0, sm_first = 0, sm_edge = 0;
     bool fft_ok = false, out_modal = false;
-    double *d_y[2] = {nullptr, nullptr};   // [row][chunk][m][2] decimated samples between the two kernels (second: pipelined form)
-    size_t y_cap_chunks[2] = {0, 0};
-    hipStream_t pipe_a = nullptr, pipe_b = nullptr;   // pipelined form: CU-masked streams of the two stages
-    hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr}, ev_in = nullptr;
-    uint64_t pipe_k = 0;
-    int pipe_cus = 224, n_cus_total = 256;
+    double *d_y = nullptr;            // [row][chunk][m][2] decimated samples between the two kernels
+    size_t y_cap_chunks = 0;
     void *d_raw = nullptr;
     double *d_out = nullptr;
     size_t stage_cap_chunks = 0;
@@ -476,9 +472,6 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         const bool want_t = force && strcmp(force, "i8t") == 0;       // "i8t" the one-block-per-column 16x16x64 kernel
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->n_cus = cus;
-        c->n_cus_total = c->n_cus;
-        c->pipe_cus = c->n_cus / 8 * 7;                       // pipelined form: 7/8 of the units to unpack .. decimate
-        if (const char *e = getenv("SDRTERM_PIPE_CUS")) { const int v = atoi(e); if (v >= 8 && v < c->n_cus) c->pipe_cus = v / 8 * 8; }
         if (const char *e = getenv("SDRTERM_WIDE_CUS")) { const int v = atoi(e); if (v >= 8 && v <= c->n_cus) c->n_cus = v / 8 * 8; }   // diagnostics: fewer persistent workgroups
         // int8 matrix-core forms in order of preference; a form that cannot represent this configuration (unequal
         // power-of-two scales between rows, a digit overflow) releases what it uploaded and the next one is tried; the
@@ -515,12 +508,7 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_fft_shift);
     (void) hipFree(c->d_out_sos);
     (void) hipFree(c->d_otab);
-    (void) hipFree(c->d_y[0]);
-    (void) hipFree(c->d_y[1]);
-    if (c->pipe_a) (void) hipStreamDestroy(c->pipe_a);
-    if (c->pipe_b) (void) hipStreamDestroy(c->pipe_b);
-    for (int i = 0; i < 2; ++i) { if (c->ev_chain[i]) (void) hipEventDestroy(c->ev_chain[i]); if (c->ev_post[i]) (void) hipEventDestroy(c->ev_post[i]); }
-    if (c->ev_in) (void) hipEventDestroy(c->ev_in);
+    (void) hipFree(c->d_y);
     (void) hipFree(c->d_w8);
     (void) hipFree(c->d_w8mid);
     (void) hipFree(c->d_tab8);
@@ -578,14 +566,14 @@ int sdrt_rows(const sdrt_ctx *c) { return c ? c->rows : -1; }
 
 namespace {
 
-// scratch for the decimated samples between the two stages (slot 1: second buffer of the pipelined form)
-int ensure_ybuf(sdrt_ctx *c, int slot, size_t n_chunks) {
-    if (n_chunks > c->y_cap_chunks[slot]) {
-        (void) hipFree(c->d_y[slot]);
-        c->d_y[slot] = nullptr;
-        c->y_cap_chunks[slot] = 0;
-        HIP_TRY(hipMalloc((void **) &c->d_y[slot], n_chunks * (size_t) c->rows * c->m * 2 * sizeof(double)));
-        c->y_cap_chunks[slot] = n_chunks;
+// scratch for the decimated samples between the two stages
+int ensure_ybuf(sdrt_ctx *c, size_t n_chunks) {
+    if (n_chunks > c->y_cap_chunks) {
+        (void) hipFree(c->d_y);
+        c->d_y = nullptr;
+        c->y_cap_chunks = 0;
+        HIP_TRY(hipMalloc((void **) &c->d_y, n_chunks * (size_t) c->rows * c->m * 2 * sizeof(double)));
+        c->y_cap_chunks = n_chunks;
     }
     return SDRT_OK;
 }
@@ -742,69 +730,13 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     hipStream_t s = (hipStream_t) stream;
     double *ybuf = ydec_dev;
     if (!ybuf) {
-        rc = ensure_ybuf(c, 0, n_chunks);
+        rc = ensure_ybuf(c, n_chunks);
         if (rc != SDRT_OK) return rc;
-        ybuf = c->d_y[0];
+        ybuf = c->d_y;
     }
     rc = enqueue_chain(c, raw_dev, n_chunks, ybuf, s, c->n_cus);
     if (rc != SDRT_OK) return rc;
     return enqueue_post(c, ybuf, n_chunks, out_dev, s);
-}
-
-/*
- * Pipelined form: the two stages of consecutive calls overlap.  Unpack .. decimate of call k runs on a stream confined to
- * the first pipe_cus compute units, the demodulation stage of call k on a stream confined to the rest (CU masks), so the
- * demodulation stage -- short dependent chains, far from the chip's power limit -- runs beside the next call's matrix-core
- * kernel instead of after it.  `out` of call k is ordered before work submitted to `stream` after call k + 1, or after
- * sdrt_flush.
- */
-int sdrt_process_device_pipelined(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *out_dev, void *stream) {
-    if (!c) return fail(SDRT_EINVAL, "null context");
-    if (n_chunks == 0) return SDRT_OK;
-    int rc = check_process_args(c, raw_dev, n_chunks, out_dev);
-    if (rc != SDRT_OK) return rc;
-    HIP_TRY(hipSetDevice(c->cfg.device));
-    hipStream_t s = (hipStream_t) stream;
-    if (!c->pipe_a) {
-        // mask bits are dealt to the XCDs in turn (bit i -> XCD i % 8): the first pipe_cus bits leave every XCD pipe_cus / 8 units
-        const int total = c->n_cus_total, words = (total + 31) / 32;
-        std::vector<uint32_t> ma(words, 0u), mb(words, 0u);
-        for (int i = 0; i < total; ++i) (i < c->pipe_cus ? ma : mb)[i / 32] |= 1u << (i % 32);
-        HIP_TRY(hipExtStreamCreateWithCUMask(&c->pipe_a, (uint32_t) words, ma.data()));
-        HIP_TRY(hipExtStreamCreateWithCUMask(&c->pipe_b, (uint32_t) words, mb.data()));
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(hipEventCreateWithFlags(&c->ev_chain[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&c->ev_post[i], hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-    }
-    const int slot = (int) (c->pipe_k & 1);
-    rc = ensure_ybuf(c, slot, n_chunks);
-    if (rc != SDRT_OK) return rc;
-    // A: after the caller's earlier work on `stream` (the input is ready) and after the demodulation stage that last read this
-    // slot of the decimated samples (call k - 2)
-    HIP_TRY(hipEventRecord(c->ev_in, s));
-    HIP_TRY(hipStreamWaitEvent(c->pipe_a, c->ev_in, 0));
-    if (c->pipe_k >= 2) HIP_TRY(hipStreamWaitEvent(c->pipe_a, c->ev_post[slot], 0));
-    rc = enqueue_chain(c, raw_dev, n_chunks, c->d_y[slot], c->pipe_a, c->pipe_cus);
-    if (rc != SDRT_OK) return rc;
-    HIP_TRY(hipEventRecord(c->ev_chain[slot], c->pipe_a));
-    HIP_TRY(hipStreamWaitEvent(c->pipe_b, c->ev_chain[slot], 0));
-    rc = enqueue_post(c, c->d_y[slot], n_chunks, out_dev, c->pipe_b);
-    if (rc != SDRT_OK) return rc;
-    HIP_TRY(hipEventRecord(c->ev_post[slot], c->pipe_b));
-    // the caller's stream: behind the PREVIOUS call's results
-    if (c->pipe_k >= 1) HIP_TRY(hipStreamWaitEvent(s, c->ev_post[slot ^ 1], 0));
-    c->pipe_k += 1;
-    return SDRT_OK;
-}
-
-int sdrt_flush(sdrt_ctx *c, void *stream) {
-    if (!c) return fail(SDRT_EINVAL, "null context");
-    if (!c->pipe_a || c->pipe_k == 0) return SDRT_OK;
-    HIP_TRY(hipSetDevice(c->cfg.device));
-    HIP_TRY(hipStreamWaitEvent((hipStream_t) stream, c->ev_post[(c->pipe_k - 1) & 1], 0));
-    return SDRT_OK;
 }
 
 int sdrt_process_device(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *out_dev, void *stream) {

@@ -139,14 +139,6 @@ class Engine:
         nat.check(nat.lib().sdrt_process_host(self._ctx, buf.ctypes.data, n_chunks, out.ctypes.data))
         return out
 
-    def process_device_pipelined(self, raw_ptr: int, n_chunks: int, out_ptr: int, stream: int = 0):
-        """As process_device, the demodulation stage of this call running beside the next call's chain kernel; results are
-        ordered on ``stream`` after the next call or ``flush`` (include/sdrterm_hip.h: sdrt_process_device_pipelined)."""
-        nat.check(nat.lib().sdrt_process_device_pipelined(self._ctx, raw_ptr, n_chunks, out_ptr, stream or None))
-
-    def flush(self, stream: int = 0):
-        nat.check(nat.lib().sdrt_flush(self._ctx, stream or None))
-
     def process_device(self, raw_ptr: int, n_chunks: int, out_ptr: int, stream: int = 0, ydec_ptr: int = 0):
         """Device pointers in/out, asynchronous on ``stream`` (hipStream_t handle, 0 = default).  One stream per context:
         the decimated samples and the IQ prefix tables of a call live in per-context scratch buffers."""
