@@ -33,8 +33,10 @@ enum sdrt_dtype {
     SDRT_S8 = 0, SDRT_U8 = 1, SDRT_S16 = 2, SDRT_U16 = 3, SDRT_S32 = 4, SDRT_U32 = 5, SDRT_F32 = 6, SDRT_F64 = 7
 };
 
-/* Demodulation: DspProcessor.selectOutputFm / selectOutputAm (dsp_processor.py:116-128). */
-enum sdrt_mode { SDRT_FM = 0, SDRT_AM = 1 };
+/* Demodulation: DspProcessor.selectOutputFm / selectOutputAm (dsp_processor.py:116-128) with the output lowpass, and
+ * selectOutputReal / selectOutputImag (dsp_processor.py:130-138): the real / imaginary part of the decimated samples
+ * (demodulation.py:51-68) with no output filter (out_sos is ignored and may be NULL). */
+enum sdrt_mode { SDRT_FM = 0, SDRT_AM = 1, SDRT_RE = 2, SDRT_IM = 3 };
 
 enum sdrt_status {
     SDRT_OK = 0,
@@ -101,6 +103,17 @@ int sdrt_rows(const sdrt_ctx *ctx);
  */
 int sdrt_process_device(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, double *out_dev, void *stream);
 int sdrt_process_host(sdrt_ctx *ctx, const void *raw_host, size_t n_chunks, double *out_host);
+
+/*
+ * Host buffers, batches in flight: sdrt_submit_host starts copy-in, kernels and copy-out of one batch and returns a ticket;
+ * sdrt_wait(ticket) returns when that batch's `out_host` is filled.  Up to three batches are in flight (the copy-in of
+ * batch k+1 beside the kernels of batch k and the copy-out of batch k-1); a fourth submit first completes the oldest.
+ * `raw_host` may be reused once the call has returned if it is pageable, after sdrt_wait if it came from sdrt_host_alloc;
+ * `out_host` must stay valid until sdrt_wait.  Batches are processed in submission order (the IQ offset carries over).
+ * sdrt_process_host is submit + wait.
+ */
+int sdrt_submit_host(sdrt_ctx *ctx, const void *raw_host, size_t n_chunks, double *out_host, int64_t *ticket);
+int sdrt_wait(sdrt_ctx *ctx, int64_t ticket);
 
 /* Same as sdrt_process_device, additionally storing the decimated complex samples (the value of `y` after
  * dsp_processor.py:147) as interleaved float64 (re, im), layout [row][chunk][m][2].  For parity tests. */

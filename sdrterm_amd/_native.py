@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('SDRTERM_HIP_LIB') or os.path.join(_HERE, 'libsdrterm_
 # enum sdrt_dtype, keyed by the reference's DataType names (src/misc/file_util.py:44-56)
 DTYPES = {'b': 0, 'B': 1, 'h': 2, 'H': 3, 'i': 4, 'I': 5, 'f': 6, 'd': 7}
 ITEM_SIZE = {'b': 1, 'B': 1, 'h': 2, 'H': 2, 'i': 4, 'I': 4, 'f': 4, 'd': 8}
-MODES = {'fm': 0, 'am': 1}
+MODES = {'fm': 0, 'am': 1, 're': 2, 'im': 3}
 OK, EINVAL, EHIP, ENOMEM, ENODEVICE = 0, 1, 2, 3, 4
 
 ABI_VERSION = 3
@@ -29,7 +29,7 @@ EXPORTS = (
     'sdrt_stream_create', 'sdrt_stream_destroy', 'sdrt_stream_synchronize', 'sdrt_host_alloc', 'sdrt_host_free',
     'sdrt_memcpy_h2d_async', 'sdrt_memcpy_d2h_async', 'sdrt_stream_wait_stream',
     'sdrt_comm_unique_id', 'sdrt_comm_init', 'sdrt_comm_bcast', 'sdrt_comm_allgather', 'sdrt_comm_world', 'sdrt_comm_rank',
-    'sdrt_comm_destroy',
+    'sdrt_comm_destroy', 'sdrt_submit_host', 'sdrt_wait',
 )
 
 
@@ -107,6 +107,8 @@ def lib():
     l.sdrt_rows.argtypes = [C.c_void_p]
     l.sdrt_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     l.sdrt_process_device_debug.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    l.sdrt_submit_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int64)]
+    l.sdrt_wait.argtypes = [C.c_void_p, C.c_int64]
     l.sdrt_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     l.sdrt_get_iq_offset.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     l.sdrt_set_iq_offset.argtypes = [C.c_void_p, C.c_double, C.c_double]
@@ -159,6 +161,28 @@ def device_count() -> int:
     n = C.c_int(0)
     rc = lib().sdrt_device_count(C.byref(n))
     return n.value if rc == OK else 0
+
+
+def pinned_array(nbytes: int):
+    """A page-locked host buffer (sdrt_host_alloc) as a numpy uint8 array: copies from / to it are asynchronous and run at
+    the full PCIe rate.  The memory is released when the array's base object goes away."""
+    import numpy as np
+    p = C.c_void_p()
+    check(lib().sdrt_host_alloc(C.byref(p), int(nbytes)))
+
+    class _Owner:
+        def __init__(self, ptr):
+            self.ptr = ptr
+
+        def __del__(self):
+            try:
+                lib().sdrt_host_free(self.ptr)
+            except Exception:
+                pass
+    owner = _Owner(p.value)
+    buf = (C.c_uint8 * int(nbytes)).from_address(p.value)
+    buf._owner = owner
+    return np.frombuffer(buf, dtype=np.uint8)
 
 
 class DeviceBuffer:

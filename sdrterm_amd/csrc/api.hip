@@ -53,6 +53,16 @@ struct Pending {
 
 }  // namespace
 
+#define SDRT_HOST_SLOTS 3
+struct HostSlot {
+    void *d_raw = nullptr;
+    double *d_out = nullptr, *h_out = nullptr, *out_host = nullptr;
+    size_t cap_chunks = 0, out_bytes = 0;
+    hipEvent_t e_in = nullptr, e_run = nullptr, e_out = nullptr;
+    bool busy = false, direct_out = false;
+    int64_t ticket = -1;
+};
+
 struct sdrt_ctx {
     sdrt_config cfg;
     int L = 0, m = 0, n_tiles = 0, rows = 1;
@@ -67,9 +77,9 @@ struct sdrt_ctx {
     bool fft_ok = false, out_modal = false;
     double *d_y = nullptr;            // [row][chunk][m][2] decimated samples between the two kernels
     size_t y_cap_chunks = 0;
-    void *d_raw = nullptr;
-    double *d_out = nullptr;
-    size_t stage_cap_chunks = 0;
+    HostSlot hs[SDRT_HOST_SLOTS];     // host path: batches in flight (sdrt_submit_host / sdrt_wait)
+    int64_t hs_next = 0;
+    hipStream_t hs_h2d = nullptr, hs_run = nullptr, hs_d2h = nullptr;
     bool use_i8 = false;              // stage A on the int8 matrix cores (8/16-bit integer encodings): use_i8w || use_i8t
     bool use_i8t = false;             //   ... one block per column (16x16x64), no IQ correction
     bool use_i8w = false;             //   ... wide columns, persistent workgroups (default where supported)
@@ -332,9 +342,10 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         return fail(SDRT_EINVAL, "sdrt_config size mismatch (got %u, built with %zu)", cfg->struct_size, sizeof(sdrt_config));
     if (cfg->decimation < 2) return fail(SDRT_EINVAL, "Decimation must be at least 2.");  // dsp_processor.py:94-95
     if (cfg->dtype < 0 || cfg->dtype > 7) return fail(SDRT_EINVAL, "unknown dtype %d", cfg->dtype);
-    if (cfg->mode != SDRT_FM && cfg->mode != SDRT_AM) return fail(SDRT_EINVAL, "unknown mode %d", cfg->mode);
-    if (!cfg->dec_sos || !cfg->out_sos) return fail(SDRT_EINVAL, "dec_sos and out_sos are required");
-    if (cfg->out_sections < 1 || cfg->out_sections > SDRT_MAX_OUT_SECTIONS)
+    if (cfg->mode < SDRT_FM || cfg->mode > SDRT_IM) return fail(SDRT_EINVAL, "unknown mode %d", cfg->mode);
+    const bool filtered = cfg->mode == SDRT_FM || cfg->mode == SDRT_AM;      // real / imaginary output: no output lowpass
+    if (!cfg->dec_sos || (filtered && !cfg->out_sos)) return fail(SDRT_EINVAL, "dec_sos and out_sos are required");
+    if (filtered && (cfg->out_sections < 1 || cfg->out_sections > SDRT_MAX_OUT_SECTIONS))
         return fail(SDRT_EINVAL, "out_sections must be 1..%d", SDRT_MAX_OUT_SECTIONS);
     if (cfg->n_rows < 1) return fail(SDRT_EINVAL, "n_rows must be >= 1");
     if (cfg->apply_shift && !cfg->row_freqs) return fail(SDRT_EINVAL, "row_freqs required when apply_shift is set");
@@ -356,7 +367,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     {
         const int Nh = m / 2;
         const bool fft_fm = cfg->mode == SDRT_FM && (Nh == 256 || Nh == 512 || Nh == 1024 || Nh == 2048);
-        if (!fft_fm && post_waves_per_block(m, cfg->mode) == 0 && !(m >= 8192 && post_big_supported(m, cfg->mode)))
+        if (filtered && !fft_fm && post_waves_per_block(m, cfg->mode) == 0 && !(m >= 8192 && post_big_supported(m, cfg->mode)))
             return fail(SDRT_EINVAL, "%d outputs per chunk (n_samples / decimation) exceed what the demodulation stage holds in LDS", m);
     }
     const int iq_gs = seq ? 16 : L / 4;                      // samples per group of the IQ prefix tables
@@ -435,8 +446,8 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
             rc = upload(&c->d_iq_state, zero, sizeof(zero));
         }
     }
-    if (rc == SDRT_OK) rc = upload(&c->d_out_sos, cfg->out_sos, sizeof(double) * 6 * cfg->out_sections);
-    if (rc == SDRT_OK) {
+    if (rc == SDRT_OK && filtered) rc = upload(&c->d_out_sos, cfg->out_sos, sizeof(double) * 6 * cfg->out_sections);
+    if (rc == SDRT_OK && filtered) {
         OutTables otab;
         sdrt_build_out_tables(cfg->out_sos, cfg->out_sections, m, &otab);
         rc = upload(&c->d_otab, &otab, sizeof(otab));
@@ -524,8 +535,13 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_iq_group);
     (void) hipFree(c->d_iq_agg);
     (void) hipFree(c->d_iq_chunk);
-    (void) hipFree(c->d_raw);
-    (void) hipFree(c->d_out);
+    for (auto &sl : c->hs) {
+        (void) hipFree(sl.d_raw);
+        (void) hipFree(sl.d_out);
+        if (sl.h_out) (void) hipHostFree(sl.h_out);
+        if (sl.e_in) { (void) hipEventDestroy(sl.e_in); (void) hipEventDestroy(sl.e_run); (void) hipEventDestroy(sl.e_out); }
+    }
+    if (c->hs_h2d) { (void) hipStreamDestroy(c->hs_h2d); (void) hipStreamDestroy(c->hs_run); (void) hipStreamDestroy(c->hs_d2h); }
     delete c;
 }
 
@@ -743,28 +759,102 @@ int sdrt_process_device(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, doubl
     return sdrt_process_device_debug(c, raw_dev, n_chunks, out_dev, nullptr, stream);
 }
 
+/*
+ * Host path (read_file.py:119-125 -> Queue -> dsp_processor.py:164-183): three slots of device buffers + page-locked
+ * output staging and three streams, so that the copy-in of batch k+1 runs beside the kernels of batch k and the copy-out of
+ * batch k-1.  Kernels of consecutive batches stay in order on one stream (the IQ offset and the per-context scratch are
+ * sequential).  Slots grow when a larger batch arrives and are reused otherwise: no allocation on the steady-state path.
+ */
+namespace {
+
+int host_slot_prepare(sdrt_ctx *c, HostSlot &sl, size_t n_chunks, size_t in_bytes, size_t out_bytes) {
+    if (!c->hs_h2d) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->hs_h2d, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->hs_run, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->hs_d2h, hipStreamNonBlocking));
+    }
+    if (!sl.e_in) {
+        HIP_TRY(hipEventCreateWithFlags(&sl.e_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.e_run, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.e_out, hipEventDisableTiming));
+    }
+    if (n_chunks > sl.cap_chunks) {
+        if (sl.d_raw) HIP_TRY(hipFree(sl.d_raw));
+        if (sl.d_out) HIP_TRY(hipFree(sl.d_out));
+        if (sl.h_out) HIP_TRY(hipHostFree(sl.h_out));
+        sl.d_raw = nullptr; sl.d_out = nullptr; sl.h_out = nullptr; sl.cap_chunks = 0;
+        HIP_TRY(hipMalloc(&sl.d_raw, n_chunks * in_bytes));
+        HIP_TRY(hipMalloc((void **) &sl.d_out, n_chunks * out_bytes));
+        HIP_TRY(hipHostMalloc((void **) &sl.h_out, n_chunks * out_bytes, hipHostMallocDefault));
+        sl.cap_chunks = n_chunks;
+    }
+    return SDRT_OK;
+}
+
+// the slot's batch is finished: results into the caller's buffer (unless the copy-out went there directly)
+int host_slot_finish(HostSlot &sl) {
+    if (!sl.busy) return SDRT_OK;
+    HIP_TRY(hipEventSynchronize(sl.e_out));
+    if (!sl.direct_out) memcpy(sl.out_host, sl.h_out, sl.out_bytes);
+    sl.busy = false;
+    return SDRT_OK;
+}
+
+bool is_pinned(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void) hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+}  // namespace
+
+int sdrt_submit_host(sdrt_ctx *c, const void *raw_host, size_t n_chunks, double *out_host, int64_t *ticket) {
+    if (!c || !ticket) return fail(SDRT_EINVAL, "null argument");
+    if (!raw_host || !out_host || n_chunks == 0) return fail(SDRT_EINVAL, "null or empty buffer");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const size_t in_bytes = (size_t) c->cfg.n_samples * 2 * kItemSize[c->cfg.dtype];
+    const size_t out_bytes = (size_t) c->rows * c->m * sizeof(double);
+    const int64_t t = c->hs_next++;
+    HostSlot &sl = c->hs[t % SDRT_HOST_SLOTS];
+    int rc = host_slot_finish(sl);                      // the ring has come round: that batch's results are due now
+    if (rc == SDRT_OK) rc = host_slot_prepare(c, sl, n_chunks, in_bytes, out_bytes);
+    if (rc != SDRT_OK) return rc;
+    // copy-in: asynchronous from page-locked memory (sdrt_host_alloc); from pageable memory the runtime stages the copy and
+    // this call returns when it is done -- the previous batch's kernels run meanwhile either way
+    HIP_TRY(hipMemcpyAsync(sl.d_raw, raw_host, n_chunks * in_bytes, hipMemcpyHostToDevice, c->hs_h2d));
+    HIP_TRY(hipEventRecord(sl.e_in, c->hs_h2d));
+    HIP_TRY(hipStreamWaitEvent(c->hs_run, sl.e_in, 0));
+    rc = sdrt_process_device(c, sl.d_raw, n_chunks, sl.d_out, c->hs_run);
+    if (rc != SDRT_OK) return rc;
+    HIP_TRY(hipEventRecord(sl.e_run, c->hs_run));
+    HIP_TRY(hipStreamWaitEvent(c->hs_d2h, sl.e_run, 0));
+    sl.direct_out = is_pinned(out_host);
+    sl.out_host = out_host;
+    sl.out_bytes = n_chunks * out_bytes;
+    HIP_TRY(hipMemcpyAsync(sl.direct_out ? (void *) out_host : (void *) sl.h_out, sl.d_out, sl.out_bytes, hipMemcpyDeviceToHost, c->hs_d2h));
+    HIP_TRY(hipEventRecord(sl.e_out, c->hs_d2h));
+    sl.busy = true;
+    sl.ticket = t;
+    *ticket = t;
+    return SDRT_OK;
+}
+
+int sdrt_wait(sdrt_ctx *c, int64_t ticket) {
+    if (!c) return fail(SDRT_EINVAL, "null context");
+    if (ticket < 0 || ticket >= c->hs_next) return fail(SDRT_EINVAL, "unknown ticket");
+    HostSlot &sl = c->hs[ticket % SDRT_HOST_SLOTS];
+    if (!sl.busy || sl.ticket != ticket) return SDRT_OK;          // already delivered (the ring came round, or waited before)
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    return host_slot_finish(sl);
+}
+
 int sdrt_process_host(sdrt_ctx *c, const void *raw_host, size_t n_chunks, double *out_host) {
     if (!c) return fail(SDRT_EINVAL, "null context");
     if (n_chunks == 0) return SDRT_OK;
-    if (!raw_host || !out_host) return fail(SDRT_EINVAL, "null buffer");
-    HIP_TRY(hipSetDevice(c->cfg.device));
-    const size_t in_bytes = (size_t) c->cfg.n_samples * 2 * kItemSize[c->cfg.dtype];
-    const size_t out_elems = (size_t) c->rows * c->m;
-    if (n_chunks > c->stage_cap_chunks) {
-        if (c->d_raw) HIP_TRY(hipFree(c->d_raw));
-        if (c->d_out) HIP_TRY(hipFree(c->d_out));
-        c->d_raw = nullptr;
-        c->d_out = nullptr;
-        c->stage_cap_chunks = 0;
-        HIP_TRY(hipMalloc(&c->d_raw, n_chunks * in_bytes));
-        HIP_TRY(hipMalloc((void **) &c->d_out, n_chunks * out_elems * sizeof(double)));
-        c->stage_cap_chunks = n_chunks;
-    }
-    HIP_TRY(hipMemcpy(c->d_raw, raw_host, n_chunks * in_bytes, hipMemcpyHostToDevice));
-    int rc = sdrt_process_device(c, c->d_raw, n_chunks, c->d_out, nullptr);
+    int64_t t = -1;
+    int rc = sdrt_submit_host(c, raw_host, n_chunks, out_host, &t);
     if (rc != SDRT_OK) return rc;
-    HIP_TRY(hipMemcpy(out_host, c->d_out, n_chunks * out_elems * sizeof(double), hipMemcpyDeviceToHost));
-    return SDRT_OK;
+    return sdrt_wait(c, t);
 }
 
 int sdrt_get_iq_offset(sdrt_ctx *c, double *re, double *im) {

@@ -372,7 +372,18 @@ size_t post_lds_bytes(int m, int mode) {
     return post_lds_bytes_w(m, mode, w ? w : 1);
 }
 
+// realOutput / imagOutput (demodulation.py:51-68) of the decimated samples; no output filter follows (dsp_processor.py:130-138)
+__global__ __launch_bounds__(256) void part_kernel(const double *__restrict__ y, double *__restrict__ out, size_t count, int imag) {
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t) gridDim.x * 256) out[i] = y[2 * i + imag];
+}
+
 hipError_t launch_post(const PostArgs &a, hipStream_t s) {
+    if (a.mode == SDRT_RE || a.mode == SDRT_IM) {
+        const size_t count = a.items * (size_t) a.m;
+        const size_t wgs = (count + 255) / 256;
+        hipLaunchKernelGGL(part_kernel, dim3((unsigned) (wgs < 4096 ? wgs : 4096)), dim3(256), 0, s, a.y, a.out, count, a.mode == SDRT_IM ? 1 : 0);
+        return hipGetLastError();
+    }
     // FFT form of the resampler where it applies: FM, N = m/2 in {256, 512, 1024}, output lowpass in modal form
     if (a.mode == SDRT_FM && a.fft_tw && a.fft_shift && a.fft_ok) {
         switch (a.m) {

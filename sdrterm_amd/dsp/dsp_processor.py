@@ -11,6 +11,7 @@ ctypes or HIP handle exists until ``processData`` runs there; the GPU context is
 where the reference allocates its x/y/z buffers (dsp_processor.py:171-178).
 """
 import json
+import os
 import sys
 from queue import Empty
 
@@ -64,6 +65,7 @@ class DspProcessor(DataProcessor):
         self._engine = None
         self._engineReader = {}
         self._device = int(kwargs.get('device') or 0)
+        self._workingReIm = bool(kwargs.get('workingReIm') or os.environ.get('SDRTERM_WORKING_REIM') == '1')
 
     # ---- rates ----------------------------------------------------------------------------------------
     @property
@@ -166,12 +168,14 @@ class DspProcessor(DataProcessor):
         mode = getattr(self.demod, 'mode', None)
         if mode not in ('fm', 'am', 're', 'im'):
             raise TypeError(f'{self.demod!r} is not a demodulation selector of this package')
-        if mode in ('re', 'im') or not len(self._outputFilters):
+        if not len(self._outputFilters) and not (mode in ('re', 'im') and self._workingReIm):
             # the reference gets here with an empty filter list and scipy.signal.sosfilt([]) raises
-            # (dsp_processor.py:130-138,149); same exception type and text
+            # (dsp_processor.py:130-138,149); same exception type and text.  workingReIm=True (keyword or
+            # SDRTERM_WORKING_REIM=1) writes the real / imaginary part of the decimated samples instead, which is what
+            # selectOutputReal / selectOutputImag set out to do
             raise ValueError('sos array must be 2D')
         from ..engine import Engine
-        sos = np.asarray(self._outputFilters, dtype=np.float64).reshape(-1, 6)
+        sos = np.asarray(self._outputFilters, dtype=np.float64).reshape(-1, 6) if len(self._outputFilters) else None
         self._engine = Engine(self._fs, self._decimationFactor, mode, code, n_samples=n, row_freqs=self._rowFreqs(),
                               apply_shift=self._applyShift(), out_sos=sos, device=self._device, smooth=window, **reader)
         self._engineReader = reader
@@ -214,30 +218,57 @@ class DspProcessor(DataProcessor):
     def _isChunk(item) -> bool:
         return isinstance(item, np.ndarray) or type(item).__name__ == 'RawChunk'
 
-    def _runBatch(self, chunks) -> np.ndarray:
+    def _submitBatch(self, chunks):
+        """Starts the batch on the GPU (copy-in, kernels and copy-out are asynchronous: Engine.submit) and returns a handle for
+        ``_collectBatch``: the next batch's copy-in then overlaps this one's kernels."""
         eng = self._getEngine(chunks[0].size, self._encodingOf(chunks[0]), **self._readerSteps(chunks[0]))
         if self._readerSteps(chunks[0]):
             raw = b''.join(c.data for c in chunks)
         else:
             raw = np.ascontiguousarray(np.stack(chunks) if len(chunks) > 1 else chunks[0])
-        return eng.process(raw, len(chunks)).reshape(self._nFreq, len(chunks), eng.m)
+        return eng, eng.submit(raw, len(chunks)), len(chunks)
+
+    def _collectBatch(self, pending) -> np.ndarray:
+        eng, handle, n = pending
+        return eng.collect(handle).reshape(self._nFreq, n, eng.m)
+
+    def _runBatch(self, chunks) -> np.ndarray:
+        return self._collectBatch(self._submitBatch(chunks))
 
     def _emit(self, z: np.ndarray, file) -> None:
         """z (nFreq, chunks, m): the reference writes chunk after chunk, native-endian doubles."""
         for c in range(z.shape[1]):
             file.write(np.ascontiguousarray(z[:, c, :], dtype='=f8').tobytes())
 
+    @staticmethod
+    def _moreQueued(buffer) -> bool:
+        try:
+            return not buffer.empty()
+        except (OSError, ValueError, NotImplementedError):
+            return False
+
     def _processData(self, isDead, buffer, file=None) -> None:
-        while not (self._isDead or isDead.value):
-            chunks, eof = self._takeBatch(buffer)
-            if chunks:
-                if self._shift is None:
-                    self._generateShift(chunks[0].size)
-                self._emit(self._runBatch(chunks), file)
-            if eof:
-                # the reference's loop ends on the ValueError numpy raises for ``x[0, :] = b''``
-                # (dsp_processor.py:170, swallowed by processData's finally/return)
-                raise _EndOfStream('end of stream')
+        pending = None              # a batch whose kernels run while the next one is taken from the Queue and copied in
+        try:
+            while not (self._isDead or isDead.value):
+                chunks, eof = self._takeBatch(buffer)
+                if chunks:
+                    if self._shift is None:
+                        self._generateShift(chunks[0].size)
+                    started = self._submitBatch(chunks)
+                    if pending is not None:
+                        self._emit(self._collectBatch(pending), file)
+                    pending = started
+                    if eof or not self._moreQueued(buffer):      # nothing to overlap with: write it out now (latency)
+                        self._emit(self._collectBatch(pending), file)
+                        pending = None
+                if eof:
+                    # the reference's loop ends on the ValueError numpy raises for ``x[0, :] = b''``
+                    # (dsp_processor.py:170, swallowed by processData's finally/return)
+                    raise _EndOfStream('end of stream')
+        finally:
+            if pending is not None:
+                self._emit(self._collectBatch(pending), file)
 
     def _generateShift(self, c: int) -> None:
         """Host copy of the NCO row for callers that inspect ``_shift`` (dsp_processor.py:185-187: only when

@@ -123,9 +123,15 @@ class VfoProcessor(DspProcessor):
             blk.size = self._blockKind['samples']
         return ([blk] if blk.n else []), blk.eof
 
-    def _runBatch(self, chunks) -> np.ndarray:
+    def _submitBatch(self, chunks):
         if self._world == 1:
-            return super()._runBatch(chunks)
+            return super()._submitBatch(chunks)
+        return None, self._runBlock(chunks), 0             # several GPUs: the block exchange is synchronous already
+
+    def _collectBatch(self, pending) -> np.ndarray:
+        return super()._collectBatch(pending) if pending[0] is not None else pending[1]
+
+    def _runBlock(self, chunks) -> np.ndarray:
         blk, k = chunks[0], self._blockKind
         reader = dict(normalize=k['normalize'], correct_iq=k['correctIq'], impedance=k['impedance'],
                       big_endian=k['bigEndian']) if k['raw'] else {}

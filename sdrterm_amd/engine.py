@@ -87,8 +87,11 @@ class Engine:
             apply_shift = self.rows > 1 or any(f != 0 for f in freqs)
         self._freqs = np.ascontiguousarray(freqs, dtype=np.float64)
         self._dec_sos = decimator_sos(self.q)
-        self._out_sos = np.ascontiguousarray(
-            out_sos if out_sos is not None else output_sos(int(fs) // self.q, omega_out), dtype=np.float64)
+        if mode in ('re', 'im'):
+            self._out_sos = np.zeros((0, 6))         # realOutput / imagOutput: no output filter (dsp_processor.py:130-138)
+        else:
+            self._out_sos = np.ascontiguousarray(
+                out_sos if out_sos is not None else output_sos(int(fs) // self.q, omega_out), dtype=np.float64)
         dom = generate_domain(code) if normalize else None
         swap = bool(big_endian) != (sys.byteorder == 'big') and nat.ITEM_SIZE[code] > 1
 
@@ -137,6 +140,27 @@ class Engine:
             raise ValueError(f'{n_chunks} chunks need {n_chunks * self.chunk_bytes} bytes, got {buf.size}')
         out = np.empty((self.rows, n_chunks * self.m), dtype=np.float64)
         nat.check(nat.lib().sdrt_process_host(self._ctx, buf.ctypes.data, n_chunks, out.ctypes.data))
+        return out
+
+    def submit(self, raw, n_chunks=None):
+        """Start a batch from host memory (copy-in, kernels, copy-out all asynchronous) and return a handle for
+        ``collect``; up to three batches overlap (include/sdrterm_hip.h: sdrt_submit_host)."""
+        buf = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else \
+            np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+        if n_chunks is None:
+            if buf.size % self.chunk_bytes:
+                raise ValueError(f'input is not a whole number of {self.chunk_bytes}-byte chunks')
+            n_chunks = buf.size // self.chunk_bytes
+        elif buf.size < n_chunks * self.chunk_bytes:
+            raise ValueError(f'{n_chunks} chunks need {n_chunks * self.chunk_bytes} bytes, got {buf.size}')
+        out = np.empty((self.rows, n_chunks * self.m), dtype=np.float64)
+        t = C.c_int64(-1)
+        nat.check(nat.lib().sdrt_submit_host(self._ctx, buf.ctypes.data, n_chunks, out.ctypes.data, C.byref(t)))
+        return t.value, out, buf            # buf: page-locked input must outlive the copy
+
+    def collect(self, handle) -> np.ndarray:
+        ticket, out, _buf = handle
+        nat.check(nat.lib().sdrt_wait(self._ctx, ticket))
         return out
 
     def process_device(self, raw_ptr: int, n_chunks: int, out_ptr: int, stream: int = 0, ydec_ptr: int = 0):

@@ -389,3 +389,38 @@ def test_rccl_transport_single_rank_roundtrip():
         assert (dst.download(np.empty(1024, dtype=np.uint8)) == 7).all()
     finally:
         t.close()
+
+
+@pytest.mark.parametrize('mode', ['re', 'im'])
+def test_working_real_and_imaginary_streaming_modes(mode, tmp_path):
+    """selectOutputReal / selectOutputImag (dsp_processor.py:130-138): the reference itself raises there (sosfilt of an empty
+    filter list); with workingReIm the processor writes the real / imaginary part of the decimated samples
+    (demodulation.py:51-68), checked against the oracle's decimated samples."""
+    import queue
+    from oracle import ref_chain
+    from sdrterm_amd.dsp.dsp_processor import DspProcessor
+    from tests.golden import prng
+    fs, q, n, nch = 1024000, 64, 32768, 3
+    raw = prng.raw_bytes('h', n * nch, seed=91, amp=4000)
+    ch = ref_chain.Chain(fs, q, 'fm', 'h', center=15700, omega_out=5000)
+    p = DspProcessor(fs, center=15700, omegaOut=5000, dec=q, fileInfo={'bitsPerSample': 'int16'}, workingReIm=True)
+    (p.selectOutputReal if mode == 're' else p.selectOutputImag)()
+    buf = queue.Queue()
+    exp = []
+    for c in range(nch):
+        z = ch.read(raw[c * n * 4:(c + 1) * n * 4])
+        buf.put(z)
+        _, y = ref_chain.process_chunk(z, q, 'fm', ch.shift, ch.out_sos, return_decimated=True)
+        exp.append(y[0].real if mode == 're' else y[0].imag)
+    buf.put(b'')
+    buf.close = lambda: None
+    buf.join_thread = lambda: None
+
+    class _Flag:
+        value = 0
+    f = tmp_path / 'out.bin'
+    p.processData(_Flag(), buf, str(f))
+    got = np.frombuffer(f.read_bytes(), dtype='=f8')
+    exp = np.concatenate(exp)
+    assert got.size == exp.size
+    assert np.abs(got - exp).max() <= 1e-6 * max(1.0, np.abs(exp).max())
