@@ -44,10 +44,12 @@ I8_PEAK_POPS = 5.0             # dense int8 matrix peak, Pop/s (2 x bf16 per clo
 FP64_PEAK_TFLOPS = 78.6
 
 WORKLOADS = {
-    # name: (decimation, total rows, default chunks per step, scaling)
-    'fm64': (64, 1, 131072, 'weak'),
-    'simo64': (32, 64, 512, 'strong'),
+    # name: (decimation, total rows, default chunks per step, scaling, encoding, sample rate)
+    'fm64': (64, 1, 131072, 'weak', 'h', 256_000_000),
+    'simo64': (32, 64, 512, 'strong', 'h', 256_000_000),
+    'f32x256': (64, 256, 128, 'strong', 'f', 1_000_000_000),
 }
+ITEM = {'h': 2, 'f': 4}
 
 
 def simo_rows(n_rows):
@@ -58,12 +60,14 @@ def simo_rows(n_rows):
     return [float(o + CENTER) for o in offs] + [float(CENTER)]
 
 
-def synth_iq_torch(n_samples, seed, device):
-    """FM tone at +CENTER with 1 kHz modulation, amplitude 8000, Gaussian noise sigma 300, int16."""
+def synth_iq_torch(n_samples, seed, device, code='h', fs=FS):
+    """FM tone at +CENTER with 1 kHz modulation, amplitude 8000, Gaussian noise sigma 300, int16; float32: the
+    same stream scaled by 2^-15, not rounded."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    out = torch.empty((n_samples, 2), dtype=torch.int16, device=device)
+    FS = fs
+    out = torch.empty((n_samples, 2), dtype=torch.int16 if code == 'h' else torch.float32, device=device)
     step = 1 << 24
     fm, dev = 1000.0, 2500.0
     for s in range(0, n_samples, step):
@@ -73,25 +77,29 @@ def synth_iq_torch(n_samples, seed, device):
             2 * math.pi * torch.remainder(t * (fm / FS), 1.0))
         re = 8000.0 * torch.cos(ph) + 300.0 * torch.randn(e - s, device=device, generator=g, dtype=torch.float64)
         im = 8000.0 * torch.sin(ph) + 300.0 * torch.randn(e - s, device=device, generator=g, dtype=torch.float64)
-        out[s:e, 0] = torch.round(re).clamp_(-32768, 32767).to(torch.int16)
-        out[s:e, 1] = torch.round(im).clamp_(-32768, 32767).to(torch.int16)
+        if code == 'h':
+            out[s:e, 0] = torch.round(re).clamp_(-32768, 32767).to(torch.int16)
+            out[s:e, 1] = torch.round(im).clamp_(-32768, 32767).to(torch.int16)
+        else:
+            out[s:e, 0] = (re / 32768.0).to(torch.float32)
+            out[s:e, 1] = (im / 32768.0).to(torch.float32)
     return out
 
 
-def cpu_baseline(raw_bytes, q, freqs, budget_s=10.0):
+def cpu_baseline(raw_bytes, q, freqs, budget_s=10.0, code='h', N=N, FS=FS):
     """The plain-C oracle (oracle/chain.c) timed on this host's cores on a bounded sample of the same workload: all cores
     (OpenMP over chunks) and one core."""
     from oracle import c_chain, ref_chain
     shift = c_chain.shift_table(freqs, FS, N)
     dec, outs = ref_chain.cheby_sos(q), ref_chain.ellip_sos(FS // q, OMEGA_OUT)
-    chunk_b = N * 4
+    chunk_b = N * 2 * ITEM[code]
     avail = len(raw_bytes) // chunk_b
 
     def timed(threads, budget):
         want = max(threads, min(avail, (avail // threads) * threads))
         if threads == 1:
             want = min(avail, 8)
-        run = lambda: c_chain.process_stream(raw_bytes[:want * chunk_b], 'h', N, q, 'fm', shift, dec, outs, threads=threads)
+        run = lambda: c_chain.process_stream(raw_bytes[:want * chunk_b], code, N, q, 'fm', shift, dec, outs, threads=threads)
         run()                                                   # warm (thread pool, page faults)
         t0 = time.perf_counter()
         run()
@@ -107,7 +115,7 @@ def cpu_baseline(raw_bytes, q, freqs, budget_s=10.0):
     v_all, reps, want, dt = timed(threads, budget_s)
     v_one, reps1, want1, dt1 = timed(1, budget_s / 2)
     return {'value': round(v_all, 3), 'unit': 'MSamples/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{reps} pass(es) over {want} chunks x {N} samples of the same int16 stream ({len(freqs)} row(s), dec={q}), '
+            'sample': f'{reps} pass(es) over {want} chunks x {N} samples of the same stream ({len(freqs)} row(s), dec={q}), '
                       f'oracle/chain.c (fp64 C port of the reference chain), {threads} OpenMP threads, {dt:.1f} s',
             'single_core': {'value': round(v_one, 3), 'unit': 'MSamples/s', 'cores': 1,
                             'sample': f'{reps1} pass(es) over {want1} chunks, 1 thread, {dt1:.1f} s'}}
@@ -142,6 +150,7 @@ def launch_ranks(args, argv):
 
 
 def main():
+    global FS, N
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=1500)
@@ -174,7 +183,8 @@ def main():
 
     from sdrterm_amd import _native as nat, parallel
     from sdrterm_amd.engine import Engine
-    q, rows_total, default_chunks, scaling = WORKLOADS[args.workload]
+    q, rows_total, default_chunks, scaling, code, FS = WORKLOADS[args.workload]
+    N = 131072 // (2 * ITEM[code])            # complex samples per 131072-byte chunk
     n_chunks = args.chunks or default_chunks
     n_samples = n_chunks * N
     if args.workload == 'fm64':
@@ -188,14 +198,14 @@ def main():
         freqs, (lo, hi) = parallel.shard_rows(freqs_all, world, rank)
         # the stream lives on rank 0 (where the reader's Queue ends); two block buffers per rank: block k+1 arrives beside
         # the kernels of block k
-        src = synth_iq_torch(2 * n_samples, seed=1234, device=device) if rank == 0 else None
-        bufs = [torch.empty((n_samples, 2), dtype=torch.int16, device=device) for _ in range(2)]
+        src = synth_iq_torch(2 * n_samples, seed=1234, device=device, code=code, fs=FS) if rank == 0 else None
+        bufs = [torch.empty((n_samples, 2), dtype=src.dtype if rank == 0 else (torch.int16 if code == 'h' else torch.float32), device=device) for _ in range(2)]
         comm = None
         if world > 1:
             uid = [parallel.RcclTransport.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             comm = parallel.RcclTransport(rank, world, local_rank, uid[0])
-    eng = Engine(FS, q, 'fm', 'h', row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_rank)
+    eng = Engine(FS, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_rank)
     rows = len(freqs)
     out = torch.empty((rows, n_chunks * eng.m), dtype=torch.float64, device=device)
     lib = nat.lib()
@@ -210,7 +220,7 @@ def main():
         s_comm = p.value
     torch.cuda.synchronize()
 
-    block_bytes = n_samples * 4
+    block_bytes = n_samples * 2 * ITEM[code]
     state = {'k': 0}
 
     def fetch(k):
@@ -227,7 +237,7 @@ def main():
 
     def step():
         k = state['k']
-        if args.workload == 'simo64':
+        if args.workload != 'fm64':
             fetch(k + 1)                                               # beside this step's kernels (other buffer)
         run(bufs[k % len(bufs)].data_ptr(), n_chunks, out.data_ptr(), S)
         if comm is not None:
@@ -238,7 +248,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    if args.workload == 'simo64':
+    if args.workload != 'fm64':
         fetch(0)
         if comm is not None:
             nat.check(lib.sdrt_stream_wait_stream(S, s_comm))
@@ -295,14 +305,14 @@ def main():
         value = total_samples / elapsed / 1e6
         ms_per_step = elapsed / args.steps * 1e3
         # algorithmic bytes per input sample on ONE GPU: 4 B of int16 IQ in + 8 B per row and q samples out
-        alg_bps = 4.0 + 8.0 * rows / q
+        alg_bps = 2.0 * ITEM[code] + 8.0 * rows / q
         k_avg_ms = k_ms / max(k_n, 1) if k_n else None
         p_avg_ms = p_ms / max(p_n, 1) if p_n else None
         # the chain kernel's own algorithmic bytes: input + the decimated complex128 samples it hands to the post kernel
         achieved = alg_bps * n_samples / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms else None
         path_achieved = alg_bps * n_samples / (ms_per_step * 1e-3) / 1e9
         # int8 matrix work of the dominant kernel: matrix instructions per 4096-sample tile x 16*16*64*2 operations
-        mfma_per_tile = {64: 184, 32: 216}[q] if eng.stage_a == 'i8w' else None
+        mfma_per_tile = {64: 184, 32: 216}[q] if eng.stage_a == 'i8w' else ({'h': 160, 'f': 224}[code] if eng.stage_a == 'i8t' else None)
         i8_ops = mfma_per_tile * 32768.0 * rows * n_samples / 4096 if mfma_per_tile else None
         pmc = (committed_record('pmc_record.json') or committed_record('pmc_traffic.json')) if args.workload == 'fm64' else None
         pmc_ok = bool(pmc) and pmc.get('chunks_per_step_per_gpu') == n_chunks and pmc.get('kernel', '') in KERNEL_OF[eng.stage_a]
@@ -318,17 +328,18 @@ def main():
                 'int8_frac': round(i8_ops / (k_avg_ms * 1e-3) / 1e15 / I8_PEAK_POPS, 4) if (i8_ops and k_avg_ms) else None,
                 'mfma_i8_busy': pmc.get('mfma_busy') if pmc_ok else None}
         line = {
-            'metric': 'input MSamples/s IQ->FM demod, dec=64' if args.workload == 'fm64' else 'input MSamples/s 64-VFO --simo FM, dec=32',
+            'metric': {'fm64': 'input MSamples/s IQ->FM demod, dec=64', 'simo64': 'input MSamples/s 64-VFO --simo FM, dec=32',
+                       'f32x256': 'input MSamples/s 256-VFO --simo FM, float32 IQ, dec=64'}[args.workload],
             'value': round(value, 1), 'unit': 'MSamples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
             'scaling': scaling, 'vs_baseline': None,
             # what the arithmetic is: int8 x int8 -> int32 matrix products of 5 base-256 weight digits x 2 byte slices (exact),
             # recombined and finished in fp64; 'f64' when the fp64 matrix-core kernel runs
-            'dtype': 'i8x5-split+f64' if eng.stage_a in ('i8w', 'i8t') else 'f64', 'data': 'synthetic',
+            'dtype': ('i8x5-split+f64' if code == 'h' else 'f32->4 x i8 block fixed point, i8x5-split+f64') if eng.stage_a in ('i8w', 'i8t') else 'f64', 'data': 'synthetic',
             'config': {'workload': (f'configs[1]: {FS // 1_000_000} MS/s synthetic int16 IQ (FM tone + noise), FM demod, dec={q}, single VFO, '
                                     f'center={CENTER} Hz, {n_chunks} chunks x {N} samples per GPU per step, inputs resident in HBM')
                        if args.workload == 'fm64' else
-                       (f'configs[3]: --simo {rows_total} VFO rows sharded {rows}/GPU, {FS // 1_000_000} MS/s synthetic int16 IQ, FM, dec={q}, '
+                       (f'configs[{3 if code == "h" else 4}]: --simo {rows_total} VFO rows sharded {rows}/GPU, {FS // 1_000_000} MS/s synthetic {"int16" if code == "h" else "float32"} IQ, FM, dec={q}, '
                         f'{n_chunks} chunks x {N} samples per step resident on rank 0, RCCL broadcast per step'),
                        'chunks_per_step_per_gpu': n_chunks, 'samples_per_chunk': N, 'rows_per_gpu': rows,
                        'parallelism': f'chunk-sharded x{world}' if args.workload == 'fm64' else f'rows-sharded x{world} + bcast',
@@ -343,7 +354,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             sample = (bufs[0] if args.workload == 'fm64' else src)[:min(n_samples, 2048 * N)].cpu().numpy().tobytes()
-            line['cpu_baseline'] = cpu_baseline(sample, q, freqs_all)
+            line['cpu_baseline'] = cpu_baseline(sample, q, freqs_all, code=code, N=N, FS=FS)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)

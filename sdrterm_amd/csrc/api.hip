@@ -93,6 +93,7 @@ struct sdrt_ctx {
     DecimTables *d_tab8 = nullptr;    // tables for columns of SDRT_I8T_G blocks
     double *d_nco_tile8 = nullptr, *d_nco_phase8 = nullptr;
     double *d_ybias = nullptr;
+    double *d_wsum = nullptr;         // float32 on the int8 matrix cores: weight-row sums (DecimArgs.wsum)
     double w8_combine = 0.0, w8mid_combine = 0.0, x_offset = 0.0;
     int n_tiles8 = 0;
     bool iq = false;
@@ -173,7 +174,7 @@ int upload(T **dst, const void *src, size_t bytes) {
 void free_stage_a(sdrt_ctx *c) {
     auto drop = [](auto *&p) { if (p) (void) hipFree(p); p = nullptr; };
     drop(c->d_wtab); drop(c->d_edge_ab); drop(c->d_edge_pq); drop(c->d_gvec);
-    drop(c->d_w8); drop(c->d_w8mid); drop(c->d_tab8); drop(c->d_nco_tile8); drop(c->d_nco_phase8);
+    drop(c->d_w8); drop(c->d_w8mid); drop(c->d_tab8); drop(c->d_nco_tile8); drop(c->d_nco_phase8); drop(c->d_wsum);
     c->use_i8w = c->use_i8t = c->wide_rs = false;
     c->w8_combine = c->w8mid_combine = 0.0;
 }
@@ -263,6 +264,24 @@ int setup_i8t(sdrt_ctx *c, const sdrt_config *cfg, ScaleFn &scale_tables) {
     }
     if (rc == SDRT_OK) rc = upload(&c->d_w8, w8.data(), w8.size());
     if (rc == SDRT_OK && per_row_mid) rc = upload(&c->d_w8mid, w8m.data(), per_row_mid * c->rows);
+    if (rc == SDRT_OK && cfg->dtype == SDRT_F32) {
+        // sum over K of every weight row, from the digit planes as the matrix cores see them: what the constant 0x808080 that
+        // the XOR leaves out of the three lower slices contributes per column (kernels_i8t.hip: I8Enc<SDRT_F32>)
+        std::vector<double> ws((size_t) c->rows * 32, 0.0);
+        for (int r = 0; r < c->rows; ++r)
+            for (int tile = 0; tile < 2; ++tile)
+                for (int d = 0; d < S; ++d) {
+                    const double wd = std::ldexp(c->w8_combine, 8 * d);
+                    for (int ks = 0; ks < KS; ++ks)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const signed char *p = &w8[per_row * r + ((((size_t) tile * S + d) * KS + ks) * 64 + lane) * 16];
+                            long sum = 0;
+                            for (int j = 0; j < 16; ++j) sum += p[j];
+                            ws[(size_t) r * 32 + tile * 16 + (lane & 15)] += wd * (double) sum;
+                        }
+                }
+        rc = upload(&c->d_wsum, ws.data(), ws.size() * sizeof(double));
+    }
     c->use_i8t = rc == SDRT_OK;
     return rc;
 }
@@ -530,6 +549,7 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_nco_tile8);
     (void) hipFree(c->d_nco_phase8);
     (void) hipFree(c->d_ybias);
+    (void) hipFree(c->d_wsum);
     (void) hipFree(c->d_iq_state);
     (void) hipFree(c->d_iq_pow);
     (void) hipFree(c->d_iq_group);
@@ -658,6 +678,7 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
     da.w8_combine = c->w8_combine;
     da.w8mid_combine = c->w8mid_combine;
     da.x_offset = c->x_offset;
+    da.wsum = c->d_wsum;
     da.wtab = c->d_wtab;
     da.edge_ab = c->d_edge_ab;
     da.edge_pq = c->d_edge_pq;

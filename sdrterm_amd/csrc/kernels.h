@@ -34,6 +34,7 @@ struct DecimArgs {
     const double *ybias;        // [rows][m][2] decimator response to the constant the slices leave out (or NULL)
     double w8_combine;          // scale * 2^-(8S-1)
     double x_offset;            // what the slices leave out of every component: x = x' + x_offset
+    const double *wsum;         // float32 (kernels_i8t.hip): [rows][32] sum over K of every weight row of the two row tiles
     const WideTables *wtab;     // wide-column kernel (kernels_i8w.hip) only; there w8mid holds the local-row planes
     const double *edge_ab;      //   [rows][16][32][4] edge operators as per-sample coefficients (sdrt_build_wide_edge)
     const double *edge_pq;      //   [rows][16][4]     their IQ-offset terms

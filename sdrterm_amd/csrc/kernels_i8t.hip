@@ -13,15 +13,24 @@ template <> struct I8Enc<SDRT_S8> { static constexpr int slices = 1; static cons
 template <> struct I8Enc<SDRT_U8> { static constexpr int slices = 1; static constexpr unsigned xlo = 0x80808080u, xhi = 0u; };
 template <> struct I8Enc<SDRT_S16> { static constexpr int slices = 2; static constexpr unsigned xlo = 0x80808080u, xhi = 0u; };
 template <> struct I8Enc<SDRT_U16> { static constexpr int slices = 2; static constexpr unsigned xlo = 0x80808080u, xhi = 0x80808080u; };
+// float32 records: every matrix-core column (L samples) is taken as block fixed point against the column's own exponent:
+// i = trunc(x 2^(30 - E)), |x| < 2^E for all of the column's samples; the four bytes of i are the four slices (the lower
+// three made signed by the XOR; the constant that leaves out comes back as a rank-one term, DecimArgs.wsum).  What is lost
+// is below 2^-30 of the column's largest sample.
+template <> struct I8Enc<SDRT_F32> { static constexpr int slices = 4; static constexpr unsigned xlo = 0x80808080u, xhi = 0u; };
 }  // namespace
 
 template <int LB, int DT, int S, int G>
-__global__ __launch_bounds__(256, (G > 1 ? 2 : 3)) void chain_i8t_kernel(DecimArgs a) {
+__global__ __launch_bounds__(256, (G > 1 || DT == SDRT_F32 ? 2 : 3)) void chain_i8t_kernel(DecimArgs a) {
     // LB = block length (output spacing), a matrix-core column is G consecutive blocks: L = G * LB samples
     constexpr int L = LB * G;
     constexpr int NSL = I8Enc<DT>::slices;
     constexpr int KS64 = L / 32;                    // 64-deep MFMA k-steps per column (2 components x 8 samples x 4 lane groups)
-    constexpr int NLV = S + NSL - 1;                // accumulator levels (weight 256^level)
+    constexpr bool F32 = DT == SDRT_F32;
+    // digit d x slice s adds to level d + s (weight 256^level); float32: levels below LMIN are under the slices' own
+    // truncation step and are not computed (14 of the 20 products remain)
+    constexpr int LMIN = F32 ? 3 : 0;
+    constexpr int NLV = S + NSL - 1 - LMIN;         // accumulator levels kept
     constexpr int NR = 2 * (G - 1);                 // rows of the compact mid tile
     static_assert(G == 1 || G == 2, "columns of 1 or 2 blocks");
     const bool nco = a.nco_tile != nullptr;
@@ -79,6 +88,9 @@ __global__ __launch_bounds__(256, (G > 1 ? 2 : 3)) void chain_i8t_kernel(DecimAr
     for (int k = 0; k < 4; ++k) mup[k] = mk(tab->mu_pow[k][g][0], tab->mu_pow[k][g][1]);
     const double d0p = tab->d0p;
     const double cs = a.w8_combine;
+    double wsum[8];                                  // float32: sum of this lane's eight weight rows (both row tiles), see I8Enc<SDRT_F32>
+#pragma unroll
+    for (int v = 0; v < 8; ++v) wsum[v] = F32 ? a.wsum[(size_t) row * 32 + (v >> 2) * 16 + 4 * g + (v & 3)] : 0.0;
 
     uint32_t cur[NW];
 #pragma unroll
@@ -96,7 +108,42 @@ __global__ __launch_bounds__(256, (G > 1 ? 2 : 3)) void chain_i8t_kernel(DecimAr
         // slices of this lane's L/4 samples: dword = [re.lo re.hi im.lo im.hi] -> 8 samples (16 int8) per k-step and slice
         double u0r, u0i;
         v4i blo[KS64], bhi[KS64];
-        if constexpr (ITEM == 2) {
+        v4i bsl[F32 ? KS64 : 1][4];                  // float32: [k-step][slice]
+        double colscale = 1.0;                       // float32: 2^(E - 30) of this lane's column
+        if constexpr (F32) {
+            // the column's exponent: largest magnitude over this lane's samples, then over the four lanes of the column
+            unsigned mx = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const unsigned w = swap ? __builtin_bswap32(cur[i]) : cur[i];
+                cur[i] = w;
+                mx = max(mx, w & 0x7fffffffu);
+            }
+            mx = max(mx, (unsigned) __shfl_xor((int) mx, 16));
+            mx = max(mx, (unsigned) __shfl_xor((int) mx, 32));
+            const int e = (int) (mx >> 23) - 126;    // |x| < 2^e for every sample of the column (e = -126 for an all-zero column)
+            colscale = __hiloint2double((1023 + e - 30) << 20, 0);
+            u0r = (double) __uint_as_float(cur[0]);
+            u0i = (double) __uint_as_float(cur[1]);
+#pragma unroll
+            for (int s = 0; s < KS64; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // four values (two samples) -> fixed point -> 4 x 4 byte transpose: one dword per slice
+                    int q0 = (int) ldexpf(__uint_as_float(cur[16 * s + 4 * i + 0]), 30 - e);
+                    int q1 = (int) ldexpf(__uint_as_float(cur[16 * s + 4 * i + 1]), 30 - e);
+                    int q2 = (int) ldexpf(__uint_as_float(cur[16 * s + 4 * i + 2]), 30 - e);
+                    int q3 = (int) ldexpf(__uint_as_float(cur[16 * s + 4 * i + 3]), 30 - e);
+                    const unsigned a01 = __builtin_amdgcn_perm((unsigned) q1, (unsigned) q0, 0x05010400u);   // [q0.b0 q1.b0 q0.b1 q1.b1]
+                    const unsigned a23 = __builtin_amdgcn_perm((unsigned) q3, (unsigned) q2, 0x05010400u);
+                    const unsigned c01 = __builtin_amdgcn_perm((unsigned) q1, (unsigned) q0, 0x07030602u);   // [q0.b2 q1.b2 q0.b3 q1.b3]
+                    const unsigned c23 = __builtin_amdgcn_perm((unsigned) q3, (unsigned) q2, 0x07030602u);
+                    bsl[s][0][i] = (int) (__builtin_amdgcn_perm(a23, a01, 0x05040100u) ^ 0x80808080u);
+                    bsl[s][1][i] = (int) (__builtin_amdgcn_perm(a23, a01, 0x07060302u) ^ 0x80808080u);
+                    bsl[s][2][i] = (int) (__builtin_amdgcn_perm(c23, c01, 0x05040100u) ^ 0x80808080u);
+                    bsl[s][3][i] = (int) __builtin_amdgcn_perm(c23, c01, 0x07060302u);
+                }
+        } else if constexpr (ITEM == 2) {
             const unsigned sel_lo = swap ? 0x07050301u : 0x06040200u, sel_hi = swap ? 0x06040200u : 0x07050301u;
             u0r = decode<DT>((uint16_t) (cur[0] & 0xffffu), swap) - xoff;
             u0i = decode<DT>((uint16_t) (cur[0] >> 16), swap) - xoff;
@@ -150,11 +197,29 @@ __global__ __launch_bounds__(256, (G > 1 ? 2 : 3)) void chain_i8t_kernel(DecimAr
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, S>([&](auto dc) {
                 constexpr int d = decltype(dc)::value;
-                acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Afrag[i & 1][d], blo[s], acc[d], 0, 0, 0);
-                if constexpr (NSL == 2) acc[d + 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Afrag[i & 1][d], bhi[s], acc[d + 1], 0, 0, 0);
+                if constexpr (F32) {
+                    static_for<0, 4>([&](auto slc) {
+                        constexpr int sl = decltype(slc)::value;
+                        if constexpr (d + sl >= LMIN)
+                            acc[d + sl - LMIN] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Afrag[i & 1][d], bsl[s][sl], acc[d + sl - LMIN], 0, 0, 0);
+                    });
+                } else {
+                    acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Afrag[i & 1][d], blo[s], acc[d], 0, 0, 0);
+                    if constexpr (NSL == 2) acc[d + 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Afrag[i & 1][d], bhi[s], acc[d + 1], 0, 0, 0);
+                }
             });
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (s == KS64 - 1) {
+            if constexpr (F32 && s == KS64 - 1) {
+                // up to four products of 2^14 x 128 terms per level: no pairing in int32; value = cs 2^(E-30) 256^LMIN sum_q 256^q acc[q]
+                // + the constant the XOR left out of the three lower slices, times the row's weight sum
+                static_for<0, 4>([&](auto vc) {
+                    constexpr int v = decltype(vc)::value;
+                    double dsum = (double) acc[NLV - 1][v];
+#pragma unroll
+                    for (int q = NLV - 2; q >= 0; --q) dsum = fma(dsum, 256.0, (double) acc[q][v]);
+                    val[4 * rt + v] = fma(dsum, cs * 16777216.0, 8421504.0 * wsum[4 * rt + v]) * colscale;
+                });
+            } else if constexpr (s == KS64 - 1) {
                 // value = cs * sum_q 256^q acc[q]: pairs of levels first in int32 (|acc| <= 2^22), then fp64
                 static_for<0, (rt < 2 ? 4 : NR)>([&](auto vc) {
                     constexpr int v = decltype(vc)::value;
@@ -275,7 +340,7 @@ __global__ void i8t_selftest_kernel(const int *A, const int *B, int *D) {
 
 // ---- launch helpers -----------------------------------------------------------------------------------------------
 bool chain_i8t_supported(int L, int dt, int n) {
-    return (L == 32 || L == 64) && (dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16) &&
+    return (L == 32 || L == 64) && (dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16 || dt == SDRT_F32) &&
            n % (SDRT_TB * L * SDRT_I8T_G) == 0;
 }
 
@@ -302,6 +367,7 @@ static hipError_t launch_i8t_l(const DecimArgs &a, int dt, dim3 grid, size_t lds
         case SDRT_U8: return launch_i8t_k<L, SDRT_U8>(a, grid, lds, s);
         case SDRT_S16: return launch_i8t_k<L, SDRT_S16>(a, grid, lds, s);
         case SDRT_U16: return launch_i8t_k<L, SDRT_U16>(a, grid, lds, s);
+        case SDRT_F32: return launch_i8t_k<L, SDRT_F32>(a, grid, lds, s);
     }
     return hipErrorInvalidValue;
 }
