@@ -195,6 +195,22 @@ void sdrt_comm_destroy(sdrt_comm *comm);
  */
 int sdrt_demodulate_host(int mode, const double *y_host, int rows, int m, double *out_host);
 
+/*
+ * FFT taps of the plots, on raw chunks as the reader hands them on (host buffers, synchronous).  Both decode the records (and
+ * normalise them when asked, read_file.py:82-96), shift by shift_hz (AbstractPlot._omega = -2j pi offset/fs applied with
+ * shiftFreq, plots/abstract_plot.py:76, spectrum_analyzer_plot.py:77, waterfall_plot.py:97) and transform:
+ *   sdrt_spectrum_host  SpectrumAnalyzerPlot.update (plots/spectrum_analyzer_plot.py:74-88): log10(|fftshift(fft(y) / n)|^2) of each
+ *                       whole chunk -> out_host [n_chunks][n_samples]
+ *   sdrt_stft_host      WaterfallPlot.update (plots/waterfall_plot.py:47-58,90-100): 10 log10 |ShortTimeFFT.stft(y)| with the
+ *                       window the caller passes already scaled (scipy scale_to='magnitude'), fft_mode 'centered', frames centred
+ *                       on multiples of hop, zeros beyond the chunk -> out_host [n_chunks][mfft][n_samples / hop + 1]
+ */
+int sdrt_spectrum_host(int dtype, int swap_endianness, const void *raw_host, int n_samples, int n_chunks, double shift_hz, double fs,
+                       int normalize, double norm_xmin, double norm_inv_range, double *out_host);
+int sdrt_stft_host(int dtype, int swap_endianness, const void *raw_host, int n_samples, int n_chunks, double shift_hz, double fs,
+                   int normalize, double norm_xmin, double norm_inv_range, int nperseg, int hop, int mfft, const double *window,
+                   double *out_host);
+
 /* Diagnostic: one sdrt_process_device call in which the first n_wgs workgroups record s_memtime at their phase
  * boundaries; stamps_host receives n_wgs*4*16 uint64 ([workgroup][wave][16]).  Not for production use. */
 int sdrt_debug_stamps(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, double *out_dev,

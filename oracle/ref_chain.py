@@ -180,3 +180,22 @@ class Chain:
     def process(self, raw: bytes, return_decimated=False, faithful_dtype=True):
         return process_chunk(self.read(raw), self.q, self.mode, self.shift, self.out_sos, return_decimated,
                              faithful_dtype)
+
+
+def spectrum_tap(z: np.ndarray, fs: float, offset: float) -> np.ndarray:
+    """plots/spectrum_analyzer_plot.py:74-88 -- shiftFreq with exp(-2j*pi*(offset/fs)*t) (abstract_plot.py:76,151-153), then
+    amp = abs(fftshift(fftn(y, norm='forward'))); log10(amp * amp)."""
+    from scipy.fft import fftn, fftshift
+    y = np.array([z], dtype=np.complex128)
+    y = y * np.array([np.exp(-2j * np.pi * (offset / fs) * np.arange(y.size))])
+    amp = np.abs(fftshift(fftn(y, norm='forward')))
+    return np.log10(amp * amp)[0]
+
+
+def waterfall_tap(z: np.ndarray, fs: int, offset: float) -> np.ndarray:
+    """plots/waterfall_plot.py:47-58,90-100 -- ShortTimeFFT(kaiser 5, 256, hop 128, mfft 1024, centered, magnitude) of the
+    shifted chunk; image = 10 log10 |stft|, shape (1024, n/128 + 1)."""
+    y = np.asarray(z, dtype=np.complex128) * np.exp(-2j * np.pi * (offset / fs) * np.arange(z.size))
+    sft = signal.ShortTimeFFT.from_window(('kaiser', 5), fs, 256, 128, mfft=1024, fft_mode='centered', scale_to='magnitude',
+                                          phase_shift=None)
+    return 10.0 * np.log10(np.abs(sft.stft(y)))

@@ -29,7 +29,7 @@ EXPORTS = (
     'sdrt_stream_create', 'sdrt_stream_destroy', 'sdrt_stream_synchronize', 'sdrt_host_alloc', 'sdrt_host_free',
     'sdrt_memcpy_h2d_async', 'sdrt_memcpy_d2h_async', 'sdrt_stream_wait_stream',
     'sdrt_comm_unique_id', 'sdrt_comm_init', 'sdrt_comm_bcast', 'sdrt_comm_allgather', 'sdrt_comm_world', 'sdrt_comm_rank',
-    'sdrt_comm_destroy', 'sdrt_submit_host', 'sdrt_wait',
+    'sdrt_comm_destroy', 'sdrt_submit_host', 'sdrt_wait', 'sdrt_spectrum_host', 'sdrt_stft_host',
 )
 
 
@@ -109,6 +109,10 @@ def lib():
     l.sdrt_process_device_debug.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     l.sdrt_submit_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int64)]
     l.sdrt_wait.argtypes = [C.c_void_p, C.c_int64]
+    l.sdrt_spectrum_host.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double,
+                                     C.c_double, C.c_void_p]
+    l.sdrt_stft_host.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double,
+                                 C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     l.sdrt_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     l.sdrt_get_iq_offset.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     l.sdrt_set_iq_offset.argtypes = [C.c_void_p, C.c_double, C.c_double]

@@ -1023,6 +1023,105 @@ int sdrt_demodulate_host(int mode, const double *y_host, int rows, int m, double
     return SDRT_OK;
 }
 
+namespace {
+
+// device buffers of one tap call, freed on every path
+struct TapBufs {
+    void *raw = nullptr;
+    double *u = nullptr, *scratch = nullptr, *out = nullptr, *tw = nullptr, *tile = nullptr, *phase = nullptr, *win = nullptr;
+    ~TapBufs() {
+        (void) hipFree(raw); (void) hipFree(u); (void) hipFree(scratch); (void) hipFree(out);
+        (void) hipFree(tw); (void) hipFree(tile); (void) hipFree(phase); (void) hipFree(win);
+    }
+};
+
+int tap_common(int dtype, int swap, const void *raw_host, int n, int chunks, double shift_hz, double fs, int normalize, double norm_xmin,
+               double norm_inv_range, TapBufs &b, TapArgs &ta) {
+    if (dtype < 0 || dtype > 7 || !raw_host || n < 256 || (n & (n - 1)) || chunks < 1 || !(fs > 0))
+        return fail(SDRT_EINVAL, "bad argument (n must be a power of two >= 256)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(SDRT_ENODEVICE, "no HIP device available");
+    const size_t in_bytes = (size_t) chunks * n * 2 * kItemSize[dtype], cbytes = (size_t) chunks * n * 2 * sizeof(double);
+    HIP_TRY(hipMalloc(&b.raw, in_bytes));
+    HIP_TRY(hipMalloc((void **) &b.u, cbytes));
+    HIP_TRY(hipMemcpy(b.raw, raw_host, in_bytes, hipMemcpyHostToDevice));
+    memset(&ta, 0, sizeof(ta));
+    ta.raw = b.raw;
+    ta.u = b.u;
+    ta.chunks = (size_t) chunks;
+    ta.n = n;
+    ta.swap = swap && kItemSize[dtype] > 1;
+    ta.normalize = normalize;
+    if (normalize) {                        // read_file.py:96: 1.6 (z - xmin) d - 0.8 with complex z: only Re is offset
+        ta.norm_scale = 1.6 * norm_inv_range;
+        ta.norm_bias = -norm_xmin - 0.5 / norm_inv_range;
+    }
+    if (shift_hz != 0.0) {
+        std::vector<double> tile(64 * 2), phase((size_t) (n / 64) * 2);
+        sdrt_build_nco(shift_hz, fs, 64, n / 64, tile.data(), phase.data());
+        int rc = upload(&b.tile, tile.data(), tile.size() * sizeof(double));
+        if (rc == SDRT_OK) rc = upload(&b.phase, phase.data(), phase.size() * sizeof(double));
+        if (rc != SDRT_OK) return rc;
+        ta.nco_tile = b.tile;
+        ta.nco_phase = b.phase;
+    }
+    HIP_TRY(launch_tap_decode(ta, dtype, nullptr));
+    return SDRT_OK;
+}
+
+int tap_twiddles(int N, TapBufs &b) {
+    std::vector<double> tw((size_t) N * 2), unused((size_t) N * 2);
+    sdrt_build_fft_resample(N, tw.data(), unused.data());
+    return upload(&b.tw, tw.data(), tw.size() * sizeof(double));
+}
+
+}  // namespace
+
+int sdrt_spectrum_host(int dtype, int swap_endianness, const void *raw_host, int n_samples, int n_chunks, double shift_hz, double fs,
+                       int normalize, double norm_xmin, double norm_inv_range, double *out_host) {
+    if (!out_host) return fail(SDRT_EINVAL, "null buffer");
+    TapBufs b;
+    TapArgs ta;
+    int rc = tap_common(dtype, swap_endianness, raw_host, n_samples, n_chunks, shift_hz, fs, normalize, norm_xmin, norm_inv_range, b, ta);
+    if (rc != SDRT_OK) return rc;
+    const size_t cbytes = (size_t) n_chunks * n_samples * 2 * sizeof(double), obytes = (size_t) n_chunks * n_samples * sizeof(double);
+    HIP_TRY(hipMalloc((void **) &b.scratch, cbytes));
+    HIP_TRY(hipMalloc((void **) &b.out, obytes));
+    rc = tap_twiddles(n_samples, b);
+    if (rc != SDRT_OK) return rc;
+    ta.scratch = b.scratch;
+    ta.out = b.out;
+    ta.tw = b.tw;
+    HIP_TRY(launch_tap_fft(ta, nullptr));
+    HIP_TRY(hipMemcpy(out_host, b.out, obytes, hipMemcpyDeviceToHost));
+    return SDRT_OK;
+}
+
+int sdrt_stft_host(int dtype, int swap_endianness, const void *raw_host, int n_samples, int n_chunks, double shift_hz, double fs,
+                   int normalize, double norm_xmin, double norm_inv_range, int nperseg, int hop, int mfft, const double *window,
+                   double *out_host) {
+    if (!out_host || !window) return fail(SDRT_EINVAL, "null buffer");
+    if (mfft != 1024 || nperseg < 2 || nperseg > 256 || hop < 1 || n_samples % hop)
+        return fail(SDRT_EINVAL, "supported: mfft 1024, nperseg <= 256, hop dividing the chunk (the waterfall plot's 256 / 128 / 1024)");
+    TapBufs b;
+    TapArgs ta;
+    int rc = tap_common(dtype, swap_endianness, raw_host, n_samples, n_chunks, shift_hz, fs, normalize, norm_xmin, norm_inv_range, b, ta);
+    if (rc != SDRT_OK) return rc;
+    const size_t obytes = (size_t) n_chunks * mfft * (size_t) (n_samples / hop + 1) * sizeof(double);
+    HIP_TRY(hipMalloc((void **) &b.out, obytes));
+    rc = tap_twiddles(mfft, b);
+    if (rc == SDRT_OK) rc = upload(&b.win, window, (size_t) nperseg * sizeof(double));
+    if (rc != SDRT_OK) return rc;
+    ta.out = b.out;
+    ta.tw = b.tw;
+    ta.window = b.win;
+    ta.nperseg = nperseg;
+    ta.hop = hop;
+    HIP_TRY(launch_tap_stft(ta, nullptr));
+    HIP_TRY(hipMemcpy(out_host, b.out, obytes, hipMemcpyDeviceToHost));
+    return SDRT_OK;
+}
+
 int sdrt_debug_stamps(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *out_dev, unsigned long long *stamps_host,
                       int n_wgs) {
     if (!c || !stamps_host || n_wgs < 1) return fail(SDRT_EINVAL, "bad argument");

@@ -81,6 +81,22 @@ struct SmoothArgs {
     const double *taps, *left, *right;
 };
 hipError_t launch_smooth(const SmoothArgs &a, hipStream_t s);
+// FFT taps of the plots (kernels_post.hip)
+struct TapArgs {
+    const void *raw;            // [chunks][n][2] records
+    double *u;                  // [chunks][n][2] decoded, normalised, shifted samples (overwritten by the spectrum transform)
+    double *scratch;            // [chunks][n][2] second buffer of the spectrum transform
+    double *out;                // spectrum: [chunks][n]; waterfall: [chunks][1024][n/hop + 1]
+    const double *tw;           // exp(-2 pi i k/N): N = n (spectrum) or 1024 (waterfall)
+    const double *nco_tile, *nco_phase;   // [64][2], [n/64][2] or NULL
+    const double *window;       // [nperseg] (waterfall)
+    size_t chunks;
+    int n, swap, normalize, nperseg, hop;
+    double norm_bias, norm_scale;
+};
+hipError_t launch_tap_decode(const TapArgs &a, int dt, hipStream_t s);
+hipError_t launch_tap_fft(const TapArgs &a, hipStream_t s);
+hipError_t launch_tap_stft(const TapArgs &a, hipStream_t s);
 int smooth_waves_per_block(int m);                // 0: one item does not fit LDS
 size_t post_lds_bytes(int m, int mode);
 int post_waves_per_block(int m, int mode);       // 0: the post stage cannot hold one item in LDS

@@ -372,6 +372,133 @@ size_t post_lds_bytes(int m, int mode) {
     return post_lds_bytes_w(m, mode, w ? w : 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// FFT taps of the plots (plots/spectrum_analyzer_plot.py:74-88, plots/waterfall_plot.py:47-58,90-100): both take the reader's
+// chunk, shift it by the plot's own offset (demodulation.shiftFreq) and transform it.
+//   tap_decode_kernel   raw records -> complex128, optional normalisation, NCO                        (one pass, any encoding)
+//   tap_fft_kernel      spectrum analyser: log10 |fftshift(fft(y) / n)|^2 over the WHOLE chunk: Stockham radix-2 passes of
+//                       one workgroup per chunk through a ping-pong buffer in global memory (n = 8192 .. 65536)
+//   tap_stft_kernel     waterfall: 10 log10 |ShortTimeFFT(Kaiser(5), 256, hop 128, mfft 1024, centered, magnitude)|: one wave
+//                       per frame on the in-wave 1024-point transform of the resampler
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void tap_decode_kernel(TapArgs a) {
+    const size_t total = a.chunks * (size_t) a.n;
+    typedef typename Enc<DT>::raw raw_t;
+    const raw_t *rp = (const raw_t *) a.raw;
+    cd *u = (cd *) a.u;
+    const cd *tile = (const cd *) a.nco_tile, *phase = (const cd *) a.nco_phase;
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t) gridDim.x * 256) {
+        double xr = decode<DT>(rp[2 * i], a.swap != 0), xi = decode<DT>(rp[2 * i + 1], a.swap != 0);
+        if (a.normalize) xr = fma(xr + a.norm_bias, a.norm_scale, 0.0), xi *= a.norm_scale;
+        const size_t t = i % (size_t) a.n;
+        if (tile) {
+            const cd c = cmul(tile[t & 63], phase[t >> 6]);
+            const double tr = xr * c.re - xi * c.im;
+            xi = xr * c.im + xi * c.re;
+            xr = tr;
+        }
+        u[i] = mk(xr, xi);
+    }
+}
+
+__global__ __launch_bounds__(256) void tap_fft_kernel(TapArgs a) {
+    const int n = a.n, tid = threadIdx.x;
+    const cd *tw = (const cd *) a.tw;                          // exp(-2 pi i k/n), k < n
+    cd *x = (cd *) a.u + (size_t) blockIdx.x * n;               // the chunk; overwritten
+    cd *y = (cd *) a.scratch + (size_t) blockIdx.x * n;
+    int len = n, s = 1;
+    while (len > 1) {
+        const int half = len >> 1;
+        for (int j = tid; j < n / 2; j += 256) {
+            const int p = j / s, q = j - p * s;
+            const cd va = x[q + s * p], vb = x[q + s * (p + half)], w = tw[(size_t) p * (n / len)];
+            const cd d = mk(va.re - vb.re, va.im - vb.im);
+            y[q + s * 2 * p] = mk(va.re + vb.re, va.im + vb.im);
+            y[q + s * (2 * p + 1)] = mk(d.re * w.re - d.im * w.im, d.re * w.im + d.im * w.re);
+        }
+        __syncthreads();                                       // the workgroup's global stores are visible to it after the barrier
+        cd *t = x; x = y; y = t;
+        len = half;
+        s <<= 1;
+    }
+    double *out = a.out + (size_t) blockIdx.x * n;
+    const double inv = 1.0 / ((double) n * (double) n);
+    for (int k = tid; k < n; k += 256) {
+        const cd v = x[k];
+        out[(k + n / 2) & (n - 1)] = log10((v.re * v.re + v.im * v.im) * inv);      // fftshift; norm='forward'; amp * amp
+    }
+}
+
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void tap_stft_kernel(TapArgs a) {
+    constexpr int B = 4, N = 1024;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cd *tw = (cd *) smem;
+    constexpr int XL = N + N / 4 + 1;
+    cd *X = tw + N + (size_t) wave * XL;
+    for (int i = tid; i < N; i += 64 * WPB) tw[i] = ((const cd *) a.tw)[i];
+    __syncthreads();
+    const int n = a.n, cols = n / a.hop + 1;
+    const size_t frames = a.chunks * (size_t) cols;
+    for (size_t f = (size_t) blockIdx.x * WPB + wave; f < frames; f += (size_t) gridDim.x * WPB) {
+        const size_t chunk = f / cols;
+        const int p = (int) (f % cols);
+        const cd *u = (const cd *) a.u + chunk * (size_t) n;
+        const long start = (long) p * a.hop - a.nperseg / 2;    // frame p is centred on sample p * hop; zeros outside the chunk
+        cd x[B][4];
+        auto frame = [&]() {
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const int i = lane + 64 * b;                    // window index (nperseg = 256: element k = 0 of every lane's four)
+                const long t = start + i;
+                cd v = mk(0.0, 0.0);
+                if (i < a.nperseg && t >= 0 && t < n) { const double w = a.window[i]; v = mk(u[t].re * w, u[t].im * w); }
+                x[b][0] = v;
+                x[b][1] = x[b][2] = x[b][3] = mk(0.0, 0.0);
+            }
+        };
+        double *img = a.out + chunk * (size_t) N * cols + p;
+        fft_wave<B, false>(x, X, tw, lane, frame, [&](int o, cd v) {
+            img[(size_t) ((o + N / 2) & (N - 1)) * cols] = 5.0 * log10(v.re * v.re + v.im * v.im);     // 10 log10 |S|, fft_mode 'centered'
+        });
+    }
+}
+
+hipError_t launch_tap_decode(const TapArgs &a, int dt, hipStream_t s) {
+    const dim3 grid(2048);
+    switch (dt) {
+        case SDRT_S8: hipLaunchKernelGGL(tap_decode_kernel<SDRT_S8>, grid, dim3(256), 0, s, a); break;
+        case SDRT_U8: hipLaunchKernelGGL(tap_decode_kernel<SDRT_U8>, grid, dim3(256), 0, s, a); break;
+        case SDRT_S16: hipLaunchKernelGGL(tap_decode_kernel<SDRT_S16>, grid, dim3(256), 0, s, a); break;
+        case SDRT_U16: hipLaunchKernelGGL(tap_decode_kernel<SDRT_U16>, grid, dim3(256), 0, s, a); break;
+        case SDRT_S32: hipLaunchKernelGGL(tap_decode_kernel<SDRT_S32>, grid, dim3(256), 0, s, a); break;
+        case SDRT_U32: hipLaunchKernelGGL(tap_decode_kernel<SDRT_U32>, grid, dim3(256), 0, s, a); break;
+        case SDRT_F32: hipLaunchKernelGGL(tap_decode_kernel<SDRT_F32>, grid, dim3(256), 0, s, a); break;
+        case SDRT_F64: hipLaunchKernelGGL(tap_decode_kernel<SDRT_F64>, grid, dim3(256), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_tap_fft(const TapArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(tap_fft_kernel, dim3((unsigned) a.chunks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_tap_stft(const TapArgs &a, hipStream_t s) {
+    constexpr int WPB = 2, N = 1024;
+    const size_t lds = (size_t) (N + WPB * (N + N / 4 + 1)) * 16;
+    hipError_t e = hipFuncSetAttribute((const void *) tap_stft_kernel<WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    if (e != hipSuccess) return e;
+    const size_t frames = a.chunks * (size_t) (a.n / a.hop + 1);
+    size_t wgs = (frames + WPB - 1) / WPB;
+    if (wgs > 2048) wgs = 2048;
+    hipLaunchKernelGGL(tap_stft_kernel<WPB>, dim3((unsigned) wgs), dim3(64 * WPB), lds, s, a);
+    return hipGetLastError();
+}
+
 // realOutput / imagOutput (demodulation.py:51-68) of the decimated samples; no output filter follows (dsp_processor.py:130-138)
 __global__ __launch_bounds__(256) void part_kernel(const double *__restrict__ y, double *__restrict__ out, size_t count, int imag) {
     for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t) gridDim.x * 256) out[i] = y[2 * i + imag];

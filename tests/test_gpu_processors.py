@@ -424,3 +424,36 @@ def test_working_real_and_imaginary_streaming_modes(mode, tmp_path):
     exp = np.concatenate(exp)
     assert got.size == exp.size
     assert np.abs(got - exp).max() <= 1e-6 * max(1.0, np.abs(exp).max())
+
+
+@pytest.mark.parametrize('code,normalize', [('h', False), ('B', True), ('f', False)])
+def test_plot_fft_taps_match_the_reference_plots_arithmetic(code, normalize):
+    """Spectrum analyser and waterfall arrays (plots/spectrum_analyzer_plot.py:74-88, plots/waterfall_plot.py:90-100) from raw
+    chunks on the GPU against the numpy/scipy restatement of those lines.  Compared as amplitudes relative to the largest bin
+    (the plots take logarithms: empty bins are rounding noise in both)."""
+    from oracle import ref_chain
+    from sdrterm_amd.misc.read_file import RawChunk
+    from sdrterm_amd.plots import SpectrumTap, WaterfallTap
+    from tests.golden import prng
+    fs, off = 1024000, 15700
+    n = samples_per_chunk_of(code)
+    raw = prng.raw_bytes(code, n, seed=5, amp=100 if code == 'B' else 3000)
+    z = ref_chain.unpack(raw, code, False)
+    if normalize:
+        z = ref_chain.normalize(z, code)
+    chunk = RawChunk(raw, code, False, normalize, False, 50)
+    got = SpectrumTap(fs, center=off)(chunk)
+    exp = ref_chain.spectrum_tap(z, fs, off)
+    ga, ea = 10.0 ** (got / 2), 10.0 ** (exp / 2)
+    assert got.shape == exp.shape and np.abs(ga - ea).max() <= 1e-9 * ea.max()
+    img = WaterfallTap(fs, center=off)(chunk)
+    ref = ref_chain.waterfall_tap(z, fs, off)
+    gi, ri = 10.0 ** (img / 10), 10.0 ** (ref / 10)
+    assert img.shape == ref.shape == (1024, n // 128 + 1) and np.abs(gi - ri).max() <= 1e-9 * ri.max()
+    # the reference reader's complex arrays go the same way
+    got2 = SpectrumTap(fs, center=off)(z.astype(np.complex128))
+    assert np.abs(10.0 ** (got2 / 2) - ea).max() <= 1e-9 * ea.max()
+
+
+def samples_per_chunk_of(code):
+    return 131072 // (2 * {'b': 1, 'B': 1, 'h': 2, 'H': 2, 'i': 4, 'I': 4, 'f': 4, 'd': 8}[code])
