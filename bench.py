@@ -316,17 +316,25 @@ def main():
         i8_ops = mfma_per_tile * 32768.0 * rows * n_samples / 4096 if mfma_per_tile else None
         pmc = (committed_record('pmc_record.json') or committed_record('pmc_traffic.json')) if args.workload == 'fm64' else None
         pmc_ok = bool(pmc) and pmc.get('chunks_per_step_per_gpu') == n_chunks and pmc.get('kernel', '') in KERNEL_OF[eng.stage_a]
-        roof = {'bound': 'hbm', 'kernel': KERNEL_OF[eng.stage_a],
-                'achieved': round(achieved, 1) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                'traffic': pmc.get('hbm_bytes_per_launch') if pmc_ok else None,
-                'avg_kernel_ms': round(k_avg_ms, 4) if k_avg_ms else None, 'launches': k_n,
-                'alg_bytes_per_sample': alg_bps,
-                # the whole step (chain + post + gaps) against the same bytes: what north_star's 50 % is asked of
-                'path_achieved': round(path_achieved, 1), 'path_frac': round(path_achieved / HBM_PEAK_GBS, 4),
-                'int8_pops': round(i8_ops / (k_avg_ms * 1e-3) / 1e15, 3) if (i8_ops and k_avg_ms) else None,
-                'int8_frac': round(i8_ops / (k_avg_ms * 1e-3) / 1e15 / I8_PEAK_POPS, 4) if (i8_ops and k_avg_ms) else None,
-                'mfma_i8_busy': pmc.get('mfma_busy') if pmc_ok else None}
+        hbm = {'bound': 'hbm', 'kernel': KERNEL_OF[eng.stage_a],
+               'achieved': round(achieved, 1) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+               'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+               'traffic': pmc.get('hbm_bytes_per_launch') if pmc_ok else None,
+               'avg_kernel_ms': round(k_avg_ms, 4) if k_avg_ms else None, 'launches': k_n,
+               'alg_bytes_per_sample': alg_bps,
+               # the whole step (chain + post + gaps) against the same bytes: what north_star's 50 % is asked of
+               'path_achieved': round(path_achieved, 1), 'path_frac': round(path_achieved / HBM_PEAK_GBS, 4)}
+        i8 = {'int8_pops': round(i8_ops / (k_avg_ms * 1e-3) / 1e15, 3) if (i8_ops and k_avg_ms) else None,
+              'int8_frac': round(i8_ops / (k_avg_ms * 1e-3) / 1e15 / I8_PEAK_POPS, 4) if (i8_ops and k_avg_ms) else None,
+              'mfma_i8_busy': pmc.get('mfma_busy') if pmc_ok else None, 'clock_mhz': pmc.get('clock_mhz') if pmc_ok else None}
+        if rows == 1 or not i8['int8_pops']:
+            roof = dict(hbm, **i8)
+        else:
+            # many rows per input sample: the int8 matrix work, not the input stream, is what bounds the kernel
+            roof = {'bound': 'mfma', 'kernel': KERNEL_OF[eng.stage_a], 'achieved': round(i8['int8_pops'] * 1e3, 1),
+                    'peak': I8_PEAK_POPS * 1e3, 'unit': 'TFLOP/s', 'frac': i8['int8_frac'], 'traffic': None,
+                    'avg_kernel_ms': hbm['avg_kernel_ms'], 'launches': k_n, 'ops': 'int8 multiply-adds x 2 (dense int8 matrix peak)',
+                    'hbm': {k: hbm[k] for k in ('achieved', 'frac', 'alg_bytes_per_sample', 'path_achieved', 'path_frac')}}
         line = {
             'metric': {'fm64': 'input MSamples/s IQ->FM demod, dec=64', 'simo64': 'input MSamples/s 64-VFO --simo FM, dec=32',
                        'f32x256': 'input MSamples/s 256-VFO --simo FM, float32 IQ, dec=64'}[args.workload],
