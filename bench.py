@@ -314,7 +314,7 @@ def main():
         # int8 matrix work of the dominant kernel: matrix instructions per 4096-sample tile x 16*16*64*2 operations
         mfma_per_tile = {64: 184, 32: 216}[q] if eng.stage_a == 'i8w' else ({'h': 160, 'f': 224}[code] if eng.stage_a == 'i8t' else None)
         i8_ops = mfma_per_tile * 32768.0 * rows * n_samples / 4096 if mfma_per_tile else None
-        pmc = (committed_record('pmc_record.json') or committed_record('pmc_traffic.json')) if args.workload == 'fm64' else None
+        pmc = (committed_record('r02_pmc_record.json') or committed_record('pmc_traffic.json')) if args.workload == 'fm64' else None
         pmc_ok = bool(pmc) and pmc.get('chunks_per_step_per_gpu') == n_chunks and pmc.get('kernel', '') in KERNEL_OF[eng.stage_a]
         hbm = {'bound': 'hbm', 'kernel': KERNEL_OF[eng.stage_a],
                'achieved': round(achieved, 1) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
