@@ -27,7 +27,7 @@ for pas in sorted(os.listdir(out)):
 def big(vals):
     """the workload's launches (sdrt_create also runs small one-chunk launches)"""
     top = max(vals)
-    sel = [v for v in vals if v > 0.5 * top]
+    sel = [v for v in vals if v >= 0.5 * top]
     return sum(sel) / len(sel)
 
 rec = {}
@@ -46,7 +46,7 @@ for k, cs in sorted(acc.items()):
         e['clock_mhz'] = round(cyc / (big(dur[k]) * 1e-3) / 1e6, 1)
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in cs:
             e['mfma_busy'] = round(big(cs['SQ_VALU_MFMA_BUSY_CYCLES']) / (1024.0 * cyc), 4)   # 1024 SIMDs
-        if 'SQ_VALU_MFMA_COEXEC_CYCLES' in cs and 'SQ_VALU_MFMA_BUSY_CYCLES' in cs:
+        if 'SQ_VALU_MFMA_COEXEC_CYCLES' in cs and 'SQ_VALU_MFMA_BUSY_CYCLES' in cs and big(cs['SQ_VALU_MFMA_BUSY_CYCLES']) > 0:
             e['mfma_valu_coexec'] = round(big(cs['SQ_VALU_MFMA_COEXEC_CYCLES']) / big(cs['SQ_VALU_MFMA_BUSY_CYCLES']), 4)
     rec[e['kernel']] = e
 chain = next((v for k, v in rec.items() if k.startswith('chain')), None)
