@@ -93,7 +93,10 @@ struct sdrt_ctx {
     DecimTables *d_tab8 = nullptr;    // tables for columns of SDRT_I8T_G blocks
     double *d_nco_tile8 = nullptr, *d_nco_phase8 = nullptr;
     double *d_ybias = nullptr;
-    double *d_wsum = nullptr;         // float32 on the int8 matrix cores: weight-row sums (DecimArgs.wsum)
+    double *d_wsum = nullptr;
+    signed char *d_w8iq = nullptr;    // wide kernel with IQ correction: packed offset rows, their constants, the offset response R
+    double *d_iq_consts = nullptr, *d_iq_R = nullptr;
+    double iq_combine = 0.0;         // float32 on the int8 matrix cores: weight-row sums (DecimArgs.wsum)
     double w8_combine = 0.0, w8mid_combine = 0.0, x_offset = 0.0;
     int n_tiles8 = 0;
     bool iq = false;
@@ -175,6 +178,7 @@ void free_stage_a(sdrt_ctx *c) {
     auto drop = [](auto *&p) { if (p) (void) hipFree(p); p = nullptr; };
     drop(c->d_wtab); drop(c->d_edge_ab); drop(c->d_edge_pq); drop(c->d_gvec);
     drop(c->d_w8); drop(c->d_w8mid); drop(c->d_tab8); drop(c->d_nco_tile8); drop(c->d_nco_phase8); drop(c->d_wsum);
+    drop(c->d_w8iq); drop(c->d_iq_consts); drop(c->d_iq_R);
     c->use_i8w = c->use_i8t = c->wide_rs = false;
     c->w8_combine = c->w8mid_combine = 0.0;
 }
@@ -227,6 +231,41 @@ int setup_wide(sdrt_ctx *c, const sdrt_config *cfg, ScaleFn &) {
     if (rc == SDRT_OK) rc = upload(&c->d_edge_ab, eab.data(), eab.size() * sizeof(double));
     if (rc == SDRT_OK) rc = upload(&c->d_edge_pq, epq.data(), epq.size() * sizeof(double));
     if (rc == SDRT_OK) rc = upload(&c->d_gvec, gv.data(), gv.size() * sizeof(double));
+    if (rc == SDRT_OK && c->iq) {
+        // the offsets come out of two more matrix rows (no second pass over the input) ...
+        std::vector<signed char> wq((size_t) KS * 64 * 16);
+        std::vector<double> consts(SDRT_IQROW_CONSTS);
+        if (sdrt_build_i8_offset_rows(lam, S, wq.data(), &c->iq_combine, consts.data()) != 0) { free_stage_a(c); return SDRT_OK; }
+        rc = upload(&c->d_w8iq, wq.data(), wq.size());
+        if (rc == SDRT_OK) rc = upload(&c->d_iq_consts, consts.data(), consts.size() * sizeof(double));
+        // ... relative to a zero offset at the chunk's start; the true one enters linearly: R = D(nco (1-lambda)^t) per row, from
+        // the fp64 kernel on that sequence
+        std::vector<double> gz((size_t) n * 2, 0.0), pw((size_t) n + 1);
+        sdrt_build_iq_pow(lam, n, pw.data());
+        for (int i = 0; i < n; ++i) gz[2 * i] = pw[i];
+        double *d_gz = nullptr;
+        if (rc == SDRT_OK) rc = upload(&d_gz, gz.data(), gz.size() * sizeof(double));
+        if (rc == SDRT_OK && hipMalloc((void **) &c->d_iq_R, (size_t) c->rows * c->m * 2 * sizeof(double)) != hipSuccess)
+            rc = fail(SDRT_ENOMEM, "hipMalloc failed");
+        if (rc == SDRT_OK) {
+            DecimArgs da;
+            memset(&da, 0, sizeof(da));
+            da.raw = d_gz;
+            da.tab = c->d_tab;
+            da.nco_tile = c->d_nco_tile;
+            da.nco_phase = c->d_nco_phase;
+            da.ydec = c->d_iq_R;
+            da.n_chunks = 1;
+            da.n = n;
+            da.m = c->m;
+            da.n_tiles = c->n_tiles;
+            da.rows = c->rows;
+            hipError_t e = launch_chain(da, c->L, SDRT_F64, c->nco, false, 1, nullptr);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e != hipSuccess) rc = fail(SDRT_EHIP, "offset response kernel failed: %s", hipGetErrorString(e));
+        }
+        (void) hipFree(d_gz);
+    }
     c->use_i8w = rc == SDRT_OK;
     return rc;
 }
@@ -508,7 +547,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         // fp64 matrix-core kernel takes whatever is left
         if (seq) {
             // nothing to set up: the per-sample form reads DecimTables only
-        } else if (want_i8 && !want_t && chain_i8w_supported(q, cfg->dtype, n) && chain_i8w_lds_bytes(q, n) <= 160 * 1024)
+        } else if (want_i8 && !want_t && chain_i8w_supported(q, cfg->dtype, n) && chain_i8w_lds_bytes(q, n, c->iq) <= 160 * 1024)
             rc = setup_wide(c, cfg, scale_tables);
         if (rc == SDRT_OK && !seq && !c->use_i8w && want_i8 && !c->iq && want_i8_fallback_t(L, cfg->dtype, n, m))
             rc = setup_i8t(c, cfg, scale_tables);
@@ -550,6 +589,9 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_nco_phase8);
     (void) hipFree(c->d_ybias);
     (void) hipFree(c->d_wsum);
+    (void) hipFree(c->d_w8iq);
+    (void) hipFree(c->d_iq_consts);
+    (void) hipFree(c->d_iq_R);
     (void) hipFree(c->d_iq_state);
     (void) hipFree(c->d_iq_pow);
     (void) hipFree(c->d_iq_group);
@@ -635,6 +677,8 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
     da.iq_chunk_off = nullptr;
     da.iq_pow = c->d_iq_pow;
     da.iq_lambda = c->cfg.iq_inductance;
+    IqArgs iq_after;
+    memset(&iq_after, 0, sizeof(iq_after));
     if (c->iq) {
         const int gs = c->iq_gs;
         if (n_chunks > c->iq_cap_chunks) {
@@ -643,7 +687,8 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
             (void) hipFree(c->d_iq_chunk);
             c->d_iq_group = c->d_iq_agg = c->d_iq_chunk = nullptr;
             c->iq_cap_chunks = 0;
-            HIP_TRY(hipMalloc((void **) &c->d_iq_group, n_chunks * (size_t) (c->cfg.n_samples / gs) * 2 * sizeof(double)));
+            if (!c->use_i8w)
+                HIP_TRY(hipMalloc((void **) &c->d_iq_group, n_chunks * (size_t) (c->cfg.n_samples / gs) * 2 * sizeof(double)));
             HIP_TRY(hipMalloc((void **) &c->d_iq_agg, n_chunks * 2 * sizeof(double)));
             HIP_TRY(hipMalloc((void **) &c->d_iq_chunk, (n_chunks + 1) * 2 * sizeof(double)));
             c->iq_cap_chunks = n_chunks;
@@ -664,14 +709,20 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
         ia.pow_tab = c->d_iq_pow;
         ia.pow_g = c->iq_pow_e;
         ia.pow_n = c->iq_pow_n;
-        {
+        if (!c->use_i8w) {
+            // prefix pass over the input, then the chunks chained: the kernels below take offsets from these tables
             Timed t(c, s, 2);
             HIP_TRY(launch_iq_local(ia, s));
             HIP_TRY(launch_iq_scan(ia, s));
+            da.iq_group_off = c->d_iq_group;
+            da.iq_chunk_off = c->d_iq_chunk;
         }
-        da.iq_group_off = c->d_iq_group;
-        da.iq_chunk_off = c->d_iq_chunk;
+        iq_after = ia;            // wide-column kernel: it produces the chunk aggregates itself; scan + offset share follow it
     }
+    da.w8iq = c->iq && c->use_i8w ? c->d_w8iq : nullptr;
+    da.iq_consts = c->d_iq_consts;
+    da.iq_combine = c->iq_combine;
+    da.iq_chunk_agg = c->d_iq_agg;
     da.w8 = c->d_w8;
     da.w8mid = c->d_w8mid;
     da.ybias = c->d_ybias;
@@ -707,6 +758,11 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
         } else {
             HIP_TRY(launch_chain(da, c->L, c->cfg.dtype, c->nco, c->iq, n_chunks, s));
         }
+    }
+    if (c->iq && c->use_i8w) {
+        Timed t(c, s, 2);
+        HIP_TRY(launch_iq_scan(iq_after, s));
+        HIP_TRY(launch_iq_fix(ybuf, c->d_iq_R, c->d_iq_chunk, c->rows, n_chunks, c->m, s));
     }
     return SDRT_OK;
 }

@@ -42,6 +42,10 @@ struct DecimArgs {
     double e_off_re, e_off_im;  //   what the edge operators subtract from the decoded components
     double c_re, c_im;          //   IQ: the constant the slices leave out of (re, im)
     int iq_gs;                  //   IQ: samples per prefix group
+    const signed char *w8iq;    //   IQ: packed offset rows [LC/32][64][16] (sdrt_build_i8_offset_rows); non-null selects the IQ form
+    const double *iq_consts;    //   IQ: [SDRT_IQROW_CONSTS]
+    double iq_combine;          //   IQ: combine factor of the offset rows
+    double *iq_chunk_agg;       //   IQ out: [chunk][2] offset at the chunk's end when it starts from zero
     int rs;                     //   real-stream form (no shift, no IQ correction): w8 / w8mid hold sdrt_build_i8_weights_wide_rs planes
 };
 
@@ -58,6 +62,8 @@ struct IqArgs {
 };
 hipError_t launch_iq_local(const IqArgs &a, hipStream_t s);
 hipError_t launch_iq_scan(const IqArgs &a, hipStream_t s);
+// y[row][chunk][k] -= off[chunk] * R[row][k]: the share of the offset at the chunk's start (wide-column kernel, api.hip)
+hipError_t launch_iq_fix(double *ydec, const double *R, const double *chunk_off, int rows, size_t n_chunks, int m, hipStream_t s);
 
 size_t chain_lds_bytes(int n, int L, int m);
 
@@ -113,7 +119,7 @@ hipError_t launch_i8t_selftest(const int *A, const int *B, int *D, hipStream_t s
 // wide-column persistent int8 kernel (kernels_i8w.hip): q in {32, 64}, 8/16-bit integer encodings, 8 or 16 tiles per chunk
 bool chain_i8w_supported(int q, int dt, int n);
 bool chain_i8w_rs_supported(int dt, int n);       // its real-stream form (no shift, no IQ correction)
-size_t chain_i8w_lds_bytes(int q, int n);
+size_t chain_i8w_lds_bytes(int q, int n, bool iq);
 hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, int n_cus, hipStream_t s);
 // per-sample modal form for decimation < 8 and the workgroup-per-item demodulation stage for m > 4096 (kernels_seq.hip)
 bool chain_seq_supported(int q, int n);

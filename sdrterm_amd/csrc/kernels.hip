@@ -291,6 +291,28 @@ __global__ __launch_bounds__(256) void iq_scan_kernel(IqArgs a) {
     }
 }
 
+// The wide-column kernel corrects every chunk from a zero starting offset (its offsets come out of its own matrix rows, no
+// second pass over the input).  The chain is linear in the offset h at the chunk's start: y = y_local - h * D(nco * (1-lambda)^t),
+// the second factor a fixed vector R per row (computed once at sdrt_create).  This kernel subtracts that share.
+__global__ __launch_bounds__(256) void iq_fix_kernel(double *ydec, const double *__restrict__ R, const double *__restrict__ chunk_off,
+                                                     int rows, size_t n_chunks, int m) {
+    const size_t total = (size_t) rows * n_chunks * (size_t) m;
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t) gridDim.x * 256) {
+        const size_t item = i / (size_t) m, k = i - item * (size_t) m, row = item / n_chunks, chunk = item - row * n_chunks;
+        const cd h = ((const cd *) chunk_off)[chunk], r = ((const cd *) R)[row * (size_t) m + k];
+        cd y = ((cd *) ydec)[i];
+        y.re = fma(-h.re, r.re, fma(h.im, r.im, y.re));
+        y.im = fma(-h.re, r.im, fma(-h.im, r.re, y.im));
+        ((cd *) ydec)[i] = y;
+    }
+}
+
+hipError_t launch_iq_fix(double *ydec, const double *R, const double *chunk_off, int rows, size_t n_chunks, int m, hipStream_t s) {
+    const size_t total = (size_t) rows * n_chunks * (size_t) m, wgs = (total + 255) / 256;
+    hipLaunchKernelGGL(iq_fix_kernel, dim3((unsigned) (wgs < 8192 ? wgs : 8192)), dim3(256), 0, s, ydec, R, chunk_off, rows, n_chunks, m);
+    return hipGetLastError();
+}
+
 template <int DT>
 static hipError_t launch_iq_local_dt(const IqArgs &a, dim3 grid, hipStream_t s) {
     switch (a.gs) {

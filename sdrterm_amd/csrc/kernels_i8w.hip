@@ -49,10 +49,11 @@ __device__ __forceinline__ double swap16_add(double x, double y) {
 }
 
 struct WideLds {        // byte offsets
-    int wmain, wloc, cF, cG, bp, mup, tpw, tailF, tailFc, psi, gv, pq, cpow, buf, buf_stride, total;
-    // per buffer (offsets in 16-byte units from its start): carF [(NT+1)*8], carG [(NT+1)*8], F0 [8], Gu [8]
+    int wmain, wloc, cF, cG, bp, mup, tpw, tailF, tailFc, psi, gv, pq, wiq, buf, buf_stride, total;
+    // per buffer (offsets in 16-byte units from its start): carF [(NT+1)*8], carG [(NT+1)*8], F0 [8], Gu [8], IQ: tile totals of
+    // the offset [NT] and the weighted sum of the last 32 samples [1]
 };
-__host__ __device__ inline WideLds wide_lds(int S, int nout, int nt) {
+__host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, bool iq) {
     WideLds l;
     int p = 0;
     l.wmain = p; p += 2 * S * 8 * 1024;
@@ -67,9 +68,9 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt) {
     l.psi = p; p += nt * SDRT_TB * 16;              // column phasors of the row
     l.gv = p; p += 48 * 16;                         // IQ: rank-one vectors {g_re, g_im} per matrix row
     l.pq = p; p += 16 * 2 * 16;                     // IQ: offset terms of the edge operators
-    l.cpow = p; p += nt * SDRT_TB * 8;              // IQ: (1-lambda)^(column start)
+    l.wiq = p; p += iq ? (SDRT_WIDE_LC / 32) * 1024 : 0;     // IQ: offset rows, one packed fragment per k-step (sdrt_build_i8_offset_rows)
     l.buf = p;
-    l.buf_stride = (2 * (nt + 1) * 8 + 16) * 16;
+    l.buf_stride = (2 * (nt + 1) * 8 + 16 + nt + 1) * 16;
     p += 3 * l.buf_stride;
     l.total = p;
     return l;
@@ -110,17 +111,18 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     const bool swap = a.swap != 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, nb = lane & 15;
-    const WideLds lo = wide_lds(S, NOUT, NT);
+    const WideLds lo = wide_lds(S, NOUT, NT, IQ);
     const v4i *wmainL = (const v4i *) (smem + lo.wmain);
     const v4i *wlocL = (const v4i *) (smem + lo.wloc);
     cd *cFL = (cd *) (smem + lo.cF), *cGL = (cd *) (smem + lo.cG), *bpL = (cd *) (smem + lo.bp), *mupL = (cd *) (smem + lo.mup), *tpwL = (cd *) (smem + lo.tpw);
     cd *tailFL = (cd *) (smem + lo.tailF), *tailFcL = (cd *) (smem + lo.tailFc), *psiL = (cd *) (smem + lo.psi);
     cd *gvL = (cd *) (smem + lo.gv), *pqL = (cd *) (smem + lo.pq);
-    double *cpowL = (double *) (smem + lo.cpow);
+    const v4i *wiqL = (const v4i *) (smem + lo.wiq);
     auto carF = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride); };
     auto carG = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + (NT + 1) * 8; };
     auto F0L = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + 2 * (NT + 1) * 8; };
     auto GuL = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + 2 * (NT + 1) * 8 + 8; };
+    auto OtL = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + 2 * (NT + 1) * 8 + 16; };       // [NT] + tail sum at [NT]
 
     // ---- which items: workgroup (xcd, slot) keeps one row (digit planes resident) and walks over chunks of its XCD ------
     const unsigned bid = blockIdx.x, xcd = bid & 7u, slot = bid >> 3, nslot = gridDim.x >> 3;
@@ -163,7 +165,12 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     // sample l of the 32-sample window of the output: the chunk's first / last 32 samples (the operator spans 28 of them)
     const long e_idx = e_kind ? (long) n - 32 + e_l : (long) e_l;
     const double e_off_re = a.e_off_re, e_off_im = a.e_off_im;   // what the edge operators subtract from the decoded components
-    const int cgs = LC / (IQ ? a.iq_gs : LC);                    // IQ prefix groups per column
+    // IQ: the offset recurrence off' = (1-lambda) off + lambda x over whole columns (a.iq_consts: sdrt_build_i8_offset_rows)
+    const double iq_wsum = IQ ? a.iq_consts[0] : 0.0, iq_m1 = IQ ? a.iq_consts[1] : 0.0, iq_m2 = IQ ? a.iq_consts[2] : 0.0;
+    const double iq_m4 = IQ ? a.iq_consts[3] : 0.0, iq_m8 = IQ ? a.iq_consts[4] : 0.0, iq_m16 = IQ ? a.iq_consts[5] : 0.0;
+    const double iq_mnb = IQ ? a.iq_consts[39 + nb] : 0.0;                  // (1-lambda)^(LC nb): tile start -> this lane's column
+    const double iq_tw = IQ ? a.iq_consts[7 + (tid & 31)] : 0.0;            // weight of this thread's sample of the tail window
+    const double iq_cs = a.iq_combine;
     const double cs_main = a.w8_combine * (NSL == 2 ? 256.0 : 1.0), cs_loc = a.w8mid_combine * (NSL == 2 ? 256.0 : 1.0);
     const size_t chunk_bytes = (size_t) n * 2 * ITEM;
     // this lane's bytes of k-step s of a tile: column nb, samples SPK s + (SPK/4) g .. + SPK/4 - 1
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         if constexpr (IQ) {
             if (tid < 48) gvL[tid] = ((const cd *) a.gvec)[(size_t) row * 48 + tid];
             if (tid >= 64 && tid < 96) pqL[tid - 64] = ((const cd *) a.edge_pq)[(size_t) row * 32 + (tid - 64)];
-            for (int i = tid; i < NT * SDRT_TB; i += 512) cpowL[i] = a.iq_pow[i * cgs];
+            for (int i = tid; i < KS * 64; i += 512) ((v4i *) (smem + lo.wiq))[i] = ((const v4i *) a.w8iq)[i];
         }
         for (int i = tid; i < NT * SDRT_TB; i += 512) psiL[i] = nco ? nco_blk_g[i] : mk(1.0, 0.0);
         const cd *ybias = (const cd *) a.ybias + (size_t) row * m;      // always present for this kernel (zeros if there is no offset)
@@ -249,12 +256,14 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                                      // [2e + stream]; 4 per column: outputs 2 (g & 1) + (v >> 1), stream v & 1,
                                                      // lower levels in lanes g < 2, higher levels in lanes g >= 2
         cd pv[TPW][OPL];                             // P3 accumulators
+        cd oex[TPW];                                 // IQ: offset at this lane's column relative to its tile's start (item of the last K)
         double part[4][2];
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
 #pragma unroll
             for (int e = 0; e < OPL; ++e) yq[0][j][e] = yq[1][j][e] = ynew[j][e] = pv[j][e] = mk(0.0, 0.0);
             dC[j][0] = dC[j][1] = dA[j][0] = dA[j][1] = mk(0.0, 0.0);
+            oex[j] = mk(0.0, 0.0);
 #pragma unroll
             for (int v = 0; v < 4; ++v) dl[j][v] = 0.0;
         }
@@ -296,28 +305,39 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     if constexpr (IQ) yb[j][e] = mk(0.0, 0.0);          // no constant response: the offset term carries it
                     else yb[j][e] = ybias[((wave + 8 * j) * SDRT_TB + nb) * NOUT + g + 4 * e];
                 }
-            // IQ offsets (prefix kernels): at the chunk start, at the tail window and at this lane's columns of item it-1
-            cd off_head = mk(0.0, 0.0), off_tail = mk(0.0, 0.0), off_q = mk(0.0, 0.0), gq[TPW];
+            cd gq[TPW];
 #pragma unroll
             for (int j = 0; j < TPW; ++j) gq[j] = mk(0.0, 0.0);
             if constexpr (IQ) {
-                const long ck = chunk_of(HAVE_K ? it : 0), cq = chunk_of(have_q ? it - 1 : 0);
-                const int ngrp = n / a.iq_gs, gt = (n - 32) / a.iq_gs;
-                off_head = ((const cd *) a.iq_chunk_off)[ck];
-                const cd gtl = ((const cd *) a.iq_group_off)[(size_t) ck * ngrp + gt];
-                const double ptl = a.iq_pow[gt];
-                off_tail = mk(fma(ptl, off_head.re, gtl.re), fma(ptl, off_head.im, gtl.im));
-                off_q = ((const cd *) a.iq_chunk_off)[cq];
-                // the same value in every lane: keep them in scalar registers
-                auto uni = [](double v) {
-                    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-                };
-                off_head = mk(uni(off_head.re), uni(off_head.im));
-                off_tail = mk(uni(off_tail.re), uni(off_tail.im));
-                off_q = mk(uni(off_q.re), uni(off_q.im));
+                // Offsets of item it-1, relative to a zero offset at the start of its chunk (the chunk's true starting offset
+                // enters after the kernel: the chain is linear in it, api.hip).  K(it-1) left the offset at this lane's column
+                // relative to the tile start (oex) and every tile's total in LDS: chain the tiles before this one.
+                if (have_q) {
+                    const cd *ot = OtL(bQ);
 #pragma unroll
-                for (int j = 0; j < TPW; ++j)
-                    gq[j] = ((const cd *) a.iq_group_off)[(size_t) cq * ngrp + (size_t) ((wave + 8 * j) * SDRT_TB + nb) * cgs];
+                    for (int j = 0; j < TPW; ++j) {
+                        cd ts = mk(0.0, 0.0);
+                        for (int t2 = 0; t2 < wave + 8 * j; ++t2) ts = mk(fma(iq_m16, ts.re, ot[t2].re), fma(iq_m16, ts.im, ot[t2].im));
+                        gq[j] = mk(fma(iq_mnb, ts.re, oex[j].re), fma(iq_mnb, ts.im, oex[j].im));
+                    }
+                    if (wave == 0) {
+                        // the offset at the chunk's end -> chunk aggregate (the scan over chunks follows the kernel), and the
+                        // offset at the first sample of the tail window, unwound over the window's 32 samples: its share of the
+                        // tail edge operators (8 outputs) goes into Gu before P2 reads it
+                        cd te = mk(0.0, 0.0);
+                        for (int t2 = 0; t2 < NT; ++t2) te = mk(fma(iq_m16, te.re, ot[t2].re), fma(iq_m16, te.im, ot[t2].im));
+                        const cd tsum = ot[NT];
+                        const cd ow = mk((te.re - tsum.re) * a.iq_consts[6], (te.im - tsum.im) * a.iq_consts[6]);
+                        if (tid == 0) ((cd *) a.iq_chunk_agg)[chunk_of(it - 1)] = te;
+                        if (lane < 8) {
+                            const cd P = pqL[2 * (8 + lane)], Q = pqL[2 * (8 + lane) + 1];
+                            cd gu = GuL(bQ)[lane];
+                            gu.re = fma(-P.re, ow.re, fma(-Q.re, ow.im, gu.re));
+                            gu.im = fma(-P.im, ow.re, fma(-Q.im, ow.im, gu.im));
+                            GuL(bQ)[lane] = gu;
+                        }
+                    }
+                }
             }
             // ---- P2(it-2): tile carries, one wave per real stream; DPP rows = modes, lanes of a row = tiles ------------------
             if (have_p2 && (wave >> 1) == (it & 1)) {     // waves 0-3 win the issue arbitration on their SIMDs and have the slack
@@ -361,8 +381,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     if constexpr (IQ && i == 0) {
                         // IQ correction, the part that is linear in the offset at the column's first sample:
                         // row value += (c - off).re g_re[row] + (c - off).im g_im[row]
-                        const double cp = cpowL[tile * SDRT_TB + nb];
-                        const double dr = a.c_re - fma(cp, off_q.re, gq[j].re), di = a.c_im - fma(cp, off_q.im, gq[j].im);
+                        const double dr = a.c_re - gq[j].re, di = a.c_im - gq[j].im;
                         const cd g0 = gvL[4 * g + 0], g1 = gvL[4 * g + 1], g2 = gvL[4 * g + 2], g3 = gvL[4 * g + 3];
                         dC[j][0] = mk(fma(dr, g0.re, fma(di, g0.im, dC[j][0].re)), fma(dr, g1.re, fma(di, g1.im, dC[j][0].im)));
                         dC[j][1] = mk(fma(dr, g2.re, fma(di, g2.im, dC[j][1].re)), fma(dr, g3.re, fma(di, g3.im, dC[j][1].im)));
@@ -487,12 +506,17 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     // rows, then across the two rows of each half
                     const double xr = decode<DT>(e_re, swap) - e_off_re, xi = decode<DT>(e_im, swap) - e_off_im;
                     cd f = mk(fma(e_A.re, xr, e_B.re * xi), fma(e_A.im, xr, e_B.im * xi));
+                    // IQ: the offset at the head window's first sample is zero in chunk-local terms; the tail window's share is
+                    // added one iteration later, when the chunk's offsets are known.  What that needs from here: the weighted
+                    // sum of the window's 32 samples (the lanes of output 8 store it)
+                    cd tsw = mk(iq_tw * xr, iq_tw * xi);
                     if constexpr (IQ) {
-                        if (e_l == 0) {                          // the offset at the window's first sample, once per output
-                            const cd ow = e_kind ? off_tail : off_head, P = pqL[2 * e_o16], Q = pqL[2 * e_o16 + 1];
-                            f.re = fma(-P.re, ow.re, fma(-Q.re, ow.im, f.re));
-                            f.im = fma(-P.im, ow.re, fma(-Q.im, ow.im, f.im));
-                        }
+                        tsw = cadd(tsw, dpp_row<0x111>(tsw));
+                        tsw = cadd(tsw, dpp_row<0x112>(tsw));
+                        tsw = cadd(tsw, dpp_row<0x114>(tsw));
+                        tsw = cadd(tsw, dpp_row<0x118>(tsw));
+                        const double tot2 = swap16_add(tsw.re, tsw.im);
+                        if (nb == 15 && e_o16 == 8) ((double *) (OtL(bcur) + NT))[g & 1] = tot2;
                     }
                     f = cadd(f, dpp_row<0x111>(f));
                     f = cadd(f, dpp_row<0x112>(f));
@@ -661,6 +685,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     }
                 } else {
                     v4i acc[3][S];
+                    v4i accO[2];                         // IQ: offset rows x (high, low) slice
                     v4i F[S];                            // digit-plane fragments of the current group; each is reloaded for the next
                                                          // group as soon as its last matrix instruction has been issued
                     auto frag = [&](auto ic, auto dc) -> v4i {
@@ -719,6 +744,16 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                     if constexpr (!(PACK && (i + 1) % 3 == 2 && d >= NLF)) F[d] = frag(std::integral_constant<int, i + 1>{}, dc);
                                 }
                             });
+                            if constexpr (IQ && rt == 2) {
+                                // the packed offset rows of this k-step against both slices
+                                const v4i Fq = wiqL[s * 64 + lane];
+                                if constexpr (NSL == 2) {
+                                    if constexpr (s == 0) accO[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fq, bhi, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                    else accO[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fq, bhi, accO[0], 0, 0, 0);
+                                }
+                                if constexpr (s == 0) accO[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fq, blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                else accO[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fq, blo, accO[1], 0, 0, 0);
+                            }
                             __builtin_amdgcn_sched_barrier(0);
                             __builtin_amdgcn_s_setprio(0);
                         }
@@ -755,6 +790,27 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         dC[j][1] = mk(val[2], val[3]);
                         dA[j][0] = mk(val[4], val[5]);
                         dA[j][1] = mk(val[6], val[7]);
+                        if constexpr (IQ) {
+                            // what the column adds to the offset: lane (g, nb) holds digit planes 2g, 2g+1 of both sums (rows 4g + v:
+                            // plane 2g + (v >> 1), component v & 1; g == 3: empty rows)
+                            double tq[4];
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) tq[v] = NSL == 2 ? fma((double) accO[0][v], 256.0, (double) accO[1][v]) : (double) accO[1][v];
+                            const double sc = iq_cs * (g == 0 ? 1.0 : (g == 1 ? 65536.0 : 4294967296.0));
+                            double ar = fma(tq[2], 256.0, tq[0]) * sc, ai = fma(tq[3], 256.0, tq[1]) * sc;
+                            ar += __shfl_xor(ar, 16);
+                            ai += __shfl_xor(ai, 16);
+                            ar += __shfl_xor(ar, 32);
+                            ai += __shfl_xor(ai, 32);
+                            // + the constant the slices leave out; then the inclusive scan over the tile's 16 columns
+                            cd o = mk(fma(a.c_re, iq_wsum, ar), fma(a.c_im, iq_wsum, ai));
+                            o = mk(fma(iq_m1, dpp_row<0x111>(o.re), o.re), fma(iq_m1, dpp_row<0x111>(o.im), o.im));
+                            o = mk(fma(iq_m2, dpp_row<0x112>(o.re), o.re), fma(iq_m2, dpp_row<0x112>(o.im), o.im));
+                            o = mk(fma(iq_m4, dpp_row<0x114>(o.re), o.re), fma(iq_m4, dpp_row<0x114>(o.im), o.im));
+                            o = mk(fma(iq_m8, dpp_row<0x118>(o.re), o.re), fma(iq_m8, dpp_row<0x118>(o.im), o.im));
+                            if (lane == 15) OtL(bcur)[wave + 8 * j] = o;              // the tile's total
+                            oex[j] = dpp_row<0x111>(o);                               // offset at the column's first sample
+                        }
                     }
                 }
             });
@@ -803,7 +859,7 @@ static hipError_t launch_i8w_k(const DecimArgs &a, dim3 grid, size_t lds, hipStr
     if constexpr (Enc<DT>::size == 2 && NT == 8) {
         if (a.rs) return launch_i8w_q<DT, NOUT, NT, false, true>(a, grid, lds, s);
     } else if (a.rs) return hipErrorInvalidValue;
-    return a.iq_group_off ? launch_i8w_q<DT, NOUT, NT, true, false>(a, grid, lds, s) : launch_i8w_q<DT, NOUT, NT, false, false>(a, grid, lds, s);
+    return a.w8iq ? launch_i8w_q<DT, NOUT, NT, true, false>(a, grid, lds, s) : launch_i8w_q<DT, NOUT, NT, false, false>(a, grid, lds, s);
 }
 
 template <int DT>
@@ -839,8 +895,8 @@ bool chain_i8w_supported(int q, int dt, int n) {
     return n % (SDRT_TB * SDRT_WIDE_LC) == 0 && (nt == 8 || nt == 16);
 }
 
-size_t chain_i8w_lds_bytes(int q, int n) {
-    return (size_t) wide_lds(SDRT_I8_DIGITS, SDRT_WIDE_LC / q, n / (SDRT_TB * SDRT_WIDE_LC)).total;
+size_t chain_i8w_lds_bytes(int q, int n, bool iq) {
+    return (size_t) wide_lds(SDRT_I8_DIGITS, SDRT_WIDE_LC / q, n / (SDRT_TB * SDRT_WIDE_LC), iq).total;
 }
 
 hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, int n_cus, hipStream_t s) {
@@ -851,7 +907,7 @@ hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, 
     if (items < wgs) wgs = items;
     wgs = (wgs + 7) / 8 * 8;
     const dim3 grid((unsigned) wgs);
-    const size_t lds = chain_i8w_lds_bytes(q, a.n);
+    const size_t lds = chain_i8w_lds_bytes(q, a.n, a.w8iq != nullptr);
     switch (dt) {
         case SDRT_S8: case SDRT_U8: return launch_chain_i8w_bytes(a, nout, nt, dt, grid, lds, s);     // kernels_i8w_b.hip
         case SDRT_S16: return launch_i8w_d<SDRT_S16>(a, nout, nt, grid, lds, s);

@@ -587,6 +587,40 @@ extern "C" int sdrt_build_i8_weights_wide(const double *sos, int sections, int q
     return 0;
 }
 
+extern "C" int sdrt_build_i8_offset_rows(double lambda, int S, signed char *out, double *combine, double *consts) {
+    // the column's contribution to the IQ offset (read_file.py:64-77: off' = (1-lambda) off + lambda x):
+    //   off(column end) = (1-lambda)^LC off(column start) + sum_j w_j x_j,   w_j = lambda (1-lambda)^(LC-1-j)
+    const int LC = SDRT_WIDE_LC, cols = 2 * LC, KS = LC / 32;
+    if (!(lambda > 0.0) || !(lambda < 1.0) || S > 8) return -3;
+    const R lam = (R) lambda, om = (R) 1 - lam;
+    std::vector<R> pw((size_t) LC + 1);
+    pw[0] = 1;
+    for (int t = 1; t <= LC; ++t) pw[t] = pw[t - 1] * om;
+    std::vector<double> W((size_t) 2 * cols, 0.0);
+    R wsum = 0;
+    for (int j = 0; j < LC; ++j) {
+        const R w = lam * pw[LC - 1 - j];
+        wsum = wsum + w;
+        W[(size_t) 0 * cols + 2 * j] = (double) w;          // row "re": coefficient of x_re
+        W[(size_t) 1 * cols + 2 * j + 1] = (double) w;      // row "im": coefficient of x_im
+    }
+    memset(out, 0, (size_t) KS * 64 * 16);
+    *combine = quantise_planes(W.data(), 2, cols, cols, S, [&](int d, int r, int c, signed char dig) {
+        const int sample = c >> 1, comp = c & 1, ks = sample / 32, kg = (sample % 32) / 8, j = 2 * (sample % 8) + comp;
+        out[(((size_t) ks * 64) + ((2 * d + r) + 16 * kg)) * 16 + j] = dig;
+    });
+    if (*combine == 0.0) return -1;
+    consts[0] = (double) wsum;
+    R p = pw[LC];
+    for (int k = 0; k < 5; ++k) { consts[1 + k] = (double) p; p = p * p; }      // (1-lambda)^(LC 2^k), k = 0..4
+    R p32 = 1;
+    for (int t = 0; t < 32; ++t) p32 = p32 * om;
+    consts[6] = (double) ((R) 1 / p32);                                          // (1-lambda)^-32
+    for (int l = 0; l < 32; ++l) consts[7 + l] = (double) (lam * pw[31 - l]);     // tail window weights lambda (1-lambda)^(31-l)
+    for (int nb = 0; nb < SDRT_TB; ++nb) consts[39 + nb] = (double) ([&] { R q = 1; for (int t = 0; t < nb; ++t) q = q * pw[LC]; return q; })();   // (1-lambda)^(LC nb)
+    return 0;
+}
+
 extern "C" int sdrt_build_i8_weights_wide_rs(const double *sos, int sections, int q, double data_scale, int S,
                                              signed char *main_out, double *main_combine, signed char *loc_out,
                                              double *loc_combine) {

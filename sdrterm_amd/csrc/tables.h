@@ -126,6 +126,14 @@ int sdrt_build_i8_weights_wide(const double *sos, int sections, int q, double da
                                double iq_lambda, signed char *main_out, double *main_combine, signed char *loc_out,
                                double *loc_combine, double *gvec /*[48][2]*/);
 
+// Offset rows of the wide-column kernel with IQ correction (iq_lambda > 0): per column the two sums  sum_j w_j x_re[j],
+// sum_j w_j x_im[j], w_j = lambda (1-lambda)^(LC-1-j) -- what the column adds to the carried offset.  All S digit planes of
+// both rows share ONE 16-row fragment per k-step (row 2 d + component):  out[(kstep*64 + row + 16*kg)*16 + j], K positions as
+// for the other planes.  consts[55]: [0] sum_j w_j, [1..5] (1-lambda)^(LC 2^k) (k = 0..4), [6] (1-lambda)^-32,
+// [7..38] lambda (1-lambda)^(31-l) (weights of the last 32 samples), [39..54] (1-lambda)^(LC nb), nb < 16.
+#define SDRT_IQROW_CONSTS 55
+int sdrt_build_i8_offset_rows(double lambda, int S, signed char *out /*[LC/32][64][16]*/, double *combine, double *consts);
+
 // Digit planes of the wide-column kernel WITHOUT frequency shift ("real streams"): the real and the imaginary sample stream
 // are then filtered by the same real-coefficient operator, so one 16-row tile (row = 4*mode + 2*kind + part, kind 0 causal /
 // 1 anticausal column aggregate) serves both, applied to the re bytes and to the im bytes separately, 64 samples per
