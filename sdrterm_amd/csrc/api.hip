@@ -96,7 +96,8 @@ struct sdrt_ctx {
     double *d_wsum = nullptr;
     signed char *d_w8iq = nullptr;    // wide kernel with IQ correction: packed offset rows, their constants, the offset response R
     double *d_iq_consts = nullptr, *d_iq_R = nullptr;
-    double iq_combine = 0.0;         // float32 on the int8 matrix cores: weight-row sums (DecimArgs.wsum)
+    double iq_combine = 0.0;
+    bool iq_fused = false;            // wide kernel computes the offsets itself (one row; several rows share the prefix pass instead)         // float32 on the int8 matrix cores: weight-row sums (DecimArgs.wsum)
     double w8_combine = 0.0, w8mid_combine = 0.0, x_offset = 0.0;
     int n_tiles8 = 0;
     bool iq = false;
@@ -231,7 +232,7 @@ int setup_wide(sdrt_ctx *c, const sdrt_config *cfg, ScaleFn &) {
     if (rc == SDRT_OK) rc = upload(&c->d_edge_ab, eab.data(), eab.size() * sizeof(double));
     if (rc == SDRT_OK) rc = upload(&c->d_edge_pq, epq.data(), epq.size() * sizeof(double));
     if (rc == SDRT_OK) rc = upload(&c->d_gvec, gv.data(), gv.size() * sizeof(double));
-    if (rc == SDRT_OK && c->iq) {
+    if (rc == SDRT_OK && c->iq_fused) {
         // the offsets come out of two more matrix rows (no second pass over the input) ...
         std::vector<signed char> wq((size_t) KS * 64 * 16);
         std::vector<double> consts(SDRT_IQROW_CONSTS);
@@ -545,9 +546,13 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         // int8 matrix-core forms in order of preference; a form that cannot represent this configuration (unequal
         // power-of-two scales between rows, a digit overflow) releases what it uploaded and the next one is tried; the
         // fp64 matrix-core kernel takes whatever is left
+        // one row: the offsets come out of the wide kernel's own matrix rows (no second pass over the input); several rows share
+        // one prefix pass instead of each recomputing them (diagnostics: SDRTERM_IQ_FUSED=0 / 1 forces either)
+        c->iq_fused = c->iq && c->rows == 1;
+        if (const char *e = getenv("SDRTERM_IQ_FUSED")) c->iq_fused = c->iq && atoi(e) != 0;
         if (seq) {
             // nothing to set up: the per-sample form reads DecimTables only
-        } else if (want_i8 && !want_t && chain_i8w_supported(q, cfg->dtype, n) && chain_i8w_lds_bytes(q, n, c->iq) <= 160 * 1024)
+        } else if (want_i8 && !want_t && chain_i8w_supported(q, cfg->dtype, n) && chain_i8w_lds_bytes(q, n, c->iq ? (c->iq_fused ? 2 : 1) : 0) <= 160 * 1024)
             rc = setup_wide(c, cfg, scale_tables);
         if (rc == SDRT_OK && !seq && !c->use_i8w && want_i8 && !c->iq && want_i8_fallback_t(L, cfg->dtype, n, m))
             rc = setup_i8t(c, cfg, scale_tables);
@@ -687,7 +692,7 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
             (void) hipFree(c->d_iq_chunk);
             c->d_iq_group = c->d_iq_agg = c->d_iq_chunk = nullptr;
             c->iq_cap_chunks = 0;
-            if (!c->use_i8w)
+            if (!(c->use_i8w && c->iq_fused))
                 HIP_TRY(hipMalloc((void **) &c->d_iq_group, n_chunks * (size_t) (c->cfg.n_samples / gs) * 2 * sizeof(double)));
             HIP_TRY(hipMalloc((void **) &c->d_iq_agg, n_chunks * 2 * sizeof(double)));
             HIP_TRY(hipMalloc((void **) &c->d_iq_chunk, (n_chunks + 1) * 2 * sizeof(double)));
@@ -709,7 +714,7 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
         ia.pow_tab = c->d_iq_pow;
         ia.pow_g = c->iq_pow_e;
         ia.pow_n = c->iq_pow_n;
-        if (!c->use_i8w) {
+        if (!(c->use_i8w && c->iq_fused)) {
             // prefix pass over the input, then the chunks chained: the kernels below take offsets from these tables
             Timed t(c, s, 2);
             HIP_TRY(launch_iq_local(ia, s));
@@ -719,7 +724,7 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
         }
         iq_after = ia;            // wide-column kernel: it produces the chunk aggregates itself; scan + offset share follow it
     }
-    da.w8iq = c->iq && c->use_i8w ? c->d_w8iq : nullptr;
+    da.w8iq = c->iq && c->use_i8w && c->iq_fused ? c->d_w8iq : nullptr;
     da.iq_consts = c->d_iq_consts;
     da.iq_combine = c->iq_combine;
     da.iq_chunk_agg = c->d_iq_agg;
@@ -759,7 +764,7 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
             HIP_TRY(launch_chain(da, c->L, c->cfg.dtype, c->nco, c->iq, n_chunks, s));
         }
     }
-    if (c->iq && c->use_i8w) {
+    if (c->iq && c->use_i8w && c->iq_fused) {
         Timed t(c, s, 2);
         HIP_TRY(launch_iq_scan(iq_after, s));
         HIP_TRY(launch_iq_fix(ybuf, c->d_iq_R, c->d_iq_chunk, c->rows, n_chunks, c->m, s));

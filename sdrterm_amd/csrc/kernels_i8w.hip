@@ -49,11 +49,11 @@ __device__ __forceinline__ double swap16_add(double x, double y) {
 }
 
 struct WideLds {        // byte offsets
-    int wmain, wloc, cF, cG, bp, mup, tpw, tailF, tailFc, psi, gv, pq, wiq, buf, buf_stride, total;
+    int wmain, wloc, cF, cG, bp, mup, tpw, tailF, tailFc, psi, gv, pq, cpow, wiq, buf, buf_stride, total;
     // per buffer (offsets in 16-byte units from its start): carF [(NT+1)*8], carG [(NT+1)*8], F0 [8], Gu [8], IQ: tile totals of
     // the offset [NT] and the weighted sum of the last 32 samples [1]
 };
-__host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, bool iq) {
+__host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq) {
     WideLds l;
     int p = 0;
     l.wmain = p; p += 2 * S * 8 * 1024;
@@ -68,7 +68,8 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, bool iq) {
     l.psi = p; p += nt * SDRT_TB * 16;              // column phasors of the row
     l.gv = p; p += 48 * 16;                         // IQ: rank-one vectors {g_re, g_im} per matrix row
     l.pq = p; p += 16 * 2 * 16;                     // IQ: offset terms of the edge operators
-    l.wiq = p; p += iq ? (SDRT_WIDE_LC / 32) * 1024 : 0;     // IQ: offset rows, one packed fragment per k-step (sdrt_build_i8_offset_rows)
+    l.cpow = p; p += iq == 1 ? nt * SDRT_TB * 8 : 0;       // IQ from prefix tables: (1-lambda)^(column start)
+    l.wiq = p; p += iq == 2 ? (SDRT_WIDE_LC / 32) * 1024 : 0;     // IQ fused: offset rows, one packed fragment per k-step (sdrt_build_i8_offset_rows)
     l.buf = p;
     l.buf_stride = (2 * (nt + 1) * 8 + 16 + nt + 1) * 16;
     p += 3 * l.buf_stride;
@@ -81,9 +82,12 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, bool iq) {
 // the same real-coefficient operator: ONE 16-row aggregate tile applied to the re bytes and to the im bytes separately, 64
 // samples per k-step, and a local tile of NOUT rows per stream in which 16 / NOUT digit planes share one instruction: 96
 // (NOUT = 4) or 112 (NOUT = 8) matrix instructions per tile instead of 184 / 216.
-template <int DT, int NOUT, int NT, int S, bool IQ, bool RS>
+// IQ: 0 no correction; 1 offsets at column starts from the prefix kernels' tables (iq_local_kernel / iq_scan_kernel: a second pass
+// over the input, shared by all rows); 2 offsets from two more matrix rows of this kernel (no second pass; one row: see api.hip)
+template <int DT, int NOUT, int NT, int S, int IQ, bool RS>
 __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
-    static_assert(!(RS && IQ), "the real-stream form has no IQ correction");
+    static_assert(!(RS && IQ != 0), "the real-stream form has no IQ correction");
+    constexpr bool IQA = IQ != 0, IQT = IQ == 1, IQF = IQ == 2;
     constexpr int LC = SDRT_WIDE_LC, KS = RS ? LC / 64 : LC / 32, SPK = LC / KS;   // k-steps per column, samples per k-step
     constexpr int NSL = W8Enc<DT>::slices;
     constexpr int ITEM = Enc<DT>::size;
@@ -118,6 +122,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     cd *tailFL = (cd *) (smem + lo.tailF), *tailFcL = (cd *) (smem + lo.tailFc), *psiL = (cd *) (smem + lo.psi);
     cd *gvL = (cd *) (smem + lo.gv), *pqL = (cd *) (smem + lo.pq);
     const v4i *wiqL = (const v4i *) (smem + lo.wiq);
+    double *cpowL = (double *) (smem + lo.cpow);
     auto carF = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride); };
     auto carG = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + (NT + 1) * 8; };
     auto F0L = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + 2 * (NT + 1) * 8; };
@@ -165,11 +170,12 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     // sample l of the 32-sample window of the output: the chunk's first / last 32 samples (the operator spans 28 of them)
     const long e_idx = e_kind ? (long) n - 32 + e_l : (long) e_l;
     const double e_off_re = a.e_off_re, e_off_im = a.e_off_im;   // what the edge operators subtract from the decoded components
-    // IQ: the offset recurrence off' = (1-lambda) off + lambda x over whole columns (a.iq_consts: sdrt_build_i8_offset_rows)
-    const double iq_wsum = IQ ? a.iq_consts[0] : 0.0, iq_m1 = IQ ? a.iq_consts[1] : 0.0, iq_m2 = IQ ? a.iq_consts[2] : 0.0;
-    const double iq_m4 = IQ ? a.iq_consts[3] : 0.0, iq_m8 = IQ ? a.iq_consts[4] : 0.0, iq_m16 = IQ ? a.iq_consts[5] : 0.0;
-    const double iq_mnb = IQ ? a.iq_consts[39 + nb] : 0.0;                  // (1-lambda)^(LC nb): tile start -> this lane's column
-    const double iq_tw = IQ ? a.iq_consts[7 + (tid & 31)] : 0.0;            // weight of this thread's sample of the tail window
+    const int cgs = LC / (IQT ? a.iq_gs : LC);                   // IQ prefix groups per column
+    // IQ fused: the offset recurrence off' = (1-lambda) off + lambda x over whole columns (a.iq_consts: sdrt_build_i8_offset_rows)
+    const double iq_wsum = IQF ? a.iq_consts[0] : 0.0, iq_m1 = IQF ? a.iq_consts[1] : 0.0, iq_m2 = IQF ? a.iq_consts[2] : 0.0;
+    const double iq_m4 = IQF ? a.iq_consts[3] : 0.0, iq_m8 = IQF ? a.iq_consts[4] : 0.0, iq_m16 = IQF ? a.iq_consts[5] : 0.0;
+    const double iq_mnb = IQF ? a.iq_consts[39 + nb] : 0.0;                 // (1-lambda)^(LC nb): tile start -> this lane's column
+    const double iq_tw = IQF ? a.iq_consts[7 + (tid & 31)] : 0.0;           // weight of this thread's sample of the tail window
     const double iq_cs = a.iq_combine;
     const double cs_main = a.w8_combine * (NSL == 2 ? 256.0 : 1.0), cs_loc = a.w8mid_combine * (NSL == 2 ? 256.0 : 1.0);
     const size_t chunk_bytes = (size_t) n * 2 * ITEM;
@@ -220,10 +226,11 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         // coefficients of this thread's sample in its edge operator (NCO phasor and IQ correction of the window folded in)
         const cd e_A = ((const cd *) a.edge_ab)[(((size_t) row * 16 + e_o16) * 32 + e_l) * 2];
         const cd e_B = ((const cd *) a.edge_ab)[(((size_t) row * 16 + e_o16) * 32 + e_l) * 2 + 1];
-        if constexpr (IQ) {
+        if constexpr (IQA) {
             if (tid < 48) gvL[tid] = ((const cd *) a.gvec)[(size_t) row * 48 + tid];
             if (tid >= 64 && tid < 96) pqL[tid - 64] = ((const cd *) a.edge_pq)[(size_t) row * 32 + (tid - 64)];
-            for (int i = tid; i < KS * 64; i += 512) ((v4i *) (smem + lo.wiq))[i] = ((const v4i *) a.w8iq)[i];
+            if constexpr (IQT) for (int i = tid; i < NT * SDRT_TB; i += 512) cpowL[i] = a.iq_pow[i * cgs];
+            if constexpr (IQF) for (int i = tid; i < KS * 64; i += 512) ((v4i *) (smem + lo.wiq))[i] = ((const v4i *) a.w8iq)[i];
         }
         for (int i = tid; i < NT * SDRT_TB; i += 512) psiL[i] = nco ? nco_blk_g[i] : mk(1.0, 0.0);
         const cd *ybias = (const cd *) a.ybias + (size_t) row * m;      // always present for this kernel (zeros if there is no offset)
@@ -302,13 +309,33 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             for (int j = 0; j < TPW; ++j)
 #pragma unroll
                 for (int e = 0; e < OPL; ++e) {
-                    if constexpr (IQ) yb[j][e] = mk(0.0, 0.0);          // no constant response: the offset term carries it
+                    if constexpr (IQA) yb[j][e] = mk(0.0, 0.0);          // no constant response: the offset term carries it
                     else yb[j][e] = ybias[((wave + 8 * j) * SDRT_TB + nb) * NOUT + g + 4 * e];
                 }
-            cd gq[TPW];
+            cd off_head = mk(0.0, 0.0), off_tail = mk(0.0, 0.0), off_q = mk(0.0, 0.0), gq[TPW];
 #pragma unroll
             for (int j = 0; j < TPW; ++j) gq[j] = mk(0.0, 0.0);
-            if constexpr (IQ) {
+            if constexpr (IQT) {
+                // offsets from the prefix kernels: at the chunk start, at the tail window and at this lane's columns of item it-1
+                const long ck = chunk_of(HAVE_K ? it : 0), cq = chunk_of(have_q ? it - 1 : 0);
+                const int ngrp = n / a.iq_gs, gt = (n - 32) / a.iq_gs;
+                off_head = ((const cd *) a.iq_chunk_off)[ck];
+                const cd gtl = ((const cd *) a.iq_group_off)[(size_t) ck * ngrp + gt];
+                const double ptl = a.iq_pow[gt];
+                off_tail = mk(fma(ptl, off_head.re, gtl.re), fma(ptl, off_head.im, gtl.im));
+                off_q = ((const cd *) a.iq_chunk_off)[cq];
+                // the same value in every lane: keep them in scalar registers
+                auto uni = [](double v) {
+                    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+                };
+                off_head = mk(uni(off_head.re), uni(off_head.im));
+                off_tail = mk(uni(off_tail.re), uni(off_tail.im));
+                off_q = mk(uni(off_q.re), uni(off_q.im));
+#pragma unroll
+                for (int j = 0; j < TPW; ++j)
+                    gq[j] = ((const cd *) a.iq_group_off)[(size_t) cq * ngrp + (size_t) ((wave + 8 * j) * SDRT_TB + nb) * cgs];
+            }
+            if constexpr (IQF) {
                 // Offsets of item it-1, relative to a zero offset at the start of its chunk (the chunk's true starting offset
                 // enters after the kernel: the chain is linear in it, api.hip).  K(it-1) left the offset at this lane's column
                 // relative to the tile start (oex) and every tile's total in LDS: chain the tiles before this one.
@@ -378,10 +405,11 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                 constexpr int j = decltype(jc)::value, i = decltype(ic)::value;
                 const int tile = wave + 8 * j;
                 if (have_q) {
-                    if constexpr (IQ && i == 0) {
+                    if constexpr (IQA && i == 0) {
                         // IQ correction, the part that is linear in the offset at the column's first sample:
                         // row value += (c - off).re g_re[row] + (c - off).im g_im[row]
-                        const double dr = a.c_re - gq[j].re, di = a.c_im - gq[j].im;
+                        const double cp = IQT ? cpowL[tile * SDRT_TB + nb] : 0.0;        // fused: zero offset at the chunk start
+                        const double dr = a.c_re - fma(cp, off_q.re, gq[j].re), di = a.c_im - fma(cp, off_q.im, gq[j].im);
                         const cd g0 = gvL[4 * g + 0], g1 = gvL[4 * g + 1], g2 = gvL[4 * g + 2], g3 = gvL[4 * g + 3];
                         dC[j][0] = mk(fma(dr, g0.re, fma(di, g0.im, dC[j][0].re)), fma(dr, g1.re, fma(di, g1.im, dC[j][0].im)));
                         dC[j][1] = mk(fma(dr, g2.re, fma(di, g2.im, dC[j][1].re)), fma(dr, g3.re, fma(di, g3.im, dC[j][1].im)));
@@ -506,11 +534,18 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     // rows, then across the two rows of each half
                     const double xr = decode<DT>(e_re, swap) - e_off_re, xi = decode<DT>(e_im, swap) - e_off_im;
                     cd f = mk(fma(e_A.re, xr, e_B.re * xi), fma(e_A.im, xr, e_B.im * xi));
-                    // IQ: the offset at the head window's first sample is zero in chunk-local terms; the tail window's share is
+                    // IQ fused: the offset at the head window's first sample is zero in chunk-local terms; the tail window's share is
                     // added one iteration later, when the chunk's offsets are known.  What that needs from here: the weighted
                     // sum of the window's 32 samples (the lanes of output 8 store it)
                     cd tsw = mk(iq_tw * xr, iq_tw * xi);
-                    if constexpr (IQ) {
+                    if constexpr (IQT) {
+                        if (e_l == 0) {                          // the offset at the window's first sample, once per output
+                            const cd ow = e_kind ? off_tail : off_head, P = pqL[2 * e_o16], Q = pqL[2 * e_o16 + 1];
+                            f.re = fma(-P.re, ow.re, fma(-Q.re, ow.im, f.re));
+                            f.im = fma(-P.im, ow.re, fma(-Q.im, ow.im, f.im));
+                        }
+                    }
+                    if constexpr (IQF) {
                         tsw = cadd(tsw, dpp_row<0x111>(tsw));
                         tsw = cadd(tsw, dpp_row<0x112>(tsw));
                         tsw = cadd(tsw, dpp_row<0x114>(tsw));
@@ -744,7 +779,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                     if constexpr (!(PACK && (i + 1) % 3 == 2 && d >= NLF)) F[d] = frag(std::integral_constant<int, i + 1>{}, dc);
                                 }
                             });
-                            if constexpr (IQ && rt == 2) {
+                            if constexpr (IQF && rt == 2) {
                                 // the packed offset rows of this k-step against both slices
                                 const v4i Fq = wiqL[s * 64 + lane];
                                 if constexpr (NSL == 2) {
@@ -790,7 +825,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         dC[j][1] = mk(val[2], val[3]);
                         dA[j][0] = mk(val[4], val[5]);
                         dA[j][1] = mk(val[6], val[7]);
-                        if constexpr (IQ) {
+                        if constexpr (IQF) {
                             // what the column adds to the offset: lane (g, nb) holds digit planes 2g, 2g+1 of both sums (rows 4g + v:
                             // plane 2g + (v >> 1), component v & 1; g == 3: empty rows)
                             double tq[4];
@@ -838,7 +873,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
 // SDRT_I8W_BYTES defined) so that the two halves compile in parallel.
 hipError_t launch_chain_i8w_bytes(const DecimArgs &a, int nout, int nt, int dt, dim3 grid, size_t lds, hipStream_t s);
 
-template <int DT, int NOUT, int NT, bool IQ, bool RS>
+template <int DT, int NOUT, int NT, int IQ, bool RS>
 static hipError_t launch_i8w_q(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     // once per device and instantiation (a driver call per launch costs more than the gap between two kernels)
     static thread_local int done_dev = -1;
@@ -857,9 +892,10 @@ template <int DT, int NOUT, int NT>
 static hipError_t launch_i8w_k(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     // no shift, no IQ correction: real streams (instantiated for the 16-bit encodings at 8 tiles per chunk only)
     if constexpr (Enc<DT>::size == 2 && NT == 8) {
-        if (a.rs) return launch_i8w_q<DT, NOUT, NT, false, true>(a, grid, lds, s);
+        if (a.rs) return launch_i8w_q<DT, NOUT, NT, 0, true>(a, grid, lds, s);
     } else if (a.rs) return hipErrorInvalidValue;
-    return a.w8iq ? launch_i8w_q<DT, NOUT, NT, true, false>(a, grid, lds, s) : launch_i8w_q<DT, NOUT, NT, false, false>(a, grid, lds, s);
+    if (a.w8iq) return launch_i8w_q<DT, NOUT, NT, 2, false>(a, grid, lds, s);
+    return a.iq_group_off ? launch_i8w_q<DT, NOUT, NT, 1, false>(a, grid, lds, s) : launch_i8w_q<DT, NOUT, NT, 0, false>(a, grid, lds, s);
 }
 
 template <int DT>
@@ -895,7 +931,7 @@ bool chain_i8w_supported(int q, int dt, int n) {
     return n % (SDRT_TB * SDRT_WIDE_LC) == 0 && (nt == 8 || nt == 16);
 }
 
-size_t chain_i8w_lds_bytes(int q, int n, bool iq) {
+size_t chain_i8w_lds_bytes(int q, int n, int iq) {
     return (size_t) wide_lds(SDRT_I8_DIGITS, SDRT_WIDE_LC / q, n / (SDRT_TB * SDRT_WIDE_LC), iq).total;
 }
 
@@ -907,7 +943,7 @@ hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, 
     if (items < wgs) wgs = items;
     wgs = (wgs + 7) / 8 * 8;
     const dim3 grid((unsigned) wgs);
-    const size_t lds = chain_i8w_lds_bytes(q, a.n, a.w8iq != nullptr);
+    const size_t lds = chain_i8w_lds_bytes(q, a.n, a.w8iq ? 2 : (a.iq_group_off ? 1 : 0));
     switch (dt) {
         case SDRT_S8: case SDRT_U8: return launch_chain_i8w_bytes(a, nout, nt, dt, grid, lds, s);     // kernels_i8w_b.hip
         case SDRT_S16: return launch_i8w_d<SDRT_S16>(a, nout, nt, grid, lds, s);

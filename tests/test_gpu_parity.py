@@ -172,3 +172,21 @@ def test_resampler_forms_agree(name, golden, monkeypatch):
         assert np.abs(got - exp).max() <= ref_tol(case, exp)
         outs.append(got)
     assert np.abs(outs[0] - outs[1]).max() < 1e-9 and np.abs(outs[0] - outs[2]).max() < 1e-9
+
+
+@pytest.mark.parametrize('name,fused', [('h_q64_fm_iq', '0'), ('h_q32_fm_vfo9_iq', '1'), ('h_q32_am_norm_vfo9_iq', '1')])
+def test_both_forms_of_the_iq_correction_on_the_wide_kernel(name, fused, golden, monkeypatch):
+    """--correct-iq on the wide-column kernel: offsets from the prefix pass over the input (default for several rows) or from the
+    kernel's own matrix rows (default for one row).  The golden sweep runs every case in its default form; here each runs in
+    the other one (three chunks, offset carried across them)."""
+    z, _ = golden
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    monkeypatch.setenv('SDRTERM_IQ_FUSED', fused)
+    case = BY_NAME[name]
+    eng = _engine(case)
+    assert eng.stage_a == 'i8w'
+    out, _ = eng.process_debug(case_raw(case))
+    exp = z[f'{name}/z']
+    nch, rows, m = exp.shape
+    got = out.reshape(rows, nch, m).transpose(1, 0, 2)
+    assert np.abs(got - exp).max() <= ref_tol(case, exp)
