@@ -94,6 +94,8 @@ struct sdrt_ctx {
     double *d_nco_tile8 = nullptr, *d_nco_phase8 = nullptr;
     double *d_ybias = nullptr;
     double *d_wsum = nullptr;
+    void *d_pair_raw = nullptr;       // wide kernel, chunks of four tiles: a single chunk doubled into a pair
+    double *d_pair_y = nullptr;
     signed char *d_w8iq = nullptr;    // wide kernel with IQ correction: packed offset rows, their constants, the offset response R
     double *d_iq_consts = nullptr, *d_iq_R = nullptr;
     double iq_combine = 0.0;
@@ -552,7 +554,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         if (const char *e = getenv("SDRTERM_IQ_FUSED")) c->iq_fused = c->iq && atoi(e) != 0;
         if (seq) {
             // nothing to set up: the per-sample form reads DecimTables only
-        } else if (want_i8 && !want_t && chain_i8w_supported(q, cfg->dtype, n) && chain_i8w_lds_bytes(q, n, c->iq ? (c->iq_fused ? 2 : 1) : 0) <= 160 * 1024)
+        } else if (want_i8 && !want_t && chain_i8w_supported(q, cfg->dtype, n, c->iq) && chain_i8w_lds_bytes(q, n, c->iq ? (c->iq_fused ? 2 : 1) : 0) <= 160 * 1024)
             rc = setup_wide(c, cfg, scale_tables);
         if (rc == SDRT_OK && !seq && !c->use_i8w && want_i8 && !c->iq && want_i8_fallback_t(L, cfg->dtype, n, m))
             rc = setup_i8t(c, cfg, scale_tables);
@@ -594,6 +596,8 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_nco_phase8);
     (void) hipFree(c->d_ybias);
     (void) hipFree(c->d_wsum);
+    (void) hipFree(c->d_pair_raw);
+    (void) hipFree(c->d_pair_y);
     (void) hipFree(c->d_w8iq);
     (void) hipFree(c->d_iq_consts);
     (void) hipFree(c->d_iq_R);
@@ -665,6 +669,7 @@ int ensure_ybuf(sdrt_ctx *c, size_t n_chunks) {
 int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybuf, hipStream_t s, int n_cus) {
     DecimArgs da;
     da.raw = raw_dev;
+    da.n_count = 0;
     da.tab = c->d_tab;
     da.nco_tile = c->d_nco_tile;
     da.nco_phase = c->d_nco_phase;
@@ -755,6 +760,35 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
         Timed t(c, s, 0);
         if (c->use_seq) {
             HIP_TRY(launch_chain_seq(da, c->cfg.decimation, c->cfg.dtype, c->nco, c->iq, n_chunks, s));
+        } else if (c->use_i8w && c->cfg.n_samples == 4 * SDRT_TB * SDRT_WIDE_LC) {
+            // chunks of four tiles go two to an item: an odd batch ends with the pair (n-2, n-1) once more (chunk n-2 comes out the
+            // same twice); a single chunk is doubled into a scratch pair
+            const size_t cb = (size_t) c->cfg.n_samples * 2 * kItemSize[c->cfg.dtype], yb = (size_t) c->m * 2;
+            if (n_chunks == 1) {
+                if (!c->d_pair_raw) {
+                    HIP_TRY(hipMalloc(&c->d_pair_raw, 2 * cb));
+                    HIP_TRY(hipMalloc((void **) &c->d_pair_y, (size_t) c->rows * 2 * yb * sizeof(double)));
+                }
+                HIP_TRY(hipMemcpyAsync(c->d_pair_raw, raw_dev, cb, hipMemcpyDeviceToDevice, s));
+                HIP_TRY(hipMemcpyAsync((char *) c->d_pair_raw + cb, raw_dev, cb, hipMemcpyDeviceToDevice, s));
+                DecimArgs d2 = da;
+                d2.raw = c->d_pair_raw;
+                d2.ydec = c->d_pair_y;
+                d2.n_chunks = 2;
+                HIP_TRY(launch_chain_i8w(d2, c->cfg.decimation, c->cfg.dtype, 2, n_cus, s));
+                HIP_TRY(hipMemcpy2DAsync(ybuf, yb * sizeof(double), c->d_pair_y, 2 * yb * sizeof(double), yb * sizeof(double), (size_t) c->rows,
+                                         hipMemcpyDeviceToDevice, s));
+            } else {
+                da.n_count = n_chunks & ~(size_t) 1;
+                HIP_TRY(launch_chain_i8w(da, c->cfg.decimation, c->cfg.dtype, da.n_count, n_cus, s));
+                if (n_chunks & 1) {
+                    DecimArgs d2 = da;
+                    d2.raw = (const char *) raw_dev + (n_chunks - 2) * cb;
+                    d2.ydec = ybuf + (n_chunks - 2) * yb;
+                    d2.n_count = 2;
+                    HIP_TRY(launch_chain_i8w(d2, c->cfg.decimation, c->cfg.dtype, 2, n_cus, s));
+                }
+            }
         } else if (c->use_i8w) {
             HIP_TRY(launch_chain_i8w(da, c->cfg.decimation, c->cfg.dtype, n_chunks, n_cus, s));
         } else if (c->use_i8t) {

@@ -17,7 +17,8 @@ struct DecimArgs {
     double *ydec;               // [row][chunk][m][2] decimated complex samples (input of the post kernel)
     unsigned long long *stamps; // optional diagnostic: [wg < stamp_wgs][wave][8] s_memtime at phase boundaries
     int stamp_wgs;
-    size_t n_chunks;
+    size_t n_chunks;            // chunks in the batch = row stride of ydec
+    size_t n_count;             // wide-column kernel: chunks to process (0 = n_chunks); raw / ydec then point at the first of them
     int n, m, n_tiles, rows, swap;
     double norm_bias;           // added to Re before everything else (normalisation offset / scale; the scale itself is
                                 // folded into the operator tables on the host)
@@ -117,7 +118,7 @@ size_t chain_i8t_lds_bytes(int n, int L, int m);
 hipError_t launch_chain_i8t(const DecimArgs &a, int L, int dt, size_t n_chunks, hipStream_t s);
 hipError_t launch_i8t_selftest(const int *A, const int *B, int *D, hipStream_t s);
 // wide-column persistent int8 kernel (kernels_i8w.hip): q in {32, 64}, 8/16-bit integer encodings, 8 or 16 tiles per chunk
-bool chain_i8w_supported(int q, int dt, int n);
+bool chain_i8w_supported(int q, int dt, int n, bool iq);
 bool chain_i8w_rs_supported(int dt, int n);       // its real-stream form (no shift, no IQ correction)
 size_t chain_i8w_lds_bytes(int q, int n, int iq);      // iq: 0 none, 1 prefix tables, 2 fused (chain_i8w_kernel)
 hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, int n_cus, hipStream_t s);

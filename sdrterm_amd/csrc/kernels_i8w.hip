@@ -34,6 +34,8 @@ template <> struct W8Enc<SDRT_S8> { static constexpr int slices = 1; static cons
 template <> struct W8Enc<SDRT_U8> { static constexpr int slices = 1; static constexpr unsigned xlo = 0x80808080u, xhi = 0u; };
 template <> struct W8Enc<SDRT_S16> { static constexpr int slices = 2; static constexpr unsigned xlo = 0x80808080u, xhi = 0u; };
 template <> struct W8Enc<SDRT_U16> { static constexpr int slices = 2; static constexpr unsigned xlo = 0x80808080u, xhi = 0x80808080u; };
+// float32: block fixed point against the exponent of the tile (16 columns), four byte slices (kernels_i8t.hip: I8Enc<SDRT_F32>)
+template <> struct W8Enc<SDRT_F32> { static constexpr int slices = 4; static constexpr unsigned xlo = 0x80808080u, xhi = 0u; };
 
 // x' + y' after exchanging halves: lanes 0-31 get x(l) + x(l+32), lanes 32-63 get y(l-32) + y(l)
 __device__ __forceinline__ double swap32_add(double x, double y) {
@@ -50,10 +52,10 @@ __device__ __forceinline__ double swap16_add(double x, double y) {
 
 struct WideLds {        // byte offsets
     int wmain, wloc, cF, cG, bp, mup, tpw, tailF, tailFc, psi, gv, pq, cpow, wiq, buf, buf_stride, total;
-    // per buffer (offsets in 16-byte units from its start): carF [(NT+1)*8], carG [(NT+1)*8], F0 [8], Gu [8], IQ: tile totals of
+    // per buffer (offsets in 16-byte units from its start): carF [SLOTS*8], carG [SLOTS*8], F0 [8 SEG], Gu [8 SEG], IQ: tile totals of
     // the offset [NT] and the weighted sum of the last 32 samples [1]
 };
-__host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq) {
+__host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int ntc) {
     WideLds l;
     int p = 0;
     l.wmain = p; p += 2 * S * 8 * 1024;
@@ -71,7 +73,8 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq) {
     l.cpow = p; p += iq == 1 ? nt * SDRT_TB * 8 : 0;       // IQ from prefix tables: (1-lambda)^(column start)
     l.wiq = p; p += iq == 2 ? (SDRT_WIDE_LC / 32) * 1024 : 0;     // IQ fused: offset rows, one packed fragment per k-step (sdrt_build_i8_offset_rows)
     l.buf = p;
-    l.buf_stride = (2 * (nt + 1) * 8 + 16 + nt + 1) * 16;
+    const int seg = nt / ntc, slots = seg * (ntc + 1);          // carry slots: ntc + 1 per chunk of the item
+    l.buf_stride = (2 * slots * 8 + 16 * seg + nt + 1) * 16;
     p += 3 * l.buf_stride;
     l.total = p;
     return l;
@@ -84,12 +87,21 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq) {
 // (NOUT = 4) or 112 (NOUT = 8) matrix instructions per tile instead of 184 / 216.
 // IQ: 0 no correction; 1 offsets at column starts from the prefix kernels' tables (iq_local_kernel / iq_scan_kernel: a second pass
 // over the input, shared by all rows); 2 offsets from two more matrix rows of this kernel (no second pass; one row: see api.hip)
-template <int DT, int NOUT, int NT, int S, int IQ, bool RS>
+// NTC: tiles per chunk.  The workgroup's eight waves take eight (or sixteen) tiles per item: chunks of four tiles (float32
+// records, or half-size chunks) go two to an item, SEG = 2, with carries, edge operators and column phasors per chunk.
+template <int DT, int NOUT, int NTC, int S, int IQ, bool RS>
 __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
+    constexpr int NT = NTC < 8 ? 8 : NTC, SEG = NT / NTC, SLOTS = SEG * (NTC + 1);
+    static_assert(SEG == 1 || (IQ == 0 && !RS), "two chunks per item: plain form only");
     static_assert(!(RS && IQ != 0), "the real-stream form has no IQ correction");
     constexpr bool IQA = IQ != 0, IQT = IQ == 1, IQF = IQ == 2;
     constexpr int LC = SDRT_WIDE_LC, KS = RS ? LC / 64 : LC / 32, SPK = LC / KS;   // k-steps per column, samples per k-step
     constexpr int NSL = W8Enc<DT>::slices;
+    constexpr bool F32 = DT == SDRT_F32;
+    static_assert(!F32 || (IQ == 0 && !RS), "float32: plain form only");
+    // digit d x slice s adds to level d + s; levels below LMIN lie under the accuracy of the planes (integers) or of the slices
+    // themselves (float32) and are not computed; accumulator index = level - LMIN
+    constexpr int LMIN = F32 ? 3 : (NSL == 2 ? 1 : 0);
     constexpr int ITEM = Enc<DT>::size;
     constexpr int NR = 2 * NOUT;                     // rows of the local tile
     constexpr int OPL = NOUT / 4;                    // outputs a lane finishes per tile
@@ -102,10 +114,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     constexpr int PPF = RS ? 16 / NOUT : (PACK ? 2 : 1);         // digit planes per local-tile fragment
     constexpr int NHF = (S + PPF - 1) / PPF;                      // fragments used with the high (or only) slice
     constexpr int NLF = (PACK || RS) ? NHF + (NSL == 2 ? (S - 1 + PPF - 1) / PPF : 0) : S;   // local-tile fragments per k-step
-    constexpr int NSLOT = RS ? 1 : 4;                             // raw-sample register ring (RS: reloaded in place once sliced)
-    constexpr int PF = (NOUT == 8 || RS) ? 1 : 2;            // k-steps of raw samples in flight (registers are scarcer with 8 outputs per column)
+    constexpr int NSLOT = RS ? 1 : (F32 ? 2 : 4);                             // raw-sample register ring (RS: reloaded in place once sliced)
+    constexpr int PF = (NOUT == 8 || RS || F32) ? 1 : 2;            // k-steps of raw samples in flight (registers are scarcer with 8 outputs per column)
     static_assert(NOUT == 4 || NOUT == 8, "4 or 8 outputs per column");
-    static_assert(NT == 8 || NT == 16, "8 or 16 tiles per chunk");
+    static_assert(NTC == 4 || NTC == 8 || NTC == 16, "4, 8 or 16 tiles per chunk");
     typedef typename Enc<DT>::raw raw_t;
 
     extern __shared__ __align__(16) unsigned char smem[];
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     const bool swap = a.swap != 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, nb = lane & 15;
-    const WideLds lo = wide_lds(S, NOUT, NT, IQ);
+    const WideLds lo = wide_lds(S, NOUT, NT, IQ, NTC);
     const v4i *wmainL = (const v4i *) (smem + lo.wmain);
     const v4i *wlocL = (const v4i *) (smem + lo.wloc);
     cd *cFL = (cd *) (smem + lo.cF), *cGL = (cd *) (smem + lo.cG), *bpL = (cd *) (smem + lo.bp), *mupL = (cd *) (smem + lo.mup), *tpwL = (cd *) (smem + lo.tpw);
@@ -124,10 +136,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     const v4i *wiqL = (const v4i *) (smem + lo.wiq);
     double *cpowL = (double *) (smem + lo.cpow);
     auto carF = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride); };
-    auto carG = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + (NT + 1) * 8; };
-    auto F0L = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + 2 * (NT + 1) * 8; };
-    auto GuL = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + 2 * (NT + 1) * 8 + 8; };
-    auto OtL = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + 2 * (NT + 1) * 8 + 16; };       // [NT] + tail sum at [NT]
+    auto carG = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + SLOTS * 8; };
+    auto F0L = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + 2 * SLOTS * 8; };              // [seg][8]
+    auto GuL = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + 2 * SLOTS * 8 + 8 * SEG; };
+    auto OtL = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride) + 2 * SLOTS * 8 + 16 * SEG; };       // [NT] + tail sum at [NT]
 
     // ---- which items: workgroup (xcd, slot) keeps one row (digit planes resident) and walks over chunks of its XCD ------
     const unsigned bid = blockIdx.x, xcd = bid & 7u, slot = bid >> 3, nslot = gridDim.x >> 3;
@@ -141,8 +153,9 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     } else {
         nstreams = 1; stream = 0; row0 = slot; rstep = nslot;
     }
-    // chunk of step k: ((k * nstreams + stream) * 8 + xcd); the groups of 8 chunks this XCD sees: gi < ngroups
-    const long ngroups = (long) a.n_chunks > (long) xcd ? ((long) a.n_chunks - (long) xcd + 7) / 8 : 0;
+    // item of step k: ((k * nstreams + stream) * 8 + xcd) (= its chunk when SEG == 1); the groups of 8 items this XCD sees: gi < ngroups
+    const long n_items = (long) (a.n_count ? a.n_count : a.n_chunks) / SEG;    // SEG consecutive chunks per item (the host passes a multiple)
+    const long ngroups = n_items > (long) xcd ? (n_items - (long) xcd + 7) / 8 : 0;
     const int cnt = ngroups > (long) stream ? (int) ((ngroups - (long) stream + (long) nstreams - 1) / (long) nstreams) : 0;
     if (cnt == 0) return;
     auto chunk_of = [&](int k) -> long { return ((long) k * (long) nstreams + (long) stream) * 8 + (long) xcd; };
@@ -177,8 +190,8 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     const double iq_mnb = IQF ? a.iq_consts[39 + nb] : 0.0;                 // (1-lambda)^(LC nb): tile start -> this lane's column
     const double iq_tw = IQF ? a.iq_consts[7 + (tid & 31)] : 0.0;           // weight of this thread's sample of the tail window
     const double iq_cs = a.iq_combine;
-    const double cs_main = a.w8_combine * (NSL == 2 ? 256.0 : 1.0), cs_loc = a.w8mid_combine * (NSL == 2 ? 256.0 : 1.0);
-    const size_t chunk_bytes = (size_t) n * 2 * ITEM;
+    const double cs_main0 = a.w8_combine * (LMIN == 3 ? 16777216.0 : (LMIN == 1 ? 256.0 : 1.0)), cs_loc0 = a.w8mid_combine * (LMIN == 3 ? 16777216.0 : (LMIN == 1 ? 256.0 : 1.0));
+    const size_t chunk_bytes = (size_t) n * 2 * ITEM * SEG;      // bytes of one item
     // this lane's bytes of k-step s of a tile: column nb, samples SPK s + (SPK/4) g .. + SPK/4 - 1
     const size_t lane_off = ((size_t) nb * LC + (size_t) g * (SPK / 4)) * 2 * ITEM;
 
@@ -226,25 +239,51 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         // coefficients of this thread's sample in its edge operator (NCO phasor and IQ correction of the window folded in)
         const cd e_A = ((const cd *) a.edge_ab)[(((size_t) row * 16 + e_o16) * 32 + e_l) * 2];
         const cd e_B = ((const cd *) a.edge_ab)[(((size_t) row * 16 + e_o16) * 32 + e_l) * 2 + 1];
+        if constexpr (F32) { if (tid < 48) gvL[tid] = ((const cd *) a.gvec)[(size_t) row * 48 + tid]; }
         if constexpr (IQA) {
             if (tid < 48) gvL[tid] = ((const cd *) a.gvec)[(size_t) row * 48 + tid];
             if (tid >= 64 && tid < 96) pqL[tid - 64] = ((const cd *) a.edge_pq)[(size_t) row * 32 + (tid - 64)];
             if constexpr (IQT) for (int i = tid; i < NT * SDRT_TB; i += 512) cpowL[i] = a.iq_pow[i * cgs];
             if constexpr (IQF) for (int i = tid; i < KS * 64; i += 512) ((v4i *) (smem + lo.wiq))[i] = ((const v4i *) a.w8iq)[i];
         }
-        for (int i = tid; i < NT * SDRT_TB; i += 512) psiL[i] = nco ? nco_blk_g[i] : mk(1.0, 0.0);
+        for (int i = tid; i < NT * SDRT_TB; i += 512) psiL[i] = nco ? nco_blk_g[i % (NTC * SDRT_TB)] : mk(1.0, 0.0);      // the phase restarts with every chunk
         const cd *ybias = (const cd *) a.ybias + (size_t) row * m;      // always present for this kernel (zeros if there is no offset)
         __syncthreads();
 
         uint32_t raw[NSLOT][WPK];
+        int e_cur[TPW], e_nxt[TPW];                  // float32: exponent of this wave's tile of the item K works on / of the next item
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) e_cur[j] = e_nxt[j] = 0;
         auto issue = [&](const unsigned char *chunk_raw, auto sc) {
             // k-step st (0 .. NSTEP-1) of the item: tile wave + 8 (st / KS), k-step st % KS
             constexpr int st = decltype(sc)::value;
             const unsigned char *p = chunk_raw + ((size_t) (wave + 8 * (st / KS)) * TILE + (size_t) (st % KS) * SPK) * 2 * ITEM + lane_off;
             load_words<WPK * 4, SDRT_RAW_NT != 0>(p, raw[st % NSLOT]);
         };
+        // float32: the exponent of a tile (|x| < 2^e for all of its samples) from the largest magnitude bits; the tile of the NEXT
+        // item is scanned beside the matrix instructions of the current one (two loads per group, second read from L2 / MALL)
+        auto wave_max = [&](unsigned v) {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) v = max(v, (unsigned) __shfl_xor((int) v, d));
+            return v;
+        };
+        auto mag = [&](uint4 v) {
+            if (swap) { v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y); v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w); }
+            return max(max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), max(v.z & 0x7fffffffu, v.w & 0x7fffffffu));
+        };
+        auto scan_ptr = [&](const unsigned char *item_raw, int tile, int i) {       // load i (0 .. 31) of the tile's 32 KiB
+            return (const uint4 *) (item_raw + (size_t) tile * TILE * 2 * ITEM) + (size_t) i * 64 + lane;
+        };
         {
             const unsigned char *c0 = (const unsigned char *) a.raw + (size_t) chunk_of(0) * chunk_bytes;
+            if constexpr (F32) {
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) {
+                    unsigned mx = 0;
+                    for (int i = 0; i < 32; ++i) mx = max(mx, mag(*scan_ptr(c0, wave + 8 * j, i)));
+                    e_cur[j] = (int) (wave_max(mx) >> 23) - 126;
+                }
+            }
             static_for<0, PF>([&](auto sc) { issue(c0, sc); });
         }
         // Software pipeline over the items k = 0 .. cnt-1 of this workgroup; in iteration `it`:
@@ -263,6 +302,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                                      // [2e + stream]; 4 per column: outputs 2 (g & 1) + (v >> 1), stream v & 1,
                                                      // lower levels in lanes g < 2, higher levels in lanes g >= 2
         cd pv[TPW][OPL];                             // P3 accumulators
+        double ccon[TPW];                            // float32: the constant the slices leave out, in the tile's scale (item of the last K)
         cd oex[TPW];                                 // IQ: offset at this lane's column relative to its tile's start (item of the last K)
         double part[4][2];
 #pragma unroll
@@ -271,6 +311,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             for (int e = 0; e < OPL; ++e) yq[0][j][e] = yq[1][j][e] = ynew[j][e] = pv[j][e] = mk(0.0, 0.0);
             dC[j][0] = dC[j][1] = dA[j][0] = dA[j][1] = mk(0.0, 0.0);
             oex[j] = mk(0.0, 0.0);
+            ccon[j] = 0.0;
 #pragma unroll
             for (int v = 0; v < 4; ++v) dl[j][v] = 0.0;
         }
@@ -296,21 +337,25 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             // small global loads first: everything issued later (the raw stream) is younger, so waiting for these never
             // waits for the prefetch ring
             const unsigned char *chunk_raw = (const unsigned char *) a.raw + (size_t) chunk_of(HAVE_K ? it : 0) * chunk_bytes;
-            raw_t e_re = 0, e_im = 0;
-            if constexpr (HAVE_K) {                  // raw edge sample of E(it) (lanes beyond the pad read sample 27, weight 0)
-                const raw_t *rp = (const raw_t *) chunk_raw + 2 * e_idx;
-                e_re = rp[0];
-                e_im = rp[1];
+            raw_t e_re[SEG], e_im[SEG];              // raw edge sample of E(it) per chunk of the item (lanes beyond the pad read sample 27, weight 0)
+#pragma unroll
+            for (int sg = 0; sg < SEG; ++sg) {
+                e_re[sg] = e_im[sg] = 0;
+                if constexpr (HAVE_K) {
+                    const raw_t *rp = (const raw_t *) chunk_raw + 2 * (e_idx + (long) sg * n);
+                    e_re[sg] = rp[0];
+                    e_im[sg] = rp[1];
+                }
             }
             // outputs of item it-3 (the first three iterations store to item 0's place, which P3(0) rewrites in iteration 3)
-            double *yd = a.ydec + ((size_t) row * a.n_chunks + (size_t) chunk_of(have_p3 ? it - 3 : 0)) * (size_t) m * 2;
+            double *yd = a.ydec + ((size_t) row * a.n_chunks + (size_t) chunk_of(have_p3 ? it - 3 : 0) * SEG) * (size_t) m * 2;
             cd yb[TPW][OPL];
 #pragma unroll
             for (int j = 0; j < TPW; ++j)
 #pragma unroll
                 for (int e = 0; e < OPL; ++e) {
-                    if constexpr (IQA) yb[j][e] = mk(0.0, 0.0);          // no constant response: the offset term carries it
-                    else yb[j][e] = ybias[((wave + 8 * j) * SDRT_TB + nb) * NOUT + g + 4 * e];
+                    if constexpr (IQA || F32) yb[j][e] = mk(0.0, 0.0);          // no constant response: the offset term carries it
+                    else yb[j][e] = ybias[(((wave + 8 * j) % NTC) * SDRT_TB + nb) * NOUT + g + 4 * e];
                 }
             cd off_head = mk(0.0, 0.0), off_tail = mk(0.0, 0.0), off_q = mk(0.0, 0.0), gq[TPW];
 #pragma unroll
@@ -368,34 +413,37 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             }
             // ---- P2(it-2): tile carries, one wave per real stream; DPP rows = modes, lanes of a row = tiles ------------------
             if (have_p2 && (wave >> 1) == (it & 1)) {     // waves 0-3 win the issue arbitration on their SIMDs and have the slack
-                const int st = wave & 1, o = g * 2 + st, t = nb;
+                // lane t <-> tile t of the item = tile tin of its chunk sg; carry slot sl: NTC + 1 slots per chunk.  The scans run
+                // inside a chunk only: a step that would reach across the chunk boundary gets a zero multiplier
+                const int st = wave & 1, o = g * 2 + st, t = nb, sg = t < NT ? t / NTC : 0, tin = t - sg * NTC, sl = t + sg;
                 cd *cf = carF(bP2), *cg = carG(bP2);
-                const cd m1 = tpwL[1 * 4 + g], m2 = tpwL[2 * 4 + g], m4 = tpwL[4 * 4 + g], m8 = tpwL[8 * 4 + g];
-                cd x = t < NT ? cf[(t + 1) * 8 + o] : mk(0.0, 0.0);
-                x = cfma(m1, dpp_row<0x111>(x), x);
-                x = cfma(m2, dpp_row<0x112>(x), x);
-                x = cfma(m4, dpp_row<0x114>(x), x);
-                if constexpr (NT > 8) x = cfma(m8, dpp_row<0x118>(x), x);
-                const cd f0 = F0L(bP2)[o];
-                x = cfma(tpwL[(t < NT ? t + 1 : 0) * 4 + g], f0, x);
-                if (t < NT) cf[(t + 1) * 8 + o] = x;
-                if (t == 0) cf[o] = f0;
-                // anticausal state at the right edge from the causal states there (all four modes of this stream) + edge samples
-                cd G = GuL(bP2)[o];
+                auto mstep = [&](int d, bool ok) { return (d < NTC && ok) ? tpwL[d * 4 + g] : mk(0.0, 0.0); };
+                cd x = t < NT ? cf[(sl + 1) * 8 + o] : mk(0.0, 0.0);
+                x = cfma(mstep(1, tin >= 1), dpp_row<0x111>(x), x);
+                x = cfma(mstep(2, tin >= 2), dpp_row<0x112>(x), x);
+                if constexpr (NTC > 4) x = cfma(mstep(4, tin >= 4), dpp_row<0x114>(x), x);
+                if constexpr (NTC > 8) x = cfma(mstep(8, tin >= 8), dpp_row<0x118>(x), x);
+                const cd f0 = F0L(bP2)[sg * 8 + o];
+                x = cfma(tpwL[(t < NT ? tin + 1 : 0) * 4 + g], f0, x);
+                if (t < NT) cf[(sl + 1) * 8 + o] = x;
+                if (t < NT && tin == 0) cf[sl * 8 + o] = f0;
+                // anticausal state at the chunk's right edge from the causal states there (all four modes of this stream) + edge samples
+                cd G = GuL(bP2)[sg * 8 + o];
+                const int send = sg * (NTC + 1) + NTC;          // slot of the chunk's end
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const cd Fj = cf[NT * 8 + j * 2 + st];
+                    const cd Fj = cf[send * 8 + j * 2 + st];
                     G = cfma(tailFL[g * 4 + j], Fj, G);
                     G = cfma(tailFcL[g * 4 + j], mk(Fj.re, -Fj.im), G);
                 }
-                cd y = t < NT ? cg[t * 8 + o] : mk(0.0, 0.0);
-                y = cfma(m1, dpp_row<0x101>(y), y);
-                y = cfma(m2, dpp_row<0x102>(y), y);
-                y = cfma(m4, dpp_row<0x104>(y), y);
-                if constexpr (NT > 8) y = cfma(m8, dpp_row<0x108>(y), y);
-                y = cfma(tpwL[(t < NT ? NT - t : 0) * 4 + g], G, y);
-                if (t < NT) cg[t * 8 + o] = y;
-                if (t == 0) cg[NT * 8 + o] = G;
+                cd y = t < NT ? cg[sl * 8 + o] : mk(0.0, 0.0);
+                y = cfma(mstep(1, tin + 1 < NTC), dpp_row<0x101>(y), y);
+                y = cfma(mstep(2, tin + 2 < NTC), dpp_row<0x102>(y), y);
+                if constexpr (NTC > 4) y = cfma(mstep(4, tin + 4 < NTC), dpp_row<0x104>(y), y);
+                if constexpr (NTC > 8) y = cfma(mstep(8, tin + 8 < NTC), dpp_row<0x108>(y), y);
+                y = cfma(tpwL[(t < NT ? NTC - tin : 0) * 4 + g], G, y);
+                if (t < NT) cg[sl * 8 + o] = y;
+                if (t < NT && tin == 0) cg[send * 8 + o] = G;
             }
             SDRT_STAMP(1);
 
@@ -405,11 +453,12 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                 constexpr int j = decltype(jc)::value, i = decltype(ic)::value;
                 const int tile = wave + 8 * j;
                 if (have_q) {
-                    if constexpr (IQA && i == 0) {
+                    if constexpr ((IQA || F32) && i == 0) {
                         // IQ correction, the part that is linear in the offset at the column's first sample:
                         // row value += (c - off).re g_re[row] + (c - off).im g_im[row]
                         const double cp = IQT ? cpowL[tile * SDRT_TB + nb] : 0.0;        // fused: zero offset at the chunk start
-                        const double dr = a.c_re - fma(cp, off_q.re, gq[j].re), di = a.c_im - fma(cp, off_q.im, gq[j].im);
+                        // float32: no offset, only the constant the XOR left out of the three lower slices, in the tile's scale
+                        const double dr = F32 ? ccon[j] : a.c_re - fma(cp, off_q.re, gq[j].re), di = F32 ? ccon[j] : a.c_im - fma(cp, off_q.im, gq[j].im);
                         const cd g0 = gvL[4 * g + 0], g1 = gvL[4 * g + 1], g2 = gvL[4 * g + 2], g3 = gvL[4 * g + 3];
                         dC[j][0] = mk(fma(dr, g0.re, fma(di, g0.im, dC[j][0].re)), fma(dr, g1.re, fma(di, g1.im, dC[j][0].im)));
                         dC[j][1] = mk(fma(dr, g2.re, fma(di, g2.im, dC[j][1].re)), fma(dr, g3.re, fma(di, g3.im, dC[j][1].im)));
@@ -464,8 +513,9 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     } else if constexpr (i == 11) {
                         // tile aggregates: causal inclusive at the last column -> slot tile+1, anticausal inclusive at the first -> slot tile
                         cd *cf = carF(bQ), *cg = carG(bQ);
-                        if (nb == 15) { cf[(tile + 1) * 8 + g * 2 + 0] = dC[j][0]; cf[(tile + 1) * 8 + g * 2 + 1] = dC[j][1]; }
-                        if (nb == 0) { cg[tile * 8 + g * 2 + 0] = dA[j][0]; cg[tile * 8 + g * 2 + 1] = dA[j][1]; }
+                        const int sl = tile + tile / NTC;            // carry slot of the tile's start (NTC + 1 slots per chunk)
+                        if (nb == 15) { cf[(sl + 1) * 8 + g * 2 + 0] = dC[j][0]; cf[(sl + 1) * 8 + g * 2 + 1] = dC[j][1]; }
+                        if (nb == 0) { cg[sl * 8 + g * 2 + 0] = dA[j][0]; cg[sl * 8 + g * 2 + 1] = dA[j][1]; }
                         // from here on: states at the column's edges from inside the tile (causal at its start, anticausal at its end)
                         dC[j][0] = dpp_row<0x111>(dC[j][0]);
                         dC[j][1] = dpp_row<0x111>(dC[j][1]);
@@ -512,8 +562,9 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     if (have_p3) {
                         constexpr int mode = i - P3_0;
                         const cd *cf = carF(bP3), *cg = carG(bP3);
-                        const cd Fa = cf[tile * 8 + mode * 2 + 0], Fb = cf[tile * 8 + mode * 2 + 1];
-                        const cd Ga = cg[(tile + 1) * 8 + mode * 2 + 0], Gb = cg[(tile + 1) * 8 + mode * 2 + 1];
+                        const int sl = tile + tile / NTC;
+                        const cd Fa = cf[sl * 8 + mode * 2 + 0], Fb = cf[sl * 8 + mode * 2 + 1];
+                        const cd Ga = cg[(sl + 1) * 8 + mode * 2 + 0], Gb = cg[(sl + 1) * 8 + mode * 2 + 1];
 #pragma unroll
                         for (int e = 0; e < OPL; ++e) {
                             const cd f = cFL[(e * 4 + mode) * 64 + lane], gq = cGL[(e * 4 + mode) * 64 + lane];
@@ -532,7 +583,9 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                 if constexpr (HAVE_K && j == 0 && i == P3_0 + 5) {
                     // E(it): this thread's term of its edge operator, summed over the 32 lanes of the output: inside the DPP
                     // rows, then across the two rows of each half
-                    const double xr = decode<DT>(e_re, swap) - e_off_re, xi = decode<DT>(e_im, swap) - e_off_im;
+#pragma unroll
+                    for (int sg = 0; sg < SEG; ++sg) {
+                    const double xr = decode<DT>(e_re[sg], swap) - e_off_re, xi = decode<DT>(e_im[sg], swap) - e_off_im;
                     cd f = mk(fma(e_A.re, xr, e_B.re * xi), fma(e_A.im, xr, e_B.im * xi));
                     // IQ fused: the offset at the head window's first sample is zero in chunk-local terms; the tail window's share is
                     // added one iteration later, when the chunk's offsets are known.  What that needs from here: the weighted
@@ -559,8 +612,9 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     f = cadd(f, dpp_row<0x118>(f));     // lane 15 of every row: the row's sum
                     const double tot = swap16_add(f.re, f.im);   // even rows: re(row) + re(row+1); odd rows: im(row-1) + im(row)
                     if (nb == 15) {
-                        double *dst = (double *) ((e_kind ? GuL(bcur) : F0L(bcur)) + e_o);
+                        double *dst = (double *) ((e_kind ? GuL(bcur) : F0L(bcur)) + sg * 8 + e_o);
                         dst[g & 1] = tot;
+                    }
                     }
                 }
             };
@@ -695,8 +749,8 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                 sr_ = fma(sr_, 256.0, (double) accR[q][v]);
                                 si_ = fma(si_, 256.0, (double) accI[q][v]);
                             }
-                            vr[v] = sr_ * cs_main;
-                            vi[v] = si_ * cs_main;
+                            vr[v] = sr_ * cs_main0;
+                            vi[v] = si_ * cs_main0;
                         }
                         dC[j][0] = mk(vr[0], vr[1]);
                         dA[j][0] = mk(vr[2], vr[3]);
@@ -704,7 +758,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         dA[j][1] = mk(vi[2], vi[3]);
                         // local tile: this lane holds level group rg of outputs (NOUT == 4: b = v; 8: b = 4 (g & 1) + v)
                         const int rg = PPF == 4 ? g : (g >> 1);
-                        const double csl = cs_loc * (rg == 0 ? 1.0 : (rg == 1 ? 256.0 : (rg == 2 ? 65536.0 : 16777216.0)));
+                        const double csl = cs_loc0 * (rg == 0 ? 1.0 : (rg == 1 ? 256.0 : (rg == 2 ? 65536.0 : 16777216.0)));
                         constexpr double STEP = PPF == 4 ? 4294967296.0 : 65536.0;      // 256^PPF between accumulators
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
@@ -730,13 +784,41 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     };
                     if constexpr (HAVE_K) static_for<0, S>([&](auto dc) { F[decltype(dc)::value] = frag(std::integral_constant<int, 0>{}, dc); });
                     v4i blo, bhi;
+                    v4i bsl[F32 ? 4 : 1];                // float32: the four slices of the k-step
+                    uint4 ps0 = make_uint4(0, 0, 0, 0), ps1 = ps0;      // float32: scan of the next item's tile, two loads in flight
+                    unsigned pmx = 0;
                     static_for<0, KS * 3>([&](auto ic) {
                         constexpr int i = decltype(ic)::value, s = i / 3, rt = i % 3, stg = j * KS + s;
+                        if constexpr (HAVE_K && F32) {
+                            if constexpr (i >= 1 && i <= 16) pmx = max(pmx, max(mag(ps0), mag(ps1)));
+                            if constexpr (i < 16) {
+                                ps0 = *scan_ptr(next_raw, wave + 8 * j, 2 * i);
+                                ps1 = *scan_ptr(next_raw, wave + 8 * j, 2 * i + 1);
+                            }
+                        }
                         if constexpr (HAVE_K) {
                             if constexpr (rt == 0) {
                                 // slices of this k-step's 8 complex samples; then its raw registers take the k-step PF ahead
-                                const uint32_t *cur = raw[stg & 3];
-                                if constexpr (ITEM == 2) {
+                                const uint32_t *cur = raw[stg % NSLOT];
+                                if constexpr (F32) {
+                                    // 16 values (8 samples) -> fixed point against the tile's exponent -> 4 x 4 byte transposes
+                                    const int sh = 30 - e_cur[j];
+#pragma unroll
+                                    for (int w = 0; w < 4; ++w) {
+                                        unsigned q_[4];
+#pragma unroll
+                                        for (int u = 0; u < 4; ++u) {
+                                            const unsigned bits = swap ? __builtin_bswap32(cur[4 * w + u]) : cur[4 * w + u];
+                                            q_[u] = (unsigned) (int) ldexpf(__uint_as_float(bits), sh);
+                                        }
+                                        const unsigned a01 = __builtin_amdgcn_perm(q_[1], q_[0], 0x05010400u), a23 = __builtin_amdgcn_perm(q_[3], q_[2], 0x05010400u);
+                                        const unsigned c01 = __builtin_amdgcn_perm(q_[1], q_[0], 0x07030602u), c23 = __builtin_amdgcn_perm(q_[3], q_[2], 0x07030602u);
+                                        bsl[0][w] = (int) (__builtin_amdgcn_perm(a23, a01, 0x05040100u) ^ 0x80808080u);
+                                        bsl[1][w] = (int) (__builtin_amdgcn_perm(a23, a01, 0x07060302u) ^ 0x80808080u);
+                                        bsl[2][w] = (int) (__builtin_amdgcn_perm(c23, c01, 0x05040100u) ^ 0x80808080u);
+                                        bsl[3][w] = (int) __builtin_amdgcn_perm(c23, c01, 0x07060302u);
+                                    }
+                                } else if constexpr (ITEM == 2) {
                                     const unsigned sel_lo = swap ? 0x07050301u : 0x06040200u, sel_hi = swap ? 0x06040200u : 0x07050301u;
     #pragma unroll
                                     for (int w = 0; w < 4; ++w) {
@@ -756,7 +838,29 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                 constexpr int d = decltype(dc)::value;
                                 __builtin_amdgcn_sched_barrier(0);
                                 const v4i A = F[d];
-                                if constexpr (PACK && rt == 2) {
+                                if constexpr (F32 && PACK && rt == 2) {
+                                    // packed local tile, fragments (0|1) (2|3) (4|-) (1|2) (3|4): accumulator a holds levels (2a+3 | 2a+4);
+                                    // the first product into every accumulator is the one with the top slice
+                                    auto mm = [&](auto ac, auto slc, auto first) {
+                                        constexpr int a_ = decltype(ac)::value, sl_ = decltype(slc)::value;
+                                        if constexpr (decltype(first)::value && s == 0) acc[2][a_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bsl[sl_], (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                        else acc[2][a_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bsl[sl_], acc[2][a_], 0, 0, 0);
+                                    };
+                                    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+                                    if constexpr (d == 0) mm(I0{}, I3{}, std::true_type{});
+                                    if constexpr (d == 1) { mm(I1{}, I3{}, std::true_type{}); mm(I0{}, I1{}, std::false_type{}); }
+                                    if constexpr (d == 2) { mm(I2{}, I3{}, std::true_type{}); mm(I1{}, I1{}, std::false_type{}); }
+                                    if constexpr (d == 3) mm(I0{}, I2{}, std::false_type{});
+                                    if constexpr (d == 4) { mm(I1{}, I2{}, std::false_type{}); mm(I0{}, I0{}, std::false_type{}); }
+                                } else if constexpr (F32) {
+                                    static_for<0, 4>([&](auto slc) {
+                                        constexpr int sl_ = 3 - decltype(slc)::value;      // top slice first: it opens its accumulator
+                                        if constexpr (d + sl_ >= LMIN) {
+                                            if constexpr (sl_ == 3 && s == 0) acc[rt][d + sl_ - LMIN] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bsl[sl_], (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                            else acc[rt][d + sl_ - LMIN] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bsl[sl_], acc[rt][d + sl_ - LMIN], 0, 0, 0);
+                                        }
+                                    });
+                                } else if constexpr (PACK && rt == 2) {
                                     // packed local tile: fragment d < 3 with the high (or only) slice starts accumulator d,
                                     // fragment 3 + a with the low slice adds to accumulator a
                                     if constexpr (d < 3) {
@@ -799,6 +903,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     if constexpr (HAVE_K) {
                         // int32 levels -> fp64: value = cs * sum_q 256^q acc[q]; lane (g, nb): rows 4g+v of column nb (v = 2*stream + part)
                         double val[8];
+                        // float32: everything of this tile in units of 2^(E - 30)
+                        const double esc = F32 ? __hiloint2double((1023 + e_cur[j] - 30) << 20, 0) : 1.0;
+                        const double cs_main = cs_main0 * esc, cs_loc = cs_loc0 * esc;
+                        if constexpr (F32) { ccon[j] = 8421504.0 * esc; e_nxt[j] = (int) (wave_max(pmx) >> 23) - 126; }
                         static_for<0, 3>([&](auto rc) {
                             constexpr int rt = decltype(rc)::value;
                             if constexpr (PACK && rt == 2) {
@@ -854,6 +962,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             for (int j = 0; j < TPW; ++j)
 #pragma unroll
                 for (int e = 0; e < OPL; ++e) { yq[0][j][e] = yq[1][j][e]; yq[1][j][e] = ynew[j][e]; }
+            if constexpr (F32 && HAVE_K) {
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) e_cur[j] = e_nxt[j];
+            }
             SDRT_STAMP(3);
             __syncthreads();
             SDRT_STAMP(4);
@@ -873,38 +985,51 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
 // SDRT_I8W_BYTES defined) so that the two halves compile in parallel.
 hipError_t launch_chain_i8w_bytes(const DecimArgs &a, int nout, int nt, int dt, dim3 grid, size_t lds, hipStream_t s);
 
-template <int DT, int NOUT, int NT, int IQ, bool RS>
+template <int DT, int NOUT, int NTC, int IQ, bool RS>
 static hipError_t launch_i8w_q(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     // once per device and instantiation (a driver call per launch costs more than the gap between two kernels)
     static thread_local int done_dev = -1;
     int dev = 0;
     (void) hipGetDevice(&dev);
     if (done_dev != dev) {
-        hipError_t e = hipFuncSetAttribute((const void *) chain_i8w_kernel<DT, NOUT, NT, SDRT_I8_DIGITS, IQ, RS>,
+        hipError_t e = hipFuncSetAttribute((const void *) chain_i8w_kernel<DT, NOUT, NTC, SDRT_I8_DIGITS, IQ, RS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
         done_dev = dev;
     }
-    hipLaunchKernelGGL((chain_i8w_kernel<DT, NOUT, NT, SDRT_I8_DIGITS, IQ, RS>), grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((chain_i8w_kernel<DT, NOUT, NTC, SDRT_I8_DIGITS, IQ, RS>), grid, dim3(512), lds, s, a);
     return hipGetLastError();
 }
 template <int DT, int NOUT, int NT>
 static hipError_t launch_i8w_k(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
-    // no shift, no IQ correction: real streams (instantiated for the 16-bit encodings at 8 tiles per chunk only)
-    if constexpr (Enc<DT>::size == 2 && NT == 8) {
-        if (a.rs) return launch_i8w_q<DT, NOUT, NT, 0, true>(a, grid, lds, s);
-    } else if (a.rs) return hipErrorInvalidValue;
-    if (a.w8iq) return launch_i8w_q<DT, NOUT, NT, 2, false>(a, grid, lds, s);
-    return a.iq_group_off ? launch_i8w_q<DT, NOUT, NT, 1, false>(a, grid, lds, s) : launch_i8w_q<DT, NOUT, NT, 0, false>(a, grid, lds, s);
+    // four tiles per chunk (two chunks per item): the plain form only
+    if constexpr (NT == 4) {
+        if (a.rs || a.w8iq || a.iq_group_off) return hipErrorInvalidValue;
+        return launch_i8w_q<DT, NOUT, 4, 0, false>(a, grid, lds, s);
+    } else {
+        // no shift, no IQ correction: real streams (instantiated for the 16-bit encodings at 8 tiles per chunk only)
+        if constexpr (Enc<DT>::size == 2 && NT == 8) {
+            if (a.rs) return launch_i8w_q<DT, NOUT, NT, 0, true>(a, grid, lds, s);
+        } else if (a.rs) return hipErrorInvalidValue;
+        if (a.w8iq) return launch_i8w_q<DT, NOUT, NT, 2, false>(a, grid, lds, s);
+        return a.iq_group_off ? launch_i8w_q<DT, NOUT, NT, 1, false>(a, grid, lds, s) : launch_i8w_q<DT, NOUT, NT, 0, false>(a, grid, lds, s);
+    }
 }
 
 template <int DT>
 static hipError_t launch_i8w_d(const DecimArgs &a, int nout, int nt, dim3 grid, size_t lds, hipStream_t s) {
+    if constexpr (DT == SDRT_F32 || DT == SDRT_S16 || DT == SDRT_U16) {
+        if (nout == 4 && nt == 4) return launch_i8w_k<DT, 4, 4>(a, grid, lds, s);
+        if (nout == 8 && nt == 4) return launch_i8w_k<DT, 8, 4>(a, grid, lds, s);
+    }
+    if constexpr (DT == SDRT_F32) return hipErrorInvalidValue;
+    else {
     if (nout == 4 && nt == 8) return launch_i8w_k<DT, 4, 8>(a, grid, lds, s);
     if (nout == 4 && nt == 16) return launch_i8w_k<DT, 4, 16>(a, grid, lds, s);
     if (nout == 8 && nt == 8) return launch_i8w_k<DT, 8, 8>(a, grid, lds, s);
     if (nout == 8 && nt == 16) return launch_i8w_k<DT, 8, 16>(a, grid, lds, s);
     return hipErrorInvalidValue;
+    }
 }
 
 #ifdef SDRT_I8W_BYTES
@@ -924,15 +1049,19 @@ bool chain_i8w_rs_supported(int dt, int n) {
     return (dt == SDRT_S16 || dt == SDRT_U16) && n == 8 * SDRT_TB * SDRT_WIDE_LC;
 }
 
-bool chain_i8w_supported(int q, int dt, int n) {
+bool chain_i8w_supported(int q, int dt, int n, bool iq) {
     if (!(q == 32 || q == 64)) return false;
-    if (!(dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16)) return false;
     const int nt = n / (SDRT_TB * SDRT_WIDE_LC);
-    return n % (SDRT_TB * SDRT_WIDE_LC) == 0 && (nt == 8 || nt == 16);
+    if (n % (SDRT_TB * SDRT_WIDE_LC)) return false;
+    // chunks of four tiles go two to an item (float32 records; 16-bit records in half-size chunks): plain form only
+    if (nt == 4) return !iq && (dt == SDRT_F32 || dt == SDRT_S16 || dt == SDRT_U16);
+    if (!(dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16)) return false;
+    return nt == 8 || nt == 16;
 }
 
 size_t chain_i8w_lds_bytes(int q, int n, int iq) {
-    return (size_t) wide_lds(SDRT_I8_DIGITS, SDRT_WIDE_LC / q, n / (SDRT_TB * SDRT_WIDE_LC), iq).total;
+    const int ntc = n / (SDRT_TB * SDRT_WIDE_LC);
+    return (size_t) wide_lds(SDRT_I8_DIGITS, SDRT_WIDE_LC / q, ntc < 8 ? 8 : ntc, iq, ntc).total;
 }
 
 hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, int n_cus, hipStream_t s) {
@@ -948,6 +1077,7 @@ hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, 
         case SDRT_S8: case SDRT_U8: return launch_chain_i8w_bytes(a, nout, nt, dt, grid, lds, s);     // kernels_i8w_b.hip
         case SDRT_S16: return launch_i8w_d<SDRT_S16>(a, nout, nt, grid, lds, s);
         case SDRT_U16: return launch_i8w_d<SDRT_U16>(a, nout, nt, grid, lds, s);
+        case SDRT_F32: return launch_i8w_d<SDRT_F32>(a, nout, nt, grid, lds, s);
     }
     return hipErrorInvalidValue;
 }

@@ -546,7 +546,7 @@ extern "C" int sdrt_build_i8_weights_wide(const double *sos, int sections, int q
                         Wf[(size_t) r * cols + 2 * t + 1] = cxi[stream][part];
                     }
             }
-    if (iq_lambda > 0.0)
+    if (gvec)                                  // lambda == 0: the rows stay, gvec = the rows' sums (float32: the slices' constant)
         for (int r = 0; r < 32; ++r) fold_iq(&Wf[(size_t) r * cols], LC, iq_lambda, gvec + 2 * r);
     *main_combine = quantise_planes(Wf.data(), 32, cols, cols, S, [&](int d, int r, int c, signed char dig) {
         int ks, kg, j;
@@ -574,7 +574,7 @@ extern "C" int sdrt_build_i8_weights_wide(const double *sos, int sections, int q
             Wl[(size_t) (2 * b + 1) * cols + 2 * t] = mt * ti(t);        // stream im: mt (xr ti + xi tr)
             Wl[(size_t) (2 * b + 1) * cols + 2 * t + 1] = mt * tr(t);
         }
-    if (iq_lambda > 0.0) {
+    if (gvec) {
         for (int r = 0; r < 16; ++r) gvec[2 * (32 + r)] = gvec[2 * (32 + r) + 1] = 0.0;
         for (int r = 0; r < NR; ++r) fold_iq(&Wl[(size_t) r * cols], LC, iq_lambda, gvec + 2 * (32 + r));
     }

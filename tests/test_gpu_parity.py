@@ -190,3 +190,24 @@ def test_both_forms_of_the_iq_correction_on_the_wide_kernel(name, fused, golden,
     nch, rows, m = exp.shape
     got = out.reshape(rows, nch, m).transpose(1, 0, 2)
     assert np.abs(got - exp).max() <= ref_tol(case, exp)
+
+
+@pytest.mark.parametrize('code,q,nch', [('h', 64, 6), ('h', 64, 5), ('h', 32, 1), ('f', 64, 7), ('f', 32, 4), ('f', 64, 1)])
+def test_two_chunks_per_item_on_the_wide_kernel(code, q, nch, monkeypatch):
+    """Chunks of four tiles (float32 records; 16-bit records in 16384-sample chunks) go two to an item of the wide-column
+    kernel: carries, edge operators and column phasors per chunk.  Even and odd chunk counts and a single chunk, two rows,
+    against oracle/chain.c."""
+    from sdrterm_amd.engine import Engine
+    from tests.golden import prng
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    fs, n = 1024000, 16384
+    freqs = [15700.0, -203300.0]
+    raw = prng.raw_bytes(code, n * nch, seed=40 + nch, amp=3000)
+    eng = Engine(fs, q, 'fm', code, n_samples=n, row_freqs=freqs, apply_shift=True, omega_out=5000)
+    assert eng.stage_a == 'i8w'
+    out = eng.process(raw)
+    exp = _oracle_rows(raw, code, n, q, 'fm', freqs, fs, 5000, range(nch), range(2))
+    got = out.reshape(2, nch, n // q).transpose(1, 0, 2)
+    err = np.abs(got - exp).max()
+    print(f'{code} q={q} {nch} chunk(s): max abs err {err:.3e}')
+    assert err <= 1e-6
