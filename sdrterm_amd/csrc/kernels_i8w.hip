@@ -113,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     constexpr bool PACK = NOUT == 4 && !RS;
     constexpr int PPF = RS ? 16 / NOUT : (PACK ? 2 : 1);         // digit planes per local-tile fragment
     constexpr int NHF = (S + PPF - 1) / PPF;                      // fragments used with the high (or only) slice
-    constexpr int NLF = (PACK || RS) ? NHF + (NSL == 2 ? (S - 1 + PPF - 1) / PPF : 0) : S;   // local-tile fragments per k-step
+    constexpr int NLF = (PACK || RS) ? NHF + (NSL >= 2 ? (S - 1 + PPF - 1) / PPF : 0) : S;   // local-tile fragments per k-step (both plane pairings)
     constexpr int NSLOT = RS ? 1 : (F32 ? 2 : 4);                             // raw-sample register ring (RS: reloaded in place once sliced)
     constexpr int PF = (NOUT == 8 || RS || F32) ? 1 : 2;            // k-steps of raw samples in flight (registers are scarcer with 8 outputs per column)
     static_assert(NOUT == 4 || NOUT == 8, "4 or 8 outputs per column");
