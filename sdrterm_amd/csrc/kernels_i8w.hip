@@ -114,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     constexpr int PPF = RS ? 16 / NOUT : (PACK ? 2 : 1);         // digit planes per local-tile fragment
     constexpr int NHF = (S + PPF - 1) / PPF;                      // fragments used with the high (or only) slice
     constexpr int NLF = (PACK || RS) ? NHF + (NSL >= 2 ? (S - 1 + PPF - 1) / PPF : 0) : S;   // local-tile fragments per k-step (both plane pairings)
-    constexpr int NSLOT = RS ? 1 : (F32 ? 2 : 4);                             // raw-sample register ring (RS: reloaded in place once sliced)
+    constexpr int NSLOT = (RS || F32) ? 1 : 4;                             // raw-sample register ring (RS: reloaded in place once sliced)
     constexpr int PF = (NOUT == 8 || RS || F32) ? 1 : 2;            // k-steps of raw samples in flight (registers are scarcer with 8 outputs per column)
     static_assert(NOUT == 4 || NOUT == 8, "4 or 8 outputs per column");
     static_assert(NTC == 4 || NTC == 8 || NTC == 16, "4, 8 or 16 tiles per chunk");
@@ -237,8 +237,8 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         }
         const cd *nco_blk_g = nco ? (const cd *) a.nco_phase + (size_t) row * (size_t) (n / LC) : nullptr;  // exp(i theta LC c)
         // coefficients of this thread's sample in its edge operator (NCO phasor and IQ correction of the window folded in)
-        const cd e_A = ((const cd *) a.edge_ab)[(((size_t) row * 16 + e_o16) * 32 + e_l) * 2];
-        const cd e_B = ((const cd *) a.edge_ab)[(((size_t) row * 16 + e_o16) * 32 + e_l) * 2 + 1];
+        const cd *e_ab = (const cd *) a.edge_ab + (((size_t) row * 16 + e_o16) * 32 + e_l) * 2;
+        cd e_A = e_ab[0], e_B = e_ab[1];             // float32 (registers are short) reloads them in every iteration instead
         if constexpr (F32) { if (tid < 48) gvL[tid] = ((const cd *) a.gvec)[(size_t) row * 48 + tid]; }
         if constexpr (IQA) {
             if (tid < 48) gvL[tid] = ((const cd *) a.gvec)[(size_t) row * 48 + tid];
@@ -251,39 +251,28 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         __syncthreads();
 
         uint32_t raw[NSLOT][WPK];
-        int e_cur[TPW], e_nxt[TPW];                  // float32: exponent of this wave's tile of the item K works on / of the next item
+        int e_cur[TPW];                              // float32: exponent K slices this wave's tile against (before K: the guess)
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) e_cur[j] = e_nxt[j] = 0;
+        for (int j = 0; j < TPW; ++j) e_cur[j] = 1;
         auto issue = [&](const unsigned char *chunk_raw, auto sc) {
             // k-step st (0 .. NSTEP-1) of the item: tile wave + 8 (st / KS), k-step st % KS
             constexpr int st = decltype(sc)::value;
             const unsigned char *p = chunk_raw + ((size_t) (wave + 8 * (st / KS)) * TILE + (size_t) (st % KS) * SPK) * 2 * ITEM + lane_off;
             load_words<WPK * 4, SDRT_RAW_NT != 0>(p, raw[st % NSLOT]);
         };
-        // float32: the exponent of a tile (|x| < 2^e for all of its samples) from the largest magnitude bits; the tile of the NEXT
-        // item is scanned beside the matrix instructions of the current one (two loads per group, second read from L2 / MALL)
+        // float32: the exponent of a tile (|x| < 2^e for all of its samples) is not known before the tile has been read, and a
+        // scan ahead of the matrix phase would read the stream twice (measured: the fabric, not the CU, then sets the rate).
+        // Instead the tile is sliced against a guess -- the exponent its predecessor (same wave, previous item) needed, plus
+        // one -- while the largest magnitude is tracked beside the slicing; a guess that turns out too small (overflow) or
+        // more than two bits too large (precision) sends the wave through the matrix phase of that tile once more with the
+        // exact exponent.  Stationary input never takes the second pass.
         auto wave_max = [&](unsigned v) {
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) v = max(v, (unsigned) __shfl_xor((int) v, d));
             return v;
         };
-        auto mag = [&](uint4 v) {
-            if (swap) { v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y); v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w); }
-            return max(max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), max(v.z & 0x7fffffffu, v.w & 0x7fffffffu));
-        };
-        auto scan_ptr = [&](const unsigned char *item_raw, int tile, int i) {       // load i (0 .. 31) of the tile's 32 KiB
-            return (const uint4 *) (item_raw + (size_t) tile * TILE * 2 * ITEM) + (size_t) i * 64 + lane;
-        };
         {
             const unsigned char *c0 = (const unsigned char *) a.raw + (size_t) chunk_of(0) * chunk_bytes;
-            if constexpr (F32) {
-#pragma unroll
-                for (int j = 0; j < TPW; ++j) {
-                    unsigned mx = 0;
-                    for (int i = 0; i < 32; ++i) mx = max(mx, mag(*scan_ptr(c0, wave + 8 * j, i)));
-                    e_cur[j] = (int) (wave_max(mx) >> 23) - 126;
-                }
-            }
             static_for<0, PF>([&](auto sc) { issue(c0, sc); });
         }
         // Software pipeline over the items k = 0 .. cnt-1 of this workgroup; in iteration `it`:
@@ -337,6 +326,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             // small global loads first: everything issued later (the raw stream) is younger, so waiting for these never
             // waits for the prefetch ring
             const unsigned char *chunk_raw = (const unsigned char *) a.raw + (size_t) chunk_of(HAVE_K ? it : 0) * chunk_bytes;
+            if constexpr (F32) { e_A = e_ab[0]; e_B = e_ab[1]; }
             raw_t e_re[SEG], e_im[SEG];              // raw edge sample of E(it) per chunk of the item (lanes beyond the pad read sample 27, weight 0)
 #pragma unroll
             for (int sg = 0; sg < SEG; ++sg) {
@@ -782,20 +772,23 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         if constexpr (rt < 2) return wmainL[((rt * S + d) * KS + s) * 64 + lane];
                         else return wlocL[(d * KS + s) * 64 + lane];
                     };
-                    if constexpr (HAVE_K) static_for<0, S>([&](auto dc) { F[decltype(dc)::value] = frag(std::integral_constant<int, 0>{}, dc); });
+                    // float32 (registers are short): a rolling window of three fragments over the flattened (group, digit) sequence
+                    constexpr int FWN = 3;
+                    v4i Fw[F32 ? FWN : 1];
+                    auto frag_flat = [&](auto fc) -> v4i {
+                        constexpr int f = decltype(fc)::value;
+                        return frag(std::integral_constant<int, f / S>{}, std::integral_constant<int, f % S>{});
+                    };
                     v4i blo, bhi;
                     v4i bsl[F32 ? 4 : 1];                // float32: the four slices of the k-step
-                    uint4 ps0 = make_uint4(0, 0, 0, 0), ps1 = ps0;      // float32: scan of the next item's tile, two loads in flight
-                    unsigned pmx = 0;
+                    float mxf = 0.f;                     // float32: largest magnitude of the tile, per lane
+                    // the matrix phase of the tile; pcs: with the pieces of the other phases between its groups (the float32
+                    // second pass runs without them)
+                    auto kpass = [&](auto pcs) {
+                    if constexpr (HAVE_K && F32) static_for<0, FWN>([&](auto fc) { Fw[decltype(fc)::value] = frag_flat(fc); });
+                    if constexpr (HAVE_K && !F32) static_for<0, S>([&](auto dc) { F[decltype(dc)::value] = frag(std::integral_constant<int, 0>{}, dc); });
                     static_for<0, KS * 3>([&](auto ic) {
                         constexpr int i = decltype(ic)::value, s = i / 3, rt = i % 3, stg = j * KS + s;
-                        if constexpr (HAVE_K && F32) {
-                            if constexpr (i >= 1 && i <= 16) pmx = max(pmx, max(mag(ps0), mag(ps1)));
-                            if constexpr (i < 16) {
-                                ps0 = *scan_ptr(next_raw, wave + 8 * j, 2 * i);
-                                ps1 = *scan_ptr(next_raw, wave + 8 * j, 2 * i + 1);
-                            }
-                        }
                         if constexpr (HAVE_K) {
                             if constexpr (rt == 0) {
                                 // slices of this k-step's 8 complex samples; then its raw registers take the k-step PF ahead
@@ -803,14 +796,21 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                 if constexpr (F32) {
                                     // 16 values (8 samples) -> fixed point against the tile's exponent -> 4 x 4 byte transposes
                                     const int sh = 30 - e_cur[j];
+                                    uint32_t *curw = raw[stg % NSLOT];
+                                    if (swap) {
+#pragma unroll
+                                        for (int w = 0; w < 16; ++w) curw[w] = __builtin_bswap32(curw[w]);
+                                    }
+                                    // the largest magnitude so far (before anything else, so that nothing has to be kept for it)
+#pragma unroll
+                                    for (int w = 0; w < 16; w += 2)
+                                        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mxf) : "v"(curw[w]), "v"(curw[w + 1]));
+                                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                                     for (int w = 0; w < 4; ++w) {
                                         unsigned q_[4];
 #pragma unroll
-                                        for (int u = 0; u < 4; ++u) {
-                                            const unsigned bits = swap ? __builtin_bswap32(cur[4 * w + u]) : cur[4 * w + u];
-                                            q_[u] = (unsigned) (int) ldexpf(__uint_as_float(bits), sh);
-                                        }
+                                        for (int u = 0; u < 4; ++u) q_[u] = (unsigned) (int) ldexpf(__uint_as_float(cur[4 * w + u]), sh);
                                         const unsigned a01 = __builtin_amdgcn_perm(q_[1], q_[0], 0x05010400u), a23 = __builtin_amdgcn_perm(q_[3], q_[2], 0x05010400u);
                                         const unsigned c01 = __builtin_amdgcn_perm(q_[1], q_[0], 0x07030602u), c23 = __builtin_amdgcn_perm(q_[3], q_[2], 0x07030602u);
                                         bsl[0][w] = (int) (__builtin_amdgcn_perm(a23, a01, 0x05040100u) ^ 0x80808080u);
@@ -837,7 +837,8 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                             static_for<0, S>([&](auto dc) {
                                 constexpr int d = decltype(dc)::value;
                                 __builtin_amdgcn_sched_barrier(0);
-                                const v4i A = F[d];
+                                v4i A;
+                                if constexpr (F32) A = Fw[(i * S + d) % FWN]; else A = F[d];
                                 if constexpr (F32 && PACK && rt == 2) {
                                     // packed local tile, fragments (0|1) (2|3) (4|-) (1|2) (3|4): accumulator a holds levels (2a+3 | 2a+4);
                                     // the first product into every accumulator is the one with the top slice
@@ -878,6 +879,9 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                     if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
                                     else acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[rt][d], 0, 0, 0);
                                 }
+                                if constexpr (F32) {
+                                    if constexpr (i * S + d + FWN < KS * 3 * S) Fw[(i * S + d) % FWN] = frag_flat(std::integral_constant<int, i * S + d + FWN>{});
+                                } else
                                 // the fragment's register takes the next group's fragment (none for the unused slots of a packed tile)
                                 if constexpr (i + 1 < KS * 3) {
                                     if constexpr (!(PACK && (i + 1) % 3 == 2 && d >= NLF)) F[d] = frag(std::integral_constant<int, i + 1>{}, dc);
@@ -896,9 +900,20 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                             __builtin_amdgcn_sched_barrier(0);
                             __builtin_amdgcn_s_setprio(0);
                         }
-                        piece(jc, ic);
+                        if constexpr (decltype(pcs)::value) piece(jc, ic);
                         __builtin_amdgcn_sched_barrier(0);
                     });
+                    };
+                    kpass(std::true_type{});
+                    int e_true = 0;
+                    if constexpr (F32 && HAVE_K) {
+                        e_true = __builtin_amdgcn_readfirstlane((int) (wave_max(__float_as_uint(mxf)) >> 23) - 126);
+                        if (e_true > e_cur[j] || e_true < e_cur[j] - 2) {
+                            e_cur[j] = e_true;
+                            static_for<0, PF>([&](auto pc) { issue(chunk_raw, std::integral_constant<int, j * KS + decltype(pc)::value>{}); });
+                            kpass(std::false_type{});
+                        }
+                    }
                     if constexpr (j == 0) SDRT_STAMP(2);
                     if constexpr (HAVE_K) {
                         // int32 levels -> fp64: value = cs * sum_q 256^q acc[q]; lane (g, nb): rows 4g+v of column nb (v = 2*stream + part)
@@ -906,7 +921,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         // float32: everything of this tile in units of 2^(E - 30)
                         const double esc = F32 ? __hiloint2double((1023 + e_cur[j] - 30) << 20, 0) : 1.0;
                         const double cs_main = cs_main0 * esc, cs_loc = cs_loc0 * esc;
-                        if constexpr (F32) { ccon[j] = 8421504.0 * esc; e_nxt[j] = (int) (wave_max(pmx) >> 23) - 126; }
+                        if constexpr (F32) { ccon[j] = 8421504.0 * esc; e_cur[j] = e_true + 1; }      // the next item's guess
                         static_for<0, 3>([&](auto rc) {
                             constexpr int rt = decltype(rc)::value;
                             if constexpr (PACK && rt == 2) {
@@ -962,10 +977,6 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             for (int j = 0; j < TPW; ++j)
 #pragma unroll
                 for (int e = 0; e < OPL; ++e) { yq[0][j][e] = yq[1][j][e]; yq[1][j][e] = ynew[j][e]; }
-            if constexpr (F32 && HAVE_K) {
-#pragma unroll
-                for (int j = 0; j < TPW; ++j) e_cur[j] = e_nxt[j];
-            }
             SDRT_STAMP(3);
             __syncthreads();
             SDRT_STAMP(4);

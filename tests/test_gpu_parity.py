@@ -123,6 +123,52 @@ def test_float32_nine_rows_against_the_fp64_oracle():
     assert err <= 1e-6
 
 
+def test_float32_levels_that_jump_between_tiles_and_chunks(monkeypatch):
+    """float32 on the wide-column kernel is block fixed point against each 4096-sample tile's exponent, sliced against a guess
+    (the exponent the same wave's previous tile needed, plus one) and redone when the guess was too small or more than two
+    bits too large.  A stream whose level jumps by up to 2^30 between chunks and 2^6 between the tiles of a chunk, with silent
+    tiles, silent chunks and tiles whose only large sample is their last one, long enough that every workgroup works through
+    several items.  Block fixed point carries 30 bits below the tile's largest sample (28 at least with the guess at its
+    loosest), and the decimator is a weighted mean, so every decimated sample must agree with the fp64 oracle to 2^-28 of the
+    largest input sample of its tile and the two next to it; a stream of even level stays 1e-9 of the peak
+    (test_float32_input_against_the_fp64_oracle)."""
+    from sdrterm_amd.engine import Engine
+    from oracle import ref_chain
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    fs, q, n, nch = 1024000, 64, 16384, 1101
+    rng = np.random.default_rng(2026)
+    x = rng.normal(size=(nch, 4, 4096, 2)).astype(np.float32)
+    lvl = 2.0 ** (rng.integers(-20, 11, size=(nch, 1, 1, 1)) + rng.integers(0, 7, size=(nch, 4, 1, 1)))
+    x *= lvl.astype(np.float32)
+    silent_tile = rng.random((nch, 4)) < 0.05
+    x[silent_tile] = 0
+    x[rng.random(nch) < 0.03] = 0
+    spike = rng.random((nch, 4)) < 0.1
+    x[spike, -1, :] *= np.float32(2.0 ** 9)              # the tile's exponent is decided by its last sample
+    raw = x.tobytes()
+    eng = Engine(fs, q, 'fm', 'f', n_samples=n, row_freqs=[15700.0], apply_shift=True, omega_out=5000)
+    assert eng.stage_a == 'i8w'
+    _out, y = eng.process_debug(raw)
+    m = n // q
+    y = y.reshape(nch, 4, m // 4)
+    top = np.abs(x).max(axis=(2, 3))                     # (chunk, tile)
+    scale = top.copy()
+    scale[:, 1:] = np.maximum(scale[:, 1:], top[:, :-1])
+    scale[:, :-1] = np.maximum(scale[:, :-1], top[:, 1:])
+    ch = ref_chain.Chain(fs, q, 'fm', 'f', center=15700, omega_out=5000)
+    worst = 0.0
+    for c in range(nch):
+        _exp, ydec = ch.process(raw[c * n * 8:(c + 1) * n * 8], return_decimated=True, faithful_dtype=False)
+        err = np.abs(y[c] - np.asarray(ydec).reshape(4, m // 4)).max(axis=1)
+        ok = scale[c] > 0
+        if ok.any():
+            worst = max(worst, float((err[ok] / scale[c][ok]).max()))
+        # silent surroundings: the far tail of a tile further away, or (silent chunk) what is left of the constant the slices leave out
+        assert np.all(err[~ok] <= 1e-12 * top[c].max() + 1e-40)
+    print(f'float32 with jumping levels: worst error relative to the largest input sample nearby {worst:.3e} (2^-28 = {2.0 ** -28:.3e})')
+    assert worst <= 2.0 ** -28
+
+
 @pytest.mark.parametrize('rows,nch', [(64, 3), (300, 2), (33, 17), (5, 100)])
 def test_item_distribution_of_the_persistent_kernel(rows, nch, monkeypatch):
     """Many rows x few chunks and few rows x many chunks (rows above and below the number of workgroup slots, chunk counts

@@ -12,9 +12,10 @@ from tests.golden import prng
 def main():
     n_chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     center = int(sys.argv[2]) if len(sys.argv) > 2 else 15000
-    eng = Engine(256_000_000, 64, 'fm', 'h', row_freqs=[center], omega_out=12500)
+    code = sys.argv[4] if len(sys.argv) > 4 else 'h'          # 'f': float32 records (16384-sample chunks, two to an item)
+    eng = Engine(256_000_000, 64, 'fm', code, row_freqs=[center], omega_out=12500)
     assert eng.stage_a == 'i8w', eng.stage_a
-    one = np.frombuffer(prng.raw_bytes('h', 32768 * 64, 3, 8000), dtype=np.uint8)
+    one = np.frombuffer(prng.raw_bytes(code, eng.n * 64, 3, 8000), dtype=np.uint8)
     d_raw = nat.DeviceBuffer(n_chunks * eng.chunk_bytes)
     for i in range(0, n_chunks, 64):
         nat.check(nat.lib().sdrt_memcpy_h2d(d_raw.ptr + i * eng.chunk_bytes, one.ctypes.data, min(64, n_chunks - i) * eng.chunk_bytes))
