@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SDRT_ABI_VERSION 3
+#define SDRT_ABI_VERSION 4
 
 /* Input encodings: src/misc/file_util.py:44-56 (DataType b,B,h,H,i,I,f,d). */
 enum sdrt_dtype {
@@ -134,6 +134,14 @@ int sdrt_set_smoothing(sdrt_ctx *ctx, int window, int ntaps, int tap_first, cons
 /* The carried IQ-correction offset (read_file.py:53): get/set as (re, im). */
 int sdrt_get_iq_offset(sdrt_ctx *ctx, double *re, double *im);
 int sdrt_set_iq_offset(sdrt_ctx *ctx, double re, double im);
+/*
+ * What a range of chunks does to the carried offset, without processing it: off_end = a * off_start + (b_re + i b_im)
+ * (the recursion of iq_correction.py:19-26 is affine in its state).  One pass over the input, the context's own state is
+ * left alone.  For a stream whose chunks are split over several GPUs ("by chunk"): every rank calls this on
+ * its range, the (a, b) pairs are exchanged (48 bytes per rank), each rank folds the pairs of the ranks before it into
+ * its starting offset (sdrt_set_iq_offset) and then processes its range.
+ */
+int sdrt_iq_range_device(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, double *a, double *b_re, double *b_im, void *stream);
 
 /*
  * Per-kernel device timing with HIP events recorded on the launch stream (for bench.py's roofline line).

@@ -18,7 +18,7 @@ ITEM_SIZE = {'b': 1, 'B': 1, 'h': 2, 'H': 2, 'i': 4, 'I': 4, 'f': 4, 'd': 8}
 MODES = {'fm': 0, 'am': 1, 're': 2, 'im': 3}
 OK, EINVAL, EHIP, ENOMEM, ENODEVICE = 0, 1, 2, 3, 4
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 EXPORTS = (
     'sdrt_abi_version', 'sdrt_config_size', 'sdrt_device_count', 'sdrt_last_error', 'sdrt_create', 'sdrt_destroy',
     'sdrt_out_per_chunk', 'sdrt_rows', 'sdrt_process_device', 'sdrt_process_host',
@@ -29,7 +29,7 @@ EXPORTS = (
     'sdrt_stream_create', 'sdrt_stream_destroy', 'sdrt_stream_synchronize', 'sdrt_host_alloc', 'sdrt_host_free',
     'sdrt_memcpy_h2d_async', 'sdrt_memcpy_d2h_async', 'sdrt_stream_wait_stream',
     'sdrt_comm_unique_id', 'sdrt_comm_init', 'sdrt_comm_bcast', 'sdrt_comm_allgather', 'sdrt_comm_world', 'sdrt_comm_rank',
-    'sdrt_comm_destroy', 'sdrt_submit_host', 'sdrt_wait', 'sdrt_spectrum_host', 'sdrt_stft_host',
+    'sdrt_comm_destroy', 'sdrt_submit_host', 'sdrt_wait', 'sdrt_spectrum_host', 'sdrt_stft_host', 'sdrt_iq_range_device',
 )
 
 
@@ -116,6 +116,8 @@ def lib():
     l.sdrt_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     l.sdrt_get_iq_offset.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     l.sdrt_set_iq_offset.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    l.sdrt_iq_range_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double), C.c_void_p]
     l.sdrt_profile_enable.argtypes = [C.c_void_p, C.c_int]
     l.sdrt_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     l.sdrt_profile_reset.argtypes = [C.c_void_p]

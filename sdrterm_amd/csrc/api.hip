@@ -994,6 +994,48 @@ int sdrt_set_iq_offset(sdrt_ctx *c, double re, double im) {
     return SDRT_OK;
 }
 
+int sdrt_iq_range_device(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *a, double *b_re, double *b_im, void *stream) {
+    if (!c) return fail(SDRT_EINVAL, "null context");
+    if (!c->iq) return fail(SDRT_EINVAL, "context was created without correct_iq");
+    if (!raw_dev && n_chunks) return fail(SDRT_EINVAL, "null input");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    hipStream_t s = (hipStream_t) stream;
+    double v[2] = {0.0, 0.0};
+    if (n_chunks) {
+        // chunk aggregates from a zero start (no group table), chained from a zero state: the end value is b
+        double *d_tmp = nullptr;                               // [n_chunks] aggregates, [n_chunks + 1] offsets, [1] state
+        HIP_TRY(hipMalloc((void **) &d_tmp, (2 * n_chunks + 2) * 2 * sizeof(double)));
+        IqArgs ia;
+        memset(&ia, 0, sizeof(ia));
+        ia.raw = raw_dev;
+        ia.group_off = nullptr;
+        ia.chunk_agg = d_tmp;
+        ia.chunk_off = d_tmp + 2 * n_chunks;
+        ia.state = d_tmp + 2 * (2 * n_chunks + 1);
+        ia.n_chunks = n_chunks;
+        ia.n = c->cfg.n_samples;
+        ia.gs = c->iq_gs;
+        ia.dt = c->cfg.dtype;
+        ia.swap = c->cfg.swap_endianness && kItemSize[c->cfg.dtype] > 1;
+        ia.norm_bias = c->norm_bias;
+        ia.lambda = c->cfg.iq_inductance;
+        ia.pow_tab = c->d_iq_pow;
+        ia.pow_g = c->iq_pow_e;
+        ia.pow_n = c->iq_pow_n;
+        hipError_t e = hipMemsetAsync(ia.state, 0, 2 * sizeof(double), s);
+        if (e == hipSuccess) e = launch_iq_local(ia, s);
+        if (e == hipSuccess) e = launch_iq_scan(ia, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(v, ia.state, sizeof(v), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void) hipFree(d_tmp);
+        if (e != hipSuccess) return fail(SDRT_EHIP, "offset range kernels failed: %s", hipGetErrorString(e));
+    }
+    if (a) *a = exp((double) n_chunks * (double) c->cfg.n_samples * log1p(-c->cfg.iq_inductance));
+    if (b_re) *b_re = v[0] * c->norm_scale;
+    if (b_im) *b_im = v[1] * c->norm_scale;
+    return SDRT_OK;
+}
+
 int sdrt_profile_enable(sdrt_ctx *c, int enable) {
     if (!c) return fail(SDRT_EINVAL, "null context");
     c->profile = enable != 0;

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void iq_local_kernel(IqArgs a) {
     const double plane = a.pow_tab[lane], ptid = a.pow_tab[tid];          // (1-lambda)^(GS lane), (1-lambda)^(GS tid)
     const double ag256 = a.pow_tab[256];
     cd carry = mk(0.0, 0.0);                           // offset at the first sample of the current sweep
-    cd *gout = (cd *) a.group_off + (size_t) chunk * (size_t) ngroups;
+    cd *gout = a.group_off ? (cd *) a.group_off + (size_t) chunk * (size_t) ngroups : nullptr;     // null: chunk aggregates only
     for (int g0 = 0; g0 < ngroups; g0 += 256) {
         const int grp = g0 + tid;
         cd s = mk(0.0, 0.0);
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void iq_local_kernel(IqArgs a) {
         for (int wv = 0; wv < wave; ++wv) wp = mk(fma(ag64, wp.re, wtot[wv].re), fma(ag64, wp.im, wtot[wv].im));
         // offset at this group's first sample = (carry propagated over tid groups) + (wave start propagated over lane groups) + ex
         const cd off = mk(fma(ptid, carry.re, fma(plane, wp.re, ex.re)), fma(ptid, carry.im, fma(plane, wp.im, ex.im)));
-        if (grp < ngroups) gout[grp] = off;
+        if (gout && grp < ngroups) gout[grp] = off;
         // carry to the next sweep: everything of this sweep + the old carry over 256 groups
         cd tot = mk(0.0, 0.0);
         for (int wv = 0; wv < 4; ++wv) tot = mk(fma(ag64, tot.re, wtot[wv].re), fma(ag64, tot.im, wtot[wv].im));

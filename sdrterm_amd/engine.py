@@ -201,6 +201,27 @@ class Engine:
     def iq_offset(self, v: complex):
         nat.check(nat.lib().sdrt_set_iq_offset(self._ctx, float(v.real), float(v.imag)))
 
+    def iq_range_device(self, d_raw: int, n_chunks: int, stream: int = 0):
+        """(a, b): what these chunks do to the carried IQ offset, ``off_end = a * off_start + b``, without processing them and
+        without touching this engine's own state (chunk-sharded streams: ``parallel.chain_iq_offsets``)."""
+        a, re, im = C.c_double(), C.c_double(), C.c_double()
+        nat.check(nat.lib().sdrt_iq_range_device(self._ctx, d_raw, n_chunks, C.byref(a), C.byref(re), C.byref(im), stream or None))
+        return a.value, complex(re.value, im.value)
+
+    def iq_range(self, raw, n_chunks=None):
+        """As ``iq_range_device`` for a host buffer."""
+        buf = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else \
+            np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+        if n_chunks is None:
+            n_chunks = buf.size // self.chunk_bytes
+        elif buf.size < n_chunks * self.chunk_bytes:
+            raise ValueError(f'{n_chunks} chunks need {n_chunks * self.chunk_bytes} bytes, got {buf.size}')
+        d_raw = nat.DeviceBuffer(max(n_chunks * self.chunk_bytes, 16)).upload(buf[:n_chunks * self.chunk_bytes])
+        try:
+            return self.iq_range_device(d_raw.ptr, n_chunks)
+        finally:
+            d_raw.free()
+
     def profile(self, enable: bool = True):
         nat.check(nat.lib().sdrt_profile_enable(self._ctx, int(enable)))
 

@@ -13,6 +13,7 @@
                         CPU is what the tests use); torch is imported lazily, the single-GPU product path never needs it
 
 ``SimoShard`` is what ``VfoProcessor`` uses: which rows this rank serves, which TCP port, and the channel.
+``chain_iq_offsets`` is the one exchange a chunk-sharded stream needs when ``--correct-iq`` is on (the carried offset).
 """
 import ctypes as C
 import os
@@ -75,6 +76,13 @@ class TorchTransport:
     def bcast_block(self, data: Optional[bytes], nbytes: int, root: int = 0):
         """('host', bytes): the block as every rank's engine takes it from host memory."""
         return 'host', self.bcast_bytes(data, nbytes, root)
+
+    def allgather_bytes(self, data: bytes) -> List[bytes]:
+        """Every rank's ``data`` (same length everywhere), in rank order."""
+        mine = self._torch.frombuffer(bytearray(data), dtype=self._torch.uint8).to(self.device)
+        parts = [self._torch.empty_like(mine) for _ in range(self.world)]
+        self._dist.all_gather(parts, mine, group=self._group)
+        return [p.cpu().numpy().tobytes() for p in parts]
 
     def close(self):
         pass
@@ -158,6 +166,20 @@ class RcclTransport:
         nat.check(nat.lib().sdrt_device_synchronize())
         return self._stage.download(np.empty(nbytes, dtype=np.uint8)).tobytes()
 
+    def allgather_bytes(self, data: bytes) -> List[bytes]:
+        """Every rank's ``data`` (same length everywhere), in rank order; through device staging buffers."""
+        nat, nb = self._nat, len(data)
+        send, recv = nat.DeviceBuffer(max(nb, 16)), nat.DeviceBuffer(max(nb * self.world, 16))
+        try:
+            send.upload(np.frombuffer(data, dtype=np.uint8))
+            self.allgather_device(send.ptr, recv.ptr, nb)
+            nat.check(nat.lib().sdrt_device_synchronize())
+            allb = recv.download(np.empty(nb * self.world, dtype=np.uint8)).tobytes()
+        finally:
+            send.free()
+            recv.free()
+        return [allb[r * nb:(r + 1) * nb] for r in range(self.world)]
+
     def bcast_block(self, data: Optional[bytes], nbytes: int, root: int = 0):
         """('dev', pointer): the block stays in device memory on every rank (one upload on the root, RCCL broadcast,
         sdrt_process_device on the spot).  The buffer is reused by the next call: consume the block first."""
@@ -210,6 +232,31 @@ class BlockChannel:
             else:
                 out.host = what
         return out
+
+
+IQ_PAIR = struct.Struct('<ddd')       # a, Re b, Im b of a chunk range: off_end = a * off_start + b
+
+
+def fold_iq_pairs(pairs, rank: int, off0: complex = 0j) -> Tuple[complex, complex]:
+    """(offset at the start of ``rank``'s range, offset after the last range) from every range's (a, b) in stream order."""
+    off, mine = complex(off0), complex(off0)
+    for r, (a, b) in enumerate(pairs):
+        if r == rank:
+            mine = off
+        off = a * off + b
+    return mine, off
+
+
+def chain_iq_offsets(transport, a: float, b: complex, off0: complex = 0j) -> Tuple[complex, complex]:
+    """Chunk-sharded stream with ``--correct-iq`` ("by chunk"): the carried offset
+    (read_file.py:53, iq_correction.py:19-26) is the only thing one chunk hands to the next, and the recursion is affine in it.
+    Rank r holds the r-th contiguous range of the stream (``shard_chunks``) and passes what its range does to the offset
+    (``Engine.iq_range_device``); one all-gather of 24 bytes per rank later every rank knows the offset its range starts
+    from (set ``Engine.iq_offset`` to it, then process) and the offset the whole stream ends with (the next batch's
+    ``off0``).  No other collective on that path."""
+    got = transport.allgather_bytes(IQ_PAIR.pack(float(a), float(b.real), float(b.imag)))
+    pairs = [(v[0], complex(v[1], v[2])) for v in (IQ_PAIR.unpack(g) for g in got)]
+    return fold_iq_pairs(pairs, transport.rank, off0)
 
 
 class SimoShard:

@@ -457,3 +457,44 @@ def test_plot_fft_taps_match_the_reference_plots_arithmetic(code, normalize):
 
 def samples_per_chunk_of(code):
     return 131072 // (2 * {'b': 1, 'B': 1, 'h': 2, 'H': 2, 'i': 4, 'I': 4, 'f': 4, 'd': 8}[code])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('code,fused', [('h', '1'), ('h', '0'), ('f', '0')])
+def test_iq_offset_of_a_chunk_range_and_a_stream_processed_in_two_parts(code, fused, monkeypatch):
+    """sdrt_iq_range_device: what a range of chunks does to the carried offset (off_end = a off_start + b) equals the oracle's
+    sequential recursion; and a stream processed as two ranges, the second engine started from the folded offset
+    (parallel.fold_iq_pairs: what two GPUs sharing the stream by chunk do), gives the outputs of the stream processed whole."""
+    from sdrterm_amd.engine import Engine
+    from sdrterm_amd.parallel import fold_iq_pairs
+    from oracle import ref_chain
+    from tests.golden import prng
+    monkeypatch.setenv('SDRTERM_IQ_FUSED', fused)
+    fs, q, nch, split = 1024000, 64, 7, 3
+    kw = dict(row_freqs=[15700.0], apply_shift=True, omega_out=5000, correct_iq=True)
+    whole = Engine(fs, q, 'fm', code, **kw)
+    n = whole.n
+    raw = prng.raw_bytes(code, n * nch, seed=5, amp=3000)
+    cb = whole.chunk_bytes
+    exp_out = whole.process(raw)
+    end_whole = whole.iq_offset
+    a0, b0 = whole.iq_range(raw[:split * cb])
+    a1, b1 = whole.iq_range(raw[split * cb:])
+    assert whole.iq_offset == end_whole                      # the engine's own state is left alone
+    start1, end = fold_iq_pairs([(a0, b0), (a1, b1)], 1, 0j)
+    assert abs(end - end_whole) <= 1e-10 * abs(end_whole)    # the fused form takes its chunk aggregates from the int8 planes (2^-39)
+    first, second = Engine(fs, q, 'fm', code, **kw), Engine(fs, q, 'fm', code, **kw)
+    out0 = first.process(raw[:split * cb])
+    assert abs(first.iq_offset - b0) <= 1e-10 * abs(b0)
+    second.iq_offset = start1
+    out1 = second.process(raw[split * cb:])
+    m = n // q
+    got = np.concatenate([out0.reshape(1, split, m), out1.reshape(1, nch - split, m)], axis=1).reshape(exp_out.shape)
+    err = np.abs(got - exp_out).max()
+    print(f'{code} fused={fused}: two ranges against the whole stream, max abs difference {err:.3e}')
+    assert err <= 1e-9
+    # the oracle's recursion on the same samples
+    chain = ref_chain.Chain(fs, q, 'fm', code, center=15700, omega_out=5000, correct_iq=True)
+    for c in range(nch):
+        chain.process(raw[c * cb:(c + 1) * cb])
+    assert abs(chain.off - end_whole) <= 1e-9 * abs(end_whole)

@@ -116,7 +116,7 @@ def test_shared_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(lib, n), f'{n} declared in the header but not exported'
     assert set(_native.EXPORTS) <= names
-    assert _native.lib().sdrt_abi_version() == _native.ABI_VERSION == 3
+    assert _native.lib().sdrt_abi_version() == _native.ABI_VERSION == 4
     assert ctypes.sizeof(_native.Config) == _native.lib().sdrt_config_size()
 
 
@@ -182,6 +182,64 @@ def test_two_rank_partition_and_broadcast_under_gloo():
     assert [g['chunks'] for g in gathered] == [(0, 19), (19, 37)]
     assert gathered[0]['sum'] == gathered[1]['sum'] == int(np.arange(4096).sum())
     assert slow == 2.0
+
+
+def _iq_pair(z, fs):
+    """(a, b) of a sample range for the offset recursion of read_file.py:64-77, from the oracle's restatement."""
+    from oracle import ref_chain
+    lam = 50 / fs
+    _z, b = ref_chain.correct_iq_fast(z, 0j, fs)
+    return float(np.exp(z.size * np.log1p(-lam))), complex(b)
+
+
+def _gloo_iq_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from sdrterm_amd import parallel
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    fs, n, chunks = 48000.0, 512, 11
+    rng = np.random.default_rng(12)
+    z = (rng.normal(size=n * chunks) + 1j * rng.normal(size=n * chunks)) * 100 + (37 - 12j)
+    c0, c1 = parallel.shard_chunks(chunks, world, rank)
+    a, b = _iq_pair(z[c0 * n:c1 * n], fs)
+    start, end = parallel.chain_iq_offsets(parallel.TorchTransport(), a, b, off0=3 + 4j)
+    q.put((rank, (c0, c1), start, end))
+    dist.destroy_process_group()
+
+
+def test_chunk_sharded_iq_offsets_under_gloo():
+    """A stream split by chunk over two ranks with --correct-iq: each rank's starting offset, from one all-gather of the
+    ranges' (a, b) pairs, is the offset the sequential recursion (oracle: read_file.py:64-77) has at that chunk."""
+    import torch.multiprocessing as mp
+    from oracle import ref_chain
+    from sdrterm_amd.misc.general_util import findPort
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    world, port = 2, findPort('127.0.0.1')
+    procs = [ctx.Process(target=_gloo_iq_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    fs, n, chunks = 48000.0, 512, 11
+    rng = np.random.default_rng(12)
+    z = (rng.normal(size=n * chunks) + 1j * rng.normal(size=n * chunks)) * 100 + (37 - 12j)
+    assert [g[1] for g in got] == [(0, 6), (6, 11)]
+    _c, at_split = ref_chain.correct_iq(z[:6 * n], 3 + 4j, fs)
+    _c, at_end = ref_chain.correct_iq(z[6 * n:], at_split, fs)
+    assert got[0][2] == 3 + 4j
+    assert abs(got[1][2] - at_split) <= 1e-12 * abs(at_split)
+    assert all(abs(g[3] - at_end) <= 1e-12 * abs(at_end) for g in got)
+
+
+def test_fold_iq_pairs():
+    from sdrterm_amd.parallel import fold_iq_pairs
+    pairs = [(0.5, 1 + 1j), (0.25, 2j), (0.1, -1)]
+    assert fold_iq_pairs(pairs, 0, 8j) == (8j, 0.1 * (0.25 * (0.5 * 8j + 1 + 1j) + 2j) - 1)
+    assert fold_iq_pairs(pairs, 2, 8j)[0] == 0.25 * (0.5 * 8j + 1 + 1j) + 2j
 
 
 def test_split_range_covers_everything():
