@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         uint32_t raw[NSLOT][WPK];
         int e_cur[TPW];                              // float32: exponent K slices this wave's tile against (before K: the guess)
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) e_cur[j] = 1;
+        for (int j = 0; j < TPW; ++j) e_cur[j] = 0;
         auto issue = [&](const unsigned char *chunk_raw, auto sc) {
             // k-step st (0 .. NSTEP-1) of the item: tile wave + 8 (st / KS), k-step st % KS
             constexpr int st = decltype(sc)::value;
@@ -262,10 +262,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         };
         // float32: the exponent of a tile (|x| < 2^e for all of its samples) is not known before the tile has been read, and a
         // scan ahead of the matrix phase would read the stream twice (measured: the fabric, not the CU, then sets the rate).
-        // Instead the tile is sliced against a guess -- the exponent its predecessor (same wave, previous item) needed, plus
-        // one -- while the largest magnitude is tracked beside the slicing; a guess that turns out too small (overflow) or
-        // more than two bits too large (precision) sends the wave through the matrix phase of that tile once more with the
-        // exact exponent.  Stationary input never takes the second pass.
+        // Instead the tile is sliced against a guess -- the exponent its predecessor (same wave, previous item) used -- while
+        // the largest magnitude is tracked beside the slicing; the exponent to use is the tile's own, rounded up to a multiple
+        // of four (27 to 30 bits below the largest sample; adjacent tiles of a stream of even level agree on it), and a guess
+        // that differs sends the wave through the matrix phase of that tile once more.
         auto wave_max = [&](unsigned v) {
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) v = max(v, (unsigned) __shfl_xor((int) v, d));
@@ -907,8 +907,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     kpass(std::true_type{});
                     int e_true = 0;
                     if constexpr (F32 && HAVE_K) {
-                        e_true = __builtin_amdgcn_readfirstlane((int) (wave_max(__float_as_uint(mxf)) >> 23) - 126);
-                        if (e_true > e_cur[j] || e_true < e_cur[j] - 2) {
+                        // the exponent in use is a function of the tile's own samples (its exponent rounded up to a multiple of
+                        // four), never of the guess: an item's bits do not depend on what the workgroup saw before it
+                        e_true = (__builtin_amdgcn_readfirstlane((int) (wave_max(__float_as_uint(mxf)) >> 23) - 126) + 3) & ~3;
+                        if (e_true != e_cur[j]) {
                             e_cur[j] = e_true;
                             static_for<0, PF>([&](auto pc) { issue(chunk_raw, std::integral_constant<int, j * KS + decltype(pc)::value>{}); });
                             kpass(std::false_type{});
@@ -921,7 +923,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         // float32: everything of this tile in units of 2^(E - 30)
                         const double esc = F32 ? __hiloint2double((1023 + e_cur[j] - 30) << 20, 0) : 1.0;
                         const double cs_main = cs_main0 * esc, cs_loc = cs_loc0 * esc;
-                        if constexpr (F32) { ccon[j] = 8421504.0 * esc; e_cur[j] = e_true + 1; }      // the next item's guess
+                        if constexpr (F32) ccon[j] = 8421504.0 * esc;      // (e_cur[j] stays: the next item's guess)
                         static_for<0, 3>([&](auto rc) {
                             constexpr int rt = decltype(rc)::value;
                             if constexpr (PACK && rt == 2) {
