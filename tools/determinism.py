@@ -7,7 +7,9 @@ from tests.golden import prng
 for kw, nch in ((dict(decimation=64, mode='fm', code='h', row_freqs=[15000.0]), 4096),
                 (dict(decimation=32, mode='am', code='h', row_freqs=[1000.0 * i for i in range(8)], correct_iq=True, normalize=True), 1024),
                 (dict(decimation=64, mode='fm', code='h', row_freqs=[0.0], apply_shift=False), 4096),
-                (dict(decimation=64, mode='fm', code='B', row_freqs=[15000.0]), 2048)):
+                (dict(decimation=64, mode='fm', code='B', row_freqs=[15000.0]), 2048),
+                (dict(decimation=64, mode='fm', code='f', row_freqs=[15000.0]), 4096),
+                (dict(decimation=64, mode='fm', code='h', row_freqs=[15000.0], correct_iq=True), 4096)):
     eng = Engine(256_000_000, omega_out=12500, **kw)
     block = np.frombuffer(prng.raw_bytes(kw['code'], eng.n * 256, 5, 100 if kw['code'] == 'B' else 8000), dtype=np.uint8)
     d_raw = nat.DeviceBuffer(nch * eng.chunk_bytes)
