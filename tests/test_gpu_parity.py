@@ -172,6 +172,51 @@ def test_float32_levels_that_jump_between_tiles_and_chunks(monkeypatch):
     assert np.array_equal(y2.reshape(nch - half, 4, m // 4), y[half:])
 
 
+_OPTION_MATRIX = [
+    # code, q, mode, options -- combinations the golden cases do not hold, against oracle/chain.c
+    ('f', 64, 'fm', dict(big_endian=True)),
+    ('f', 32, 'am', dict(big_endian=True, normalize=True)),
+    ('f', 64, 'am', dict(normalize=True)),
+    ('f', 64, 'fm', dict(correct_iq=True)),
+    ('f', 32, 'fm', dict(correct_iq=True, normalize=True, big_endian=True)),
+    ('H', 64, 'fm', dict(big_endian=True, correct_iq=True)),
+    ('B', 32, 'am', dict(normalize=True, correct_iq=True)),
+    ('b', 64, 'fm', dict(correct_iq=True)),
+    ('h', 32, 'fm', dict(big_endian=True, normalize=True, correct_iq=True)),
+    ('i', 64, 'fm', dict(big_endian=True, correct_iq=True)),
+    ('d', 32, 'am', dict(big_endian=True, normalize=True)),
+]
+
+
+@pytest.mark.parametrize('code,q,mode,opt', _OPTION_MATRIX, ids=[f"{c}_q{q}_{m}_{'_'.join(sorted(o))}" for c, q, m, o in _OPTION_MATRIX])
+def test_reader_options_against_the_c_oracle(code, q, mode, opt, monkeypatch):
+    """Byte order, --normalize-input and --correct-iq in combinations (and on encodings) the golden cases leave out: two rows,
+    three chunks with a carried offset, against oracle/chain.c on the same bytes."""
+    from sdrterm_amd.engine import Engine
+    from oracle import c_chain, ref_chain
+    from tests.golden import prng
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    fs, nch = 1024000, 3
+    n = samples_per_chunk(code)
+    freqs = [15700.0, -203300.0]
+    amp = 100 if code in 'bB' else (100000 if code in 'iI' else 3000)
+    raw = prng.raw_bytes(code, n * nch, seed=61, amp=amp, dc=(amp // 6, -amp // 10), big_endian=bool(opt.get('big_endian')))
+    eng = Engine(fs, q, mode, code, row_freqs=freqs, apply_shift=True, omega_out=5000, normalize=bool(opt.get('normalize')),
+                 correct_iq=bool(opt.get('correct_iq')), big_endian=bool(opt.get('big_endian')))
+    out = eng.process(raw)
+    shift = c_chain.shift_table(freqs, fs, n)
+    norm = ref_chain.generate_domain(code) if opt.get('normalize') else None
+    exp, off = c_chain.process_stream(raw, code, n, q, mode, shift, ref_chain.cheby_sos(q), ref_chain.ellip_sos(fs // q, 5000),
+                                      big_endian=bool(opt.get('big_endian')), norm=norm,
+                                      iq_inductance=50 / fs if opt.get('correct_iq') else None, threads=4)
+    got = out.reshape(2, nch, n // q).transpose(1, 0, 2)
+    err = np.abs(got - exp).max()
+    print(f'{code} q={q} {mode} {sorted(opt)} [{eng.stage_a}]: max abs err {err:.3e} (peak {np.abs(exp).max():.3e})')
+    assert err <= tol_for(exp, mode)
+    if opt.get('correct_iq'):
+        assert abs(eng.iq_offset - off) <= 1e-9 * max(abs(off), 1e-30)
+
+
 def test_float32_non_finite_samples_stay_in_their_chunk(monkeypatch):
     """A NaN or an infinity in a float32 record: the reference's IIR passes turn that whole chunk into NaN
     (dsp_processor.py:147); block fixed point has no NaN, the chunk's outputs are unspecified here -- but every other chunk,
