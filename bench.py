@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the sdrterm DSP hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload fm64|simo64]
+    python bench.py --gpus N --steps K --warmup W [--workload fm64|fm64f|simo64|f32x256]
 
 fm64 (default; BASELINE.json configs[1]): 256 MS/s synthetic int16 IQ, FM demodulation, decimation 64, one VFO, processed in
 the reference's 131072-byte chunks (32768 complex samples).  One "step" is one pass of the whole hot path (unpack -> NCO
@@ -46,6 +46,7 @@ FP64_PEAK_TFLOPS = 78.6
 WORKLOADS = {
     # name: (decimation, total rows, default chunks per step, scaling, encoding, sample rate)
     'fm64': (64, 1, 131072, 'weak', 'h', 256_000_000),
+    'fm64f': (64, 1, 131072, 'weak', 'f', 256_000_000),          # the same stream as float32 records (16384-sample chunks)
     'simo64': (32, 64, 512, 'strong', 'h', 256_000_000),
     'f32x256': (64, 256, 128, 'strong', 'f', 1_000_000_000),
 }
@@ -187,10 +188,11 @@ def main():
     N = 131072 // (2 * ITEM[code])            # complex samples per 131072-byte chunk
     n_chunks = args.chunks or default_chunks
     n_samples = n_chunks * N
-    if args.workload == 'fm64':
+    single = rows_total == 1                  # one VFO: chunks sharded over the ranks; else rows sharded, blocks broadcast
+    if single:
         freqs_all = [float(CENTER)]
         freqs, (lo, hi) = freqs_all, (0, 1)
-        raw = synth_iq_torch(n_samples, seed=1234 + rank, device=device)
+        raw = synth_iq_torch(n_samples, seed=1234 + rank, device=device, code=code, fs=FS)
         bufs = [raw]
         comm = None
     else:
@@ -237,7 +239,7 @@ def main():
 
     def step():
         k = state['k']
-        if args.workload != 'fm64':
+        if not single:
             fetch(k + 1)                                               # beside this step's kernels (other buffer)
         run(bufs[k % len(bufs)].data_ptr(), n_chunks, out.data_ptr(), S)
         if comm is not None:
@@ -248,7 +250,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    if args.workload != 'fm64':
+    if not single:
         fetch(0)
         if comm is not None:
             nat.check(lib.sdrt_stream_wait_stream(S, s_comm))
@@ -312,7 +314,7 @@ def main():
         achieved = alg_bps * n_samples / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms else None
         path_achieved = alg_bps * n_samples / (ms_per_step * 1e-3) / 1e9
         # int8 matrix work of the dominant kernel: matrix instructions per 4096-sample tile x 16*16*64*2 operations
-        mfma_per_tile = {64: 184, 32: 216}[q] if eng.stage_a == 'i8w' else ({'h': 160, 'f': 224}[code] if eng.stage_a == 'i8t' else None)
+        mfma_per_tile = ({64: 184, 32: 216} if code == 'h' else {64: 288, 32: 336})[q] if eng.stage_a == 'i8w' else ({'h': 160, 'f': 224}[code] if eng.stage_a == 'i8t' else None)
         i8_ops = mfma_per_tile * 32768.0 * rows * n_samples / 4096 if mfma_per_tile else None
         pmc = (committed_record('r02_pmc_record.json') or committed_record('pmc_traffic.json')) if args.workload == 'fm64' else None
         pmc_ok = bool(pmc) and pmc.get('chunks_per_step_per_gpu') == n_chunks and pmc.get('kernel', '') in KERNEL_OF[eng.stage_a]
@@ -336,7 +338,7 @@ def main():
                     'avg_kernel_ms': hbm['avg_kernel_ms'], 'launches': k_n, 'ops': 'int8 multiply-adds x 2 (dense int8 matrix peak)',
                     'hbm': {k: hbm[k] for k in ('achieved', 'frac', 'alg_bytes_per_sample', 'path_achieved', 'path_frac')}}
         line = {
-            'metric': {'fm64': 'input MSamples/s IQ->FM demod, dec=64', 'simo64': 'input MSamples/s 64-VFO --simo FM, dec=32',
+            'metric': {'fm64': 'input MSamples/s IQ->FM demod, dec=64', 'fm64f': 'input MSamples/s IQ->FM demod, float32 IQ, dec=64', 'simo64': 'input MSamples/s 64-VFO --simo FM, dec=32',
                        'f32x256': 'input MSamples/s 256-VFO --simo FM, float32 IQ, dec=64'}[args.workload],
             'value': round(value, 1), 'unit': 'MSamples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
@@ -344,13 +346,13 @@ def main():
             # what the arithmetic is: int8 x int8 -> int32 matrix products of 5 base-256 weight digits x 2 byte slices (exact),
             # recombined and finished in fp64; 'f64' when the fp64 matrix-core kernel runs
             'dtype': ('i8x5-split+f64' if code == 'h' else 'f32->4 x i8 block fixed point, i8x5-split+f64') if eng.stage_a in ('i8w', 'i8t') else 'f64', 'data': 'synthetic',
-            'config': {'workload': (f'configs[1]: {FS // 1_000_000} MS/s synthetic int16 IQ (FM tone + noise), FM demod, dec={q}, single VFO, '
+            'config': {'workload': (f'configs[1]{"" if code == "h" else " as float32 records"}: {FS // 1_000_000} MS/s synthetic {"int16" if code == "h" else "float32"} IQ (FM tone + noise), FM demod, dec={q}, single VFO, '
                                     f'center={CENTER} Hz, {n_chunks} chunks x {N} samples per GPU per step, inputs resident in HBM')
-                       if args.workload == 'fm64' else
+                       if single else
                        (f'configs[{3 if code == "h" else 4}]: --simo {rows_total} VFO rows sharded {rows}/GPU, {FS // 1_000_000} MS/s synthetic {"int16" if code == "h" else "float32"} IQ, FM, dec={q}, '
                         f'{n_chunks} chunks x {N} samples per step resident on rank 0, RCCL broadcast per step'),
                        'chunks_per_step_per_gpu': n_chunks, 'samples_per_chunk': N, 'rows_per_gpu': rows,
-                       'parallelism': f'chunk-sharded x{world}' if args.workload == 'fm64' else f'rows-sharded x{world} + bcast',
+                       'parallelism': f'chunk-sharded x{world}' if single else f'rows-sharded x{world} + bcast',
                        'settle_steps': settle_steps + args.warmup},
             'step_ms': {'median': round(step_ms[len(step_ms) // 2], 4), 'min': round(step_ms[0], 4), 'max': round(step_ms[-1], 4),
                         'timed_region_s': round(elapsed, 3)},
@@ -361,7 +363,7 @@ def main():
             'stage_a': eng.stage_a,
         }
         if not args.no_cpu_baseline and world == 1:
-            sample = (bufs[0] if args.workload == 'fm64' else src)[:min(n_samples, 2048 * N)].cpu().numpy().tobytes()
+            sample = (bufs[0] if single else src)[:min(n_samples, 2048 * N)].cpu().numpy().tobytes()
             line['cpu_baseline'] = cpu_baseline(sample, q, freqs_all, code=code, N=N, FS=FS)
         else:
             line['cpu_baseline'] = None
