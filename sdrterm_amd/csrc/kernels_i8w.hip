@@ -785,124 +785,124 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     // the matrix phase of the tile; pcs: with the pieces of the other phases between its groups (the float32
                     // second pass runs without them)
                     auto kpass = [&](auto pcs) {
-                    if constexpr (HAVE_K && F32) static_for<0, FWN>([&](auto fc) { Fw[decltype(fc)::value] = frag_flat(fc); });
-                    if constexpr (HAVE_K && !F32) static_for<0, S>([&](auto dc) { F[decltype(dc)::value] = frag(std::integral_constant<int, 0>{}, dc); });
-                    static_for<0, KS * 3>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value, s = i / 3, rt = i % 3, stg = j * KS + s;
-                        if constexpr (HAVE_K) {
-                            if constexpr (rt == 0) {
-                                // slices of this k-step's 8 complex samples; then its raw registers take the k-step PF ahead
-                                const uint32_t *cur = raw[stg % NSLOT];
-                                if constexpr (F32) {
-                                    // 16 values (8 samples) -> fixed point against the tile's exponent -> 4 x 4 byte transposes
-                                    const int sh = 30 - e_cur[j];
-                                    uint32_t *curw = raw[stg % NSLOT];
-                                    if (swap) {
+                        if constexpr (HAVE_K && F32) static_for<0, FWN>([&](auto fc) { Fw[decltype(fc)::value] = frag_flat(fc); });
+                        if constexpr (HAVE_K && !F32) static_for<0, S>([&](auto dc) { F[decltype(dc)::value] = frag(std::integral_constant<int, 0>{}, dc); });
+                        static_for<0, KS * 3>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value, s = i / 3, rt = i % 3, stg = j * KS + s;
+                            if constexpr (HAVE_K) {
+                                if constexpr (rt == 0) {
+                                    // slices of this k-step's 8 complex samples; then its raw registers take the k-step PF ahead
+                                    const uint32_t *cur = raw[stg % NSLOT];
+                                    if constexpr (F32) {
+                                        // 16 values (8 samples) -> fixed point against the tile's exponent -> 4 x 4 byte transposes
+                                        const int sh = 30 - e_cur[j];
+                                        uint32_t *curw = raw[stg % NSLOT];
+                                        if (swap) {
 #pragma unroll
-                                        for (int w = 0; w < 16; ++w) curw[w] = __builtin_bswap32(curw[w]);
-                                    }
-                                    // the largest magnitude so far (before anything else, so that nothing has to be kept for it)
-#pragma unroll
-                                    for (int w = 0; w < 16; w += 2)
-                                        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mxf) : "v"(curw[w]), "v"(curw[w + 1]));
-                                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                    for (int w = 0; w < 4; ++w) {
-                                        unsigned q_[4];
-#pragma unroll
-                                        for (int u = 0; u < 4; ++u) q_[u] = (unsigned) (int) ldexpf(__uint_as_float(cur[4 * w + u]), sh);
-                                        const unsigned a01 = __builtin_amdgcn_perm(q_[1], q_[0], 0x05010400u), a23 = __builtin_amdgcn_perm(q_[3], q_[2], 0x05010400u);
-                                        const unsigned c01 = __builtin_amdgcn_perm(q_[1], q_[0], 0x07030602u), c23 = __builtin_amdgcn_perm(q_[3], q_[2], 0x07030602u);
-                                        bsl[0][w] = (int) (__builtin_amdgcn_perm(a23, a01, 0x05040100u) ^ 0x80808080u);
-                                        bsl[1][w] = (int) (__builtin_amdgcn_perm(a23, a01, 0x07060302u) ^ 0x80808080u);
-                                        bsl[2][w] = (int) (__builtin_amdgcn_perm(c23, c01, 0x05040100u) ^ 0x80808080u);
-                                        bsl[3][w] = (int) __builtin_amdgcn_perm(c23, c01, 0x07060302u);
-                                    }
-                                } else if constexpr (ITEM == 2) {
-                                    const unsigned sel_lo = swap ? 0x07050301u : 0x06040200u, sel_hi = swap ? 0x06040200u : 0x07050301u;
-    #pragma unroll
-                                    for (int w = 0; w < 4; ++w) {
-                                        blo[w] = (int) (__builtin_amdgcn_perm(cur[2 * w + 1], cur[2 * w], sel_lo) ^ W8Enc<DT>::xlo);
-                                        bhi[w] = (int) (__builtin_amdgcn_perm(cur[2 * w + 1], cur[2 * w], sel_hi) ^ W8Enc<DT>::xhi);
-                                    }
-                                } else {
-    #pragma unroll
-                                    for (int w = 0; w < 4; ++w) { blo[w] = (int) (cur[w] ^ W8Enc<DT>::xlo); bhi[w] = 0; }
-                                }
-                                if constexpr (stg + PF < NSTEP) issue(chunk_raw, std::integral_constant<int, stg + PF>{});
-                                // the next item's first k-steps follow in the same ring (in the last iteration: this item's again, unused)
-                                else issue(next_raw, std::integral_constant<int, stg + PF - NSTEP>{});
-                            }
-                            __builtin_amdgcn_s_setprio(1);           // matrix instructions first: the other wave's vector work fills the gaps
-                            static_for<0, S>([&](auto dc) {
-                                constexpr int d = decltype(dc)::value;
-                                __builtin_amdgcn_sched_barrier(0);
-                                v4i A;
-                                if constexpr (F32) A = Fw[(i * S + d) % FWN]; else A = F[d];
-                                if constexpr (F32 && PACK && rt == 2) {
-                                    // packed local tile, fragments (0|1) (2|3) (4|-) (1|2) (3|4): accumulator a holds levels (2a+3 | 2a+4);
-                                    // the first product into every accumulator is the one with the top slice
-                                    auto mm = [&](auto ac, auto slc, auto first) {
-                                        constexpr int a_ = decltype(ac)::value, sl_ = decltype(slc)::value;
-                                        if constexpr (decltype(first)::value && s == 0) acc[2][a_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bsl[sl_], (v4i) {0, 0, 0, 0}, 0, 0, 0);
-                                        else acc[2][a_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bsl[sl_], acc[2][a_], 0, 0, 0);
-                                    };
-                                    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-                                    if constexpr (d == 0) mm(I0{}, I3{}, std::true_type{});
-                                    if constexpr (d == 1) { mm(I1{}, I3{}, std::true_type{}); mm(I0{}, I1{}, std::false_type{}); }
-                                    if constexpr (d == 2) { mm(I2{}, I3{}, std::true_type{}); mm(I1{}, I1{}, std::false_type{}); }
-                                    if constexpr (d == 3) mm(I0{}, I2{}, std::false_type{});
-                                    if constexpr (d == 4) { mm(I1{}, I2{}, std::false_type{}); mm(I0{}, I0{}, std::false_type{}); }
-                                } else if constexpr (F32) {
-                                    static_for<0, 4>([&](auto slc) {
-                                        constexpr int sl_ = 3 - decltype(slc)::value;      // top slice first: it opens its accumulator
-                                        if constexpr (d + sl_ >= LMIN) {
-                                            if constexpr (sl_ == 3 && s == 0) acc[rt][d + sl_ - LMIN] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bsl[sl_], (v4i) {0, 0, 0, 0}, 0, 0, 0);
-                                            else acc[rt][d + sl_ - LMIN] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bsl[sl_], acc[rt][d + sl_ - LMIN], 0, 0, 0);
+                                            for (int w = 0; w < 16; ++w) curw[w] = __builtin_bswap32(curw[w]);
                                         }
-                                    });
-                                } else if constexpr (PACK && rt == 2) {
-                                    // packed local tile: fragment d < 3 with the high (or only) slice starts accumulator d,
-                                    // fragment 3 + a with the low slice adds to accumulator a
-                                    if constexpr (d < 3) {
-                                        if constexpr (s == 0) acc[2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, NSL == 2 ? bhi : blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
-                                        else acc[2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, NSL == 2 ? bhi : blo, acc[2][d], 0, 0, 0);
-                                    } else if constexpr (d < NLF) {
-                                        acc[2][d - 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[2][d - 3], 0, 0, 0);
+                                        // the largest magnitude so far (before anything else, so that nothing has to be kept for it)
+#pragma unroll
+                                        for (int w = 0; w < 16; w += 2)
+                                            asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mxf) : "v"(curw[w]), "v"(curw[w + 1]));
+                                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                        for (int w = 0; w < 4; ++w) {
+                                            unsigned q_[4];
+#pragma unroll
+                                            for (int u = 0; u < 4; ++u) q_[u] = (unsigned) (int) ldexpf(__uint_as_float(cur[4 * w + u]), sh);
+                                            const unsigned a01 = __builtin_amdgcn_perm(q_[1], q_[0], 0x05010400u), a23 = __builtin_amdgcn_perm(q_[3], q_[2], 0x05010400u);
+                                            const unsigned c01 = __builtin_amdgcn_perm(q_[1], q_[0], 0x07030602u), c23 = __builtin_amdgcn_perm(q_[3], q_[2], 0x07030602u);
+                                            bsl[0][w] = (int) (__builtin_amdgcn_perm(a23, a01, 0x05040100u) ^ 0x80808080u);
+                                            bsl[1][w] = (int) (__builtin_amdgcn_perm(a23, a01, 0x07060302u) ^ 0x80808080u);
+                                            bsl[2][w] = (int) (__builtin_amdgcn_perm(c23, c01, 0x05040100u) ^ 0x80808080u);
+                                            bsl[3][w] = (int) __builtin_amdgcn_perm(c23, c01, 0x07060302u);
+                                        }
+                                    } else if constexpr (ITEM == 2) {
+                                        const unsigned sel_lo = swap ? 0x07050301u : 0x06040200u, sel_hi = swap ? 0x06040200u : 0x07050301u;
+    #pragma unroll
+                                        for (int w = 0; w < 4; ++w) {
+                                            blo[w] = (int) (__builtin_amdgcn_perm(cur[2 * w + 1], cur[2 * w], sel_lo) ^ W8Enc<DT>::xlo);
+                                            bhi[w] = (int) (__builtin_amdgcn_perm(cur[2 * w + 1], cur[2 * w], sel_hi) ^ W8Enc<DT>::xhi);
+                                        }
+                                    } else {
+    #pragma unroll
+                                        for (int w = 0; w < 4; ++w) { blo[w] = (int) (cur[w] ^ W8Enc<DT>::xlo); bhi[w] = 0; }
                                     }
-                                } else if constexpr (NSL == 2) {
-                                    // digit d x high slice -> level d+1 (accumulator d); digit d x low slice -> level d (accumulator d-1)
-                                    if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, (v4i) {0, 0, 0, 0}, 0, 0, 0);
-                                    else acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, acc[rt][d], 0, 0, 0);
-                                    if constexpr (d >= 1) acc[rt][d - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[rt][d - 1], 0, 0, 0);
-                                } else {
-                                    if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
-                                    else acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[rt][d], 0, 0, 0);
+                                    if constexpr (stg + PF < NSTEP) issue(chunk_raw, std::integral_constant<int, stg + PF>{});
+                                    // the next item's first k-steps follow in the same ring (in the last iteration: this item's again, unused)
+                                    else issue(next_raw, std::integral_constant<int, stg + PF - NSTEP>{});
                                 }
-                                if constexpr (F32) {
-                                    if constexpr (i * S + d + FWN < KS * 3 * S) Fw[(i * S + d) % FWN] = frag_flat(std::integral_constant<int, i * S + d + FWN>{});
-                                } else
-                                // the fragment's register takes the next group's fragment (none for the unused slots of a packed tile)
-                                if constexpr (i + 1 < KS * 3) {
-                                    if constexpr (!(PACK && (i + 1) % 3 == 2 && d >= NLF)) F[d] = frag(std::integral_constant<int, i + 1>{}, dc);
+                                __builtin_amdgcn_s_setprio(1);           // matrix instructions first: the other wave's vector work fills the gaps
+                                static_for<0, S>([&](auto dc) {
+                                    constexpr int d = decltype(dc)::value;
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    v4i A;
+                                    if constexpr (F32) A = Fw[(i * S + d) % FWN]; else A = F[d];
+                                    if constexpr (F32 && PACK && rt == 2) {
+                                        // packed local tile, fragments (0|1) (2|3) (4|-) (1|2) (3|4): accumulator a holds levels (2a+3 | 2a+4);
+                                        // the first product into every accumulator is the one with the top slice
+                                        auto mm = [&](auto ac, auto slc, auto first) {
+                                            constexpr int a_ = decltype(ac)::value, sl_ = decltype(slc)::value;
+                                            if constexpr (decltype(first)::value && s == 0) acc[2][a_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bsl[sl_], (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                            else acc[2][a_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bsl[sl_], acc[2][a_], 0, 0, 0);
+                                        };
+                                        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+                                        if constexpr (d == 0) mm(I0{}, I3{}, std::true_type{});
+                                        if constexpr (d == 1) { mm(I1{}, I3{}, std::true_type{}); mm(I0{}, I1{}, std::false_type{}); }
+                                        if constexpr (d == 2) { mm(I2{}, I3{}, std::true_type{}); mm(I1{}, I1{}, std::false_type{}); }
+                                        if constexpr (d == 3) mm(I0{}, I2{}, std::false_type{});
+                                        if constexpr (d == 4) { mm(I1{}, I2{}, std::false_type{}); mm(I0{}, I0{}, std::false_type{}); }
+                                    } else if constexpr (F32) {
+                                        static_for<0, 4>([&](auto slc) {
+                                            constexpr int sl_ = 3 - decltype(slc)::value;      // top slice first: it opens its accumulator
+                                            if constexpr (d + sl_ >= LMIN) {
+                                                if constexpr (sl_ == 3 && s == 0) acc[rt][d + sl_ - LMIN] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bsl[sl_], (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                                else acc[rt][d + sl_ - LMIN] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bsl[sl_], acc[rt][d + sl_ - LMIN], 0, 0, 0);
+                                            }
+                                        });
+                                    } else if constexpr (PACK && rt == 2) {
+                                        // packed local tile: fragment d < 3 with the high (or only) slice starts accumulator d,
+                                        // fragment 3 + a with the low slice adds to accumulator a
+                                        if constexpr (d < 3) {
+                                            if constexpr (s == 0) acc[2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, NSL == 2 ? bhi : blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                            else acc[2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, NSL == 2 ? bhi : blo, acc[2][d], 0, 0, 0);
+                                        } else if constexpr (d < NLF) {
+                                            acc[2][d - 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[2][d - 3], 0, 0, 0);
+                                        }
+                                    } else if constexpr (NSL == 2) {
+                                        // digit d x high slice -> level d+1 (accumulator d); digit d x low slice -> level d (accumulator d-1)
+                                        if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                        else acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, acc[rt][d], 0, 0, 0);
+                                        if constexpr (d >= 1) acc[rt][d - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[rt][d - 1], 0, 0, 0);
+                                    } else {
+                                        if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                        else acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[rt][d], 0, 0, 0);
+                                    }
+                                    if constexpr (F32) {
+                                        if constexpr (i * S + d + FWN < KS * 3 * S) Fw[(i * S + d) % FWN] = frag_flat(std::integral_constant<int, i * S + d + FWN>{});
+                                    } else
+                                    // the fragment's register takes the next group's fragment (none for the unused slots of a packed tile)
+                                    if constexpr (i + 1 < KS * 3) {
+                                        if constexpr (!(PACK && (i + 1) % 3 == 2 && d >= NLF)) F[d] = frag(std::integral_constant<int, i + 1>{}, dc);
+                                    }
+                                });
+                                if constexpr (IQF && rt == 2) {
+                                    // the packed offset rows of this k-step against both slices
+                                    const v4i Fq = wiqL[s * 64 + lane];
+                                    if constexpr (NSL == 2) {
+                                        if constexpr (s == 0) accO[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fq, bhi, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                        else accO[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fq, bhi, accO[0], 0, 0, 0);
+                                    }
+                                    if constexpr (s == 0) accO[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fq, blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                    else accO[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fq, blo, accO[1], 0, 0, 0);
                                 }
-                            });
-                            if constexpr (IQF && rt == 2) {
-                                // the packed offset rows of this k-step against both slices
-                                const v4i Fq = wiqL[s * 64 + lane];
-                                if constexpr (NSL == 2) {
-                                    if constexpr (s == 0) accO[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fq, bhi, (v4i) {0, 0, 0, 0}, 0, 0, 0);
-                                    else accO[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fq, bhi, accO[0], 0, 0, 0);
-                                }
-                                if constexpr (s == 0) accO[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fq, blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
-                                else accO[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fq, blo, accO[1], 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                                __builtin_amdgcn_s_setprio(0);
                             }
+                            if constexpr (decltype(pcs)::value) piece(jc, ic);
                             __builtin_amdgcn_sched_barrier(0);
-                            __builtin_amdgcn_s_setprio(0);
-                        }
-                        if constexpr (decltype(pcs)::value) piece(jc, ic);
-                        __builtin_amdgcn_sched_barrier(0);
-                    });
+                        });
                     };
                     kpass(std::true_type{});
                     int e_true = 0;
