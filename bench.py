@@ -157,6 +157,7 @@ def main():
     ap.add_argument('--steps', type=int, default=1500)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='fm64')
+    ap.add_argument('--correct-iq', action='store_true', help='the workload with --correct-iq (single-VFO workloads)')
     ap.add_argument('--chunks', type=int, default=0, help='chunks per step (fm64: per GPU, default 131072 = 2^32 samples = 16 s of the 256 MS/s stream; simo64: 512)')
     ap.add_argument('--settle-seconds', type=float, default=2.0, help='untimed back-to-back steps before the timed region')
     ap.add_argument('--long-seconds', type=float, default=2.0, help='steady-state run after the timed region (0 = skip)')
@@ -207,7 +208,7 @@ def main():
             uid = [parallel.RcclTransport.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             comm = parallel.RcclTransport(rank, world, local_rank, uid[0])
-    eng = Engine(FS, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_rank)
+    eng = Engine(FS, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_rank, correct_iq=args.correct_iq)
     rows = len(freqs)
     out = torch.empty((rows, n_chunks * eng.m), dtype=torch.float64, device=device)
     lib = nat.lib()
@@ -314,9 +315,9 @@ def main():
         achieved = alg_bps * n_samples / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms else None
         path_achieved = alg_bps * n_samples / (ms_per_step * 1e-3) / 1e9
         # int8 matrix work of the dominant kernel: matrix instructions per 4096-sample tile x 16*16*64*2 operations
-        mfma_per_tile = ({64: 184, 32: 216} if code == 'h' else {64: 288, 32: 336})[q] if eng.stage_a == 'i8w' else ({'h': 160, 'f': 224}[code] if eng.stage_a == 'i8t' else None)
+        mfma_per_tile = (({64: 184, 32: 216} if code == 'h' else {64: 288, 32: 336})[q] + (16 if args.correct_iq and rows == 1 else 0)) if eng.stage_a == 'i8w' else ({'h': 160, 'f': 224}[code] if eng.stage_a == 'i8t' else None)
         i8_ops = mfma_per_tile * 32768.0 * rows * n_samples / 4096 if mfma_per_tile else None
-        pmc = (committed_record('r02_pmc_record.json') or committed_record('pmc_traffic.json')) if args.workload == 'fm64' else None
+        pmc = (committed_record('r02_pmc_record.json') or committed_record('pmc_traffic.json')) if args.workload == 'fm64' and not args.correct_iq else None
         pmc_ok = bool(pmc) and pmc.get('chunks_per_step_per_gpu') == n_chunks and pmc.get('kernel', '') in KERNEL_OF[eng.stage_a]
         hbm = {'bound': 'hbm', 'kernel': KERNEL_OF[eng.stage_a],
                'achieved': round(achieved, 1) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -347,7 +348,7 @@ def main():
             # recombined and finished in fp64; 'f64' when the fp64 matrix-core kernel runs
             'dtype': ('i8x5-split+f64' if code == 'h' else 'f32->4 x i8 block fixed point, i8x5-split+f64') if eng.stage_a in ('i8w', 'i8t') else 'f64', 'data': 'synthetic',
             'config': {'workload': (f'configs[1]{"" if code == "h" else " as float32 records"}: {FS // 1_000_000} MS/s synthetic {"int16" if code == "h" else "float32"} IQ (FM tone + noise), FM demod, dec={q}, single VFO, '
-                                    f'center={CENTER} Hz, {n_chunks} chunks x {N} samples per GPU per step, inputs resident in HBM')
+                                    f'center={CENTER} Hz{", --correct-iq" if args.correct_iq else ""}, {n_chunks} chunks x {N} samples per GPU per step, inputs resident in HBM')
                        if single else
                        (f'configs[{3 if code == "h" else 4}]: --simo {rows_total} VFO rows sharded {rows}/GPU, {FS // 1_000_000} MS/s synthetic {"int16" if code == "h" else "float32"} IQ, FM, dec={q}, '
                         f'{n_chunks} chunks x {N} samples per step resident on rank 0, RCCL broadcast per step'),

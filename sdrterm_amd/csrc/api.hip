@@ -666,7 +666,9 @@ int ensure_ybuf(sdrt_ctx *c, size_t n_chunks) {
 }
 
 // unpack .. decimate (feedBuffers' per-sample steps, shiftFreq, decimate: read_file.py:100-103, dsp_processor.py:144-147)
-int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybuf, hipStream_t s, int n_cus) {
+// fix_later: the share of the IQ offset at each chunk's start (wide-column kernel, fused form) is subtracted by the post
+// kernel while it loads the decimated samples (enqueue_post), not by a pass of its own
+int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybuf, hipStream_t s, int n_cus, bool fix_later = false) {
     DecimArgs da;
     da.raw = raw_dev;
     da.n_count = 0;
@@ -801,13 +803,14 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
     if (c->iq && c->use_i8w && c->iq_fused) {
         Timed t(c, s, 2);
         HIP_TRY(launch_iq_scan(iq_after, s));
-        HIP_TRY(launch_iq_fix(ybuf, c->d_iq_R, c->d_iq_chunk, c->rows, n_chunks, c->m, s));
+        if (!fix_later) HIP_TRY(launch_iq_fix(ybuf, c->d_iq_R, c->d_iq_chunk, c->rows, n_chunks, c->m, s));
     }
     return SDRT_OK;
 }
 
 // demodulate, resample, output lowpass, --smooth-output (dsp_processor.py:148-149,159-160)
-int enqueue_post(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out_dev, hipStream_t s) {
+// the demodulation stage's arguments; iq_share: it also subtracts the offset share the fused IQ form leaves to it
+PostArgs post_args(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out_dev, bool iq_share) {
     PostArgs pa;
     pa.y = ybuf;
     pa.resample_odd = c->d_resample;
@@ -821,6 +824,14 @@ int enqueue_post(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out_d
     pa.m = c->m;
     pa.mode = c->cfg.mode;
     pa.out_sections = c->cfg.out_sections;
+    pa.iq_R = iq_share ? c->d_iq_R : nullptr;
+    pa.iq_off = iq_share ? c->d_iq_chunk : nullptr;
+    pa.n_chunks = n_chunks;
+    return pa;
+}
+
+int enqueue_post(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out_dev, hipStream_t s, bool iq_share = false) {
+    const PostArgs pa = post_args(c, ybuf, n_chunks, out_dev, iq_share);
     {
         Timed t(c, s, 1);
         HIP_TRY(launch_post(pa, s));
@@ -866,9 +877,12 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
         if (rc != SDRT_OK) return rc;
         ybuf = c->d_y;
     }
-    rc = enqueue_chain(c, raw_dev, n_chunks, ybuf, s, c->n_cus);
+    // fused IQ form: when the caller does not ask for the decimated samples, the demodulation stage subtracts the offset
+    // share as it loads them (one pass over them less)
+    const bool later = !ydec_dev && c->iq && c->use_i8w && c->iq_fused && post_takes_iq_share(post_args(c, ybuf, n_chunks, out_dev, true));
+    rc = enqueue_chain(c, raw_dev, n_chunks, ybuf, s, c->n_cus, later);
     if (rc != SDRT_OK) return rc;
-    return enqueue_post(c, ybuf, n_chunks, out_dev, s);
+    return enqueue_post(c, ybuf, n_chunks, out_dev, s, later);
 }
 
 int sdrt_process_device(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *out_dev, void *stream) {

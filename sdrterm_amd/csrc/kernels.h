@@ -80,7 +80,14 @@ struct PostArgs {
     size_t items;
     int m, mode, out_sections;
     int fft_ok;                 // host check: modal lowpass available (OutTables.nmodes >= 0) and not disabled
+    // --correct-iq computed inside the wide-column kernel: the share of the offset at each chunk's start is still to be
+    // subtracted, y[row][chunk][k] -= iq_off[chunk] * iq_R[row][k] (NULL: nothing to subtract); see iq_fix_kernel
+    const double *iq_R;         // [rows][m][2]
+    const double *iq_off;       // [n_chunks][2]
+    size_t n_chunks;            // items = rows * n_chunks, row-major
 };
+// does launch_post pick a kernel that applies iq_R / iq_off while it loads the decimated samples?
+bool post_takes_iq_share(const PostArgs &a);
 struct SmoothArgs {
     double *out;                // [items][m], smoothed in place
     size_t items;

@@ -255,17 +255,31 @@ __global__ __launch_bounds__(256) void iq_local_kernel(IqArgs a) {
 }
 
 // one workgroup: chunk offsets off[c+1] = (1-lambda)^n off[c] + agg[c], off[0] = carried state
-__global__ __launch_bounds__(256) void iq_scan_kernel(IqArgs a) {
-    __shared__ cd tot[256];
-    __shared__ double pw[256];
+constexpr int IQ_SCAN_THREADS = 1024;
+__global__ __launch_bounds__(IQ_SCAN_THREADS) void iq_scan_kernel(IqArgs a) {
+    __shared__ cd tot[IQ_SCAN_THREADS];
+    __shared__ double pw[IQ_SCAN_THREADS];
     const int tid = threadIdx.x;
-    const size_t nc = a.n_chunks, per = (nc + 255) / 256;
-    const size_t c0 = (size_t) tid * per, c1 = c0 + per < nc ? c0 + per : nc;
+    const size_t nc = a.n_chunks, per = (nc + IQ_SCAN_THREADS - 1) / IQ_SCAN_THREADS;
+    const size_t c0 = (size_t) tid * per < nc ? (size_t) tid * per : nc, c1 = c0 + per < nc ? c0 + per : nc;
     const cd *agg = (const cd *) a.chunk_agg;
     cd *offc = (cd *) a.chunk_off;
     cd s = mk(0.0, 0.0);
     double p = 1.0;
-    for (size_t c = c0; c < c1; ++c) {
+    // (batches of eight loads in flight: the recurrence itself is short, the loop is bound by the latency of its loads)
+    constexpr int UB = 8;
+    size_t c = c0;
+    for (; c + UB <= c1; c += UB) {
+        cd v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) v[u] = agg[c + u];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            s = mk(fma(a.pow_n, s.re, v[u].re), fma(a.pow_n, s.im, v[u].im));
+            p *= a.pow_n;
+        }
+    }
+    for (; c < c1; ++c) {
         s = mk(fma(a.pow_n, s.re, agg[c].re), fma(a.pow_n, s.im, agg[c].im));
         p *= a.pow_n;
     }
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(256) void iq_scan_kernel(IqArgs a) {
     __syncthreads();
     if (tid == 0) {
         cd run = mk(a.state[0], a.state[1]);
-        for (int t = 0; t < 256; ++t) {
+        for (int t = 0; t < IQ_SCAN_THREADS; ++t) {
             const cd mine = tot[t];
             tot[t] = run;                                   // offset at the start of thread t's range
             run = mk(fma(pw[t], run.re, mine.re), fma(pw[t], run.im, mine.im));
@@ -285,7 +299,18 @@ __global__ __launch_bounds__(256) void iq_scan_kernel(IqArgs a) {
     }
     __syncthreads();
     cd o = tot[tid];
-    for (size_t c = c0; c < c1; ++c) {
+    c = c0;
+    for (; c + UB <= c1; c += UB) {
+        cd v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) v[u] = agg[c + u];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            offc[c + u] = o;
+            o = mk(fma(a.pow_n, o.re, v[u].re), fma(a.pow_n, o.im, v[u].im));
+        }
+    }
+    for (; c < c1; ++c) {
         offc[c] = o;
         o = mk(fma(a.pow_n, o.re, agg[c].re), fma(a.pow_n, o.im, agg[c].im));
     }
@@ -341,7 +366,7 @@ hipError_t launch_iq_local(const IqArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_iq_scan(const IqArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(iq_scan_kernel, dim3(1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(iq_scan_kernel, dim3(1), dim3(IQ_SCAN_THREADS), 0, s, a);
     return hipGetLastError();
 }
 

@@ -4,6 +4,20 @@
 // modal scan along the lanes.  Small registers and 12 m bytes of LDS per wave keep many items in flight per CU.
 #include "kernels_common.hpp"
 
+namespace {
+// decimated sample k of an item, less the share of the IQ offset at its chunk's start (same operations as iq_fix_kernel)
+__device__ __forceinline__ cd load_y(const cd *y, const cd *R, const cd h, const int k) {
+    cd v = y[k];
+    if (R) {
+        const cd r = R[k];
+        v.re = fma(-h.re, r.re, fma(h.im, r.im, v.re));
+        v.im = fma(-h.re, r.im, fma(-h.im, r.re, v.im));
+    }
+    return v;
+}
+}  // namespace
+
+
 // Output lowpass of one item in modal form, one wave: y[t] = D x[t] + sum_k Re(r_k s_k(t)), s_k(t+1) = p_k s_k(t) + x[t].
 // Lane l owns samples [l*E, l*E+E): local end state, inclusive scan along the wave, exclusive shift = state at the lane's
 // first sample.  zb: [m] demodulated samples in LDS at positions zpos(i) (one pad double per 8 samples: the lanes' strided
@@ -139,10 +153,12 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
     const size_t item = (size_t) blockIdx.x * wpb + wave;
     if (item >= a.items) return;
     const cd *y = (const cd *) a.y + item * (size_t) m;
+    const cd *R = a.iq_R ? (const cd *) a.iq_R + (item / a.n_chunks) * (size_t) m : nullptr;
+    const cd h = a.iq_R ? ((const cd *) a.iq_off)[item % a.n_chunks] : mk(0.0, 0.0);
 
     if (fm) {
         for (int j = lane; j < N; j += 64) {
-            const cd p = y[2 * j], c = y[2 * j + 1];
+            const cd p = load_y(y, R, h, 2 * j), c = load_y(y, R, h, 2 * j + 1);
             av[j] = atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);    // angle(d[i] * conj(d[i+1]))
         }
         // even samples are the input, odd samples the circulant product with the half-sample Dirichlet kernel
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
         }
     } else {
         for (int k = lane; k < m; k += 64) {
-            const cd v = y[k];
+            const cd v = load_y(y, R, h, k);
             zb[zpos(k)] = v.re * v.re + v.im * v.im;
         }
     }
@@ -302,6 +318,8 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
     // into one complex transform would make the last bits of one depend on the other)
     for (size_t item = (size_t) blockIdx.x * WPB + wave; item < a.items; item += (size_t) gridDim.x * WPB) {
         const cd *y = (const cd *) a.y + item * (size_t) M;
+        const cd *R = a.iq_R ? (const cd *) a.iq_R + (item / a.n_chunks) * (size_t) M : nullptr;
+        const cd h = a.iq_R ? ((const cd *) a.iq_off)[item % a.n_chunks] : mk(0.0, 0.0);
         cd x[B][4];
         double ev[B][4];
         auto angles = [&]() {
@@ -310,7 +328,7 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int j = lane + 64 * b + k * (N / 4);
-                    const cd p = y[2 * j], c = y[2 * j + 1];
+                    const cd p = load_y(y, R, h, 2 * j), c = load_y(y, R, h, 2 * j + 1);
                     // angle(d[i] * conj(d[i+1])) (demodulation.py:25-32)
                     const double an = atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);
                     x[b][k] = mk(an, 0.0);
@@ -502,6 +520,13 @@ hipError_t launch_tap_stft(const TapArgs &a, hipStream_t s) {
 // realOutput / imagOutput (demodulation.py:51-68) of the decimated samples; no output filter follows (dsp_processor.py:130-138)
 __global__ __launch_bounds__(256) void part_kernel(const double *__restrict__ y, double *__restrict__ out, size_t count, int imag) {
     for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t) gridDim.x * 256) out[i] = y[2 * i + imag];
+}
+
+bool post_takes_iq_share(const PostArgs &a) {
+    if (a.mode == SDRT_RE || a.mode == SDRT_IM) return false;                                // part_kernel
+    if (a.mode == SDRT_FM && a.fft_tw && a.fft_shift && a.fft_ok && (a.m == 512 || a.m == 1024 || a.m == 2048 || a.m == 4096)) return true;
+    if (a.m >= 8192 && post_big_supported(a.m, a.mode)) return false;                       // post_big_kernel
+    return post_waves_per_block(a.m, a.mode) != 0;                                           // post_kernel
 }
 
 hipError_t launch_post(const PostArgs &a, hipStream_t s) {

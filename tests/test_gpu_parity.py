@@ -241,6 +241,24 @@ def test_float32_non_finite_samples_stay_in_their_chunk(monkeypatch):
     assert np.array_equal(again, clean)                  # and the exponent guesses carry no damage into the next call
 
 
+def test_float32_256_rows_sampled_against_the_fp64_oracle():
+    """BASELINE.json configs[4]'s shape on one GPU: 256 VFO rows of float32 records, decimation 64.  Rows sampled across the
+    range (first, last = center, and some in between) x 3 chunks against oracle/chain.c at the north-star tolerance."""
+    from sdrterm_amd.engine import Engine
+    from tests.golden import prng
+    fs, q, n, nch = 1_000_000_000, 64, samples_per_chunk('f'), 3
+    freqs = [float((i - 127) * 3_000_000 + 15000) for i in range(255)] + [15000.0]
+    raw = prng.raw_bytes('f', n * nch, seed=256, amp=8000)
+    eng = Engine(fs, q, 'fm', 'f', row_freqs=freqs, apply_shift=True, omega_out=12500)
+    out = eng.process(raw)
+    pick = [0, 1, 63, 64, 127, 128, 200, 254, 255]
+    exp = _oracle_rows(raw, 'f', n, q, 'fm', freqs, fs, 12500, range(nch), pick)
+    got = out.reshape(256, nch, n // q)[pick].transpose(1, 0, 2)
+    err = np.abs(got - exp).max()
+    print(f'float32 x 256 rows [{eng.stage_a}]: max abs err over {len(pick)} sampled rows {err:.3e}')
+    assert err <= 1e-6
+
+
 @pytest.mark.parametrize('rows,nch', [(64, 3), (300, 2), (33, 17), (5, 100)])
 def test_item_distribution_of_the_persistent_kernel(rows, nch, monkeypatch):
     """Many rows x few chunks and few rows x many chunks (rows above and below the number of workgroup slots, chunk counts

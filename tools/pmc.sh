@@ -4,8 +4,9 @@
 set -u
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/pmc
-mkdir -p "$OUT"
+OUT=/tmp/pmc_$$                 # raw profiler output stays on the box (it exceeds what gpurun copies back)
+KEEP=$ROOT/gpurun_out/pmc
+mkdir -p "$OUT" "$KEEP"
 cd /tmp
 ARGS="--steps 3 --warmup 1 --settle-seconds 0.5 --long-seconds 0 --no-cpu-baseline ${BENCH_ARGS:-}"
 pass() {
@@ -19,3 +20,4 @@ pass sq3 SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_
 pass fetch FETCH_SIZE GRBM_GUI_ACTIVE
 pass write WRITE_SIZE GRBM_GUI_ACTIVE
 python3 "$ROOT/tools/pmc_summary.py" "$OUT" | tee "$OUT/summary.txt"
+cp "$OUT"/summary.txt "$OUT"/*.json "$OUT"/*.log "$KEEP"/ 2>/dev/null
