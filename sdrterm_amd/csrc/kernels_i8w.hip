@@ -958,10 +958,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                             for (int v = 0; v < 4; ++v) tq[v] = NSL == 2 ? fma((double) accO[0][v], 256.0, (double) accO[1][v]) : (double) accO[1][v];
                             const double sc = iq_cs * (g == 0 ? 1.0 : (g == 1 ? 65536.0 : 4294967296.0));
                             double ar = fma(tq[2], 256.0, tq[0]) * sc, ai = fma(tq[3], 256.0, tq[1]) * sc;
-                            ar += __shfl_xor(ar, 16);
-                            ai += __shfl_xor(ai, 16);
-                            ar += __shfl_xor(ar, 32);
-                            ai += __shfl_xor(ai, 32);
+                            ar = swap16_add(ar, ar);                                  // all-reduce over the four lanes 16 apart
+                            ai = swap16_add(ai, ai);
+                            ar = swap32_add(ar, ar);
+                            ai = swap32_add(ai, ai);
                             // + the constant the slices leave out; then the inclusive scan over the tile's 16 columns
                             cd o = mk(fma(a.c_re, iq_wsum, ar), fma(a.c_im, iq_wsum, ai));
                             o = mk(fma(iq_m1, dpp_row<0x111>(o.re), o.re), fma(iq_m1, dpp_row<0x111>(o.im), o.im));

@@ -13,7 +13,8 @@ def main():
     n_chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     center = int(sys.argv[2]) if len(sys.argv) > 2 else 15000
     code = sys.argv[4] if len(sys.argv) > 4 else 'h'          # 'f': float32 records (16384-sample chunks, two to an item)
-    eng = Engine(256_000_000, 64, 'fm', code, row_freqs=[center], omega_out=12500)
+    iq = len(sys.argv) > 5 and sys.argv[5] == 'iq'               # --correct-iq (fused form)
+    eng = Engine(256_000_000, 64, 'fm', code, row_freqs=[center], omega_out=12500, correct_iq=iq)
     assert eng.stage_a == 'i8w', eng.stage_a
     one = np.frombuffer(prng.raw_bytes(code, eng.n * 64, 3, 8000), dtype=np.uint8)
     d_raw = nat.DeviceBuffer(n_chunks * eng.chunk_bytes)
