@@ -267,9 +267,15 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         // of four (27 to 30 bits below the largest sample; adjacent tiles of a stream of even level agree on it), and a guess
         // that differs sends the wave through the matrix phase of that tile once more.
         auto wave_max = [&](unsigned v) {
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) v = max(v, (unsigned) __shfl_xor((int) v, d));
-            return v;
+            // all-reduce without LDS: rotations inside the 16-lane rows (DPP row_ror), then the rows exchanged by permlane swaps
+            v = max(v, (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x121, 0xf, 0xf, false));
+            v = max(v, (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x122, 0xf, 0xf, false));
+            v = max(v, (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x124, 0xf, 0xf, false));
+            v = max(v, (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x128, 0xf, 0xf, false));
+            const v2u a16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+            v = max(a16[0], a16[1]);
+            const v2u a32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+            return max(a32[0], a32[1]);
         };
         {
             const unsigned char *c0 = (const unsigned char *) a.raw + (size_t) chunk_of(0) * chunk_bytes;
