@@ -668,7 +668,8 @@ int ensure_ybuf(sdrt_ctx *c, size_t n_chunks) {
 // unpack .. decimate (feedBuffers' per-sample steps, shiftFreq, decimate: read_file.py:100-103, dsp_processor.py:144-147)
 // fix_later: the share of the IQ offset at each chunk's start (wide-column kernel, fused form) is subtracted by the post
 // kernel while it loads the decimated samples (enqueue_post), not by a pass of its own
-int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybuf, hipStream_t s, int n_cus, bool fix_later = false) {
+// pair_out: the wide-column kernel writes the products y[2i] conj(y[2i+1]) instead of the samples (FM, PostArgs.pairs)
+int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybuf, hipStream_t s, int n_cus, bool fix_later = false, bool pair_out = false) {
     DecimArgs da;
     da.raw = raw_dev;
     da.n_count = 0;
@@ -678,6 +679,7 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
     da.ydec = ybuf;
     da.stamps = c->stamps_dev;
     da.stamp_wgs = c->stamp_wgs;
+    da.pair_out = pair_out ? 1 : 0;
     da.n_chunks = n_chunks;
     da.n = c->cfg.n_samples;
     da.m = c->m;
@@ -765,11 +767,11 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
         } else if (c->use_i8w && c->cfg.n_samples == 4 * SDRT_TB * SDRT_WIDE_LC) {
             // chunks of four tiles go two to an item: an odd batch ends with the pair (n-2, n-1) once more (chunk n-2 comes out the
             // same twice); a single chunk is doubled into a scratch pair
-            const size_t cb = (size_t) c->cfg.n_samples * 2 * kItemSize[c->cfg.dtype], yb = (size_t) c->m * 2;
+            const size_t cb = (size_t) c->cfg.n_samples * 2 * kItemSize[c->cfg.dtype], yb = (size_t) c->m * (pair_out ? 1 : 2);
             if (n_chunks == 1) {
                 if (!c->d_pair_raw) {
                     HIP_TRY(hipMalloc(&c->d_pair_raw, 2 * cb));
-                    HIP_TRY(hipMalloc((void **) &c->d_pair_y, (size_t) c->rows * 2 * yb * sizeof(double)));
+                    HIP_TRY(hipMalloc((void **) &c->d_pair_y, (size_t) c->rows * 2 * (size_t) c->m * 2 * sizeof(double)));
                 }
                 HIP_TRY(hipMemcpyAsync(c->d_pair_raw, raw_dev, cb, hipMemcpyDeviceToDevice, s));
                 HIP_TRY(hipMemcpyAsync((char *) c->d_pair_raw + cb, raw_dev, cb, hipMemcpyDeviceToDevice, s));
@@ -810,7 +812,7 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
 
 // demodulate, resample, output lowpass, --smooth-output (dsp_processor.py:148-149,159-160)
 // the demodulation stage's arguments; iq_share: it also subtracts the offset share the fused IQ form leaves to it
-PostArgs post_args(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out_dev, bool iq_share) {
+PostArgs post_args(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out_dev, bool iq_share, bool pairs = false) {
     PostArgs pa;
     pa.y = ybuf;
     pa.resample_odd = c->d_resample;
@@ -827,11 +829,12 @@ PostArgs post_args(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out
     pa.iq_R = iq_share ? c->d_iq_R : nullptr;
     pa.iq_off = iq_share ? c->d_iq_chunk : nullptr;
     pa.n_chunks = n_chunks;
+    pa.pairs = pairs ? 1 : 0;
     return pa;
 }
 
-int enqueue_post(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out_dev, hipStream_t s, bool iq_share = false) {
-    const PostArgs pa = post_args(c, ybuf, n_chunks, out_dev, iq_share);
+int enqueue_post(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out_dev, hipStream_t s, bool iq_share = false, bool pairs = false) {
+    const PostArgs pa = post_args(c, ybuf, n_chunks, out_dev, iq_share, pairs);
     {
         Timed t(c, s, 1);
         HIP_TRY(launch_post(pa, s));
@@ -880,9 +883,12 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     // fused IQ form: when the caller does not ask for the decimated samples, the demodulation stage subtracts the offset
     // share as it loads them (one pass over them less)
     const bool later = !ydec_dev && c->iq && c->use_i8w && c->iq_fused && post_takes_iq_share(post_args(c, ybuf, n_chunks, out_dev, true));
-    rc = enqueue_chain(c, raw_dev, n_chunks, ybuf, s, c->n_cus, later);
+    // FM on the wide-column kernel, likewise without a debug buffer: the pair products instead of the samples (half the bytes
+    // between the two stages); not with the offset share still to come
+    const bool pairs = !ydec_dev && c->use_i8w && !c->stamps_dev && !later && post_takes_pairs(post_args(c, ybuf, n_chunks, out_dev, false, true));
+    rc = enqueue_chain(c, raw_dev, n_chunks, ybuf, s, c->n_cus, later, pairs);
     if (rc != SDRT_OK) return rc;
-    return enqueue_post(c, ybuf, n_chunks, out_dev, s, later);
+    return enqueue_post(c, ybuf, n_chunks, out_dev, s, later, pairs);
 }
 
 int sdrt_process_device(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *out_dev, void *stream) {

@@ -17,6 +17,7 @@ struct DecimArgs {
     double *ydec;               // [row][chunk][m][2] decimated complex samples (input of the post kernel)
     unsigned long long *stamps; // optional diagnostic: [wg < stamp_wgs][wave][8] s_memtime at phase boundaries
     int stamp_wgs;
+    int pair_out;               // wide-column kernel: ydec takes [row][chunk][m/2] products y[2i] conj(y[2i+1]) instead of the samples
     size_t n_chunks;            // chunks in the batch = row stride of ydec
     size_t n_count;             // wide-column kernel: chunks to process (0 = n_chunks); raw / ydec then point at the first of them
     int n, m, n_tiles, rows, swap;
@@ -85,7 +86,10 @@ struct PostArgs {
     const double *iq_R;         // [rows][m][2]
     const double *iq_off;       // [n_chunks][2]
     size_t n_chunks;            // items = rows * n_chunks, row-major
+    int pairs;                  // FM: y holds [items][m/2] products y[2i] conj(y[2i+1]) (DecimArgs.pair_out)
 };
+// does launch_post pick a kernel that reads pair products (PostArgs.pairs)?
+bool post_takes_pairs(const PostArgs &a);
 // does launch_post pick a kernel that applies iq_R / iq_off while it loads the decimated samples?
 bool post_takes_iq_share(const PostArgs &a);
 struct SmoothArgs {

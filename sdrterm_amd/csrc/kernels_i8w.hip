@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                 }
             }
             // outputs of item it-3 (the first three iterations store to item 0's place, which P3(0) rewrites in iteration 3)
-            double *yd = a.ydec + ((size_t) row * a.n_chunks + (size_t) chunk_of(have_p3 ? it - 3 : 0) * SEG) * (size_t) m * 2;
+            double *yd = a.ydec + ((size_t) row * a.n_chunks + (size_t) chunk_of(have_p3 ? it - 3 : 0) * SEG) * (size_t) m * (a.pair_out ? 1 : 2);
             cd yb[TPW][OPL];
 #pragma unroll
             for (int j = 0; j < TPW; ++j)
@@ -570,10 +570,23 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         }
                     }
                 } else if constexpr (i == P3_0 + 4) {
+                    // the decimated samples leave as they are, or (pair_out: FM without a debug buffer) as the products
+                    // y[2i] conj(y[2i+1]) the discriminator takes the angle of (demodulation.py:25-32): half the bytes written here
+                    // and read by the demodulation stage.  Outputs g and g + 1 sit in lanes 16 apart: one permlane swap per dword;
+                    // one store instruction either way (lanes of odd g masked off for pairs)
+                    const bool pr = a.pair_out != 0;
 #pragma unroll
                     for (int e = 0; e < OPL; ++e) {
                         const int k = (tile * SDRT_TB + nb) * NOUT + g + 4 * e;
-                        *(double2 *) (yd + 2 * (size_t) k) = make_double2(pv[j][e].re, pv[j][e].im);
+                        const cd own = pv[j][e];
+                        const v2u s0 = __builtin_amdgcn_permlane16_swap((unsigned) __double2loint(own.re), (unsigned) __double2loint(own.re), false, false);
+                        const v2u s1 = __builtin_amdgcn_permlane16_swap((unsigned) __double2hiint(own.re), (unsigned) __double2hiint(own.re), false, false);
+                        const v2u s2 = __builtin_amdgcn_permlane16_swap((unsigned) __double2loint(own.im), (unsigned) __double2loint(own.im), false, false);
+                        const v2u s3 = __builtin_amdgcn_permlane16_swap((unsigned) __double2hiint(own.im), (unsigned) __double2hiint(own.im), false, false);
+                        const cd nx = mk(__hiloint2double((int) s1[1], (int) s0[1]), __hiloint2double((int) s3[1], (int) s2[1]));     // even g: output g + 1
+                        const cd z = mk(fma(own.re, nx.re, own.im * nx.im), fma(own.im, nx.re, -(own.re * nx.im)));
+                        const cd o = pr ? z : own;
+                        if (!pr || (g & 1) == 0) *(double2 *) (yd + (pr ? (size_t) k : 2 * (size_t) k)) = make_double2(o.re, o.im);
                     }
                 }
                 if constexpr (HAVE_K && j == 0 && i == P3_0 + 5) {

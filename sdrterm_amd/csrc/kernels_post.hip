@@ -152,15 +152,22 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
     }
     const size_t item = (size_t) blockIdx.x * wpb + wave;
     if (item >= a.items) return;
-    const cd *y = (const cd *) a.y + item * (size_t) m;
+    const cd *y = (const cd *) a.y + item * (size_t) (a.pairs ? N : m);
     const cd *R = a.iq_R ? (const cd *) a.iq_R + (item / a.n_chunks) * (size_t) m : nullptr;
     const cd h = a.iq_R ? ((const cd *) a.iq_off)[item % a.n_chunks] : mk(0.0, 0.0);
 
-    if (fm) {
+    if (fm && a.pairs) {
+        for (int j = lane; j < N; j += 64) {
+            const cd z = y[j];                                                      // d[2j] * conj(d[2j+1]) from the chain kernel
+            av[j] = atan2(z.im, z.re);
+        }
+    } else if (fm) {
         for (int j = lane; j < N; j += 64) {
             const cd p = load_y(y, R, h, 2 * j), c = load_y(y, R, h, 2 * j + 1);
             av[j] = atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);    // angle(d[i] * conj(d[i+1]))
         }
+    }
+    if (fm) {
         // even samples are the input, odd samples the circulant product with the half-sample Dirichlet kernel
         for (int j = lane; j < N; j += 64) zb[zpos(2 * j)] = av[j];
         switch (N >> 6) {
@@ -298,7 +305,7 @@ __device__ __forceinline__ void fft_wave(cd (&x)[B][4], cd *X, const cd *tw, con
 }
 }  // namespace
 
-template <int B, int WPB>
+template <int B, int WPB, bool PAIRS>
 __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
     constexpr int N = 256 * B, M = 2 * N;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
     // one item per wave and turn: every item's result is a function of that item alone, bit for bit (pairing two items
     // into one complex transform would make the last bits of one depend on the other)
     for (size_t item = (size_t) blockIdx.x * WPB + wave; item < a.items; item += (size_t) gridDim.x * WPB) {
-        const cd *y = (const cd *) a.y + item * (size_t) M;
+        const cd *y = (const cd *) a.y + item * (size_t) (PAIRS ? N : M);
         const cd *R = a.iq_R ? (const cd *) a.iq_R + (item / a.n_chunks) * (size_t) M : nullptr;
         const cd h = a.iq_R ? ((const cd *) a.iq_off)[item % a.n_chunks] : mk(0.0, 0.0);
         cd x[B][4];
@@ -328,9 +335,15 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int j = lane + 64 * b + k * (N / 4);
-                    const cd p = load_y(y, R, h, 2 * j), c = load_y(y, R, h, 2 * j + 1);
-                    // angle(d[i] * conj(d[i+1])) (demodulation.py:25-32)
-                    const double an = atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);
+                    // angle(d[i] * conj(d[i+1])) (demodulation.py:25-32); pairs: the product comes from the chain kernel
+                    double an;
+                    if constexpr (PAIRS) {
+                        const cd z = y[j];
+                        an = atan2(z.im, z.re);
+                    } else {
+                        const cd p = load_y(y, R, h, 2 * j), c = load_y(y, R, h, 2 * j + 1);
+                        an = atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);
+                    }
                     x[b][k] = mk(an, 0.0);
                     ev[b][k] = an;                              // even output samples are the input
                 }
@@ -356,23 +369,27 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
     }
 }
 
-template <int B, int WPB>
-static hipError_t launch_post_fft(const PostArgs &a, hipStream_t s) {
+template <int B, int WPB, bool PAIRS>
+static hipError_t launch_post_fft_p(const PostArgs &a, hipStream_t s) {
     constexpr int N = 256 * B;
     const size_t lds = (size_t) (N + WPB * (N + N / 4 + 1)) * 16;
     static thread_local int done_dev = -1;                      // once per device and instantiation
     int dev = 0;
     (void) hipGetDevice(&dev);
     if (done_dev != dev) {
-        hipError_t e = hipFuncSetAttribute((const void *) post_fft_kernel<B, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        hipError_t e = hipFuncSetAttribute((const void *) post_fft_kernel<B, WPB, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
         done_dev = dev;
     }
     size_t wgs = (a.items + WPB - 1) / WPB;
     const size_t cap = 256 * 8;                                  // a few workgroups per CU; waves walk over the rest
     if (wgs > cap) wgs = cap;
-    hipLaunchKernelGGL((post_fft_kernel<B, WPB>), dim3((unsigned) wgs), dim3(64 * WPB), lds, s, a);
+    hipLaunchKernelGGL((post_fft_kernel<B, WPB, PAIRS>), dim3((unsigned) wgs), dim3(64 * WPB), lds, s, a);
     return hipGetLastError();
+}
+template <int B, int WPB>
+static hipError_t launch_post_fft(const PostArgs &a, hipStream_t s) {
+    return a.pairs ? launch_post_fft_p<B, WPB, true>(a, s) : launch_post_fft_p<B, WPB, false>(a, s);
 }
 
 static size_t post_lds_bytes_w(int m, int mode, int wpb) {
@@ -520,6 +537,13 @@ hipError_t launch_tap_stft(const TapArgs &a, hipStream_t s) {
 // realOutput / imagOutput (demodulation.py:51-68) of the decimated samples; no output filter follows (dsp_processor.py:130-138)
 __global__ __launch_bounds__(256) void part_kernel(const double *__restrict__ y, double *__restrict__ out, size_t count, int imag) {
     for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t) gridDim.x * 256) out[i] = y[2 * i + imag];
+}
+
+bool post_takes_pairs(const PostArgs &a) {
+    if (a.mode != SDRT_FM) return false;
+    if (a.fft_tw && a.fft_shift && a.fft_ok && (a.m == 512 || a.m == 1024 || a.m == 2048 || a.m == 4096)) return true;
+    if (a.m >= 8192 && post_big_supported(a.m, a.mode)) return false;
+    return post_waves_per_block(a.m, a.mode) != 0;
 }
 
 bool post_takes_iq_share(const PostArgs &a) {

@@ -217,6 +217,27 @@ def test_reader_options_against_the_c_oracle(code, q, mode, opt, monkeypatch):
         assert abs(eng.iq_offset - off) <= 1e-9 * max(abs(off), 1e-30)
 
 
+@pytest.mark.parametrize('code,q,rows', [('h', 64, 1), ('h', 32, 3), ('B', 64, 1), ('f', 64, 2)])
+def test_pair_products_between_the_stages_equal_the_sample_path(code, q, rows, monkeypatch):
+    """FM without a debug buffer: the wide-column kernel hands the demodulation stage the products y[2i] conj(y[2i+1])
+    (demodulation.py:25-32) instead of the decimated samples.  Same outputs as the path that writes the samples (taken when
+    the caller asks for them), to rounding."""
+    from sdrterm_amd.engine import Engine
+    from tests.golden import prng
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    fs, nch = 1024000, 5
+    n = samples_per_chunk(code)
+    freqs = [15700.0, -203300.0, 100100.0][:rows]
+    raw = prng.raw_bytes(code, n * nch, seed=77, amp=100 if code == 'B' else 3000)
+    eng = Engine(fs, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=5000)
+    assert eng.stage_a == 'i8w'
+    a = eng.process(raw)
+    b, _y = eng.process_debug(raw)
+    err = np.abs(a - b).max()
+    print(f'{code} q={q} rows={rows}: pair path against sample path, max abs difference {err:.3e}')
+    assert err <= 1e-12
+
+
 def test_float32_non_finite_samples_stay_in_their_chunk(monkeypatch):
     """A NaN or an infinity in a float32 record: the reference's IIR passes turn that whole chunk into NaN
     (dsp_processor.py:147); block fixed point has no NaN, the chunk's outputs are unspecified here -- but every other chunk,
