@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     // edge operator of this thread: output o16 = tid >> 5 (kind: 0 head -> F0, 1 tail -> Gu; chain o = mode*2 + stream), sample l
     const int e_o16 = tid >> 5, e_l = tid & 31, e_kind = e_o16 >> 3, e_o = e_o16 & 7;
     // sample l of the 32-sample window of the output: the chunk's first / last 32 samples (the operator spans 28 of them)
-    const long e_idx = e_kind ? (long) n - 32 + e_l : (long) e_l;
+    const int e_idx = e_kind ? n - 32 + e_l : e_l;
     const double e_off_re = a.e_off_re, e_off_im = a.e_off_im;   // what the edge operators subtract from the decoded components
     const int cgs = LC / (IQT ? a.iq_gs : LC);                   // IQ prefix groups per column
     // IQ fused: the offset recurrence off' = (1-lambda) off + lambda x over whole columns (a.iq_consts: sdrt_build_i8_offset_rows)
@@ -338,7 +338,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             for (int sg = 0; sg < SEG; ++sg) {
                 e_re[sg] = e_im[sg] = 0;
                 if constexpr (HAVE_K) {
-                    const raw_t *rp = (const raw_t *) chunk_raw + 2 * (e_idx + (long) sg * n);
+                    // (a 32-bit lane offset on the chunk pointer: a 64-bit one is a loop invariant the register allocator spills and
+                    // reloads in the loop's preheader, and its first use inside the loop then waits with s_waitcnt vmcnt(0) in EVERY
+                    // iteration -- a drain of the prefetch ring at the top of each one)
+                    const raw_t *rp = (const raw_t *) (chunk_raw + (unsigned) (2 * (e_idx + sg * n)) * (unsigned) sizeof(raw_t));
                     e_re[sg] = rp[0];
                     e_im[sg] = rp[1];
                 }
