@@ -193,7 +193,7 @@ static void dft_any(const cplx *in, cplx *out, size_t n, int sign) {
     if ((n & 1) == 0) {
         size_t h = n / 2;
         cplx *ev = (cplx *) malloc(n * sizeof(cplx)), *od = ev + h;
-        cplx *t = (cplx *) malloc(n * sizeof(cplx));
+        cplx *t = (cplx *) calloc(n, sizeof(cplx));
         for (size_t i = 0; i < h; ++i) { t[i] = in[2 * i]; t[h + i] = in[2 * i + 1]; }
         dft_any(t, ev, h, sign);
         dft_any(t + h, od, h, sign);
