@@ -192,6 +192,21 @@ __global__ __launch_bounds__(256, 4) void chain_kernel(DecimArgs a) {
 // (GS steps of the recurrence from zero), an inclusive scan of the aggregates over the 256 lanes with multiplier
 // (1-lambda)^GS (wave shuffles + 4 wave totals through LDS), and the carry of the previous sweeps.  The exclusive value is
 // the offset at the group's first sample when the chunk starts from zero.
+namespace {
+// v + m * t for a real multiplier
+__device__ __forceinline__ cd cfma_r(double m, cd t, cd v) { return mk(fma(m, t.re, v.re), fma(m, t.im, v.im)); }
+// DPP move that only the rows of ROWS take (the others read zero)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ cd dpp_masked(cd v) {
+    auto one = [](double x) {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWS, 0xF, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWS, 0xF, false);
+        return __hiloint2double(hi, lo);
+    };
+    return mk(one(v.re), one(v.im));
+}
+}  // namespace
+
 template <int DT, int GS>
 __global__ __launch_bounds__(256) void iq_local_kernel(IqArgs a) {
     constexpr int ITEM = Enc<DT>::size;
@@ -211,15 +226,25 @@ __global__ __launch_bounds__(256) void iq_local_kernel(IqArgs a) {
     for (int i = 1; i < 6; ++i) mp[i] = mp[i - 1] * mp[i - 1];
     const double ag64 = mp[5] * mp[5];                 // (1-lambda)^(64 GS): one wave
     const double plane = a.pow_tab[lane], ptid = a.pow_tab[tid];          // (1-lambda)^(GS lane), (1-lambda)^(GS tid)
+    const double mrow = a.pow_tab[(lane & 15) + 1], mhalf = lane >= 32 ? a.pow_tab[lane - 31] : 0.0;   // distance to lane 15 of the row before / to lane 31
     const double ag256 = a.pow_tab[256];
     cd carry = mk(0.0, 0.0);                           // offset at the first sample of the current sweep
     cd *gout = a.group_off ? (cd *) a.group_off + (size_t) chunk * (size_t) ngroups : nullptr;     // null: chunk aggregates only
+    // the records of the next sweep are requested before this sweep's are worked on (a workgroup is otherwise one HBM round
+    // trip per sweep long); chunks have at least 256 groups (sdrt_create), so the first load is always inside the chunk
+    uint32_t nxt[NW];
+    load_words<BYTES>(chunk_raw + (size_t) (tid < ngroups ? tid : 0) * BYTES, nxt);
     for (int g0 = 0; g0 < ngroups; g0 += 256) {
         const int grp = g0 + tid;
         cd s = mk(0.0, 0.0);
+        uint32_t wds[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) wds[w] = nxt[w];
+        {
+            const int gn = grp + 256;
+            load_words<BYTES>(chunk_raw + (size_t) (gn < ngroups ? gn : grp < ngroups ? grp : 0) * BYTES, nxt);
+        }
         if (grp < ngroups) {
-            uint32_t wds[NW];
-            load_words<BYTES>(chunk_raw + (size_t) grp * BYTES, wds);
             static_for<0, GS>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 const double xr = decode<DT>(get_item<DT, 2 * j>(wds), swap) + nbias;
@@ -229,18 +254,17 @@ __global__ __launch_bounds__(256) void iq_local_kernel(IqArgs a) {
             });
         }
         __syncthreads();                               // wtot of the previous sweep has been consumed
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int d = 1 << i;
-            double tr = __shfl_up(s.re, d), ti = __shfl_up(s.im, d);
-            if (lane < d) { tr = 0.0; ti = 0.0; }
-            s.re = fma(mp[i], tr, s.re);
-            s.im = fma(mp[i], ti, s.im);
-        }
+        // inclusive scan over the wave without LDS: four shifts inside the 16-lane rows, then the row totals handed on with
+        // row_bcast15 (rows 1, 3 take lane 15 of the row before) and row_bcast31 (rows 2, 3 take lane 31)
+        s = cfma_r(mp[0], dpp_row<0x111>(s), s);
+        s = cfma_r(mp[1], dpp_row<0x112>(s), s);
+        s = cfma_r(mp[2], dpp_row<0x114>(s), s);
+        s = cfma_r(mp[3], dpp_row<0x118>(s), s);
+        s = cfma_r(mrow, dpp_masked<0x142, 0xa>(s), s);
+        s = cfma_r(mhalf, dpp_masked<0x143, 0xc>(s), s);
         if (lane == 63) wtot[wave] = s;
         __syncthreads();
-        cd ex = mk(__shfl_up(s.re, 1), __shfl_up(s.im, 1));
-        if (lane == 0) ex = mk(0.0, 0.0);
+        const cd ex = dpp_row<0x138>(s);               // wave_shr:1, lane 0 reads zero
         cd wp = mk(0.0, 0.0);                          // offset at the start of this wave, relative to the sweep start
         for (int wv = 0; wv < wave; ++wv) wp = mk(fma(ag64, wp.re, wtot[wv].re), fma(ag64, wp.im, wtot[wv].im));
         // offset at this group's first sample = (carry propagated over tid groups) + (wave start propagated over lane groups) + ex
@@ -257,8 +281,8 @@ __global__ __launch_bounds__(256) void iq_local_kernel(IqArgs a) {
 // one workgroup: chunk offsets off[c+1] = (1-lambda)^n off[c] + agg[c], off[0] = carried state
 constexpr int IQ_SCAN_THREADS = 1024;
 __global__ __launch_bounds__(IQ_SCAN_THREADS) void iq_scan_kernel(IqArgs a) {
-    __shared__ cd tot[IQ_SCAN_THREADS];
-    __shared__ double pw[IQ_SCAN_THREADS];
+    __shared__ cd tot[IQ_SCAN_THREADS / 64];
+    __shared__ double pw[IQ_SCAN_THREADS / 64];
     const int tid = threadIdx.x;
     const size_t nc = a.n_chunks, per = (nc + IQ_SCAN_THREADS - 1) / IQ_SCAN_THREADS;
     const size_t c0 = (size_t) tid * per < nc ? (size_t) tid * per : nc, c1 = c0 + per < nc ? c0 + per : nc;
@@ -283,22 +307,36 @@ __global__ __launch_bounds__(IQ_SCAN_THREADS) void iq_scan_kernel(IqArgs a) {
         s = mk(fma(a.pow_n, s.re, agg[c].re), fma(a.pow_n, s.im, agg[c].im));
         p *= a.pow_n;
     }
-    tot[tid] = s;
-    pw[tid] = p;
-    __syncthreads();
-    if (tid == 0) {
-        cd run = mk(a.state[0], a.state[1]);
-        for (int t = 0; t < IQ_SCAN_THREADS; ++t) {
-            const cd mine = tot[t];
-            tot[t] = run;                                   // offset at the start of thread t's range
-            run = mk(fma(pw[t], run.re, mine.re), fma(pw[t], run.im, mine.im));
+    // a thread's range maps the offset o at its start to p o + s: inclusive scan of these maps over the wave (composition),
+    // then over the 16 wave totals
+    const int lane = tid & 63, wave = tid >> 6;
+    double P = p;
+    cd S = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double Pu = __shfl_up(P, d);
+        const cd Su = mk(__shfl_up(S.re, d), __shfl_up(S.im, d));
+        if (lane >= d) {
+            S = mk(fma(P, Su.re, S.re), fma(P, Su.im, S.im));
+            P *= Pu;
         }
+    }
+    if (lane == 63) { tot[wave] = S; pw[wave] = P; }
+    __syncthreads();
+    const cd run0 = mk(a.state[0], a.state[1]);
+    cd base = run0;                                         // offset at the start of this wave's range
+    for (int w = 0; w < wave; ++w) base = mk(fma(pw[w], base.re, tot[w].re), fma(pw[w], base.im, tot[w].im));
+    double Pe = __shfl_up(P, 1);
+    cd Se = mk(__shfl_up(S.re, 1), __shfl_up(S.im, 1));
+    if (lane == 0) { Pe = 1.0; Se = mk(0.0, 0.0); }
+    cd o = mk(fma(Pe, base.re, Se.re), fma(Pe, base.im, Se.im));      // offset at the start of this thread's range
+    __syncthreads();                                        // every thread has read the carried state
+    if (tid == IQ_SCAN_THREADS - 1) {
+        const cd run = mk(fma(P, base.re, S.re), fma(P, base.im, S.im));
         offc[nc] = run;
         a.state[0] = run.re;
         a.state[1] = run.im;
     }
-    __syncthreads();
-    cd o = tot[tid];
     c = c0;
     for (; c + UB <= c1; c += UB) {
         cd v[UB];
