@@ -8,6 +8,7 @@ Field meanings follow the reference CLI (src/sdrterm.py:54-107): ``code`` is the
 READ_SIZE = 131072  # bytes per chunk, misc/read_file.py:38
 
 _VFOS8 = '-200000,-150000,-100000,-50000,50000,100000,150000,200000'
+_VFOS7_BENCH = '-9000000,-6000000,-3000000,3000000,6000000,9000000,12000000'     # bench.py simo_rows(8) less the centre
 
 
 def _c(name, code, q, mode, center=0, vfos=None, omega_out=5000, fs=1024000, n_chunks=2, seed=1, amp=3000,
@@ -50,6 +51,19 @@ CASES = [
     _c('h_q8_fm_c', 'h', 8, 'fm', center=15700, omega_out=30000, seed=35),
     _c('B_q16_fm_c', 'B', 16, 'fm', center=15700, omega_out=15000, amp=100, seed=36),
     _c('f_q4_fm_c', 'f', 4, 'fm', center=15700, omega_out=60000, seed=37),
+    # BASELINE.json configs at their own parameters (round 3): configs[1] (256 MS/s, centre 15 kHz, omega_out 12.5 kHz),
+    # configs[2] (7 csv rows + centre = 8 rows as _nFreq counts them, q = 32, --correct-iq, one run per demodulation),
+    # configs[4] (1 GS/s float32, rows from both ends and the middle of bench.py's 256-row layout)
+    _c('h_q64_fm_bench', 'h', 64, 'fm', center=15000, omega_out=12500, fs=256000000, seed=38),
+    _c('h_q32_fm_vfo8_iq_bench', 'h', 32, 'fm', center=15000, vfos=_VFOS7_BENCH, omega_out=12500, fs=256000000,
+       correct_iq=True, n_chunks=3, dc=(500, -300), seed=39),
+    _c('h_q32_am_norm_vfo8_iq_bench', 'h', 32, 'am', center=15000, vfos=_VFOS7_BENCH, omega_out=12500, fs=256000000,
+       normalize=True, correct_iq=True, n_chunks=3, dc=(500, -300), seed=40),
+    _c('f_q64_fm_vfo5_1g', 'f', 64, 'fm', center=15000, vfos='-381000000,-3000000,6000000,384000000', omega_out=12500,
+       fs=1000000000, seed=41),
+    # the same normalise flag in an FM and an AM run of one 9-row layout: what a context with per-row modes must equal
+    _c('h_q32_fm_norm_vfo9_iq', 'h', 32, 'fm', center=15700, vfos=_VFOS8, normalize=True, correct_iq=True,
+       n_chunks=3, dc=(500, -300), seed=20),
 ]
 
 BY_NAME = {c['name']: c for c in CASES}

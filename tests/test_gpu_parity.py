@@ -280,14 +280,15 @@ def test_float32_256_rows_sampled_against_the_fp64_oracle():
     assert err <= 1e-6
 
 
-@pytest.mark.parametrize('rows,nch', [(64, 3), (300, 2), (33, 17), (5, 100)])
-def test_item_distribution_of_the_persistent_kernel(rows, nch, monkeypatch):
+@pytest.mark.parametrize('rows,nch,q', [(64, 3, 64), (64, 3, 32), (300, 2, 64), (33, 17, 64), (5, 100, 32)])
+def test_item_distribution_of_the_persistent_kernel(rows, nch, q, monkeypatch):
     """Many rows x few chunks and few rows x many chunks (rows above and below the number of workgroup slots, chunk counts
     that are not multiples of 8): the wide-column persistent kernel must cover every (chunk, row) item exactly once --
-    checked against the independently written one-block-per-column kernel."""
+    checked against the independently written one-block-per-column kernel.  (64 rows at decimation 32 is the per-GPU shape
+    of bench.py's simo64 workload.)"""
     from sdrterm_amd.engine import Engine
     from tests.golden import prng
-    fs, q = 1024000, 64
+    fs = 1024000
     freqs = [1000.0 * (i - rows // 2) for i in range(rows)]
     raw = prng.raw_bytes('h', 32768 * nch, seed=rows, amp=5000)
     monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
