@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SDRT_ABI_VERSION 4
+#define SDRT_ABI_VERSION 5
 
 /* Input encodings: src/misc/file_util.py:44-56 (DataType b,B,h,H,i,I,f,d). */
 enum sdrt_dtype {
@@ -72,6 +72,10 @@ typedef struct sdrt_config {
     int32_t dec_sections;
     int32_t out_sections;
     const double *out_sos;    /* output lowpass SOS [out_sections][6]: generateEllipFilter, dsp_processor.py:39-45 */
+    const int32_t *row_modes; /* NULL: every row demodulates as `mode`, as in the reference, whose mode is processor-wide
+                                 (io_args.py:118).  Else [n_rows] of SDRT_FM / SDRT_AM: a build extension for --simo with FM
+                                 and AM channels in one pass over the input (BASELINE configs[2]); row r then equals row r of a
+                                 context created with mode = row_modes[r] and otherwise the same settings. */
 } sdrt_config;
 
 /* Library / device discovery. */
@@ -176,6 +180,17 @@ int sdrt_memcpy_h2d_async(void *dst_dev, const void *src_host, size_t bytes, voi
 int sdrt_memcpy_d2h_async(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 /* `waiter` waits (on the device) for everything submitted to `signaller` so far. */
 int sdrt_stream_wait_stream(void *waiter, void *signaller);
+/* Events: a point in a stream's work that other streams can wait for on the device (sdrt_stream_wait_event) and the host can
+ * poll without blocking (sdrt_event_query: *done = 1 once everything before the record has completed).  The multi-GPU driver
+ * uses them for its two block buffers -- the broadcast of block k+1 waits for the kernels of block k-1 only, not for those of
+ * block k -- and to bound its waits: a rank polls with a deadline and watches the halt flag instead of sitting in
+ * sdrt_device_synchronize behind a collective whose peer has died (vfo_processor.py:113-126 is the reference's teardown). */
+int sdrt_event_create(void **event);
+int sdrt_event_destroy(void *event);
+int sdrt_event_record(void *event, void *stream);
+int sdrt_stream_wait_event(void *stream, void *event);
+int sdrt_event_query(void *event, int *done);
+int sdrt_event_synchronize(void *event);
 
 /*
  * Multi-GPU --simo: one process per GPU runs VfoProcessor (vfo_processor.py:38-57,80-126) on its

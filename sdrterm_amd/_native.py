@@ -18,7 +18,7 @@ ITEM_SIZE = {'b': 1, 'B': 1, 'h': 2, 'H': 2, 'i': 4, 'I': 4, 'f': 4, 'd': 8}
 MODES = {'fm': 0, 'am': 1, 're': 2, 'im': 3}
 OK, EINVAL, EHIP, ENOMEM, ENODEVICE = 0, 1, 2, 3, 4
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 EXPORTS = (
     'sdrt_abi_version', 'sdrt_config_size', 'sdrt_device_count', 'sdrt_last_error', 'sdrt_create', 'sdrt_destroy',
     'sdrt_out_per_chunk', 'sdrt_rows', 'sdrt_process_device', 'sdrt_process_host',
@@ -30,6 +30,8 @@ EXPORTS = (
     'sdrt_memcpy_h2d_async', 'sdrt_memcpy_d2h_async', 'sdrt_stream_wait_stream',
     'sdrt_comm_unique_id', 'sdrt_comm_init', 'sdrt_comm_bcast', 'sdrt_comm_allgather', 'sdrt_comm_world', 'sdrt_comm_rank',
     'sdrt_comm_destroy', 'sdrt_submit_host', 'sdrt_wait', 'sdrt_spectrum_host', 'sdrt_stft_host', 'sdrt_iq_range_device',
+    'sdrt_event_create', 'sdrt_event_destroy', 'sdrt_event_record', 'sdrt_stream_wait_event', 'sdrt_event_query',
+    'sdrt_event_synchronize',
 )
 
 
@@ -52,7 +54,7 @@ class Config(C.Structure):
         ('apply_shift', C.c_int32), ('normalize', C.c_int32), ('norm_xmin', C.c_double),
         ('norm_inv_range', C.c_double), ('correct_iq', C.c_int32), ('reserved0', C.c_int32),
         ('iq_inductance', C.c_double), ('dec_sos', C.POINTER(C.c_double)), ('dec_sections', C.c_int32),
-        ('out_sections', C.c_int32), ('out_sos', C.POINTER(C.c_double)),
+        ('out_sections', C.c_int32), ('out_sos', C.POINTER(C.c_double)), ('row_modes', C.POINTER(C.c_int32)),
     ]
 
 
@@ -144,6 +146,12 @@ def lib():
     l.sdrt_memcpy_h2d_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     l.sdrt_memcpy_d2h_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     l.sdrt_stream_wait_stream.argtypes = [C.c_void_p, C.c_void_p]
+    l.sdrt_event_create.argtypes = [C.POINTER(C.c_void_p)]
+    l.sdrt_event_destroy.argtypes = [C.c_void_p]
+    l.sdrt_event_record.argtypes = [C.c_void_p, C.c_void_p]
+    l.sdrt_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p]
+    l.sdrt_event_query.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    l.sdrt_event_synchronize.argtypes = [C.c_void_p]
     l.sdrt_comm_unique_id.argtypes = [C.c_void_p]
     l.sdrt_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     l.sdrt_comm_bcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]

@@ -72,6 +72,8 @@ struct sdrt_ctx {
     OutTables *d_otab = nullptr;
     double *d_nco_tile = nullptr, *d_nco_phase = nullptr, *d_resample = nullptr, *d_out_sos = nullptr;
     double *d_fft_tw = nullptr, *d_fft_shift = nullptr;
+    double *d_fft8 = nullptr;         // eight-lanes-per-item demodulation stage (kernels_post8.hip): transform tables ...
+    Post8Tables *d_p8tab = nullptr;   // ... and its lowpass constants
     double *d_smooth = nullptr;       // taps | left | right of --smooth-output (sdrt_set_smoothing)
     int sm_window = 0, sm_ntaps = 0, sm_first = 0, sm_edge = 0;
     bool fft_ok = false, out_modal = false;
@@ -89,6 +91,11 @@ struct sdrt_ctx {
     double *d_edge_ab = nullptr, *d_edge_pq = nullptr, *d_gvec = nullptr;
     bool wide_rs = false;             // wide kernel in its real-stream form (no shift, no IQ correction)
     int n_cus = 256;
+    // per-row demodulation modes (sdrt_config.row_modes): the rows of each mode, on the device, for the demodulation stage
+    bool mixed = false;
+    int *d_rows_of[2] = {nullptr, nullptr};      // [SDRT_FM], [SDRT_AM]
+    int n_rows_of[2] = {0, 0};
+    int sched = 0;                    // diagnostic builds only (SDRTERM_SCHED, kernels_i8w.hip: SDRT_SCHED_EXP)
     signed char *d_w8 = nullptr, *d_w8mid = nullptr;
     DecimTables *d_tab8 = nullptr;    // tables for columns of SDRT_I8T_G blocks
     double *d_nco_tile8 = nullptr, *d_nco_phase8 = nullptr;
@@ -404,7 +411,21 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     if (cfg->decimation < 2) return fail(SDRT_EINVAL, "Decimation must be at least 2.");  // dsp_processor.py:94-95
     if (cfg->dtype < 0 || cfg->dtype > 7) return fail(SDRT_EINVAL, "unknown dtype %d", cfg->dtype);
     if (cfg->mode < SDRT_FM || cfg->mode > SDRT_IM) return fail(SDRT_EINVAL, "unknown mode %d", cfg->mode);
-    const bool filtered = cfg->mode == SDRT_FM || cfg->mode == SDRT_AM;      // real / imaginary output: no output lowpass
+    // per-row modes: FM / AM only; all rows alike is the plain case with that mode
+    bool mixed = false, any_fm = cfg->mode == SDRT_FM;
+    int uniform_mode = cfg->mode;
+    if (cfg->row_modes) {
+        if (cfg->n_rows < 1) return fail(SDRT_EINVAL, "n_rows must be >= 1");
+        int cnt[2] = {0, 0};
+        for (int r = 0; r < cfg->n_rows; ++r) {
+            if (cfg->row_modes[r] != SDRT_FM && cfg->row_modes[r] != SDRT_AM) return fail(SDRT_EINVAL, "row_modes[%d] = %d: per-row modes are SDRT_FM or SDRT_AM", r, cfg->row_modes[r]);
+            cnt[cfg->row_modes[r]]++;
+        }
+        mixed = cnt[0] > 0 && cnt[1] > 0;
+        any_fm = cnt[0] > 0;
+        uniform_mode = cnt[0] ? SDRT_FM : SDRT_AM;
+    }
+    const bool filtered = mixed || uniform_mode == SDRT_FM || uniform_mode == SDRT_AM;      // real / imaginary output: no output lowpass
     if (!cfg->dec_sos || (filtered && !cfg->out_sos)) return fail(SDRT_EINVAL, "dec_sos and out_sos are required");
     if (filtered && (cfg->out_sections < 1 || cfg->out_sections > SDRT_MAX_OUT_SECTIONS))
         return fail(SDRT_EINVAL, "out_sections must be 1..%d", SDRT_MAX_OUT_SECTIONS);
@@ -423,12 +444,13 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     if (!seq && n % (SDRT_TB * L)) return fail(SDRT_EINVAL, "n_samples (%d) must be a multiple of %d", n, SDRT_TB * L);
     if (n % q) return fail(SDRT_EINVAL, "decimation must divide n_samples");   // dsp_processor.py:147,173
     const int m = n / q;
-    if (cfg->mode == SDRT_FM && (m < 2 || (m & 1))) return fail(SDRT_EINVAL, "FM needs an even number of outputs per chunk");
+    if (any_fm && (m < 2 || (m & 1))) return fail(SDRT_EINVAL, "FM needs an even number of outputs per chunk");
     // the post stage keeps one (chunk, row) item per wave in LDS: FFT resampler for m/2 in {256 .. 2048}, else the direct forms
     {
         const int Nh = m / 2;
-        const bool fft_fm = cfg->mode == SDRT_FM && (Nh == 256 || Nh == 512 || Nh == 1024 || Nh == 2048);
-        if (filtered && !fft_fm && post_waves_per_block(m, cfg->mode) == 0 && !(m >= 8192 && post_big_supported(m, cfg->mode)))
+        const bool fft_fm = any_fm && (Nh == 256 || Nh == 512 || Nh == 1024 || Nh == 2048);
+        for (int md = SDRT_FM; md <= SDRT_AM; ++md)
+            if (filtered && (mixed || md == uniform_mode) && !(md == SDRT_FM && fft_fm) && post_waves_per_block(m, md) == 0 && !(m >= 8192 && post_big_supported(m, md)))
             return fail(SDRT_EINVAL, "%d outputs per chunk (n_samples / decimation) exceed what the demodulation stage holds in LDS", m);
     }
     const int iq_gs = seq ? 16 : L / 4;                      // samples per group of the IQ prefix tables
@@ -447,6 +469,9 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     c->cfg.row_freqs = nullptr;
     c->cfg.dec_sos = nullptr;
     c->cfg.out_sos = nullptr;
+    c->cfg.row_modes = nullptr;
+    c->cfg.mode = uniform_mode;
+    c->mixed = mixed;
     c->L = L;
     c->m = m;
     c->n_tiles = n / (SDRT_TB * L);
@@ -524,7 +549,15 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         rc = upload(&c->d_nco_tile, tile.data(), tile.size() * sizeof(double));
         if (rc == SDRT_OK) rc = upload(&c->d_nco_phase, phase.data(), phase.size() * sizeof(double));
     }
-    if (rc == SDRT_OK && cfg->mode == SDRT_FM) {
+    if (rc == SDRT_OK && mixed) {
+        for (int md = SDRT_FM; md <= SDRT_AM && rc == SDRT_OK; ++md) {
+            std::vector<int> rows;
+            for (int r = 0; r < cfg->n_rows; ++r) if (cfg->row_modes[r] == md) rows.push_back(r);
+            c->n_rows_of[md] = (int) rows.size();
+            rc = upload(&c->d_rows_of[md], rows.data(), rows.size() * sizeof(int));
+        }
+    }
+    if (rc == SDRT_OK && any_fm) {
         std::vector<double> h((size_t) m / 2);
         sdrt_build_resample_odd(m / 2, h.data());
         rc = upload(&c->d_resample, h.data(), h.size() * sizeof(double));
@@ -537,6 +570,17 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
             if (rc == SDRT_OK) rc = upload(&c->d_fft_shift, sh.data(), sh.size() * sizeof(double));
             c->fft_ok = rc == SDRT_OK;
         }
+        // FM with 512 outputs per chunk (decimation 64 of 16-bit records, 32 of float32 records) and the usual output lowpass
+        // (one complex pole pair + one real pole): eight lanes per item (diagnostics: SDRTERM_POST=wave keeps one wave per item)
+        const char *pk = getenv("SDRTERM_POST");
+        if (rc == SDRT_OK && c->fft_ok && m == 512 && !(pk && strcmp(pk, "wave") == 0)) {
+            Post8Tables p8;
+            std::vector<double> ft((size_t) (4 * SDRT_P8_PPL * 8 + 8 * 8) * 2);
+            if (sdrt_build_post8_tables(cfg->out_sos, cfg->out_sections, N, 8, &p8, ft.data()) == 0) {
+                rc = upload(&c->d_fft8, ft.data(), ft.size() * sizeof(double));
+                if (rc == SDRT_OK) rc = upload(&c->d_p8tab, &p8, sizeof(p8));
+            }
+        }
     }
     if (rc == SDRT_OK) {
         const char *force = getenv("SDRTERM_STAGE_A");      // diagnostics: "f64" forces the fp64 matrix-core kernel,
@@ -544,6 +588,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         const bool want_t = force && strcmp(force, "i8t") == 0;       // "i8t" the one-block-per-column 16x16x64 kernel
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->n_cus = cus;
+        if (const char *e = getenv("SDRTERM_SCHED")) c->sched = atoi(e);
         if (const char *e = getenv("SDRTERM_WIDE_CUS")) { const int v = atoi(e); if (v >= 8 && v <= c->n_cus) c->n_cus = v / 8 * 8; }   // diagnostics: fewer persistent workgroups
         // int8 matrix-core forms in order of preference; a form that cannot represent this configuration (unequal
         // power-of-two scales between rows, a digit overflow) releases what it uploaded and the next one is tried; the
@@ -582,6 +627,10 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_smooth);
     (void) hipFree(c->d_fft_tw);
     (void) hipFree(c->d_fft_shift);
+    (void) hipFree(c->d_fft8);
+    (void) hipFree(c->d_p8tab);
+    (void) hipFree(c->d_rows_of[0]);
+    (void) hipFree(c->d_rows_of[1]);
     (void) hipFree(c->d_out_sos);
     (void) hipFree(c->d_otab);
     (void) hipFree(c->d_y);
@@ -754,6 +803,7 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
     da.c_im = c->x_offset;
     da.iq_gs = c->iq_gs;
     da.rs = c->use_i8w && c->wide_rs;
+    da.sched = c->sched;
     if (c->use_i8) {
         da.tab = c->d_tab8;
         da.n_tiles = c->n_tiles8;
@@ -830,6 +880,9 @@ PostArgs post_args(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out
     pa.iq_off = iq_share ? c->d_iq_chunk : nullptr;
     pa.n_chunks = n_chunks;
     pa.pairs = pairs ? 1 : 0;
+    pa.row_map = nullptr;
+    pa.fft8_tab = c->d_fft8;
+    pa.p8tab = c->d_p8tab;
     return pa;
 }
 
@@ -837,6 +890,16 @@ int enqueue_post(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out_d
     const PostArgs pa = post_args(c, ybuf, n_chunks, out_dev, iq_share, pairs);
     {
         Timed t(c, s, 1);
+        if (c->mixed) {
+            // per-row modes: one launch per mode over that mode's rows (PostArgs.row_map); the rows keep their places in y / out
+            for (int md = SDRT_FM; md <= SDRT_AM; ++md) {
+                PostArgs pm = pa;
+                pm.mode = md;
+                pm.row_map = c->d_rows_of[md];
+                pm.items = n_chunks * (size_t) c->n_rows_of[md];
+                HIP_TRY(launch_post(pm, s));
+            }
+        } else
         HIP_TRY(launch_post(pa, s));
         if (c->sm_window > 0) {
             SmoothArgs sa;
@@ -882,10 +945,15 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     }
     // fused IQ form: when the caller does not ask for the decimated samples, the demodulation stage subtracts the offset
     // share as it loads them (one pass over them less)
-    const bool later = !ydec_dev && c->iq && c->use_i8w && c->iq_fused && post_takes_iq_share(post_args(c, ybuf, n_chunks, out_dev, true));
+    bool later = !ydec_dev && c->iq && c->use_i8w && c->iq_fused && post_takes_iq_share(post_args(c, ybuf, n_chunks, out_dev, true));
+    if (later && c->mixed) {                                  // per-row modes: both modes' kernels must take the share
+        PostArgs pm = post_args(c, ybuf, n_chunks, out_dev, true);
+        pm.mode = SDRT_AM;
+        later = post_takes_iq_share(pm);
+    }
     // FM on the wide-column kernel, likewise without a debug buffer: the pair products instead of the samples (half the bytes
     // between the two stages); not with the offset share still to come
-    const bool pairs = !ydec_dev && c->use_i8w && !c->stamps_dev && !later && post_takes_pairs(post_args(c, ybuf, n_chunks, out_dev, false, true));
+    const bool pairs = !ydec_dev && c->use_i8w && !c->stamps_dev && !later && !c->mixed && post_takes_pairs(post_args(c, ybuf, n_chunks, out_dev, false, true));
     rc = enqueue_chain(c, raw_dev, n_chunks, ybuf, s, c->n_cus, later, pairs);
     if (rc != SDRT_OK) return rc;
     return enqueue_post(c, ybuf, n_chunks, out_dev, s, later, pairs);
@@ -1152,6 +1220,37 @@ int sdrt_stream_wait_stream(void *waiter, void *signaller) {
     if (r == hipSuccess) r = hipStreamWaitEvent((hipStream_t) waiter, e, 0);
     (void) hipEventDestroy(e);          // released once the recorded work has completed
     if (r != hipSuccess) return fail(SDRT_EHIP, "stream dependency failed: %s", hipGetErrorString(r));
+    return SDRT_OK;
+}
+
+int sdrt_event_create(void **event) {
+    if (!event) return fail(SDRT_EINVAL, "null argument");
+    hipEvent_t e = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = (void *) e;
+    return SDRT_OK;
+}
+int sdrt_event_destroy(void *event) {
+    HIP_TRY(hipEventDestroy((hipEvent_t) event));
+    return SDRT_OK;
+}
+int sdrt_event_record(void *event, void *stream) {
+    HIP_TRY(hipEventRecord((hipEvent_t) event, (hipStream_t) stream));
+    return SDRT_OK;
+}
+int sdrt_stream_wait_event(void *stream, void *event) {
+    HIP_TRY(hipStreamWaitEvent((hipStream_t) stream, (hipEvent_t) event, 0));
+    return SDRT_OK;
+}
+int sdrt_event_query(void *event, int *done) {
+    if (!done) return fail(SDRT_EINVAL, "null argument");
+    const hipError_t e = hipEventQuery((hipEvent_t) event);
+    if (e == hipSuccess) { *done = 1; return SDRT_OK; }
+    if (e == hipErrorNotReady) { (void) hipGetLastError(); *done = 0; return SDRT_OK; }
+    return fail(SDRT_EHIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+}
+int sdrt_event_synchronize(void *event) {
+    HIP_TRY(hipEventSynchronize((hipEvent_t) event));
     return SDRT_OK;
 }
 

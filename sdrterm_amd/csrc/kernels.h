@@ -48,6 +48,7 @@ struct DecimArgs {
     const double *iq_consts;    //   IQ: [SDRT_IQROW_CONSTS]
     double iq_combine;          //   IQ: combine factor of the offset rows
     double *iq_chunk_agg;       //   IQ out: [chunk][2] offset at the chunk's end when it starts from zero
+    int sched;                  //   diagnostic builds only (-DSDRT_SCHED_EXP): wave priority assignment, SDRTERM_SCHED
     int rs;                     //   real-stream form (no shift, no IQ correction): w8 / w8mid hold sdrt_build_i8_weights_wide_rs planes
 };
 
@@ -86,8 +87,15 @@ struct PostArgs {
     const double *iq_R;         // [rows][m][2]
     const double *iq_off;       // [n_chunks][2]
     size_t n_chunks;            // items = rows * n_chunks, row-major
+    const int *row_map;         // per-row demodulation modes: work item w = (k, chunk) stands for item (row_map[k], chunk) of the
+                                // batch; items = (rows of this mode) * n_chunks.  NULL: every row, item w is item w
     int pairs;                  // FM: y holds [items][m/2] products y[2i] conj(y[2i+1]) (DecimArgs.pair_out)
+    // eight-lanes-per-item form (kernels_post8.hip; FM, m = 512, lowpass = one complex pole pair + one real pole), or NULL
+    const double *fft8_tab;     // [4][128][2] + [8][8][2]: sdrt_build_post8_tables
+    const Post8Tables *p8tab;
 };
+bool post_fft8_supported(const PostArgs &a);
+hipError_t launch_post_fft8(const PostArgs &a, hipStream_t s);
 // does launch_post pick a kernel that reads pair products (PostArgs.pairs)?
 bool post_takes_pairs(const PostArgs &a);
 // does launch_post pick a kernel that applies iq_R / iq_off while it loads the decimated samples?

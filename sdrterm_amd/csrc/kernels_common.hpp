@@ -35,6 +35,24 @@ __device__ __forceinline__ cd cfma(cd a, cd b, cd c) {  // a*b + c
     return mk(fma(a.re, b.re, fma(-a.im, b.im, c.re)), fma(a.re, b.im, fma(a.im, b.re, c.im)));
 }
 
+// decimated sample k of an item, less the share of the IQ offset at its chunk's start (same operations as iq_fix_kernel)
+__device__ __forceinline__ cd load_y(const cd *y, const cd *R, const cd h, const int k) {
+    cd v = y[k];
+    if (R) {
+        const cd r = R[k];
+        v.re = fma(-h.re, r.re, fma(h.im, r.im, v.re));
+        v.im = fma(-h.re, r.im, fma(-h.im, r.re, v.im));
+    }
+    return v;
+}
+
+// which (row, chunk) item of the batch a work item of the demodulation stage is (PostArgs.row_map)
+__device__ __forceinline__ size_t post_item(const PostArgs &a, size_t w) {
+    if (!a.row_map) return w;
+    const size_t k = w / a.n_chunks;
+    return (size_t) a.row_map[k] * a.n_chunks + (w - k * a.n_chunks);
+}
+
 // DPP row shifts inside each 16-lane row, zero fill at the row boundary.  row_shr:n = 0x110+n, row_shl:n = 0x100+n.
 template <int CTRL>
 __device__ __forceinline__ double dpp_row(double v) {

@@ -25,6 +25,18 @@
 #define SDRT_RAW_NT 0          // 1: non-temporal loads of the raw sample stream (measured: see DESIGN.md section 4)
 #endif
 
+// Wave priorities around the matrix-instruction groups.  Production: 1 inside a group, 0 outside, for every wave.  With
+// -DSDRT_SCHED_EXP (a diagnostic build, tools/sched_exp.sh) DecimArgs.sched picks other assignments for the younger waves 4-7,
+// which lose the issue arbitration against waves 0-3 at equal priority (profiles/r02_i8w_phase_stamps_after_2s_load.txt).
+#ifdef SDRT_SCHED_EXP
+#define SDRT_PRIO_SET(p) do { if ((p) == 0) __builtin_amdgcn_s_setprio(0); else if ((p) == 1) __builtin_amdgcn_s_setprio(1); else if ((p) == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); } while (0)
+#define SDRT_PRIO_HI() SDRT_PRIO_SET(prio_hi)
+#define SDRT_PRIO_LO() SDRT_PRIO_SET(prio_lo)
+#else
+#define SDRT_PRIO_HI() __builtin_amdgcn_s_setprio(1)
+#define SDRT_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#endif
+
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
@@ -127,6 +139,13 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     const bool swap = a.swap != 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, nb = lane & 15;
+#ifdef SDRT_SCHED_EXP
+    const int young = __builtin_amdgcn_readfirstlane(wave) >= 4, sched = a.sched;
+    //            sched:  0 production   1 young waves' groups at 2   2 young waves one level up throughout   3 only the young waves raise
+    //                    4 no priorities at all   5 old waves' groups at 2   6 young waves at 3 inside groups, 1 outside
+    const int prio_hi = sched == 0 ? 1 : sched == 1 ? (young ? 2 : 1) : sched == 2 ? (young ? 2 : 1) : sched == 3 ? (young ? 1 : 0) : sched == 4 ? 0 : sched == 5 ? (young ? 1 : 2) : (young ? 3 : 1);
+    const int prio_lo = sched == 2 ? (young ? 1 : 0) : sched == 6 ? (young ? 1 : 0) : 0;
+#endif
     const WideLds lo = wide_lds(S, NOUT, NT, IQ, NTC);
     const v4i *wmainL = (const v4i *) (smem + lo.wmain);
     const v4i *wlocL = (const v4i *) (smem + lo.wloc);
@@ -855,7 +874,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                     // the next item's first k-steps follow in the same ring (in the last iteration: this item's again, unused)
                                     else issue(next_raw, std::integral_constant<int, stg + PF - NSTEP>{});
                                 }
-                                __builtin_amdgcn_s_setprio(1);           // matrix instructions first: the other wave's vector work fills the gaps
+                                SDRT_PRIO_HI();           // matrix instructions first: the other wave's vector work fills the gaps
                                 static_for<0, S>([&](auto dc) {
                                     constexpr int d = decltype(dc)::value;
                                     __builtin_amdgcn_sched_barrier(0);
@@ -920,7 +939,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                     else accO[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fq, blo, accO[1], 0, 0, 0);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
-                                __builtin_amdgcn_s_setprio(0);
+                                SDRT_PRIO_LO();
                             }
                             if constexpr (decltype(pcs)::value) piece(jc, ic);
                             __builtin_amdgcn_sched_barrier(0);

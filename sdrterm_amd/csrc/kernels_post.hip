@@ -4,19 +4,6 @@
 // modal scan along the lanes.  Small registers and 12 m bytes of LDS per wave keep many items in flight per CU.
 #include "kernels_common.hpp"
 
-namespace {
-// decimated sample k of an item, less the share of the IQ offset at its chunk's start (same operations as iq_fix_kernel)
-__device__ __forceinline__ cd load_y(const cd *y, const cd *R, const cd h, const int k) {
-    cd v = y[k];
-    if (R) {
-        const cd r = R[k];
-        v.re = fma(-h.re, r.re, fma(h.im, r.im, v.re));
-        v.im = fma(-h.re, r.im, fma(-h.im, r.re, v.im));
-    }
-    return v;
-}
-}  // namespace
-
 
 // Output lowpass of one item in modal form, one wave: y[t] = D x[t] + sum_k Re(r_k s_k(t)), s_k(t+1) = p_k s_k(t) + x[t].
 // Lane l owns samples [l*E, l*E+E): local end state, inclusive scan along the wave, exclusive shift = state at the lane's
@@ -150,8 +137,9 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
         for (int i = tid; i < N; i += blockDim.x) hr[i] = a.resample_odd[i == 0 ? 0 : N - i];
         __syncthreads();
     }
-    const size_t item = (size_t) blockIdx.x * wpb + wave;
-    if (item >= a.items) return;
+    const size_t witem = (size_t) blockIdx.x * wpb + wave;
+    if (witem >= a.items) return;
+    const size_t item = post_item(a, witem);
     const cd *y = (const cd *) a.y + item * (size_t) (a.pairs ? N : m);
     const cd *R = a.iq_R ? (const cd *) a.iq_R + (item / a.n_chunks) * (size_t) m : nullptr;
     const cd h = a.iq_R ? ((const cd *) a.iq_off)[item % a.n_chunks] : mk(0.0, 0.0);
@@ -323,7 +311,8 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
     const OutTables *__restrict__ ot = a.otab;
     // one item per wave and turn: every item's result is a function of that item alone, bit for bit (pairing two items
     // into one complex transform would make the last bits of one depend on the other)
-    for (size_t item = (size_t) blockIdx.x * WPB + wave; item < a.items; item += (size_t) gridDim.x * WPB) {
+    for (size_t witem = (size_t) blockIdx.x * WPB + wave; witem < a.items; witem += (size_t) gridDim.x * WPB) {
+        const size_t item = post_item(a, witem);
         const cd *y = (const cd *) a.y + item * (size_t) (PAIRS ? N : M);
         const cd *R = a.iq_R ? (const cd *) a.iq_R + (item / a.n_chunks) * (size_t) M : nullptr;
         const cd h = a.iq_R ? ((const cd *) a.iq_off)[item % a.n_chunks] : mk(0.0, 0.0);
@@ -541,6 +530,7 @@ __global__ __launch_bounds__(256) void part_kernel(const double *__restrict__ y,
 
 bool post_takes_pairs(const PostArgs &a) {
     if (a.mode != SDRT_FM) return false;
+    if (post_fft8_supported(a)) return true;
     if (a.fft_tw && a.fft_shift && a.fft_ok && (a.m == 512 || a.m == 1024 || a.m == 2048 || a.m == 4096)) return true;
     if (a.m >= 8192 && post_big_supported(a.m, a.mode)) return false;
     return post_waves_per_block(a.m, a.mode) != 0;
@@ -548,6 +538,7 @@ bool post_takes_pairs(const PostArgs &a) {
 
 bool post_takes_iq_share(const PostArgs &a) {
     if (a.mode == SDRT_RE || a.mode == SDRT_IM) return false;                                // part_kernel
+    if (post_fft8_supported(a)) return true;
     if (a.mode == SDRT_FM && a.fft_tw && a.fft_shift && a.fft_ok && (a.m == 512 || a.m == 1024 || a.m == 2048 || a.m == 4096)) return true;
     if (a.m >= 8192 && post_big_supported(a.m, a.mode)) return false;                       // post_big_kernel
     return post_waves_per_block(a.m, a.mode) != 0;                                           // post_kernel
@@ -560,6 +551,7 @@ hipError_t launch_post(const PostArgs &a, hipStream_t s) {
         hipLaunchKernelGGL(part_kernel, dim3((unsigned) (wgs < 4096 ? wgs : 4096)), dim3(256), 0, s, a.y, a.out, count, a.mode == SDRT_IM ? 1 : 0);
         return hipGetLastError();
     }
+    if (post_fft8_supported(a)) return launch_post_fft8(a, s);                                // kernels_post8.hip
     // FFT form of the resampler where it applies: FM, N = m/2 in {256, 512, 1024}, output lowpass in modal form
     if (a.mode == SDRT_FM && a.fft_tw && a.fft_shift && a.fft_ok) {
         switch (a.m) {

@@ -1,0 +1,327 @@
+// post_fft8_kernel: the FM demodulation stage (demodulation.py:25-38 fmDemod, dsp_processor.py:32-36,149 output lowpass) with
+// LPI = 8 lanes of a wave per (chunk, row) item -- eight items per wave.
+//
+// Why (profiles/r02_pmc_summary.txt, post_fft_kernel<1,4,true>): with one item per wave the two 256-point complex transforms
+// of scipy.signal.resample made six trips through a per-wave LDS buffer (99 LDS instructions per item, 41 % of the LDS
+// cycles bank conflicts) and spent half of their arithmetic on the zero imaginary parts of a real sequence.  Here
+//   * the N pair angles of an item are packed two to a complex number, z[n] = a[2n] + i a[2n+1]: ONE half-size complex
+//     transform each way (H = N/2 = 128 points); the packed spectrum of the half-sample shifted sequence comes out of the packed
+//     spectrum of the angles bin by bin, Y[k] = alpha_k Z[k] + beta_k conj(Z[H-k]) (tables: sdrt_build_post8_tables);
+//   * H = 16 x 8: every lane holds 16 points, a 16-point transform runs in its registers (constant twiddles, no memory),
+//     then ONE exchange through LDS and 8-point transforms; the lane that finishes bin k also holds bin H-k;
+//   * the exchange image is laid out so that every ds_write_b128 / ds_read_b128 is conflict free (slot = 17 n2 + k1, items 136
+//     slots apart: tools/lds_banks.py);
+//   * the output lowpass never leaves the registers: a lane holds 4 consecutive output samples of each block of 32, the
+//     blocks' states are scanned over the item's 8 lanes with DPP shifts and chained over the 16 blocks in every lane.
+// Every lane group runs the same instructions on its own item only: an item's bits do not depend on its neighbours.
+#include "kernels_common.hpp"
+
+namespace {
+
+// cos(2 pi k / 32), k = 0 .. 8
+__device__ constexpr double kCos32[9] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                                         0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173,
+                                         0.19509032201612826785, 0.0};
+constexpr double cos32(int k) {       // k in [0, 16]
+    return k <= 8 ? kCos32[k] : -kCos32[16 - k];
+}
+constexpr double sin32(int k) {       // k in [0, 16]
+    return k <= 8 ? kCos32[8 - k] : kCos32[k - 8];
+}
+
+__device__ __forceinline__ cd csub8(cd a, cd b) { return mk(a.re - b.re, a.im - b.im); }
+
+// v * exp(-2 pi i K / N_) (forward) or v * exp(+2 pi i K / N_) (INV), 0 <= K < N_/2, N_ <= 32
+template <int N_, int K, bool INV>
+__device__ __forceinline__ cd tw_mul(cd v) {
+    if constexpr (K == 0) return v;
+    else if constexpr (4 * K == N_) return INV ? mk(-v.im, v.re) : mk(v.im, -v.re);
+    else if constexpr (8 * K == N_) {
+        constexpr double r = 0.70710678118654752440;
+        return INV ? mk((v.re - v.im) * r, (v.re + v.im) * r) : mk((v.re + v.im) * r, (v.im - v.re) * r);
+    } else if constexpr (8 * K == 3 * N_) {
+        constexpr double r = 0.70710678118654752440;
+        return INV ? mk(-(v.re + v.im) * r, (v.re - v.im) * r) : mk((v.im - v.re) * r, -(v.re + v.im) * r);
+    } else {
+        constexpr double c = cos32(K * (32 / N_)), s = sin32(K * (32 / N_));
+        return INV ? mk(fma(v.re, c, -(v.im * s)), fma(v.im, c, v.re * s)) : mk(fma(v.re, c, v.im * s), fma(v.im, c, -(v.re * s)));
+    }
+}
+
+// N_-point transform of values held in registers (decimation in time, natural order in and out; every index is a compile-time
+// constant, so the arrays never exist in memory)
+template <int N_, bool INV>
+__device__ __forceinline__ void reg_fft(const cd *in, cd *out) {
+    if constexpr (N_ == 2) {
+        out[0] = cadd(in[0], in[1]);
+        out[1] = csub8(in[0], in[1]);
+    } else {
+        cd e[N_ / 2], o[N_ / 2], E[N_ / 2], O[N_ / 2];
+#pragma unroll
+        for (int k = 0; k < N_ / 2; ++k) { e[k] = in[2 * k]; o[k] = in[2 * k + 1]; }
+        reg_fft<N_ / 2, INV>(e, E);
+        reg_fft<N_ / 2, INV>(o, O);
+        static_for<0, N_ / 2>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const cd t = tw_mul<N_, k, INV>(O[k]);
+            out[k] = cadd(E[k], t);
+            out[k + N_ / 2] = csub8(E[k], t);
+        });
+    }
+}
+
+__device__ __forceinline__ double swz_bcast_last8(double v) {
+    // lane 7 of every group of 8 lanes to the whole group (ds_swizzle, bit-mask mode: and 0x18, or 0x07)
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x18 | (0x07 << 5));
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x18 | (0x07 << 5));
+    return __hiloint2double(hi, lo);
+}
+
+// atan2 for the pair angles (demodulation.py:30-32: angle()).  t = min(|x|,|y|) / max(|x|,|y|) in [0, 1] by one reciprocal, two
+// Newton steps and a residual correction; atan(t) = t q(t^2), q of degree 16 (tools/fit_atan.py: 4e-15 over [0, 1]); octant
+// and sign put back with selects.  Signed zeros as C99 / numpy: (+-0, +0) -> +-0, (+-0, -0) -> +-pi.  39 instructions against
+// the library's 70 (half of this kernel's arithmetic was atan2).
+__device__ __forceinline__ double atan2_pi(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = fmax(fmax(ax, ay), 2.2250738585072014e-308), mn = fmin(ax, ay);    // (0, 0): t = 0 / tiny = 0
+    double r = __builtin_amdgcn_rcp(mx);
+    r = fma(fma(-mx, r, 1.0), r, r);
+    r = fma(fma(-mx, r, 1.0), r, r);
+    double t = mn * r;
+    t = fma(fma(-mx, t, mn), r, t);
+    const double s = t * t;
+    double p = 7.03825190772905e-05;
+    p = fma(p, s, -0.0006752461871228126);
+    p = fma(p, s, 0.0030574650642366205);
+    p = fma(p, s, -0.008772278251586507);
+    p = fma(p, s, 0.01816674618350375);
+    p = fma(p, s, -0.02955359506524126);
+    p = fma(p, s, 0.0404892227192373);
+    p = fma(p, s, -0.049763055792462756);
+    p = fma(p, s, 0.057934563768719034);
+    p = fma(p, s, -0.06645912139302747);
+    p = fma(p, s, 0.07688758456599037);
+    p = fma(p, s, -0.09090481197187922);
+    p = fma(p, s, 0.11111076687817362);
+    p = fma(p, s, -0.1428571258641315);
+    p = fma(p, s, 0.19999999955253506);
+    p = fma(p, s, -0.3333333333285598);
+    p = fma(p, s, 0.9999999999999907);
+    double u = t * p;
+    u = ay > ax ? 1.5707963267948966 - u : u;
+    u = __double2hiint(x) < 0 ? 3.141592653589793 - u : u;
+    return copysign(u, y);
+}
+
+// DPP quad permutation (control = the four source lanes of a quad, two bits each); sources never leave the quad
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ cd dpp_quad(cd v) { return mk(dpp_quad<CTRL>(v.re), dpp_quad<CTRL>(v.im)); }
+// row_shr:4 into lanes 4-7 and 12-15 of every 16-lane row (banks 1 and 3); lanes 0-3 and 8-11 get 0
+__device__ __forceinline__ double dpp_shr4_banks13(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x114, 0xF, 0xA, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x114, 0xF, 0xA, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ cd dpp_shr4_banks13(cd v) { return mk(dpp_shr4_banks13(v.re), dpp_shr4_banks13(v.im)); }
+
+// within-wave ordering of LDS traffic between lanes: the hardware executes a wave's LDS instructions in order; this keeps
+// the compiler from moving them across
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+}  // namespace
+
+#define SDRT_P8_SO 136          // 16-byte slots of one item's exchange image (8 x 17, and = 8 mod 16)
+
+template <int WPB, bool PAIRS>
+__global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 8) void post_fft8_kernel(PostArgs a) {
+    constexpr int LPI = 8, P = SDRT_P8_PPL, H = P * LPI, N = 2 * H, M = 2 * N, IPW = 64 / LPI, TAB = P * LPI, SO = SDRT_P8_SO;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cd *tabL = (cd *) smem;                                        // tw1 | tw2 | alpha | beta
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, o = lane / LPI, l = lane % LPI;
+    cd *X = tabL + 4 * TAB + 8 * LPI + (size_t) wave * (IPW * SO) + o * SO;  // this item's exchange image
+    for (int i = tid; i < 4 * TAB + 8 * LPI; i += 64 * WPB) tabL[i] = ((const cd *) a.fft8_tab)[i];
+    __syncthreads();
+    const cd *tw1L = tabL, *tw2L = tabL + TAB, *alL = tabL + 2 * TAB, *beL = tabL + 3 * TAB, *lpL = tabL + 4 * TAB;
+    const int c0 = l, c1 = l ? 16 - l : 8;                         // the bins k1 this lane finishes: S_l
+    const bool l0 = l == 0;
+
+    const size_t ngroups = (a.items + IPW - 1) / IPW;
+    for (size_t grp = (size_t) blockIdx.x * WPB + wave; grp < ngroups; grp += (size_t) gridDim.x * WPB) {
+        const size_t item = grp * IPW + o;
+        const bool live = item < a.items;
+        const size_t it = post_item(a, live ? item : a.items - 1);    // idle lane groups redo the last item and store nothing
+        // ---- pair angles: x[k] = a[2n] + i a[2n+1], n = l + 8 k (demodulation.py:25-32) ---------------------------------
+        cd x[P];
+        if constexpr (PAIRS) {
+            const cd *y = (const cd *) a.y + it * (size_t) N;      // d[2i] conj(d[2i+1]) from the chain kernel
+            cd pp[P][2];                                           // every load of the item in flight before the first angle
+#pragma unroll
+            for (int k = 0; k < P; ++k) { pp[k][0] = y[2 * (l + LPI * k)]; pp[k][1] = y[2 * (l + LPI * k) + 1]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < P; ++k) x[k] = mk(atan2_pi(pp[k][0].im, pp[k][0].re), atan2_pi(pp[k][1].im, pp[k][1].re));
+        } else {
+            const cd *y = (const cd *) a.y + it * (size_t) M;
+            const cd *R = a.iq_R ? (const cd *) a.iq_R + (it / a.n_chunks) * (size_t) M : nullptr;
+            const cd h = a.iq_R ? ((const cd *) a.iq_off)[it % a.n_chunks] : mk(0.0, 0.0);
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const int i0 = 4 * (l + LPI * k);
+                const cd d0 = load_y(y, R, h, i0), d1 = load_y(y, R, h, i0 + 1), d2 = load_y(y, R, h, i0 + 2), d3 = load_y(y, R, h, i0 + 3);
+                x[k] = mk(atan2_pi(d0.im * d1.re - d0.re * d1.im, d0.re * d1.re + d0.im * d1.im),
+                          atan2_pi(d2.im * d3.re - d2.re * d3.im, d2.re * d3.re + d2.im * d3.im));
+            }
+        }
+        // ---- forward: 16 points in the lane, twiddle, exchange, 8 points ----------------------------------------------------
+        cd Z[2][LPI];
+        {
+            cd X1[P];
+            reg_fft<P, false>(x, X1);
+            static_for<1, P>([&](auto kc) { constexpr int k1 = decltype(kc)::value; X1[k1] = cmul(X1[k1], tw1L[k1 * LPI + l]); });
+            static_for<0, P>([&](auto kc) { constexpr int k1 = decltype(kc)::value; X[17 * l + k1] = X1[k1]; });
+            wave_lds_fence();
+            cd V[2][LPI];
+#pragma unroll
+            for (int j = 0; j < LPI; ++j) { V[0][j] = X[17 * j + c0]; V[1][j] = X[17 * j + c1]; }
+            reg_fft<LPI, false>(V[0], Z[0]);
+            reg_fft<LPI, false>(V[1], Z[1]);
+        }
+        // ---- packed spectrum of the angles -> packed spectrum of the half-sample shifted sequence ----------------------------
+        // bin k = c + 16 k2 pairs with H - k = (16 - c) + 16 (7 - k2): the lane's other bin series -- except in lane 0,
+        // whose series c = 0 and c = 8 each pair with themselves
+        cd U[2][LPI];
+        {
+            cd Y[2][LPI];
+            static_for<0, LPI>([&](auto kc) {
+                constexpr int k2 = decltype(kc)::value;
+                const cd q0 = Z[1][7 - k2], q0s = Z[0][(8 - k2) % 8], q1 = Z[0][7 - k2], q1s = Z[1][7 - k2];
+                const cd p0 = mk(l0 ? q0s.re : q0.re, l0 ? q0s.im : q0.im), p1 = mk(l0 ? q1s.re : q1.re, l0 ? q1s.im : q1.im);
+                const cd a0 = alL[(0 * LPI + k2) * LPI + l], b0 = beL[(0 * LPI + k2) * LPI + l];
+                const cd a1 = alL[(1 * LPI + k2) * LPI + l], b1 = beL[(1 * LPI + k2) * LPI + l];
+                Y[0][k2] = cfma(b0, mk(p0.re, -p0.im), cmul(a0, Z[0][k2]));
+                Y[1][k2] = cfma(b1, mk(p1.re, -p1.im), cmul(a1, Z[1][k2]));
+            });
+            reg_fft<LPI, true>(Y[0], U[0]);
+            reg_fft<LPI, true>(Y[1], U[1]);
+        }
+        // ---- back: twiddle, exchange, 16 points in the lane -------------------------------------------------------------------
+        cd zz[P];
+        {
+            static_for<1, LPI>([&](auto kc) {
+                constexpr int n2 = decltype(kc)::value;
+                U[0][n2] = cmul(U[0][n2], tw2L[(0 * LPI + n2) * LPI + l]);
+                U[1][n2] = cmul(U[1][n2], tw2L[(1 * LPI + n2) * LPI + l]);
+            });
+            wave_lds_fence();                                      // the forward step's reads are done
+#pragma unroll
+            for (int n2 = 0; n2 < LPI; ++n2) { X[17 * n2 + c0] = U[0][n2]; X[17 * n2 + c1] = U[1][n2]; }
+            wave_lds_fence();
+            cd Rr[P];
+#pragma unroll
+            for (int c = 0; c < P; ++c) Rr[c] = X[17 * l + c];
+            wave_lds_fence();                                      // ... before the next group's writes
+            reg_fft<P, true>(Rr, zz);                              // zz[n1] = b[2n] + i b[2n+1], n = l + 8 n1
+        }
+        // ---- output samples 4n .. 4n+3 = a[2n], b[2n], a[2n+1], b[2n+1]; lowpass; store ------------------------------------------
+        double *out = a.out + it * (size_t) M + 4 * l;
+        // the constants every lane shares are fetched here, not before the loop: some forty doubles that would otherwise sit in
+        // scalar registers through the transforms (and be spilled to vector lanes there)
+        const Post8Tables *pu = a.p8tab;
+        asm volatile("" : "+s"(pu));
+        const double h0 = pu->h[0], h1 = pu->h[1], h2 = pu->h[2], h3 = pu->h[3];
+        const cd p1 = mk(pu->pcp[0][0], pu->pcp[0][1]), p2 = mk(pu->pcp[1][0], pu->pcp[1][1]), p3 = mk(pu->pcp[2][0], pu->pcp[2][1]);
+        const double r1 = pu->prp[0], r2 = pu->prp[1], r3 = pu->prp[2];
+        const cd g0 = mk(pu->g[0][0], pu->g[0][1]), g1 = mk(pu->g[1][0], pu->g[1][1]), g2 = mk(pu->g[2][0], pu->g[2][1]), g3 = mk(pu->g[3][0], pu->g[3][1]);
+        const double gr0 = pu->gr[0], gr1 = pu->gr[1], gr2 = pu->gr[2], gr3 = pu->gr[3];
+        const cd pbc = mk(pu->pc_blk[0], pu->pc_blk[1]);
+        const double pbr = pu->pr_blk;
+        // ... and the lane's own: scan multipliers inside the quad (zero where the quad permutation hands a lane its own or an
+        // earlier lane's value), from the quad before, from the block's start (tables.h: the lane rows of the transform tables)
+        const cd mA1 = lpL[0 * LPI + l], mA2 = lpL[1 * LPI + l], nA = lpL[2 * LPI + l], mB = lpL[3 * LPI + l], mE = lpL[4 * LPI + l];
+        const cd nBE = lpL[5 * LPI + l], plc = lpL[6 * LPI + l], plq = lpL[7 * LPI + l];
+        const double nA1 = nA.re, nA2 = nA.im, nB = nBE.re, nE = nBE.im, plr = plq.re, q1 = plq.im;
+        cd Cc = mk(0.0, 0.0);                                      // state at the start of the block
+        double Cr = 0.0;
+        static_for<0, P>([&](auto nc) {
+            constexpr int n1 = decltype(nc)::value;
+            const double x0 = x[n1].re, x1 = zz[n1].re, x2 = x[n1].im, x3 = zz[n1].im;
+            // the lane's run of four samples from a zero state: outputs and end state
+            const double y00 = h0 * x0, y01 = fma(h0, x1, h1 * x0), y02 = fma(h0, x2, fma(h1, x1, h2 * x0));
+            const double y03 = fma(h0, x3, fma(h1, x2, fma(h2, x1, h3 * x0)));
+            const cd se = mk(fma(p3.re, x0, fma(p2.re, x1, fma(p1.re, x2, x3))), fma(p3.im, x0, fma(p2.im, x1, p1.im * x2)));
+            const double te = fma(r3, x0, fma(r2, x1, fma(r1, x2, x3)));
+            // inclusive scan of the end states over the item's eight lanes: inside the quads (quad permutations never leave the
+            // item) ...
+            cd sc = cfma(mA1, dpp_quad<0x90>(se), se);                  // [0,0,1,2]: lane q takes lane q-1
+            double sr = fma(nA1, dpp_quad<0x90>(te), te);
+            sc = cfma(mA2, dpp_quad<0x40>(sc), sc);                    // [0,0,0,1]: lane q takes lane q-2
+            sr = fma(nA2, dpp_quad<0x40>(sr), sr);
+            // ... then the first quad's total into the second: row_shr:4 written to banks 1 and 3 only (lanes 4-7, 12-15; the
+            // others keep 0: nothing crosses from the neighbouring item), its lane 3 broadcast over the quad
+            const cd cq = dpp_quad<0xFF>(dpp_shr4_banks13(sc));
+            const double cqr = dpp_quad<0xFF>(dpp_shr4_banks13(sr));
+            // state before the lane's first sample: the lanes before it in its quad, the quad before, the block's starting state
+            const cd eq = dpp_quad<0x90>(sc);
+            const double eqr = dpp_quad<0x90>(sr);
+            cd s = cfma(plc, Cc, cfma(mE, cq, mk(q1 * eq.re, q1 * eq.im)));
+            double t = fma(plr, Cr, fma(nE, cqr, q1 * eqr));
+            sc = cfma(mB, cq, sc);
+            sr = fma(nB, cqr, sr);
+            // the next block starts from this block's end state (lane 7 of the item)
+            const cd Tc = mk(swz_bcast_last8(sc.re), swz_bcast_last8(sc.im));
+            const double Tr = swz_bcast_last8(sr);
+            Cc = cfma(pbc, Cc, Tc);
+            Cr = fma(pbr, Cr, Tr);
+            // what the starting state adds to the four outputs (dsp_processor.py:32-36: sosfilt, zero state per chunk)
+            const double y0 = fma(g0.re, s.re, fma(-g0.im, s.im, fma(gr0, t, y00)));
+            const double y1 = fma(g1.re, s.re, fma(-g1.im, s.im, fma(gr1, t, y01)));
+            const double y2 = fma(g2.re, s.re, fma(-g2.im, s.im, fma(gr2, t, y02)));
+            const double y3 = fma(g3.re, s.re, fma(-g3.im, s.im, fma(gr3, t, y03)));
+            if (live) {
+                *(double2 *) (out + 4 * LPI * n1) = make_double2(y0, y1);
+                *(double2 *) (out + 4 * LPI * n1 + 2) = make_double2(y2, y3);
+            }
+        });
+    }
+}
+
+size_t post_fft8_lds_bytes(int wpb) { return ((size_t) 4 * SDRT_P8_PPL * 8 + 8 * 8 + (size_t) wpb * 8 * SDRT_P8_SO) * 16; }
+
+template <int WPB, bool PAIRS>
+static hipError_t launch_post_fft8_p(const PostArgs &a, hipStream_t s) {
+    const size_t lds = post_fft8_lds_bytes(WPB);
+    static thread_local int done_dev = -1;                      // once per device and instantiation
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    if (done_dev != dev) {
+        hipError_t e = hipFuncSetAttribute((const void *) post_fft8_kernel<WPB, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+        done_dev = dev;
+    }
+    const size_t groups = (a.items + 7) / 8;
+    size_t wgs = (groups + WPB - 1) / WPB;
+    const size_t cap = 256 * 4;                                  // a few workgroups per CU; waves walk over the rest
+    if (wgs > cap) wgs = cap;
+    hipLaunchKernelGGL((post_fft8_kernel<WPB, PAIRS>), dim3((unsigned) wgs), dim3(64 * WPB), lds, s, a);
+    return hipGetLastError();
+}
+
+bool post_fft8_supported(const PostArgs &a) {
+    return a.mode == SDRT_FM && a.fft8_tab && a.p8tab && a.m == 512;
+}
+
+hipError_t launch_post_fft8(const PostArgs &a, hipStream_t s) {
+    // few items: one wave per workgroup spreads them over more compute units
+    if (a.items <= 8 * 256) return a.pairs ? launch_post_fft8_p<1, true>(a, s) : launch_post_fft8_p<1, false>(a, s);
+    return a.pairs ? launch_post_fft8_p<4, true>(a, s) : launch_post_fft8_p<4, false>(a, s);
+}

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void post_big_kernel(PostArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ cd ptot[SDRT_OUT_MAXMODES][4];
     const int m = a.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t item = blockIdx.x;
+    const size_t item = post_item(a, blockIdx.x);
     const cd *y = (const cd *) a.y + item * (size_t) m;
     double *out = a.out + item * (size_t) m;
     if (a.mode == SDRT_FM) {

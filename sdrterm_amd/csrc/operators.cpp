@@ -215,24 +215,32 @@ extern "C" int sdrt_build_decim_tables(const double *sos, int sections, int q, i
     return 0;
 }
 
-extern "C" int sdrt_build_out_tables(const double *sos, int sections, int m, OutTables *out) {
-    std::memset(out, 0, sizeof(*out));
-    out->nmodes = -1;
-    out->E = m >= 64 ? m / 64 : 1;
-    if (sections < 1 || sections > 8) return 0;
+namespace {
+
+// Poles and residues of an SOS cascade in parallel form, y[t] = D x[t] + sum_k Re(r_k s_k(t)), s_k(t+1) = p_k s_k(t) + x[t]:
+// one entry per conjugate pair (its residue doubled) or real pole, complex ones first.  False when the cascade has repeated
+// poles, FIR sections or more modes than SDRT_OUT_MAXMODES.
+struct OutModes {
+    int nm = 0, ncomplex = 0;
+    R D = 1;
+    C p[16], r[16];
+};
+
+bool out_modes(const double *sos, int sections, OutModes &om) {
+    if (sections < 1 || sections > 8) return false;
     C poles[16];
     int npoles = 0;
     struct Num { R c[3]; int deg; } nums[8];
     R D = 1;
     for (int s = 0; s < sections; ++s) {
         R a0 = sos[6 * s + 3];
-        if (a0 == 0) return 0;
+        if (a0 == 0) return false;
         R b0 = (R) sos[6 * s] / a0, b1 = (R) sos[6 * s + 1] / a0, b2 = (R) sos[6 * s + 2] / a0;
         R a1 = (R) sos[6 * s + 4] / a0, a2 = (R) sos[6 * s + 5] / a0;
         D = D * b0;
         if (a2 != 0) {
             R disc = a1 * a1 - 4 * a2;
-            if (disc == 0) return 0;                       // repeated pole
+            if (disc == 0) return false;                   // repeated pole
             if (disc < 0) {
                 R sq = rsqrt128(-disc);
                 poles[npoles++] = C(-a1 / 2, sq / 2);
@@ -244,11 +252,11 @@ extern "C" int sdrt_build_out_tables(const double *sos, int sections, int m, Out
             }
             nums[s].c[0] = b0; nums[s].c[1] = b1; nums[s].c[2] = b2; nums[s].deg = 2;   // b0 z^2 + b1 z + b2
         } else if (a1 != 0) {
-            if (b2 != 0) return 0;                         // improper: extra pole at z = 0
+            if (b2 != 0) return false;                     // improper: extra pole at z = 0
             poles[npoles++] = C(-a1);
             nums[s].c[0] = b0; nums[s].c[1] = b1; nums[s].c[2] = 0; nums[s].deg = 1;    // b0 z + b1
         } else {
-            if (b1 != 0 || b2 != 0) return 0;              // FIR section
+            if (b1 != 0 || b2 != 0) return false;          // FIR section
             nums[s].c[0] = b0; nums[s].deg = 0;
         }
     }
@@ -256,7 +264,7 @@ extern "C" int sdrt_build_out_tables(const double *sos, int sections, int m, Out
     for (int i = 0; i < npoles; ++i)
         for (int j = i + 1; j < npoles; ++j) {
             C d = poles[i] - poles[j];
-            if ((double) (d.re * d.re + d.im * d.im) < 1e-24) return 0;
+            if ((double) (d.re * d.re + d.im * d.im) < 1e-24) return false;
         }
     int nm = 0;
     C rp[16], rr[16];
@@ -277,26 +285,124 @@ extern "C" int sdrt_build_out_tables(const double *sos, int sections, int m, Out
         rr[nm] = r;
         ++nm;
     }
-    if (nm > SDRT_OUT_MAXMODES) return 0;
+    if (nm > SDRT_OUT_MAXMODES) return false;
     // complex modes first, real ones after (the kernels handle the two kinds separately)
-    {
-        C tp[16], tr[16];
-        int w = 0;
-        for (int pass = 0; pass < 2; ++pass)
-            for (int k = 0; k < nm; ++k)
-                if ((rp[k].im != 0) == (pass == 0)) { tp[w] = rp[k]; tr[w] = rr[k]; ++w; }
-        for (int k = 0; k < nm; ++k) { rp[k] = tp[k]; rr[k] = tr[k]; }
-        out->ncomplex = 0;
-        for (int k = 0; k < nm; ++k) if (rp[k].im != 0) out->ncomplex++;
+    int w = 0;
+    om.ncomplex = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int k = 0; k < nm; ++k)
+            if ((rp[k].im != 0) == (pass == 0)) { om.p[w] = rp[k]; om.r[w] = rr[k]; ++w; if (pass == 0) om.ncomplex++; }
+    om.nm = nm;
+    om.D = D;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int sdrt_build_out_tables(const double *sos, int sections, int m, OutTables *out) {
+    std::memset(out, 0, sizeof(*out));
+    out->nmodes = -1;
+    out->E = m >= 64 ? m / 64 : 1;
+    OutModes om;
+    if (!out_modes(sos, sections, om)) return 0;
+    out->ncomplex = om.ncomplex;
+    out->D = (double) om.D;
+    for (int k = 0; k < om.nm; ++k) {
+        put(out->r[k], om.r[k]);
+        put(out->p[k], om.p[k]);
+        for (int i = 0; i < 6; ++i) put(out->pstep[k][i], cpow(om.p[k], out->E * (1 << i)));
+        for (int j = 0; j < 16; ++j) put(out->prow[k][j], cpow(om.p[k], out->E * (j + 1)));
     }
-    out->D = (double) D;
-    for (int k = 0; k < nm; ++k) {
-        put(out->r[k], rr[k]);
-        put(out->p[k], rp[k]);
-        for (int i = 0; i < 6; ++i) put(out->pstep[k][i], cpow(rp[k], out->E * (1 << i)));
-        for (int j = 0; j < 16; ++j) put(out->prow[k][j], cpow(rp[k], out->E * (j + 1)));
+    out->nmodes = om.nm;
+    return 0;
+}
+
+extern "C" int sdrt_build_post8_tables(const double *out_sos, int sections, int N, int LPI, Post8Tables *out, double *fft_tab) {
+    if (!(LPI == 8 || LPI == 16) || N != 2 * SDRT_P8_PPL * LPI) return -1;
+    OutModes om;
+    if (!out_modes(out_sos, sections, om) || om.nm != 2 || om.ncomplex != 1) return -2;
+    std::memset(out, 0, sizeof(*out));
+    out->N = N;
+    out->LPI = LPI;
+    const C pc = om.p[0], rc = om.r[0], prc = om.p[1], rrc = om.r[1];       // the real pole as a complex number with zero imaginary part
+    for (int j = 0; j < 4; ++j) {
+        const C gj = rc * cpow(pc, j), grj = rrc * cpow(prc, j);
+        put(out->g[j], gj);
+        out->gr[j] = (double) grj.re;
+        // impulse response of the run from a zero state: h[0] = D, h[j] = Re(rc pc^(j-1)) + rr pr^(j-1)
+        out->h[j] = j == 0 ? (double) om.D : (double) ((rc * cpow(pc, j - 1)).re + (rrc * cpow(prc, j - 1)).re);
     }
-    out->nmodes = nm;
+    for (int j = 0; j < 3; ++j) {
+        put(out->pcp[j], cpow(pc, j + 1));
+        out->prp[j] = (double) cpow(prc, j + 1).re;
+    }
+    put(out->pc4, cpow(pc, 4));
+    out->pr4 = (double) cpow(prc, 4).re;
+    put(out->pc8, cpow(pc, 8));
+    out->pr8 = (double) cpow(prc, 8).re;
+    for (int q = 0; q < 4; ++q) {
+        put(out->pc_q[q], cpow(pc, 4 * (q + 1)));
+        out->pr_q[q] = (double) cpow(prc, 4 * (q + 1)).re;
+    }
+    for (int l = 0; l < 16; ++l) {
+        put(out->pc_lane[l], cpow(pc, 4 * l));
+        out->pr_lane[l] = (double) cpow(prc, 4 * l).re;
+    }
+    put(out->pc_blk, cpow(pc, 4 * LPI));
+    out->pr_blk = (double) cpow(prc, 4 * LPI).re;
+
+    // transform tables (layouts: tables.h).  Angles are reduced exactly in integers before the trigonometric calls.
+    const int P = SDRT_P8_PPL, H = N / 2, T = P * LPI, NC = P / LPI;
+    const long double pi = 3.141592653589793238462643383279502884L;
+    auto W = [&](long num, long den, double *dst, bool conj_) {       // exp(-2 pi i num/den) (or its conjugate)
+        const long k = ((num % den) + den) % den;
+        const long double ang = 2.0L * pi * (long double) k / (long double) den;
+        dst[0] = (double) cosl(ang);
+        dst[1] = (double) (conj_ ? sinl(ang) : -sinl(ang));
+    };
+    auto S = [&](int l, int ci) { return LPI == 16 ? l : (ci == 0 ? l : (l ? 16 - l : 8)); };
+    double *tw1 = fft_tab, *tw2 = fft_tab + 2 * T, *al = fft_tab + 4 * T, *be = fft_tab + 6 * T, *lp = fft_tab + 8 * T;
+    // the lowpass constants that depend on the lane, [8][LPI] complex slots: scan multipliers inside the quad (zero where the quad
+    // permutation hands a lane its own or an earlier lane's value), from the quad before, from the block's start
+    for (int l = 0; l < LPI; ++l) {
+        const int q = l & 3;
+        auto slot = [&](int j) { return lp + 2 * (j * LPI + l); };
+        slot(0)[0] = q >= 1 ? out->pc4[0] : 0.0; slot(0)[1] = q >= 1 ? out->pc4[1] : 0.0;
+        slot(1)[0] = q >= 2 ? out->pc8[0] : 0.0; slot(1)[1] = q >= 2 ? out->pc8[1] : 0.0;
+        slot(2)[0] = q >= 1 ? out->pr4 : 0.0;    slot(2)[1] = q >= 2 ? out->pr8 : 0.0;
+        slot(3)[0] = out->pc_q[q][0];            slot(3)[1] = out->pc_q[q][1];
+        slot(4)[0] = out->pc_lane[q][0];         slot(4)[1] = out->pc_lane[q][1];
+        slot(5)[0] = out->pr_q[q];               slot(5)[1] = out->pr_lane[q];
+        slot(6)[0] = out->pc_lane[l][0];         slot(6)[1] = out->pc_lane[l][1];
+        slot(7)[0] = out->pr_lane[l];            slot(7)[1] = q >= 1 ? 1.0 : 0.0;
+    }
+    for (int k1 = 0; k1 < P; ++k1)
+        for (int l = 0; l < LPI; ++l) W((long) l * k1, H, tw1 + 2 * (k1 * LPI + l), false);
+    // sh[k] = exp(i pi k / N) / N for k < H, 0 at k = H (scipy drops what is left of the Nyquist bin); theta = 2 pi k / N:
+    //   alpha_k = sh[k] (1 - sin theta) + conj(sh[H - k]) (1 + sin theta),  beta_k = i cos theta (sh[k] - conj(sh[H - k]))
+    auto sh = [&](int k, long double &re, long double &im) {
+        if (k >= H) { re = im = 0.0L; return; }
+        const long double ang = pi * (long double) k / (long double) N;
+        re = cosl(ang) / (long double) N;
+        im = sinl(ang) / (long double) N;
+    };
+    for (int ci = 0; ci < NC; ++ci)
+        for (int j = 0; j < LPI; ++j)
+            for (int l = 0; l < LPI; ++l) {
+                const int c = S(l, ci), idx = (ci * LPI + j) * LPI + l;
+                W((long) j * c, H, tw2 + 2 * idx, true);
+                const int k = c + P * j;
+                long double ar, ai, br, bi;
+                sh(k, ar, ai);
+                sh(H - k, br, bi);
+                bi = -bi;                                   // conj(sh[H - k])
+                const long double th = 2.0L * pi * (long double) k / (long double) N, sn = sinl(th), cs = cosl(th);
+                al[2 * idx] = (double) (ar * (1 - sn) + br * (1 + sn));
+                al[2 * idx + 1] = (double) (ai * (1 - sn) + bi * (1 + sn));
+                // i cos theta (dr + i di) = cos theta (-di + i dr)
+                be[2 * idx] = (double) (-cs * (ai - bi));
+                be[2 * idx + 1] = (double) (cs * (ar - br));
+            }
     return 0;
 }
 

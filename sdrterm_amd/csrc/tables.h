@@ -71,9 +71,37 @@ struct OutTables {
     double prow[SDRT_OUT_MAXMODES][16][2];   // p^(E * (j+1)), j < 16: from the end of the previous 16-lane row to lane j of a row
 };
 
+// post_fft8_kernel (kernels_post8.hip): the FM demodulation stage with LPI lanes of a wave per (chunk, row) item.
+// N = m/2 pair angles per item, H = N/2 = 16 LPI points of the half-size complex transform: 16 per lane.
+//   fft tables (separate device array, [4][16 LPI][2] + [8][LPI][2] doubles, laid out as the lanes read them):
+//     tw1  [k1][l]      exp(-2 pi i l k1 / H)                       between the 16-point and the LPI-point forward steps
+//     tw2  [ci][n2][l]  exp(+2 pi i n2 c / H), c = S_l[ci]          the same on the way back
+//     alpha[ci][k2][l], beta[ci][k2][l]  for bin k = c + 16 k2:  Y[k] = alpha Z[k] + beta conj(Z[H - k]) turns the packed
+//        spectrum of the angles into the packed spectrum of their half-sample shifted copy (scipy.signal.resample's odd outputs)
+//     lane rows [8][l]  the output lowpass constants that depend on the lane (operators.cpp)
+//   S_l: LPI = 8: {l, 16 - l} (lane 0: {0, 8});  LPI = 16: {l}
+// Output lowpass (one complex pole pair + one real pole, dsp_processor.py:39-45): every lane holds 4 consecutive samples of
+// each block of 4 LPI samples.
+#define SDRT_P8_PPL 16
+struct Post8Tables {
+    int32_t N, LPI, reserved[2];
+    // y[t] = D x[t] + Re(rc sc(t)) + rr sr(t);  sc(t+1) = pc sc(t) + x[t], sr(t+1) = pr sr(t) + x[t]  (OutTables' modes 0 and 1)
+    double h[4];                            // a run of four samples from a zero state: y0[j] = sum_{i<=j} h[j-i] x[i]
+    double pcp[3][2], prp[3];               // pc^1..3, pr^1..3: the run's end state x3 + p x2 + p^2 x1 + p^3 x0
+    double g[4][2], gr[4];                  // rc pc^j, rr pr^j: what the state at the run's start adds to y[j]
+    double pc4[2], pr4, pc8[2], pr8;        // p^4, p^8: scan inside a quad of lanes
+    double pc_q[4][2], pr_q[4];             // p^(4 (q+1)): the quads before -> lane q of a quad
+    double pc_lane[16][2], pr_lane[16];     // p^(4 l):   block start -> first sample of lane l
+    double pc_blk[2], pr_blk;               // p^(4 LPI): block to block
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+// Tables of post_fft8_kernel for N pair angles per item (N = 32 LPI, LPI = 8 or 16).  fft_tab: [4][16 LPI][2] + [8][LPI][2].  Returns 0, or
+// a negative code when the output lowpass is not (one complex pole pair + one real pole) or N does not fit.
+int sdrt_build_post8_tables(const double *out_sos, int sections, int N, int LPI, struct Post8Tables *out, double *fft_tab);
+
 // Modal form of an SOS cascade for m outputs per chunk.  Returns 0; out->nmodes == -1 when the cascade has
 // repeated poles, FIR sections or more than SDRT_OUT_MAXMODES modes (the caller then uses the sequential form).
 int sdrt_build_out_tables(const double *sos, int sections, int m, struct OutTables *out);

@@ -136,6 +136,9 @@ class DspProcessor(DataProcessor):
     def _applyShift(self) -> bool:
         return bool(self.centerFreq)
 
+    def _rowModes(self):
+        return None
+
     @staticmethod
     def _encodingOf(chunk) -> str:
         """Queue items are what the reference reader's ``re + 1j*im`` produced (complex128, or complex64 for float32 input),
@@ -177,7 +180,8 @@ class DspProcessor(DataProcessor):
         from ..engine import Engine
         sos = np.asarray(self._outputFilters, dtype=np.float64).reshape(-1, 6) if len(self._outputFilters) else None
         self._engine = Engine(self._fs, self._decimationFactor, mode, code, n_samples=n, row_freqs=self._rowFreqs(),
-                              apply_shift=self._applyShift(), out_sos=sos, device=self._device, smooth=window, **reader)
+                              apply_shift=self._applyShift(), out_sos=sos, device=self._device, smooth=window,
+                              row_modes=self._rowModes(), **reader)
         self._engineReader = reader
         return self._engine
 
@@ -242,33 +246,42 @@ class DspProcessor(DataProcessor):
 
     @staticmethod
     def _moreQueued(buffer) -> bool:
+        """Is another Queue item waiting already?  (Anything that cannot tell -- a closed Queue, no Queue at all -- says no:
+        the batch in flight is then written out at once.)"""
+        if buffer is None:
+            return False
         try:
             return not buffer.empty()
-        except (OSError, ValueError, NotImplementedError):
+        except (OSError, ValueError, NotImplementedError, AttributeError):
             return False
 
     def _processData(self, isDead, buffer, file=None) -> None:
         pending = None              # a batch whose kernels run while the next one is taken from the Queue and copied in
-        try:
-            while not (self._isDead or isDead.value):
-                chunks, eof = self._takeBatch(buffer)
-                if chunks:
-                    if self._shift is None:
-                        self._generateShift(chunks[0].size)
-                    started = self._submitBatch(chunks)
-                    if pending is not None:
-                        self._emit(self._collectBatch(pending), file)
-                    pending = started
-                    if eof or not self._moreQueued(buffer):      # nothing to overlap with: write it out now (latency)
-                        self._emit(self._collectBatch(pending), file)
-                        pending = None
-                if eof:
-                    # the reference's loop ends on the ValueError numpy raises for ``x[0, :] = b''``
-                    # (dsp_processor.py:170, swallowed by processData's finally/return)
-                    raise _EndOfStream('end of stream')
-        finally:
-            if pending is not None:
-                self._emit(self._collectBatch(pending), file)
+
+        def flush():
+            # the batch leaves `pending` before it is written: a failing write (broken pipe, a HIP error surfacing in
+            # sdrt_wait) must not see the same batch collected and written a second time on the way out
+            nonlocal pending
+            p, pending = pending, None
+            if p is not None:
+                self._emit(self._collectBatch(p), file)
+
+        while not (self._isDead or isDead.value):
+            chunks, eof = self._takeBatch(buffer)
+            if chunks:
+                if self._shift is None:
+                    self._generateShift(chunks[0].size)
+                started = self._submitBatch(chunks)
+                flush()
+                pending = started
+                if eof or not self._moreQueued(buffer):      # nothing to overlap with: write it out now (latency)
+                    flush()
+            if eof:
+                flush()             # (the end marker alone in this batch: the one before it is still in flight)
+                # the reference's loop ends on the ValueError numpy raises for ``x[0, :] = b''``
+                # (dsp_processor.py:170, swallowed by processData's finally/return)
+                raise _EndOfStream('end of stream')
+        flush()                     # halt flag: what is in flight still goes out; an exception leaves it behind
 
     def _generateShift(self, c: int) -> None:
         """Host copy of the NCO row for callers that inspect ``_shift`` (dsp_processor.py:185-187: only when

@@ -13,7 +13,10 @@ processes, one per GPU.  The process the CLI started (io_args.py:92-95) is rank 
 the N-1 others, and hands every raw block to them (``parallel.BlockChannel``: RCCL broadcast between device buffers).
 Rank r computes rows [lo_r, hi_r) only and serves them on TCP port ``port + r`` -- client k of that port gets row
 lo_r + k -- with the reference's handshake per port (no processing before every row of every rank has its client: the
-block exchange is collective, so one waiting rank holds all of them).
+block exchange is collective, so one waiting rank holds all of them).  Block k+1 is uploaded and broadcast beside the
+kernels of block k (two device buffers per rank, a communication stream, events: ``parallel.RcclTransport``), as the
+single-GPU loop overlaps its copy-in.  Every wait on a collective is bounded and watches the halt flag and the helper
+processes: a rank that dies takes the job down (halt flag up, non-zero exit) instead of leaving the others in a collective.
 """
 import os
 
@@ -32,9 +35,14 @@ def _parse_host(spec: str):
 
 
 def _rank_main(processor, rank, world, uid, isDead):
-    """Entry point of the helper processes (ranks 1 .. world-1): the same processor, pickled, on another GPU."""
-    processor._enterRank(rank, world, uid)
-    processor.processData(isDead, None)
+    """Entry point of the helper processes (ranks 1 .. world-1): the same processor, pickled, on another GPU.  A helper that
+    cannot go on raises the shared halt flag: rank 0 and the reader watch it."""
+    try:
+        processor._enterRank(rank, world, uid)
+        processor.processData(isDead, None)
+    except BaseException:
+        isDead.value = 1
+        raise
 
 
 class VfoProcessor(DspProcessor):
@@ -51,15 +59,25 @@ class VfoProcessor(DspProcessor):
         self._fanout = None
         self._gpus = max(1, int(kwargs.get('gpus') or os.environ.get('SDRTERM_GPUS') or 1))
         self._rank, self._world, self._uid = 0, 1, None
+        self._deviceBase = self._device
         self._transportKind = kwargs.get('transport') or 'rccl'       # 'torch': an initialised torch.distributed group (tests)
+        # build extension (the reference's demodulation is processor-wide, io_args.py:118): one of 'fm' / 'am' per row, in the
+        # row order above (csv entries, then the center), as a list or a csv string -- FM and AM channels from one pass
+        modes = kwargs.get('rowModes')
+        if isinstance(modes, str):
+            modes = [m.strip().lower() for m in modes.split(',')]
+        if modes is not None and (len(modes) != self._nFreq or any(m not in ('fm', 'am') for m in modes)):
+            raise ValueError(f"rowModes needs one of 'fm' / 'am' for each of the {self._nFreq} rows (csv entries, then the center)")
+        self.rowModes = list(modes) if modes is not None else None
         self._channel = None
         self._helpers = []
+        self._stream, self._slots, self._moreComing = None, [None, None], False
 
     # ---- this rank's share -------------------------------------------------------------------------------------
     def _enterRank(self, rank: int, world: int, uid=None) -> None:
         self._rank, self._world, self._uid = rank, world, uid
         if self._transportKind == 'rccl':
-            self._device = rank                  # one process per GPU of the node
+            self._device = self._deviceBase + rank           # one process per GPU of the node, from ``device=`` upwards
         self._engine = None
 
     def _shard(self):
@@ -74,6 +92,12 @@ class VfoProcessor(DspProcessor):
 
     def _applyShift(self) -> bool:
         return True
+
+    def _rowModes(self):
+        if self.rowModes is None:
+            return None
+        sh = self._shard()
+        return self.rowModes[sh.lo:sh.hi]
 
     @property
     def clients(self):
@@ -97,8 +121,14 @@ class VfoProcessor(DspProcessor):
         if self._transportKind == 'torch':
             t = parallel.TorchTransport()
         else:
-            t = parallel.RcclTransport(self._rank, self._world, self._device, self._uid)
+            t = parallel.RcclTransport(self._rank, self._world, self._device, self._uid, alive=self._jobAlive)
         self._channel = parallel.BlockChannel(t, chunk_bytes)
+
+    def _jobAlive(self) -> bool:
+        """False once the job is going down: the halt flag is up, or (rank 0) a helper process has exited."""
+        if self._isDead or bool(self._halt.value):
+            return False
+        return all(p.is_alive() for p in self._helpers)
 
     def _takeBatch(self, buffer):
         """Rank 0 takes the batch from the reader's Queue as the single-GPU processor does and sends it on; the other
@@ -107,45 +137,82 @@ class VfoProcessor(DspProcessor):
             return super()._takeBatch(buffer)
         if self._rank == 0:
             chunks, eof = super()._takeBatch(buffer)
+            if self._isDead or self._halt.value:
+                raise KeyboardInterrupt                      # halted while waiting for the Queue: leave as the loop would
+            if not self._jobAlive():
+                raise RuntimeError('a helper rank has exited')
             self._announce(chunks[0] if chunks else None)
             payload = b''.join(self._bytesOf(c) for c in chunks)
-            blk = self._channel.exchange(payload, len(chunks), eof)
+            # "more input is queued behind this block": every rank then keeps this block's kernels in flight and takes the
+            # next one, exactly as this rank does (DspProcessor._processData)
+            blk = self._channel.exchange(payload, len(chunks), eof, not eof and super()._moreQueued(buffer))
             self._eofSent = eof
         else:
             if self._channel is None:
                 self._openChannel(1)
                 import ast
-                self._blockKind = ast.literal_eval(self._channel.t.bcast_bytes(None, 512).decode().strip())
+                t = self._channel.t                          # (the first block may be long in coming: wait while the job lives)
+                first = t.bcast_bytes(None, 512, timeout=0) if hasattr(t, 'wait_event') else t.bcast_bytes(None, 512)
+                self._blockKind = ast.literal_eval(first.decode().strip())
                 if self._blockKind:
                     self._channel.chunk_bytes = self._blockKind['chunk_bytes']
             blk = self._channel.exchange(None)
+        self._moreComing = blk.more
         if blk.n:
             blk.size = self._blockKind['samples']
         return ([blk] if blk.n else []), blk.eof
 
+    def _moreQueued(self, buffer) -> bool:
+        return super()._moreQueued(buffer) if self._world == 1 else self._moreComing
+
     def _submitBatch(self, chunks):
         if self._world == 1:
             return super()._submitBatch(chunks)
-        return None, self._runBlock(chunks), 0             # several GPUs: the block exchange is synchronous already
+        return None, self._startBlock(chunks[0]), 0
 
     def _collectBatch(self, pending) -> np.ndarray:
-        return super()._collectBatch(pending) if pending[0] is not None else pending[1]
+        return super()._collectBatch(pending) if pending[0] is not None else self._finishBlock(pending[1])
 
-    def _runBlock(self, chunks) -> np.ndarray:
-        blk, k = chunks[0], self._blockKind
+    def _blockEngine(self):
+        k = self._blockKind
         reader = dict(normalize=k['normalize'], correct_iq=k['correctIq'], impedance=k['impedance'],
                       big_endian=k['bigEndian']) if k['raw'] else {}
-        eng = self._getEngine(k['samples'], k['code'], **reader)
-        if blk.dev_ptr:
-            from .. import _native as nat
-            if getattr(self, '_outDev', None) is None or self._outDev.nbytes < self._nFreq * blk.n * eng.m * 8:
-                self._outDev = nat.DeviceBuffer(self._nFreq * self.MAX_BATCH * eng.m * 8)
-            eng.process_device(blk.dev_ptr, blk.n, self._outDev.ptr)
-            nat.check(nat.lib().sdrt_device_synchronize())
-            out = self._outDev.download(np.empty((self._nFreq, blk.n * eng.m), dtype=np.float64))
-        else:
-            out = eng.process(blk.host, blk.n)
-        return out.reshape(self._nFreq, blk.n, eng.m)
+        return self._getEngine(k['samples'], k['code'], **reader)
+
+    def _startBlock(self, blk):
+        """Kernels and copy-out of one exchanged block, asynchronous on this rank's stream: they wait (on the device) for the
+        block's broadcast, and the next broadcast into the same buffer waits for them."""
+        eng = self._blockEngine()
+        if not blk.dev_ptr:
+            return eng.process(blk.host, blk.n).reshape(self._nFreq, blk.n, eng.m)      # host transport (tests): synchronous
+        from .. import _native as nat
+        import ctypes as C
+        lib, t = nat.lib(), self._channel.t
+        if self._stream is None:
+            p = C.c_void_p()
+            nat.check(lib.sdrt_stream_create(C.byref(p)))
+            self._stream = p.value
+        sl = self._slots[blk.slot]
+        need = self._nFreq * blk.n * eng.m * 8
+        if sl is None or sl['cap'] < need:
+            cap = max(need, self._nFreq * self.MAX_BATCH * eng.m * 8)
+            ev = C.c_void_p()
+            nat.check(lib.sdrt_event_create(C.byref(ev)))
+            sl = self._slots[blk.slot] = dict(cap=cap, dev=nat.DeviceBuffer(cap), host=nat.pinned_array(cap), done=ev.value)
+        t.block_ready(blk.slot, self._stream)
+        eng.process_device(blk.dev_ptr, blk.n, sl['dev'].ptr, self._stream)
+        t.block_consumed(blk.slot, self._stream)
+        nat.check(lib.sdrt_memcpy_d2h_async(sl['host'].ctypes.data, sl['dev'].ptr, need, self._stream))
+        nat.check(lib.sdrt_event_record(sl['done'], self._stream))
+        return blk.slot, blk.n, eng.m
+
+    def _finishBlock(self, started) -> np.ndarray:
+        if isinstance(started, np.ndarray):
+            return started
+        slot, n, m = started
+        sl = self._slots[slot]
+        self._channel.t.wait_event(sl['done'], 'kernels of a block')
+        return sl['host'][:self._nFreq * n * m * 8].view(np.float64).reshape(self._nFreq, n, m).copy()
 
     def _announce(self, first_chunk) -> None:
         """Rank 0, once: open the channel (collective) and tell the others what the blocks hold (None: nothing will come)."""
@@ -157,14 +224,18 @@ class VfoProcessor(DspProcessor):
 
     def _releaseRanks(self) -> None:
         """Rank 0 is leaving (end of stream already sent, halt flag, error): the other ranks wait in a collective and need
-        an end-of-stream block to leave as well."""
+        an end-of-stream block to leave as well.  Only while they are all there to take it; the wait is bounded either way."""
         if self._world > 1 and self._rank == 0 and not getattr(self, '_eofSent', False):
+            self._eofSent = True
+            if not all(p.is_alive() for p in self._helpers):
+                return
             try:
+                if self._channel is not None and hasattr(self._channel.t, 'alive'):
+                    self._channel.t.alive = lambda: all(p.is_alive() for p in self._helpers)     # (the halt flag may be up already)
                 self._announce(None)
                 self._channel.exchange(b'', 0, True)
             except Exception:
                 pass
-            self._eofSent = True
 
     @staticmethod
     def _bytesOf(chunk) -> bytes:
@@ -182,7 +253,17 @@ class VfoProcessor(DspProcessor):
         """Rank 0 of ``gpus`` ranks: one more process per further GPU, started with 'spawn' before this process touches
         its GPU, each running this very processor on its share of the rows."""
         import multiprocessing as mp
+        import socket
         from ..parallel import RcclTransport
+        # every rank serves its own port: all of them must be free before anybody starts (a helper that cannot bind would
+        # leave the others in their first collective)
+        for r in range(self._gpus):
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as probe:
+                probe.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    probe.bind((self.host, self.port + r))
+                except OSError as e:
+                    raise OSError(f'{self.host}:{self.port + r} (rank {r} of --simo on {self._gpus} GPUs) is not free: {e}') from e
         uid = RcclTransport.unique_id() if self._transportKind == 'rccl' else None
         ctx = mp.get_context('spawn')
         self._helpers = [ctx.Process(target=_rank_main, args=(self, r, self._gpus, uid, isDead), daemon=True)
@@ -193,6 +274,7 @@ class VfoProcessor(DspProcessor):
 
     def processData(self, isDead, buffer, *args, **kwargs) -> None:
         self._halt = isDead
+        failed = False
         try:
             if self._world == 1 and self._gpus > 1:
                 self._startHelpers(isDead)
@@ -206,25 +288,35 @@ class VfoProcessor(DspProcessor):
         except Exception:
             import sys
             import traceback
+            failed = True
             eprint(f'{self} stopped on an error:')
             traceback.print_exc(file=sys.stderr)
         finally:
             self._isDead = True
+            if failed and self._world > 1:
+                isDead.value = 1                 # one rank down takes the job down: the others leave their waits, the reader stops
             self._releaseRanks()
             if self._fanout is not None:
                 self._fanout.close()
             if self._channel is not None:
-                self._channel.t.close()
+                try:
+                    self._channel.t.close(abandon=True) if failed and hasattr(self._channel.t, 'wait_event') else self._channel.t.close()
+                except Exception:
+                    pass
             for p in self._helpers:
                 p.join(timeout=5)
+                if p.is_alive():
+                    p.terminate()
             vprint('Multi-VFO writer halted')
+            if failed and self._world > 1 and self._rank > 0:
+                raise SystemExit(1)              # a helper: non-zero exit code for rank 0's liveness check
             return
 
     def __getstate__(self):
         state = super().__getstate__()
         state['_fanout'] = None
         state['_channel'] = None
-        state['_outDev'] = None
+        state['_stream'], state['_slots'] = None, [None, None]
         state['_helpers'] = []
         state.pop('_halt', None)
         return state

@@ -71,7 +71,9 @@ class Engine:
 
     def __init__(self, fs, decimation, mode, code='h', n_samples=None, row_freqs=None, apply_shift=None,
                  out_sos=None, omega_out=12500, normalize=False, correct_iq=False, impedance=50,
-                 big_endian=False, device=0, smooth=0):
+                 big_endian=False, device=0, smooth=0, row_modes=None):
+        """``row_modes``: None (every row demodulates as ``mode``, as the reference does, io_args.py:118) or one of 'fm' / 'am' per
+        row -- FM and AM channels of a --simo run in one pass over the input (BASELINE configs[2])."""
         if mode not in nat.MODES:
             raise ValueError(f'unsupported demodulation mode {mode!r}')
         if code not in nat.DTYPES:
@@ -116,6 +118,13 @@ class Engine:
         cfg.dec_sections = self._dec_sos.shape[0]
         cfg.out_sos = self._out_sos.ctypes.data_as(C.POINTER(C.c_double))
         cfg.out_sections = self._out_sos.shape[0]
+        self.row_modes = None
+        if row_modes is not None:
+            if len(row_modes) != self.rows or any(md not in ('fm', 'am') for md in row_modes):
+                raise ValueError("row_modes: one of 'fm' / 'am' per row")
+            self.row_modes = list(row_modes)
+            self._row_modes = np.ascontiguousarray([nat.MODES[md] for md in row_modes], dtype=np.int32)
+            cfg.row_modes = self._row_modes.ctypes.data_as(C.POINTER(C.c_int32))
         self._ctx = C.c_void_p()
         nat.check(nat.lib().sdrt_create(C.byref(cfg), C.byref(self._ctx)))
         self.m = nat.lib().sdrt_out_per_chunk(self._ctx)

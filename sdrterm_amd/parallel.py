@@ -24,7 +24,13 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
-HEADER = struct.Struct('<qq')        # chunks in the block, end-of-stream flag
+HEADER = struct.Struct('<qqq')       # chunks in the block, flags, sequence number
+F_EOF, F_MORE = 1, 2                 # flags: end of stream; more input was queued behind this block when it was sent
+SLOTS = 2                            # block buffers per rank: block k+1 arrives beside the kernels of block k
+
+
+class PeerLost(RuntimeError):
+    """A collective did not complete in time, or the halt flag went up while waiting for it."""
 
 
 def split_range(total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -73,9 +79,12 @@ class TorchTransport:
         self._dist.broadcast(t, src=root, group=self._group)
         return t.cpu().numpy().tobytes()
 
-    def bcast_block(self, data: Optional[bytes], nbytes: int, root: int = 0):
+    def bcast_block(self, data: Optional[bytes], nbytes: int, root: int = 0, slot: int = 0):
         """('host', bytes): the block as every rank's engine takes it from host memory."""
         return 'host', self.bcast_bytes(data, nbytes, root)
+
+    def block_consumed(self, slot: int, stream: int = 0) -> None:
+        pass
 
     def allgather_bytes(self, data: bytes) -> List[bytes]:
         """Every rank's ``data`` (same length everywhere), in rank order."""
@@ -94,7 +103,7 @@ class RcclTransport:
 
     on_device = True
 
-    def __init__(self, rank: int, world: int, device: int, uid: Optional[bytes] = None):
+    def __init__(self, rank: int, world: int, device: int, uid: Optional[bytes] = None, alive=None):
         from . import _native as nat
         self._nat = nat
         self.rank, self.world, self.device_index = rank, world, device
@@ -102,11 +111,43 @@ class RcclTransport:
             uid = self._exchange_uid(rank, world)
         self._comm = C.c_void_p()
         buf = C.create_string_buffer(uid, 128)
-        nat.check(nat.lib().sdrt_comm_init(buf, world, rank, device, C.byref(self._comm)))
-        self._stage = None          # device staging buffer for bcast_bytes
+        # joining the communicator is collective and cannot be interrupted: it runs beside a watch on the job, so that a peer
+        # that never arrives fails this rank instead of holding it for ever
+        import threading
+        box = {}
+
+        def join_comm():
+            try:
+                box['rc'] = nat.lib().sdrt_comm_init(buf, world, rank, device, C.byref(self._comm))
+                box['err'] = nat.lib().sdrt_last_error().decode(errors='replace') if box['rc'] else ''
+            except BaseException as e:                       # noqa: BLE001 -- reported by the waiting thread
+                box['exc'] = e
+        th = threading.Thread(target=join_comm, daemon=True)
+        th.start()
+        deadline = time.monotonic() + float(os.environ.get('SDRTERM_COMM_INIT_TIMEOUT', '180'))
+        while th.is_alive():
+            th.join(0.05)
+            if th.is_alive() and ((alive is not None and not alive()) or time.monotonic() > deadline):
+                raise PeerLost('communicator: not every rank arrived')
+        if 'exc' in box:
+            raise box['exc']
+        if box.get('rc'):
+            raise nat.SdrtError(box['rc'], box['err'])
+        nat.check(nat.lib().sdrt_set_device(device))         # (the communicator was joined on another thread: bind this one too)
+        self.timeout = float(os.environ.get('SDRTERM_COMM_TIMEOUT', '60'))      # seconds a collective may take
+        self.alive = alive          # callable: False once the job is going down (halt flag, a dead helper process)
+        p = C.c_void_p()
+        nat.check(nat.lib().sdrt_stream_create(C.byref(p)))
+        self._s_comm = p.value      # every collective of this transport runs on this stream
+        self._ev_sync = self._event()
+        self._stage = None          # device + page-locked staging buffers of bcast_bytes
+        self._stage_host = None
         self._stage_cap = 0
-        self._block = None          # device buffer of bcast_block
-        self._block_cap = 0
+        self._block = [None] * SLOTS          # device buffers of bcast_block
+        self._block_host = [None] * SLOTS     # the root's page-locked copies
+        self._block_cap = [0] * SLOTS
+        self._ev_ready = [None] * SLOTS       # broadcast into the buffer done
+        self._ev_free = [None] * SLOTS        # kernels reading the buffer done
 
     @staticmethod
     def unique_id() -> bytes:
@@ -153,18 +194,53 @@ class RcclTransport:
     def allgather_device(self, send_ptr: int, recv_ptr: int, bytes_per_rank: int, stream: int = 0) -> None:
         self._nat.check(self._nat.lib().sdrt_comm_allgather(self._comm, send_ptr, recv_ptr, bytes_per_rank, stream or None))
 
-    def bcast_bytes(self, data: Optional[bytes], nbytes: int, root: int = 0) -> bytes:
-        """Small host messages (the block header) through a device staging buffer."""
+    # ---- waiting with a deadline ---------------------------------------------------------------------------------------------
+    def _event(self):
+        p = C.c_void_p()
+        self._nat.check(self._nat.lib().sdrt_event_create(C.byref(p)))
+        return p.value
+
+    def wait_event(self, event: int, what: str, timeout: Optional[float] = None) -> None:
+        """Host wait for ``event`` by polling: returns when it has completed, raises ``PeerLost`` after ``timeout`` seconds
+        (None: this transport's) or as soon as ``self.alive()`` says the job is going down (halt flag, a dead helper)."""
+        nat, done = self._nat, C.c_int(0)
+        deadline = None if (timeout if timeout is not None else self.timeout) is None else \
+            time.monotonic() + (timeout if timeout is not None else self.timeout)
+        pause = 0.0
+        while True:
+            nat.check(nat.lib().sdrt_event_query(event, C.byref(done)))
+            if done.value:
+                return
+            if self.alive is not None and not self.alive():
+                raise PeerLost(f'{what}: the job is going down')
+            if deadline is not None and time.monotonic() > deadline:
+                raise PeerLost(f'{what}: no completion within {self.timeout} s (a peer rank is gone?)')
+            time.sleep(pause)
+            pause = min(0.002, pause + 0.0001)              # spin first: a block broadcast takes tens of microseconds
+
+    def _finish(self, what: str, timeout: Optional[float] = None) -> None:
+        """Everything submitted to the communication stream so far."""
+        self._nat.check(self._nat.lib().sdrt_event_record(self._ev_sync, self._s_comm))
+        self.wait_event(self._ev_sync, what, timeout)
+
+    def bcast_bytes(self, data: Optional[bytes], nbytes: int, root: int = 0, timeout: Optional[float] = None) -> bytes:
+        """Small host messages (the block header) through a page-locked staging buffer; returns when the message is here.
+        ``timeout``: None = this transport's; 0 = wait for as long as the job is alive (a rank waiting for the next block of
+        a live stream)."""
         nat = self._nat
         if nbytes > self._stage_cap:
             if self._stage is not None:
                 self._stage.free()
             self._stage, self._stage_cap = nat.DeviceBuffer(max(nbytes, 4096)), max(nbytes, 4096)
+            self._stage_host = nat.pinned_array(self._stage_cap)
         if self.rank == root:
-            self._stage.upload(np.frombuffer(data, dtype=np.uint8))
-        self.bcast_device(self._stage.ptr, nbytes, root)
-        nat.check(nat.lib().sdrt_device_synchronize())
-        return self._stage.download(np.empty(nbytes, dtype=np.uint8)).tobytes()
+            self._stage_host[:nbytes] = np.frombuffer(data, dtype=np.uint8)
+            nat.check(nat.lib().sdrt_memcpy_h2d_async(self._stage.ptr, self._stage_host.ctypes.data, nbytes, self._s_comm))
+        self.bcast_device(self._stage.ptr, nbytes, root, self._s_comm)
+        if self.rank != root:
+            nat.check(nat.lib().sdrt_memcpy_d2h_async(self._stage_host.ctypes.data, self._stage.ptr, nbytes, self._s_comm))
+        self._finish('header broadcast', None if timeout is None else (timeout or 1e18))
+        return self._stage_host[:nbytes].tobytes()
 
     def allgather_bytes(self, data: bytes) -> List[bytes]:
         """Every rank's ``data`` (same length everywhere), in rank order; through device staging buffers."""
@@ -172,65 +248,110 @@ class RcclTransport:
         send, recv = nat.DeviceBuffer(max(nb, 16)), nat.DeviceBuffer(max(nb * self.world, 16))
         try:
             send.upload(np.frombuffer(data, dtype=np.uint8))
-            self.allgather_device(send.ptr, recv.ptr, nb)
-            nat.check(nat.lib().sdrt_device_synchronize())
+            self.allgather_device(send.ptr, recv.ptr, nb, self._s_comm)
+            self._finish('all-gather')
             allb = recv.download(np.empty(nb * self.world, dtype=np.uint8)).tobytes()
         finally:
             send.free()
             recv.free()
         return [allb[r * nb:(r + 1) * nb] for r in range(self.world)]
 
-    def bcast_block(self, data: Optional[bytes], nbytes: int, root: int = 0):
+    def bcast_block(self, data: Optional[bytes], nbytes: int, root: int = 0, slot: int = 0):
         """('dev', pointer): the block stays in device memory on every rank (one upload on the root, RCCL broadcast,
-        sdrt_process_device on the spot).  The buffer is reused by the next call: consume the block first."""
-        nat = self._nat
-        if nbytes > self._block_cap:
-            if self._block is not None:
-                self._block.free()
-            self._block, self._block_cap = nat.DeviceBuffer(nbytes), nbytes
+        sdrt_process_device on the spot).  Asynchronous: upload and broadcast are queued on the communication stream behind
+        the kernels that last read buffer ``slot`` (``block_consumed``); the caller's stream must wait for them with
+        ``block_ready`` before it reads the block."""
+        nat, lib = self._nat, self._nat.lib()
+        if nbytes > self._block_cap[slot]:
+            if self._block[slot] is not None:
+                nat.check(lib.sdrt_stream_synchronize(self._s_comm))
+                self._block[slot].free()
+            self._block[slot], self._block_cap[slot] = nat.DeviceBuffer(nbytes), nbytes
+            if self.rank == root:
+                self._block_host[slot] = nat.pinned_array(nbytes)
+        if self._ev_free[slot] is not None:
+            nat.check(lib.sdrt_stream_wait_event(self._s_comm, self._ev_free[slot]))
         if self.rank == root:
-            self._block.upload(np.frombuffer(data, dtype=np.uint8))
-        self.bcast_device(self._block.ptr, nbytes, root)
-        nat.check(nat.lib().sdrt_device_synchronize())
-        return 'dev', self._block.ptr
+            self._block_host[slot][:nbytes] = np.frombuffer(data, dtype=np.uint8)
+            nat.check(lib.sdrt_memcpy_h2d_async(self._block[slot].ptr, self._block_host[slot].ctypes.data, nbytes, self._s_comm))
+        self.bcast_device(self._block[slot].ptr, nbytes, root, self._s_comm)
+        if self._ev_ready[slot] is None:
+            self._ev_ready[slot] = self._event()
+        nat.check(lib.sdrt_event_record(self._ev_ready[slot], self._s_comm))
+        return 'dev', self._block[slot].ptr
 
-    def close(self):
-        if self._block is not None:
-            self._block.free()
-            self._block = None
-        if getattr(self, '_comm', None) is not None and self._comm.value:
-            self._nat.lib().sdrt_comm_destroy(self._comm)
-            self._comm = C.c_void_p()
-        if self._stage is not None:
-            self._stage.free()
-            self._stage = None
+    def block_ready(self, slot: int, stream: int) -> None:
+        """``stream`` waits (on the device) for the block in buffer ``slot``."""
+        self._nat.check(self._nat.lib().sdrt_stream_wait_event(stream or None, self._ev_ready[slot]))
+
+    def block_consumed(self, slot: int, stream: int = 0) -> None:
+        """Everything submitted to ``stream`` so far reads buffer ``slot``: the next broadcast into it waits for that."""
+        if self._ev_free[slot] is None:
+            self._ev_free[slot] = self._event()
+        self._nat.check(self._nat.lib().sdrt_event_record(self._ev_free[slot], stream or None))
+
+    def close(self, abandon: bool = False):
+        """``abandon``: a peer is gone and collectives may still sit in the communication stream -- nothing is waited for and
+        the communicator is left to the process exit."""
+        lib = self._nat.lib()
+        if not abandon:
+            for b in self._block:
+                if b is not None:
+                    b.free()
+            if getattr(self, '_comm', None) is not None and self._comm.value:
+                lib.sdrt_comm_destroy(self._comm)
+            if self._stage is not None:
+                self._stage.free()
+            for e in [self._ev_sync] + self._ev_ready + self._ev_free:
+                if e is not None:
+                    lib.sdrt_event_destroy(e)
+            if self._s_comm:
+                lib.sdrt_stream_destroy(self._s_comm)
+        self._block, self._stage, self._s_comm = [None] * SLOTS, None, None
+        self._ev_sync, self._ev_ready, self._ev_free = None, [None] * SLOTS, [None] * SLOTS
+        self._comm = C.c_void_p()
 
 
 class Block:
-    """One exchanged block: ``n`` chunks either in host memory (``host``: bytes) or in device memory (``dev_ptr``)."""
-    __slots__ = ('n', 'eof', 'host', 'dev_ptr', 'size')
+    """One exchanged block: ``n`` chunks either in host memory (``host``: bytes) or in device memory (``dev_ptr``, buffer
+    ``slot``); ``more``: the sender had more input queued behind it (the receivers then keep this block's kernels in flight
+    and take the next one, as the single-GPU loop does with its Queue); ``seq``: position in the stream."""
+    __slots__ = ('n', 'eof', 'more', 'seq', 'host', 'dev_ptr', 'slot', 'size')
 
-    def __init__(self, n, eof, host=None, dev_ptr=0, size=0):
-        self.n, self.eof, self.host, self.dev_ptr, self.size = n, eof, host, dev_ptr, size
+    def __init__(self, n, eof, more=False, seq=0, host=None, dev_ptr=0, slot=0, size=0):
+        self.n, self.eof, self.more, self.seq = n, eof, more, seq
+        self.host, self.dev_ptr, self.slot, self.size = host, dev_ptr, slot, size
 
 
 class BlockChannel:
-    """The reader-side rank sends (chunks in the block, end-of-stream flag, block bytes); ``exchange`` returns the same
-    ``Block`` on every rank."""
+    """The reader-side rank sends (chunks in the block, flags, sequence number, block bytes); ``exchange`` returns the same
+    ``Block`` on every rank.  The header is waited for; the block itself (device transports) is only queued, into buffer
+    ``seq % SLOTS``: see ``RcclTransport.bcast_block``."""
 
     def __init__(self, transport, chunk_bytes: int, root: int = 0):
         self.t, self.chunk_bytes, self.root = transport, chunk_bytes, root
+        self.seq = 0
 
-    def exchange(self, block: Optional[bytes], n_chunks: int = 0, eof: bool = False) -> Block:
-        hdr = HEADER.pack(n_chunks, int(eof)) if self.t.rank == self.root else None
-        n_chunks, eof = HEADER.unpack(self.t.bcast_bytes(hdr, HEADER.size, self.root))
-        out = Block(int(n_chunks), bool(eof))
+    def exchange(self, block: Optional[bytes], n_chunks: int = 0, eof: bool = False, more: bool = False) -> Block:
+        is_root = self.t.rank == self.root
+        hdr = HEADER.pack(n_chunks, (F_EOF if eof else 0) | (F_MORE if more else 0), self.seq) if is_root else None
+        # the root only gets here with a block in its hands: every peer answers at once or is gone; the others wait for as long
+        # as the stream is silent
+        if isinstance(self.t, RcclTransport):
+            raw = self.t.bcast_bytes(hdr, HEADER.size, self.root, timeout=None if is_root else 0)
+        else:
+            raw = self.t.bcast_bytes(hdr, HEADER.size, self.root)
+        n_chunks, flags, seq = HEADER.unpack(raw)
+        if seq != self.seq:
+            raise PeerLost(f'block {seq} arrived where block {self.seq} was due')
+        out = Block(int(n_chunks), bool(flags & F_EOF), bool(flags & F_MORE), int(seq), slot=int(seq % SLOTS))
         if n_chunks:
-            where, what = self.t.bcast_block(block, n_chunks * self.chunk_bytes, self.root)
+            where, what = self.t.bcast_block(block, n_chunks * self.chunk_bytes, self.root, out.slot)
             if where == 'dev':
                 out.dev_ptr = what
             else:
                 out.host = what
+        self.seq += 1
         return out
 
 

@@ -4,7 +4,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from tests.util import BY_NAME, CASES, case_raw, ref_tol, samples_per_chunk, tol_for
+from tests.util import ABS_TOL, BY_NAME, CASES, case_raw, ref_tol, samples_per_chunk, tol_for
 
 pytestmark = pytest.mark.gpu
 
@@ -298,7 +298,7 @@ def test_item_distribution_of_the_persistent_kernel(rows, nch, q, monkeypatch):
     b = Engine(fs, q, 'fm', 'h', row_freqs=freqs, omega_out=5000)
     out_b = b.process(raw)
     assert (a.stage_a, b.stage_a) == ('i8w', 'i8t')
-    assert np.isfinite(out_a).all() and np.abs(out_a - out_b).max() < 1e-8
+    assert np.isfinite(out_a).all() and np.abs(out_a - out_b).max() < 1e-7     # (two kernels, white-noise FM: each is held to the oracle below)
     # ... and sampled (chunk, row) items against the oracle (oracle/chain.c): first, last and two rows in between, on
     # the first, a middle and the last chunk
     rs = sorted({0, rows // 3, (2 * rows) // 3, rows - 1})
@@ -369,3 +369,60 @@ def test_two_chunks_per_item_on_the_wide_kernel(code, q, nch, monkeypatch):
     err = np.abs(got - exp).max()
     print(f'{code} q={q} {nch} chunk(s): max abs err {err:.3e}')
     assert err <= 1e-6
+
+
+@pytest.mark.parametrize('fused', ['0', '1', None])
+def test_per_row_modes_equal_the_two_single_mode_runs(golden, monkeypatch, fused):
+    """BASELINE configs[2] asks for FM and AM channels in one --simo run; the reference's demodulation is processor-wide
+    (io_args.py:118), so its own answer is two runs.  A context with per-row modes (sdrt_config.row_modes, one pass over the
+    input) must give, row by row, what the reference gave in its FM run and in its AM run of the same nine rows (golden cases
+    h_q32_fm_norm_vfo9_iq / h_q32_am_norm_vfo9_iq: same seed, same --normalize-input and --correct-iq)."""
+    from sdrterm_amd.engine import Engine
+    from oracle import ref_chain
+    z, _ = golden
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    if fused is not None:
+        monkeypatch.setenv('SDRTERM_IQ_FUSED', fused)
+    fm, am = BY_NAME['h_q32_fm_norm_vfo9_iq'], BY_NAME['h_q32_am_norm_vfo9_iq']
+    assert case_raw(fm) == case_raw(am)
+    rows = ref_chain.vfo_rows(fm['center'], fm['vfos'])
+    modes = ['fm', 'am'] * 4 + ['fm']
+    eng = Engine(fm['fs'], fm['q'], 'fm', 'h', row_freqs=rows, apply_shift=True, omega_out=fm['omega_out'], normalize=True,
+                 correct_iq=True, row_modes=modes)
+    out = eng.process(case_raw(fm))
+    exp = {'fm': z['h_q32_fm_norm_vfo9_iq/z'], 'am': z['h_q32_am_norm_vfo9_iq/z']}      # (chunks, rows, m)
+    nch, nrows, m = exp['fm'].shape
+    got = out.reshape(nrows, nch, m)
+    for r, md in enumerate(modes):
+        e = exp[md][:, r, :]
+        err = np.abs(got[r] - e).max()
+        assert err <= tol_for(e, md), f'row {r} ({md}): {err:.3e}'
+    # all rows alike: the plain context
+    same = Engine(fm['fs'], fm['q'], 'am', 'h', row_freqs=rows, apply_shift=True, omega_out=fm['omega_out'], normalize=True,
+                  correct_iq=True, row_modes=['fm'] * 9).process(case_raw(fm)).reshape(nrows, nch, m)
+    assert np.abs(same.transpose(1, 0, 2) - exp['fm']).max() <= ABS_TOL
+
+
+def test_per_row_modes_on_the_bench_configuration(golden, monkeypatch):
+    """The same at configs[2]'s own parameters (256 MS/s, 8 rows, decimation 32, --correct-iq): FM rows against the FM golden
+    run; the AM rows (the AM golden run normalises its input, this context does not) against the C oracle."""
+    from sdrterm_amd.engine import Engine
+    from oracle import ref_chain
+    z, _ = golden
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    case = BY_NAME['h_q32_fm_vfo8_iq_bench']
+    rows = [float(f) for f in ref_chain.vfo_rows(case['center'], case['vfos'])]
+    modes = ['fm', 'am', 'am', 'fm', 'fm', 'am', 'fm', 'am']
+    raw = case_raw(case)
+    out = Engine(case['fs'], 32, 'fm', 'h', row_freqs=rows, apply_shift=True, omega_out=12500, correct_iq=True, row_modes=modes).process(raw)
+    exp = z['h_q32_fm_vfo8_iq_bench/z']
+    nch, nrows, m = exp.shape
+    got = out.reshape(nrows, nch, m)
+    n = samples_per_chunk('h')
+    from oracle import c_chain
+    shift = c_chain.shift_table(rows, case['fs'], n)
+    am, _ = c_chain.process_stream(raw, 'h', n, 32, 'am', shift, ref_chain.cheby_sos(32), ref_chain.ellip_sos(case['fs'] // 32, 12500),
+                                   iq_inductance=50 / case['fs'], threads=4)
+    for r, md in enumerate(modes):
+        e = exp[:, r, :] if md == 'fm' else am[:, r, :]
+        assert np.abs(got[r] - e).max() <= tol_for(e, md), f'row {r} ({md})'

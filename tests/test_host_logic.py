@@ -116,7 +116,7 @@ def test_shared_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(lib, n), f'{n} declared in the header but not exported'
     assert set(_native.EXPORTS) <= names
-    assert _native.lib().sdrt_abi_version() == _native.ABI_VERSION == 4
+    assert _native.lib().sdrt_abi_version() == _native.ABI_VERSION == 5
     assert ctypes.sizeof(_native.Config) == _native.lib().sdrt_config_size()
 
 
@@ -272,3 +272,18 @@ def test_savgol_operator_reproduces_scipy():
                     if 0 <= j < m:
                         out[i] += taps[k] * z[j]
         assert np.abs(out - savgol_filter(z, w, 3)).max() < 1e-12
+
+
+def test_vfo_processor_row_modes_extension():
+    """rowModes (build extension; the reference's demodulation is processor-wide, io_args.py:118): one of fm / am per row in the
+    reference's row order (csv entries, then the center), as a list or a csv string; a rank's share follows its rows."""
+    p = VfoProcessor(DEFAULT_FS, vfoHost='127.0.0.1:1', vfos='100,200,300', dec=4, omegaOut=250, rowModes='FM, am,fm,am')
+    assert p.rowModes == ['fm', 'am', 'fm', 'am'] and p._rowModes() == ['fm', 'am', 'fm', 'am']
+    p._enterRank(1, 2)
+    assert p._rowModes() == ['fm', 'am']
+    assert VfoProcessor(DEFAULT_FS, vfoHost='127.0.0.1:1', vfos='100', dec=4, omegaOut=250)._rowModes() is None
+    for bad in ('fm', ['fm', 'am', 'fm'], 'fm,am,re,im'):
+        with pytest.raises(ValueError):
+            VfoProcessor(DEFAULT_FS, vfoHost='127.0.0.1:1', vfos='100,200,300', dec=4, omegaOut=250, rowModes=bad)
+    q = pickle.loads(pickle.dumps(p))
+    assert q.rowModes == p.rowModes

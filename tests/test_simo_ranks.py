@@ -9,6 +9,7 @@ import threading
 import time
 
 import numpy as np
+import pytest
 
 from sdrterm_amd.dsp.vfo_processor import VfoProcessor
 
@@ -69,7 +70,7 @@ def _client(host, port, nbytes, box, idx):
     box[idx] = data
 
 
-def _rank_worker(rank, world, master_port, base_port, q):
+def _rank_worker(rank, world, master_port, base_port, q, feed='all at once'):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(master_port)
@@ -77,6 +78,16 @@ def _rank_worker(rank, world, master_port, base_port, q):
     p = StubVfo(FS, vfoHost=f'127.0.0.1:{base_port}', vfos=VFOS, center=1000, dec=Q, omegaOut=5000, transport='torch')
     p.selectOutputFm()
     p._enterRank(rank, world)
+    seen = []                                   # (chunks, end of stream, more queued) of every block this rank took
+    take = p._takeBatch
+
+    def spy(buffer):
+        chunks, eof = take(buffer)
+        seen.append((sum(c.n for c in chunks), eof, p._moreComing))
+        return chunks, eof
+    p._takeBatch = spy
+    if feed != 'all at once':
+        p.MAX_BATCH = 2
     sh = p._shard()
     m = N // Q
     box = [None] * sh.rows
@@ -94,24 +105,40 @@ def _rank_worker(rank, world, master_port, base_port, q):
     buf = None
     if rank == 0:
         buf = queue.Queue()
-        for c in chunks_for_test():
-            buf.put(c)
-        buf.put(b'')
+        if feed == 'all at once':
+            for c in chunks_for_test():
+                buf.put(c)
+            buf.put(b'')
+        else:
+            # a live source: the first three chunks are there when the clients have connected, the rest trickle in one by
+            # one, then the end marker -- several blocks that are not the last one cross the channel, some with more queued
+            # behind them (kept in flight while the next is taken), some without
+            def trickle():
+                cs = chunks_for_test()
+                for c in cs[:3]:
+                    buf.put(c)
+                for c in cs[3:]:
+                    time.sleep(0.7)
+                    buf.put(c)
+                time.sleep(0.7)
+                buf.put(b'')
+            threading.Thread(target=trickle, daemon=True).start()
     p.processData(_Flag(), buf)
     starter.join(30)
     for t in ts:
         t.join(30)
-    q.put((rank, (sh.lo, sh.hi), sh.port(base_port), [np.frombuffer(b, dtype='>f8').astype(np.float64) if b else None for b in box]))
+    q.put((rank, (sh.lo, sh.hi), sh.port(base_port), [np.frombuffer(b, dtype='>f8').astype(np.float64) if b else None for b in box], seen))
     dist.destroy_process_group()
 
 
-def test_sharded_vfo_processor_under_gloo():
+@pytest.mark.parametrize('feed', ['all at once', 'trickle'])
+def test_sharded_vfo_processor_under_gloo(feed):
     import torch.multiprocessing as mp
     from sdrterm_amd.misc.general_util import findPort
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     world, master, base = 2, findPort('127.0.0.1'), findPort('127.0.0.1')
-    procs = [ctx.Process(target=_rank_worker, args=(r, world, master, base, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, master, base, q, feed)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=150) for _ in range(world))
@@ -122,7 +149,14 @@ def test_sharded_vfo_processor_under_gloo():
     assert [g[1] for g in got] == [(0, 3), (3, 5)] and [g[2] for g in got] == [base, base + 1]
     m = N // Q
     check = [int(np.frombuffer(c.tobytes(), dtype=np.uint8).astype(np.int64).sum() % 251) for c in chunks_for_test()]
-    for _rank, (lo, hi), _port, streams in got:
+    blocks = [g[4] for g in got]
+    assert blocks[0] == blocks[1]                                  # every rank saw the same blocks, flags included
+    assert sum(b[0] for b in blocks[0]) == CHUNKS and blocks[0][-1][1] and not any(b[1] for b in blocks[0][:-1])
+    if feed == 'trickle':
+        # the helper rank runs processData(isDead, None): blocks that are not the last one must get through it (round 2: the
+        # helper died on None.empty() after the first of them), in order, with and without more queued behind them
+        assert len(blocks[0]) >= 4 and any(b[2] for b in blocks[0]) and any(not b[2] and not b[1] for b in blocks[0])
+    for _rank, (lo, hi), _port, streams, _seen in got:
         assert len(streams) == hi - lo
         for k, s in enumerate(streams):
             assert s is not None and s.size == CHUNKS * m
@@ -137,3 +171,55 @@ def test_rank_zero_releases_the_others_when_halted_before_any_data():
     p._enterRank(0, 1)
     p._releaseRanks()                      # world 1: nothing to do, must not raise
     assert not getattr(p, '_eofSent', False)
+
+
+class _FakeLib:
+    """sdrt_event_query that never completes (a collective whose peer is gone)."""
+
+    def sdrt_event_query(self, event, done):
+        done._obj.value = 0
+        return 0
+
+    def sdrt_event_record(self, event, stream):
+        return 0
+
+
+class _FakeNat:
+    def lib(self):
+        return _FakeLib()
+
+    @staticmethod
+    def check(rc):
+        assert rc == 0
+
+
+def test_collective_waits_are_bounded_and_watch_the_job():
+    """A rank never sits in a device synchronisation behind a collective: it polls an event with a deadline and asks whether
+    the job is still alive (halt flag, helper processes), so a dead peer ends the wait (rank 0 hung for ever)."""
+    from sdrterm_amd import parallel
+    t = object.__new__(parallel.RcclTransport)
+    t._nat, t.timeout, t.alive = _FakeNat(), 0.3, None
+    t0 = time.monotonic()
+    with pytest.raises(parallel.PeerLost, match='no completion'):
+        t.wait_event(1, 'header broadcast')
+    assert 0.25 < time.monotonic() - t0 < 5
+    calls = []
+    t.timeout, t.alive = 60, lambda: calls.append(1) or len(calls) < 3
+    with pytest.raises(parallel.PeerLost, match='going down'):
+        t.wait_event(1, 'header broadcast')
+    assert len(calls) == 3
+
+
+def test_ports_of_every_rank_are_probed_before_helpers_start():
+    """Rank r serves port + r: a busy one must stop the start-up in rank 0, before any helper waits in a collective."""
+    import socket
+    from sdrterm_amd.misc.general_util import findPort
+    base = findPort('127.0.0.1')
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as busy:
+        busy.bind(('127.0.0.1', base + 1))
+        busy.listen(1)
+        p = StubVfo(FS, vfoHost=f'127.0.0.1:{base}', vfos=VFOS, dec=Q, omegaOut=5000, gpus=2, device=3)
+        assert p._deviceBase == 3
+        with pytest.raises(OSError, match='rank 1'):
+            p._startHelpers(_Flag())
+        assert p._helpers == []
