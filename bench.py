@@ -10,19 +10,24 @@ in HBM.  With N > 1 each rank owns its own batch (chunks are independent, SURVEY
 data-path collective.
 
 simo64 (configs[3]): 64 VFO rows, decimation 32, FM; the rows are sharded contiguously over the ranks and every step's raw
-block is broadcast from rank 0 over RCCL (sdrt_comm_bcast, the only collective), block k+1 beside the kernels of block k.
-Total work is fixed: strong scaling; value = input samples per second.
+block reaches every rank over RCCL (the only collective), block k+1 beside the kernels of block k: --feed bcast (the stream
+lives on rank 0, where the reader's Queue ends: sdrt_comm_bcast) or --feed allgather (every rank holds 1/N of each block, as
+when every GPU is fed its share over its own host link: sdrt_comm_allgather, each xGMI link then carries 1/N of the block
+instead of the root's links carrying all of it).  Total work is fixed: strong scaling; value = input samples per second.
 
-Launch: under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this file is one rank.  Started
-plainly with --gpus N > 1 it starts the N ranks itself as child processes -- before anything touches a GPU -- and relays rank
-0's line.
+Launch: under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) this file is one rank.
+Started plainly with --gpus N > 1 it starts the N ranks itself as child processes -- before anything touches a GPU -- and
+relays rank 0's line (--dry-run prints what it would start).  The ranks talk through ONE RCCL communicator behind the C ABI
+(sdrt_comm_*: barrier, maximum over ranks and the block exchange; the 128-byte id travels over TCP at MASTER_ADDR); there
+is no torch.distributed process group.
 
 Timing: W warm-up steps, then back-to-back steps until --settle-seconds have passed (the chip lowers its clock under this
 load; a cold start would flatter the number), then EXACTLY K timed steps between barriers, maximum over ranks; after that
 a --long-seconds run without per-kernel events gives the steady-state figure next to it ("steady_state").
 
-torch is plumbing here (device buffers, synthetic data, barrier / max over ranks); the product path is the C ABI of
-libsdrterm_hip.so called through ctypes.
+torch is plumbing here (device buffers, synthetic data); the product path is the C ABI of libsdrterm_hip.so called through
+ctypes.  Every number on the line is produced by the run that prints it, except what sits under "from_profile" (hardware
+counters need rocprofv3 passes of their own: tools/pmc.sh; the committed record of the same workload is quoted with its file).
 """
 import argparse
 import json
@@ -129,18 +134,28 @@ def committed_record(name):
         return None
 
 
-def launch_ranks(args, argv):
-    """--gpus N without a launcher: start the N ranks as fresh child processes (nothing in this process has touched a GPU)."""
+def rank_environments(n_gpus, port, base=None):
+    """What each rank of a self-launched run finds in its environment (the variables torch.distributed.run would set)."""
+    base = dict(os.environ if base is None else base)
+    return [dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                 HSA_ENABLE_IPC_MODE_LEGACY=base.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')) for r in range(n_gpus)]
+
+
+def launch_ranks(args, argv, dry_run=False):
+    """--gpus N without a launcher: start the N ranks as fresh child processes (nothing in this process has touched a GPU).
+    dry_run: print one JSON line per rank (its command and the variables above) instead."""
     import socket
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != '--dry-run']
+    envs = rank_environments(args.gpus, port)
+    if dry_run:
+        keys = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY')
+        for r, env in enumerate(envs):
+            print(json.dumps({'rank': r, 'cmd': cmd, 'env': {k: env[k] for k in keys}, 'stdout': 'relayed' if r == 0 else 'discarded'}))
+        return 0
+    procs = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL) for r, env in enumerate(envs)]
     out, _ = procs[0].communicate()
     rc = procs[0].returncode
     for p in procs[1:]:
@@ -163,10 +178,13 @@ def main():
     ap.add_argument('--long-seconds', type=float, default=2.0, help='steady-state run after the timed region (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='diagnostic: no per-kernel HIP events in the timed region')
+    ap.add_argument('--feed', choices=('bcast', 'allgather'), default='bcast', help='many-row workloads: how a block reaches the ranks')
+    ap.add_argument('--no-same-arithmetic', action='store_true', help="skip the fp64 kernel's side figure")
+    ap.add_argument('--dry-run', action='store_true', help='with --gpus N > 1 and no launcher: print the ranks that would be started')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
-        sys.exit(launch_ranks(args, sys.argv[1:]))
+        sys.exit(launch_ranks(args, sys.argv[1:], dry_run=args.dry_run))
 
     import numpy as np
     import torch
@@ -177,14 +195,14 @@ def main():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from sdrterm_amd import _native as nat, parallel
     from sdrterm_amd.engine import Engine
+    # one communicator for everything the ranks say to each other (barrier, maximum, block exchange): RCCL behind the C ABI
+    comm = None
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        comm = parallel.RcclTransport(rank, world, local_rank)        # the id travels over TCP at MASTER_ADDR:MASTER_PORT+17
     q, rows_total, default_chunks, scaling, code, FS = WORKLOADS[args.workload]
     N = 131072 // (2 * ITEM[code])            # complex samples per 131072-byte chunk
     n_chunks = args.chunks or default_chunks
@@ -195,19 +213,21 @@ def main():
         freqs, (lo, hi) = freqs_all, (0, 1)
         raw = synth_iq_torch(n_samples, seed=1234 + rank, device=device, code=code, fs=FS)
         bufs = [raw]
-        comm = None
+        src = None
     else:
         freqs_all = simo_rows(rows_total)
         freqs, (lo, hi) = parallel.shard_rows(freqs_all, world, rank)
-        # the stream lives on rank 0 (where the reader's Queue ends); two block buffers per rank: block k+1 arrives beside
-        # the kernels of block k
-        src = synth_iq_torch(2 * n_samples, seed=1234, device=device, code=code, fs=FS) if rank == 0 else None
-        bufs = [torch.empty((n_samples, 2), dtype=src.dtype if rank == 0 else (torch.int16 if code == 'h' else torch.float32), device=device) for _ in range(2)]
-        comm = None
-        if world > 1:
-            uid = [parallel.RcclTransport.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            comm = parallel.RcclTransport(rank, world, local_rank, uid[0])
+        # two block buffers per rank: block k+1 arrives beside the kernels of block k.  bcast: the stream lives on rank 0 (where
+        # the reader's Queue ends).  allgather: every rank holds the same 1/N of every block (the whole stream is synthesised
+        # everywhere from one seed, a rank keeps its slice)
+        allg = args.feed == 'allgather' and world > 1
+        if n_samples % world and allg:
+            raise SystemExit('--feed allgather needs a block that divides by the number of ranks')
+        src = synth_iq_torch(2 * n_samples, seed=1234, device=device, code=code, fs=FS) if (rank == 0 or allg) else None
+        if allg:
+            per = n_samples // world
+            src = torch.stack([src[b * n_samples + rank * per:b * n_samples + (rank + 1) * per] for b in range(2)]).contiguous()
+        bufs = [torch.empty((n_samples, 2), dtype=torch.int16 if code == 'h' else torch.float32, device=device) for _ in range(2)]
     eng = Engine(FS, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_rank, correct_iq=args.correct_iq)
     rows = len(freqs)
     out = torch.empty((rows, n_chunks * eng.m), dtype=torch.float64, device=device)
@@ -217,7 +237,7 @@ def main():
     st = torch.cuda.Stream(device=device)
     S = st.cuda_stream
     s_comm = None
-    if comm is not None:
+    if comm is not None and not single:
         p = nat.C.c_void_p()
         nat.check(lib.sdrt_stream_create(nat.C.byref(p)))
         s_comm = p.value
@@ -227,12 +247,16 @@ def main():
     state = {'k': 0}
 
     def fetch(k):
-        """Block k of the stream into buffer k % 2 on every rank (simo64)."""
+        """Block k of the stream into buffer k % 2 on every rank (many-row workloads)."""
         dst = bufs[k % 2]
+        if s_comm is not None and args.feed == 'allgather':
+            nat.check(lib.sdrt_stream_wait_stream(s_comm, S))        # after the kernels still reading dst
+            comm.allgather_device(src[k % 2].data_ptr(), dst.data_ptr(), block_bytes // world, s_comm)
+            return
         if rank == 0:
             with torch.cuda.stream(st):
                 dst.copy_(src[(k % 2) * n_samples:(k % 2 + 1) * n_samples], non_blocking=True)
-        if comm is not None:
+        if s_comm is not None:
             nat.check(lib.sdrt_stream_wait_stream(s_comm, S))        # after the copy above / the kernels still reading dst
             comm.bcast_device(dst.data_ptr(), block_bytes, 0, s_comm)
 
@@ -243,17 +267,23 @@ def main():
         if not single:
             fetch(k + 1)                                               # beside this step's kernels (other buffer)
         run(bufs[k % len(bufs)].data_ptr(), n_chunks, out.data_ptr(), S)
-        if comm is not None:
+        if s_comm is not None:
             nat.check(lib.sdrt_stream_wait_stream(S, s_comm))         # the next step's kernels need that block
         state['k'] = k + 1
 
+    def over_ranks(value):
+        """Every rank's value (an all-gather of 8 bytes per rank through the communicator: also the barrier)."""
+        if comm is None:
+            return [float(value)]
+        import struct
+        return [struct.unpack('<d', b)[0] for b in comm.allgather_bytes(struct.pack('<d', float(value)))]
+
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        over_ranks(0.0)
 
     if not single:
         fetch(0)
-        if comm is not None:
+        if s_comm is not None:
             nat.check(lib.sdrt_stream_wait_stream(S, s_comm))
     for _ in range(args.warmup):
         step()
@@ -279,7 +309,7 @@ def main():
         evs[i + 1].record(st)
     torch.cuda.synchronize()
     barrier()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
+    elapsed = max(over_ranks(time.perf_counter() - t0))
     k_ms, k_n = eng.kernel_time(0)
     p_ms, p_n = eng.kernel_time(1)
     eng.profile(False)
@@ -298,7 +328,7 @@ def main():
             step()
         torch.cuda.synchronize()
         barrier()
-        dt_long = parallel.max_over_ranks(time.perf_counter() - t1, device)
+        dt_long = max(over_ranks(time.perf_counter() - t1))
         steady = {'steps': n_long, 'seconds': round(dt_long, 3), 'ms_per_step': round(dt_long / n_long * 1e3, 4)}
 
     KERNEL_OF = {'i8w': 'chain_i8w_kernel', 'i8t': 'chain_i8t_kernel', 'f64': 'chain_kernel'}
@@ -317,19 +347,28 @@ def main():
         # int8 matrix work of the dominant kernel: matrix instructions per 4096-sample tile x 16*16*64*2 operations
         mfma_per_tile = (({64: 184, 32: 216} if code == 'h' else {64: 288, 32: 336})[q] + (16 if args.correct_iq and rows == 1 else 0)) if eng.stage_a == 'i8w' else ({'h': 160, 'f': 224}[code] if eng.stage_a == 'i8t' else None)
         i8_ops = mfma_per_tile * 32768.0 * rows * n_samples / 4096 if mfma_per_tile else None
-        pmc = (committed_record('r02_pmc_record.json') or committed_record('pmc_traffic.json')) if args.workload == 'fm64' and not args.correct_iq else None
+        # hardware counters cannot be read from inside this run: the committed record of rocprofv3 passes over this very workload
+        # (tools/pmc.sh) is quoted under "from_profile", with the file it comes from and the commit it was taken at
+        pmc_file = 'r03_pmc_record.json'
+        pmc = committed_record(pmc_file) if args.workload == 'fm64' and not args.correct_iq else None
         pmc_ok = bool(pmc) and pmc.get('chunks_per_step_per_gpu') == n_chunks and pmc.get('kernel', '') in KERNEL_OF[eng.stage_a]
+        from_profile = {'file': 'profiles/' + pmc_file, 'commit': pmc.get('commit'), 'traffic': pmc.get('hbm_bytes_per_launch'),
+                        'mfma_i8_busy': pmc.get('mfma_busy'), 'clock_mhz': pmc.get('clock_mhz'),
+                        'note': 'rocprofv3 --pmc passes of this workload (tools/pmc.sh), not measured by this run'} if pmc_ok else None
+        read_bps = 2.0 * ITEM[code]
         hbm = {'bound': 'hbm', 'kernel': KERNEL_OF[eng.stage_a],
                'achieved': round(achieved, 1) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-               'traffic': pmc.get('hbm_bytes_per_launch') if pmc_ok else None,
+               'traffic': from_profile['traffic'] if from_profile else None,
                'avg_kernel_ms': round(k_avg_ms, 4) if k_avg_ms else None, 'launches': k_n,
                'alg_bytes_per_sample': alg_bps,
-               # the whole step (chain + post + gaps) against the same bytes: what north_star's 50 % is asked of
-               'path_achieved': round(path_achieved, 1), 'path_frac': round(path_achieved / HBM_PEAK_GBS, 4)}
+               # the whole step (chain + post + gaps) against the same bytes: what north_star's 50 % is asked of; read_frac: the
+               # input bytes alone (its "HBM-read roofline")
+               'path_achieved': round(path_achieved, 1), 'path_frac': round(path_achieved / HBM_PEAK_GBS, 4),
+               'read_frac': round(read_bps * n_samples / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               'from_profile': from_profile}
         i8 = {'int8_pops': round(i8_ops / (k_avg_ms * 1e-3) / 1e15, 3) if (i8_ops and k_avg_ms) else None,
-              'int8_frac': round(i8_ops / (k_avg_ms * 1e-3) / 1e15 / I8_PEAK_POPS, 4) if (i8_ops and k_avg_ms) else None,
-              'mfma_i8_busy': pmc.get('mfma_busy') if pmc_ok else None, 'clock_mhz': pmc.get('clock_mhz') if pmc_ok else None}
+              'int8_frac': round(i8_ops / (k_avg_ms * 1e-3) / 1e15 / I8_PEAK_POPS, 4) if (i8_ops and k_avg_ms) else None}
         if rows == 1 or not i8['int8_pops']:
             roof = dict(hbm, **i8)
         else:
@@ -337,7 +376,7 @@ def main():
             roof = {'bound': 'mfma', 'kernel': KERNEL_OF[eng.stage_a], 'achieved': round(i8['int8_pops'] * 1e3, 1),
                     'peak': I8_PEAK_POPS * 1e3, 'unit': 'TFLOP/s', 'frac': i8['int8_frac'], 'traffic': None,
                     'avg_kernel_ms': hbm['avg_kernel_ms'], 'launches': k_n, 'ops': 'int8 multiply-adds x 2 (dense int8 matrix peak)',
-                    'hbm': {k: hbm[k] for k in ('achieved', 'frac', 'alg_bytes_per_sample', 'path_achieved', 'path_frac')}}
+                    'hbm': {k: hbm[k] for k in ('achieved', 'frac', 'alg_bytes_per_sample', 'path_achieved', 'path_frac', 'read_frac')}}
         line = {
             'metric': {'fm64': 'input MSamples/s IQ->FM demod, dec=64', 'fm64f': 'input MSamples/s IQ->FM demod, float32 IQ, dec=64', 'simo64': 'input MSamples/s 64-VFO --simo FM, dec=32',
                        'f32x256': 'input MSamples/s 256-VFO --simo FM, float32 IQ, dec=64'}[args.workload],
@@ -351,9 +390,9 @@ def main():
                                     f'center={CENTER} Hz{", --correct-iq" if args.correct_iq else ""}, {n_chunks} chunks x {N} samples per GPU per step, inputs resident in HBM')
                        if single else
                        (f'configs[{3 if code == "h" else 4}]: --simo {rows_total} VFO rows sharded {rows}/GPU, {FS // 1_000_000} MS/s synthetic {"int16" if code == "h" else "float32"} IQ, FM, dec={q}, '
-                        f'{n_chunks} chunks x {N} samples per step resident on rank 0, RCCL broadcast per step'),
+                        f'{n_chunks} chunks x {N} samples per step ' + ('resident on rank 0, RCCL broadcast per step' if args.feed == 'bcast' else 'resident as 1/N shards per rank, RCCL all-gather per step')),
                        'chunks_per_step_per_gpu': n_chunks, 'samples_per_chunk': N, 'rows_per_gpu': rows,
-                       'parallelism': f'chunk-sharded x{world}' if single else f'rows-sharded x{world} + bcast',
+                       'parallelism': f'chunk-sharded x{world}' if single else f'rows-sharded x{world} + {args.feed}',
                        'settle_steps': settle_steps + args.warmup},
             'step_ms': {'median': round(step_ms[len(step_ms) // 2], 4), 'min': round(step_ms[0], 4), 'max': round(step_ms[-1], 4),
                         'timed_region_s': round(elapsed, 3)},
@@ -363,6 +402,26 @@ def main():
                            'post_kernel': round(p_avg_ms, 4) if p_avg_ms else None},
             'stage_a': eng.stage_a,
         }
+        # the same workload in the reference's own arithmetic: stage A on the fp64 matrix cores (SDRTERM_STAGE_A=f64), same
+        # buffers, same process, a few steps
+        if not args.no_same_arithmetic and eng.stage_a != 'f64':
+            os.environ['SDRTERM_STAGE_A'] = 'f64'
+            try:
+                e64 = Engine(FS, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_rank, correct_iq=args.correct_iq)
+            finally:
+                del os.environ['SDRTERM_STAGE_A']
+            n64 = 4 if single else 2
+            e64.process_device(bufs[0].data_ptr(), n_chunks, out.data_ptr(), S)
+            torch.cuda.synchronize()
+            t64 = time.perf_counter()
+            for _ in range(n64):
+                e64.process_device(bufs[0].data_ptr(), n_chunks, out.data_ptr(), S)
+            torch.cuda.synchronize()
+            ms64 = (time.perf_counter() - t64) / n64 * 1e3
+            line['same_arithmetic'] = {'stage_a': e64.stage_a, 'dtype': 'f64', 'steps': n64, 'ms_per_step': round(ms64, 4),
+                                       'value': round(n_samples / (ms64 * 1e-3) / 1e6, 1), 'unit': 'MSamples/s per GPU',
+                                       'path_frac': round(alg_bps * n_samples / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            e64.close()
         if not args.no_cpu_baseline and world == 1:
             sample = (bufs[0] if single else src)[:min(n_samples, 2048 * N)].cpu().numpy().tobytes()
             line['cpu_baseline'] = cpu_baseline(sample, q, freqs_all, code=code, N=N, FS=FS)
@@ -370,9 +429,8 @@ def main():
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)
     if comm is not None:
+        barrier()
         comm.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -340,13 +340,21 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         // One iteration; HAVE_K = there is an item whose matrix-core phase runs now (false only in the three drain iterations).
         // With HAVE_K every global load and store below is issued unconditionally, so that the compiler can count them and
         // wait for exactly the k-step it needs (s_waitcnt vmcnt(N)) instead of draining the whole prefetch ring.
-        auto iteration = [&](auto hk, const int it) {
-            constexpr bool HAVE_K = decltype(hk)::value;
+        // FULL: the pipeline is full (3 <= it < cnt), every phase has its item: the steady-state copy of the iteration carries no
+        // branch on what exists (each cost three scalar instructions and cut the iteration into separate scheduling regions; this
+        // kernel is bound by the instructions it issues, scalar ones included: profiles/r03_experiments.txt)
+        auto iteration = [&](auto hk, auto fullc, const int it) {
+            constexpr bool HAVE_K = decltype(hk)::value, FULL = decltype(fullc)::value;
+            static_assert(HAVE_K || !FULL, "the steady state has a matrix-core phase");
             const int bQ = bcur == 0 ? 2 : bcur - 1, bP2 = bcur == 2 ? 0 : bcur + 1, bP3 = bcur;   // (it-1)%3, (it-2)%3, (it-3)%3
-            const bool have_q = it >= 1 && it - 1 < cnt, have_p2 = it >= 2 && it - 2 < cnt, have_p3 = it >= 3;
-            // diagnostic phase stamps of iteration 6 (a.stamps == nullptr in every production call)
+            const bool have_q = FULL || (it >= 1 && it - 1 < cnt), have_p2 = FULL || (it >= 2 && it - 2 < cnt), have_p3 = FULL || it >= 3;
+#ifdef SDRT_STAMPS
+            // diagnostic build (tools/stamps_wide.py): phase stamps of iteration 6
             unsigned long long *stp = (a.stamps && it == 6 && (int) bid * 2 < a.stamp_wgs && lane == 0) ? a.stamps + ((size_t) bid * 8 + wave) * 16 : nullptr;
 #define SDRT_STAMP(i) do { if (stp) stp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SDRT_STAMP(i) do { } while (0)
+#endif
             SDRT_STAMP(0);
             // small global loads first: everything issued later (the raw stream) is younger, so waiting for these never
             // waits for the prefetch ring
@@ -365,8 +373,6 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     e_im[sg] = rp[1];
                 }
             }
-            // outputs of item it-3 (the first three iterations store to item 0's place, which P3(0) rewrites in iteration 3)
-            double *yd = a.ydec + ((size_t) row * a.n_chunks + (size_t) chunk_of(have_p3 ? it - 3 : 0) * SEG) * (size_t) m * (a.pair_out ? 1 : 2);
             cd yb[TPW][OPL];
 #pragma unroll
             for (int j = 0; j < TPW; ++j)
@@ -595,8 +601,21 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     // the decimated samples leave as they are, or (pair_out: FM without a debug buffer) as the products
                     // y[2i] conj(y[2i+1]) the discriminator takes the angle of (demodulation.py:25-32): half the bytes written here
                     // and read by the demodulation stage.  Outputs g and g + 1 sit in lanes 16 apart: one permlane swap per dword;
-                    // one store instruction either way (lanes of odd g masked off for pairs)
+                    // one store instruction either way, and no lane masked off: for pairs the lanes of odd g form the same product
+                    // from the same operands as their partners and write it to the same place (a store under a branch costs the
+                    // exact vmcnt accounting of everything after it)
                     const bool pr = a.pair_out != 0;
+                    // outputs of item it-3 (the first three iterations store to item 0's place, which P3(0) rewrites in iteration 3).
+                    // The address is put together here, from scalars, where it is used: held from the top of the iteration it is
+                    // a 64-bit value the register allocator spills, and its reload waits with vmcnt(0) -- a drain of the raw-sample
+                    // prefetch ring in every iteration
+                    // (and it is the same in every lane: in scalar registers, the lanes add 32-bit byte offsets)
+                    const uint64_t ydv = (uint64_t) (a.ydec + ((size_t) row * a.n_chunks + (size_t) chunk_of(have_p3 ? it - 3 : 0) * SEG) * (size_t) m * (pr ? 1 : 2));
+                    // (an address built from integers must say that it is global memory, or the store becomes a flat one)
+                    typedef __attribute__((address_space(1))) char gchar;
+                    typedef double v2d_ __attribute__((ext_vector_type(2)));
+                    typedef __attribute__((address_space(1))) v2d_ gdouble2;
+                    gchar *yd = (gchar *) (((uint64_t) (unsigned) __builtin_amdgcn_readfirstlane((int) (ydv >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((int) ydv));
 #pragma unroll
                     for (int e = 0; e < OPL; ++e) {
                         const int k = (tile * SDRT_TB + nb) * NOUT + g + 4 * e;
@@ -605,10 +624,13 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         const v2u s1 = __builtin_amdgcn_permlane16_swap((unsigned) __double2hiint(own.re), (unsigned) __double2hiint(own.re), false, false);
                         const v2u s2 = __builtin_amdgcn_permlane16_swap((unsigned) __double2loint(own.im), (unsigned) __double2loint(own.im), false, false);
                         const v2u s3 = __builtin_amdgcn_permlane16_swap((unsigned) __double2hiint(own.im), (unsigned) __double2hiint(own.im), false, false);
-                        const cd nx = mk(__hiloint2double((int) s1[1], (int) s0[1]), __hiloint2double((int) s3[1], (int) s2[1]));     // even g: output g + 1
-                        const cd z = mk(fma(own.re, nx.re, own.im * nx.im), fma(own.im, nx.re, -(own.re * nx.im)));
+                        // the swap of x with itself leaves {row 0, row 0, row 2, row 2} in its first result and {row 1, row 1, row 3,
+                        // row 3} in its second: every lane of a row pair holds the even output in the one, the odd output in the other
+                        const cd za = mk(__hiloint2double((int) s1[0], (int) s0[0]), __hiloint2double((int) s3[0], (int) s2[0]));     // output k & ~1
+                        const cd zb = mk(__hiloint2double((int) s1[1], (int) s0[1]), __hiloint2double((int) s3[1], (int) s2[1]));     // output (k & ~1) + 1
+                        const cd z = mk(fma(za.re, zb.re, za.im * zb.im), fma(za.im, zb.re, -(za.re * zb.im)));
                         const cd o = pr ? z : own;
-                        if (!pr || (g & 1) == 0) *(double2 *) (yd + (pr ? (size_t) k : 2 * (size_t) k)) = make_double2(o.re, o.im);
+                        *(gdouble2 *) (yd + (unsigned) (pr ? 8 * (k & ~1) : 16 * k)) = (v2d_) {o.re, o.im};
                     }
                 }
                 if constexpr (HAVE_K && j == 0 && i == P3_0 + 5) {
@@ -1027,17 +1049,32 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             bcur = bcur == 2 ? 0 : bcur + 1;
         };
         // diagnostic: core-clock and 100 MHz real-time stamps around the steady-state iterations -> in-kernel clock
+#ifdef SDRT_STAMPS
         unsigned long long *clk = (a.stamps && (int) bid * 2 < a.stamp_wgs && lane == 0) ? a.stamps + ((size_t) bid * 8 + wave) * 16 : nullptr;
+#else
+        unsigned long long *clk = nullptr;
+#endif
         if (clk) { clk[10] = __builtin_amdgcn_s_memtime(); clk[11] = __builtin_amdgcn_s_memrealtime(); }
-        for (int it = 0; it < cnt; ++it) iteration(std::true_type{}, it);
+        for (int it = 0; it < cnt && it < 3; ++it) iteration(std::true_type{}, std::false_type{}, it);
+        for (int it = 3; it < cnt; ++it) iteration(std::true_type{}, std::true_type{}, it);
         if (clk) { clk[12] = __builtin_amdgcn_s_memtime(); clk[13] = __builtin_amdgcn_s_memrealtime(); clk[14] = (unsigned long long) cnt; }
-        for (int it = cnt; it < cnt + 3; ++it) iteration(std::false_type{}, it);
+        for (int it = cnt; it < cnt + 3; ++it) iteration(std::false_type{}, std::false_type{}, it);
     }
 }
 
-// The 8-bit encodings are instantiated in a second translation unit (kernels_i8w_b.hip includes this file with
-// SDRT_I8W_BYTES defined) so that the two halves compile in parallel.
+#ifdef SDRT_I8W_PROBE
+// tools/cc_i8w.sh: one instantiation alone (the headline one unless SDRT_I8W_PROBE_ARGS says otherwise), for a quick look at its code
+#ifndef SDRT_I8W_PROBE_ARGS
+#define SDRT_I8W_PROBE_ARGS SDRT_S16, 4, 8, SDRT_I8_DIGITS, 0, false
+#endif
+template __global__ void chain_i8w_kernel<SDRT_I8W_PROBE_ARGS>(DecimArgs);
+#else
+// The instantiations are spread over four translation units that compile in parallel: this file holds the signed 16-bit
+// encoding and the dispatch; kernels_i8w_b.hip / _c.hip / _d.hip include it with SDRT_I8W_BYTES / SDRT_I8W_U16 / SDRT_I8W_F32
+// defined for the 8-bit encodings, the unsigned 16-bit one and float32.
 hipError_t launch_chain_i8w_bytes(const DecimArgs &a, int nout, int nt, int dt, dim3 grid, size_t lds, hipStream_t s);
+hipError_t launch_chain_i8w_u16(const DecimArgs &a, int nout, int nt, dim3 grid, size_t lds, hipStream_t s);
+hipError_t launch_chain_i8w_f32(const DecimArgs &a, int nout, int nt, dim3 grid, size_t lds, hipStream_t s);
 
 template <int DT, int NOUT, int NTC, int IQ, bool RS>
 static hipError_t launch_i8w_q(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
@@ -1086,9 +1123,17 @@ static hipError_t launch_i8w_d(const DecimArgs &a, int nout, int nt, dim3 grid, 
     }
 }
 
-#ifdef SDRT_I8W_BYTES
+#if defined(SDRT_I8W_BYTES)
 hipError_t launch_chain_i8w_bytes(const DecimArgs &a, int nout, int nt, int dt, dim3 grid, size_t lds, hipStream_t s) {
     return dt == SDRT_S8 ? launch_i8w_d<SDRT_S8>(a, nout, nt, grid, lds, s) : launch_i8w_d<SDRT_U8>(a, nout, nt, grid, lds, s);
+}
+#elif defined(SDRT_I8W_U16)
+hipError_t launch_chain_i8w_u16(const DecimArgs &a, int nout, int nt, dim3 grid, size_t lds, hipStream_t s) {
+    return launch_i8w_d<SDRT_U16>(a, nout, nt, grid, lds, s);
+}
+#elif defined(SDRT_I8W_F32)
+hipError_t launch_chain_i8w_f32(const DecimArgs &a, int nout, int nt, dim3 grid, size_t lds, hipStream_t s) {
+    return launch_i8w_d<SDRT_F32>(a, nout, nt, grid, lds, s);
 }
 #else
 // permlane swap self-test: out[0][l] = swap32_add(x[l], y[l]), out[1][l] = swap16_add(x[l], y[l])
@@ -1130,8 +1175,8 @@ hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, 
     switch (dt) {
         case SDRT_S8: case SDRT_U8: return launch_chain_i8w_bytes(a, nout, nt, dt, grid, lds, s);     // kernels_i8w_b.hip
         case SDRT_S16: return launch_i8w_d<SDRT_S16>(a, nout, nt, grid, lds, s);
-        case SDRT_U16: return launch_i8w_d<SDRT_U16>(a, nout, nt, grid, lds, s);
-        case SDRT_F32: return launch_i8w_d<SDRT_F32>(a, nout, nt, grid, lds, s);
+        case SDRT_U16: return launch_chain_i8w_u16(a, nout, nt, grid, lds, s);        // kernels_i8w_c.hip
+        case SDRT_F32: return launch_chain_i8w_f32(a, nout, nt, grid, lds, s);        // kernels_i8w_d.hip
     }
     return hipErrorInvalidValue;
 }
@@ -1141,3 +1186,4 @@ hipError_t launch_swap_selftest(const double *x, const double *y, double *out, h
     return hipGetLastError();
 }
 #endif
+#endif  // SDRT_I8W_PROBE

@@ -140,6 +140,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 }  // namespace
 
+#ifndef SDRT_P8_BLOCKS_AHEAD
+#define SDRT_P8_BLOCKS_AHEAD 16
+#endif
 #define SDRT_P8_SO 136          // 16-byte slots of one item's exchange image (8 x 17, and = 8 mod 16)
 
 template <int WPB, bool PAIRS>
@@ -157,9 +160,8 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 8) void post_fft8_kernel(P
 
     const size_t ngroups = (a.items + IPW - 1) / IPW;
     for (size_t grp = (size_t) blockIdx.x * WPB + wave; grp < ngroups; grp += (size_t) gridDim.x * WPB) {
-        const size_t item = grp * IPW + o;
-        const bool live = item < a.items;
-        const size_t it = post_item(a, live ? item : a.items - 1);    // idle lane groups redo the last item and store nothing
+        // (lane groups beyond the last item redo it: the same values to the same places, no branch anywhere in the loop)
+        const size_t item = grp * IPW + o, it = post_item(a, item < a.items ? item : a.items - 1);
         // ---- pair angles: x[k] = a[2n] + i a[2n+1], n = l + 8 k (demodulation.py:25-32) ---------------------------------
         cd x[P];
         if constexpr (PAIRS) {
@@ -182,6 +184,13 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 8) void post_fft8_kernel(P
                           atan2_pi(d2.im * d3.re - d2.re * d3.im, d2.re * d3.re + d2.im * d3.im));
             }
         }
+        // The angles are half of the output samples (before the lowpass) and nothing else needs them after the first transform
+        // step: they wait in the item's own place in the output buffer (every lane re-reads what it wrote itself, in one go at
+        // the start of the lowpass; the final stores overwrite them while the lines are still in L2) instead of sitting in 64
+        // registers through the transforms -- that, not the arithmetic, is what the register allocator spilled for.
+        cd *stash = (cd *) (a.out + it * (size_t) M) + l;
+#pragma unroll
+        for (int k = 0; k < P; ++k) stash[LPI * k] = x[k];
         // ---- forward: 16 points in the lane, twiddle, exchange, 8 points ----------------------------------------------------
         cd Z[2][LPI];
         {
@@ -234,6 +243,10 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 8) void post_fft8_kernel(P
         }
         // ---- output samples 4n .. 4n+3 = a[2n], b[2n], a[2n+1], b[2n+1]; lowpass; store ------------------------------------------
         double *out = a.out + it * (size_t) M + 4 * l;
+        __builtin_amdgcn_sched_barrier(0);                         // (not before the last transform has let go of its registers)
+#pragma unroll
+        for (int k = 0; k < P; ++k) x[k] = stash[LPI * k];
+        __builtin_amdgcn_sched_barrier(0);
         // the constants every lane shares are fetched here, not before the loop: some forty doubles that would otherwise sit in
         // scalar registers through the transforms (and be spilled to vector lanes there)
         const Post8Tables *pu = a.p8tab;
@@ -287,10 +300,11 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 8) void post_fft8_kernel(P
             const double y1 = fma(g1.re, s.re, fma(-g1.im, s.im, fma(gr1, t, y01)));
             const double y2 = fma(g2.re, s.re, fma(-g2.im, s.im, fma(gr2, t, y02)));
             const double y3 = fma(g3.re, s.re, fma(-g3.im, s.im, fma(gr3, t, y03)));
-            if (live) {
-                *(double2 *) (out + 4 * LPI * n1) = make_double2(y0, y1);
-                *(double2 *) (out + 4 * LPI * n1 + 2) = make_double2(y2, y3);
-            }
+            *(double2 *) (out + 4 * LPI * n1) = make_double2(y0, y1);
+            *(double2 *) (out + 4 * LPI * n1 + 2) = make_double2(y2, y3);
+            // four blocks at a time: enough independent work for the pipeline, few enough intermediate values for the registers
+            // (left alone, the scheduler starts all sixteen blocks at once and spills)
+            if constexpr (n1 % SDRT_P8_BLOCKS_AHEAD == SDRT_P8_BLOCKS_AHEAD - 1) __builtin_amdgcn_sched_barrier(0);
         });
     }
 }

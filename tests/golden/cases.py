@@ -67,3 +67,7 @@ CASES = [
 ]
 
 BY_NAME = {c['name']: c for c in CASES}
+
+# the plots' FFT taps (make_golden.py: plot_taps): encoding, --normalize-input; one reader chunk each
+TAP_CASES = [('h', False), ('B', True), ('f', False)]
+TAP_FS, TAP_OFFSET, TAP_SEED = 1024000, 15700, 5

@@ -11,7 +11,9 @@ What is captured:
   * ``DspProcessor`` / ``VfoProcessor`` ``_processChunk`` outputs for consecutive chunks, plus the
     intermediate ``decimate`` output of the first chunk;
   * the filter coefficient tables scipy produced for those cases (cheby1 SOS, sosfilt_zi, ellip SOS);
-  * the 8-sample known-answer vectors of test/dsp/demodulation_test.py.
+  * the 8-sample known-answer vectors of test/dsp/demodulation_test.py;
+  * the arrays the plots draw (``amp`` of SpectrumAnalyzerPlot.update, ``image`` of WaterfallPlot.update) from the reference's
+    own update() bodies, with tests/golden/_shim/pyqtgraph standing in for the Qt windows.
 
 Inputs come from tests/golden/prng.py (integer PRNG), so only seeds and outputs are stored.
 ``numba`` is not installed here; tests/golden/_shim/numba is a pure-numpy stand-in for
@@ -33,7 +35,7 @@ import numpy as np  # noqa: E402
 from scipy import signal  # noqa: E402
 
 from tests.golden import prng  # noqa: E402
-from tests.golden.cases import CASES, READ_SIZE  # noqa: E402
+from tests.golden.cases import CASES, READ_SIZE, TAP_CASES, TAP_FS, TAP_OFFSET, TAP_SEED  # noqa: E402
 
 from dsp.dsp_processor import DspProcessor  # noqa: E402  (reference)
 from dsp.vfo_processor import VfoProcessor  # noqa: E402  (reference)
@@ -186,6 +188,44 @@ def known_answer():
     return {'kat_in': inp, 'kat_fm': fm, 'kat_am': am, 'kat_re': re, 'kat_im': im}
 
 
+def plot_taps():
+    """``amp`` of SpectrumAnalyzerPlot.update (plots/spectrum_analyzer_plot.py:74-88) and ``image`` of WaterfallPlot.update
+    (plots/waterfall_plot.py:90-100) for one reader chunk per encoding: the reference's own constructors and update() bodies,
+    with tests/golden/_shim/pyqtgraph standing in for the windows.  The chunk is what the reference's reader enqueues."""
+    from plots.spectrum_analyzer_plot import SpectrumAnalyzerPlot  # noqa: E402  (reference)
+    from plots.waterfall_plot import WaterfallPlot  # noqa: E402  (reference)
+    res = {}
+    for code, normalize in TAP_CASES:
+        case = dict(code=code, fs=TAP_FS, n_chunks=1, seed=TAP_SEED, amp=100 if code == 'B' else 3000, normalize=normalize)
+        (z,), _n = run_reader(case)
+
+        class _One:
+            def __init__(self):
+                self.items = [z.copy()]
+
+            def get(self):
+                return self.items.pop(0)
+
+            def close(self):
+                pass
+
+            def join_thread(self):
+                pass
+        spec = SpectrumAnalyzerPlot(isDead=_Flag(), fs=TAP_FS, buffer=_One(), center=TAP_OFFSET)
+        spec.update()
+        res[f'tap/{code}/amp'] = np.asarray(spec.amp)[0].copy()
+        res[f'tap/{code}/freq'] = np.asarray(spec.freq)[::1021].copy()
+        wf = WaterfallPlot(isDead=_Flag(), fs=TAP_FS, buffer=_One(), center=TAP_OFFSET)
+        wf.update()
+        # the image is (1024, n/128 + 1) doubles: every 8th column is kept (first, last and interior frames), all 1024 bins
+        img = np.asarray(wf.image)
+        res[f'tap/{code}/image_shape'] = np.array(img.shape)
+        res[f'tap/{code}/image_cols'] = np.arange(0, img.shape[1], 8)
+        res[f'tap/{code}/image'] = img[:, ::8].copy()
+        print('tap', code, res[f'tap/{code}/amp'].shape, img.shape)
+    return res
+
+
 def main():
     out = {}
     meta = {}
@@ -204,6 +244,8 @@ def main():
         meta[case['name']] = case
         print(case['name'], res['z'].shape, float(np.abs(res['z']).max()))
     out.update(known_answer())
+    if not only or 'taps' in only:
+        out.update(plot_taps())
     # coefficient tables for every q / (fs_dec, omega) in use + a few more, straight from scipy
     for q in (4, 8, 16, 32, 64, 128, 256):
         sos = signal.cheby1(8, 0.05, 0.8 / q, output='sos')

@@ -453,6 +453,18 @@ def test_plot_fft_taps_match_the_reference_plots_arithmetic(code, normalize):
     # the reference reader's complex arrays go the same way
     got2 = SpectrumTap(fs, center=off)(z.astype(np.complex128))
     assert np.abs(10.0 ** (got2 / 2) - ea).max() <= 1e-9 * ea.max()
+    # ... and against what the reference's own plots computed in update() (tests/golden/make_golden.py: plot_taps; float32
+    # records: the reference transforms its complex64 chunk in single precision)
+    from tests.util import load_golden
+    from tests.golden.cases import TAP_FS, TAP_OFFSET, TAP_SEED
+    assert (fs, off, 5) == (TAP_FS, TAP_OFFSET, TAP_SEED)
+    gz, _ = load_golden()
+    tol = 2e-6 if code == 'f' else 1e-9
+    ra = 10.0 ** (gz[f'tap/{code}/amp'].astype(np.float64) / 2)
+    assert np.abs(ga - ra).max() <= tol * ra.max()
+    cols = gz[f'tap/{code}/image_cols']
+    rimg = 10.0 ** (gz[f'tap/{code}/image'].astype(np.float64) / 10)
+    assert np.abs(gi[:, cols] - rimg).max() <= tol * rimg.max()
 
 
 def samples_per_chunk_of(code):

@@ -287,3 +287,28 @@ def test_vfo_processor_row_modes_extension():
             VfoProcessor(DEFAULT_FS, vfoHost='127.0.0.1:1', vfos='100,200,300', dec=4, omegaOut=250, rowModes=bad)
     q = pickle.loads(pickle.dumps(p))
     assert q.rowModes == p.rowModes
+
+
+def test_bench_launcher_dry_run():
+    """bench.py --gpus N started without a launcher spawns the ranks itself; --dry-run prints what it would start: one rank per
+    GPU, the variables torch.distributed.run would export, loopback rendezvous, dmabuf IPC, rank 0's output relayed."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '7', '--workload', 'simo64', '--feed',
+                          'allgather', '--dry-run'], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    ranks = [json.loads(line) for line in out.stdout.strip().splitlines()]
+    assert [r['rank'] for r in ranks] == [0, 1, 2, 3]
+    ports = {r['env']['MASTER_PORT'] for r in ranks}
+    assert len(ports) == 1 and 1024 < int(ports.pop()) < 65536
+    for r in ranks:
+        e = r['env']
+        assert (e['RANK'], e['LOCAL_RANK'], e['WORLD_SIZE']) == (str(r['rank']), str(r['rank']), '4')
+        assert e['MASTER_ADDR'] == '127.0.0.1' and e['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+        assert r['cmd'][1].endswith('bench.py') and '--dry-run' not in r['cmd'] and r['cmd'][2:] == ['--gpus', '4', '--steps', '7', '--workload', 'simo64', '--feed', 'allgather']
+        assert r['stdout'] == ('relayed' if r['rank'] == 0 else 'discarded')
+    sys.path.insert(0, ROOT)
+    import bench
+    envs = bench.rank_environments(2, 12345, base={'HSA_ENABLE_IPC_MODE_LEGACY': '1', 'X': 'y'})
+    assert envs[1]['RANK'] == '1' and envs[1]['X'] == 'y' and envs[1]['HSA_ENABLE_IPC_MODE_LEGACY'] == '1'

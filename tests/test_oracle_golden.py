@@ -97,3 +97,29 @@ def test_generate_domain_table():
         xmin, diff = ref_chain.generate_domain(c)
         assert xmin == a and diff == 1 / (b - a)
     assert ref_chain.generate_domain('f') is None
+
+
+@pytest.mark.parametrize('code,normalize', [('h', False), ('B', True), ('f', False)])
+def test_plot_tap_restatements_match_the_reference_plots(code, normalize, golden):
+    """ref_chain.spectrum_tap / waterfall_tap against the arrays the reference's own plots computed in update()
+    (plots/spectrum_analyzer_plot.py:74-88, plots/waterfall_plot.py:90-100; captured by make_golden.py with a pyqtgraph stand-in).
+    Compared as amplitudes relative to the largest bin (the plots take logarithms; empty bins are rounding noise).  float32
+    records: the reference's chunk is complex64 and scipy transforms it in single precision."""
+    from tests.golden import prng
+    from tests.golden.cases import TAP_FS, TAP_OFFSET, TAP_SEED
+    z, _ = golden
+    n = samples_per_chunk(code)
+    raw = prng.raw_bytes(code, n, seed=TAP_SEED, amp=100 if code == 'B' else 3000)
+    x = ref_chain.unpack(raw, code, False)
+    if normalize:
+        x = ref_chain.normalize(x, code)
+    tol = 2e-6 if code == 'f' else 1e-10
+    amp = z[f'tap/{code}/amp']
+    mine = ref_chain.spectrum_tap(x, TAP_FS, TAP_OFFSET)
+    ea, ma = 10.0 ** (amp.astype(np.float64) / 2), 10.0 ** (mine / 2)
+    assert mine.shape == amp.shape and np.abs(ma - ea).max() <= tol * ea.max()
+    img, cols = z[f'tap/{code}/image'], z[f'tap/{code}/image_cols']
+    full = ref_chain.waterfall_tap(x, TAP_FS, TAP_OFFSET)
+    assert tuple(z[f'tap/{code}/image_shape']) == full.shape == (1024, n // 128 + 1)
+    ei, mi = 10.0 ** (img.astype(np.float64) / 10), 10.0 ** (full[:, cols] / 10)
+    assert np.abs(mi - ei).max() <= tol * ei.max()
