@@ -228,7 +228,8 @@ def main():
             per = n_samples // world
             src = torch.stack([src[b * n_samples + rank * per:b * n_samples + (rank + 1) * per] for b in range(2)]).contiguous()
         bufs = [torch.empty((n_samples, 2), dtype=torch.int16 if code == 'h' else torch.float32, device=device) for _ in range(2)]
-    eng = Engine(FS, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_rank, correct_iq=args.correct_iq)
+    eng = Engine(FS, q, "fm", code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_rank, correct_iq=args.correct_iq,
+                 reserve_chunks=n_chunks)         # no allocation inside the timed calls
     rows = len(freqs)
     out = torch.empty((rows, n_chunks * eng.m), dtype=torch.float64, device=device)
     lib = nat.lib()

@@ -109,6 +109,14 @@ int sdrt_process_device(sdrt_ctx *ctx, const void *raw_dev, size_t n_chunks, dou
 int sdrt_process_host(sdrt_ctx *ctx, const void *raw_host, size_t n_chunks, double *out_host);
 
 /*
+ * Everything a call with up to max_chunks chunks needs in device scratch (the decimated samples between the two stages, the
+ * IQ prefix tables, the scratch of sdrt_iq_range_device, the chunk pair of half-size chunks): allocated here, so that no
+ * sdrt_process_* / sdrt_iq_range_device call up to that size allocates.  Without it the scratch grows on the first larger batch
+ * (the reference allocates its x / y / z buffers on the first chunk as well, dsp_processor.py:171-178) and never shrinks.
+ */
+int sdrt_reserve(sdrt_ctx *ctx, size_t max_chunks);
+
+/*
  * Host buffers, batches in flight: sdrt_submit_host starts copy-in, kernels and copy-out of one batch and returns a ticket;
  * sdrt_wait(ticket) returns when that batch's `out_host` is filled.  Up to three batches are in flight (the copy-in of
  * batch k+1 beside the kernels of batch k and the copy-out of batch k-1); a fourth submit first completes the oldest.
@@ -233,6 +241,10 @@ int sdrt_spectrum_host(int dtype, int swap_endianness, const void *raw_host, int
 int sdrt_stft_host(int dtype, int swap_endianness, const void *raw_host, int n_samples, int n_chunks, double shift_hz, double fs,
                    int normalize, double norm_xmin, double norm_inv_range, int nperseg, int hop, int mfft, const double *window,
                    double *out_host);
+
+/* The tap entry points keep their device buffers from call to call (per calling thread; the plots transform a chunk per frame):
+ * this frees them. */
+int sdrt_taps_release(void);
 
 /* Diagnostic: one sdrt_process_device call in which the first n_wgs workgroups record s_memtime at their phase
  * boundaries; stamps_host receives n_wgs*4*16 uint64 ([workgroup][wave][16]).  Not for production use. */

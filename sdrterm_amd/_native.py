@@ -31,7 +31,7 @@ EXPORTS = (
     'sdrt_comm_unique_id', 'sdrt_comm_init', 'sdrt_comm_bcast', 'sdrt_comm_allgather', 'sdrt_comm_world', 'sdrt_comm_rank',
     'sdrt_comm_destroy', 'sdrt_submit_host', 'sdrt_wait', 'sdrt_spectrum_host', 'sdrt_stft_host', 'sdrt_iq_range_device',
     'sdrt_event_create', 'sdrt_event_destroy', 'sdrt_event_record', 'sdrt_stream_wait_event', 'sdrt_event_query',
-    'sdrt_event_synchronize',
+    'sdrt_event_synchronize', 'sdrt_reserve', 'sdrt_taps_release',
 )
 
 
@@ -146,6 +146,7 @@ def lib():
     l.sdrt_memcpy_h2d_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     l.sdrt_memcpy_d2h_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     l.sdrt_stream_wait_stream.argtypes = [C.c_void_p, C.c_void_p]
+    l.sdrt_reserve.argtypes = [C.c_void_p, C.c_size_t]
     l.sdrt_event_create.argtypes = [C.POINTER(C.c_void_p)]
     l.sdrt_event_destroy.argtypes = [C.c_void_p]
     l.sdrt_event_record.argtypes = [C.c_void_p, C.c_void_p]

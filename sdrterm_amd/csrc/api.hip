@@ -101,6 +101,10 @@ struct sdrt_ctx {
     double *d_nco_tile8 = nullptr, *d_nco_phase8 = nullptr;
     double *d_ybias = nullptr;
     double *d_wsum = nullptr;
+    bool f32_pre = false;             // float32 with several rows on the wide kernel: the records are sliced once per chunk, not per row
+    void *d_pre = nullptr;            //   [chunks][n][2] slices in place of the floats (launch_f32_preslice)
+    int *d_pre_exp = nullptr;         //   [chunks][4] tile exponents
+    size_t pre_cap = 0;
     void *d_pair_raw = nullptr;       // wide kernel, chunks of four tiles: a single chunk doubled into a pair
     double *d_pair_y = nullptr;
     signed char *d_w8iq = nullptr;    // wide kernel with IQ correction: packed offset rows, their constants, the offset response R
@@ -114,6 +118,8 @@ struct sdrt_ctx {
     double *d_iq_pow = nullptr;       // [n/GS + 1]
     double *d_iq_group = nullptr, *d_iq_agg = nullptr, *d_iq_chunk = nullptr;
     size_t iq_cap_chunks = 0;
+    double *d_iq_range = nullptr;     // scratch of sdrt_iq_range_device: [n] aggregates, [n + 1] offsets, [1] state
+    size_t iq_range_cap = 0;
     double iq_pow_e = 1.0, iq_pow_n = 1.0;
     unsigned long long *stamps_dev = nullptr;   // diagnostic only (sdrt_debug_stamps)
     int stamp_wgs = 0;
@@ -604,6 +610,10 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         if (rc == SDRT_OK && !seq && !c->use_i8w && want_i8 && !c->iq && want_i8_fallback_t(L, cfg->dtype, n, m))
             rc = setup_i8t(c, cfg, scale_tables);
         c->use_i8 = c->use_i8w || c->use_i8t;
+        // float32 on the wide kernel with several rows: every row of a chunk would slice the same records again (the larger part
+        // of that form's vector work); from four rows up one pass slices them once (diagnostics: SDRTERM_F32_PRE=0 / 1)
+        c->f32_pre = c->use_i8w && cfg->dtype == SDRT_F32 && c->rows >= 4;
+        if (const char *e = getenv("SDRTERM_F32_PRE")) c->f32_pre = c->use_i8w && cfg->dtype == SDRT_F32 && atoi(e) != 0;
     }
     if (rc == SDRT_OK && c->use_i8) rc = setup_ybias(c, cfg);
     if (rc != SDRT_OK) {
@@ -645,6 +655,8 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_nco_phase8);
     (void) hipFree(c->d_ybias);
     (void) hipFree(c->d_wsum);
+    (void) hipFree(c->d_pre);
+    (void) hipFree(c->d_pre_exp);
     (void) hipFree(c->d_pair_raw);
     (void) hipFree(c->d_pair_y);
     (void) hipFree(c->d_w8iq);
@@ -655,6 +667,7 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_iq_group);
     (void) hipFree(c->d_iq_agg);
     (void) hipFree(c->d_iq_chunk);
+    (void) hipFree(c->d_iq_range);
     for (auto &sl : c->hs) {
         (void) hipFree(sl.d_raw);
         (void) hipFree(sl.d_out);
@@ -714,6 +727,55 @@ int ensure_ybuf(sdrt_ctx *c, size_t n_chunks) {
     return SDRT_OK;
 }
 
+// the IQ prefix tables of a batch (grow-only, like the scratch above)
+int ensure_iqbufs(sdrt_ctx *c, size_t n_chunks) {
+    if (!c->iq || n_chunks <= c->iq_cap_chunks) return SDRT_OK;
+    (void) hipFree(c->d_iq_group);
+    (void) hipFree(c->d_iq_agg);
+    (void) hipFree(c->d_iq_chunk);
+    c->d_iq_group = c->d_iq_agg = c->d_iq_chunk = nullptr;
+    c->iq_cap_chunks = 0;
+    if (!(c->use_i8w && c->iq_fused))
+        HIP_TRY(hipMalloc((void **) &c->d_iq_group, n_chunks * (size_t) (c->cfg.n_samples / c->iq_gs) * 2 * sizeof(double)));
+    HIP_TRY(hipMalloc((void **) &c->d_iq_agg, n_chunks * 2 * sizeof(double)));
+    HIP_TRY(hipMalloc((void **) &c->d_iq_chunk, (n_chunks + 1) * 2 * sizeof(double)));
+    c->iq_cap_chunks = n_chunks;
+    return SDRT_OK;
+}
+
+int ensure_iqrange(sdrt_ctx *c, size_t n_chunks) {
+    if (n_chunks <= c->iq_range_cap) return SDRT_OK;
+    (void) hipFree(c->d_iq_range);
+    c->d_iq_range = nullptr;
+    c->iq_range_cap = 0;
+    HIP_TRY(hipMalloc((void **) &c->d_iq_range, (2 * n_chunks + 2) * 2 * sizeof(double)));
+    c->iq_range_cap = n_chunks;
+    return SDRT_OK;
+}
+
+// float32, several rows: the pre-sliced copy of a batch
+int ensure_prebufs(sdrt_ctx *c, size_t n_chunks) {
+    if (!c->f32_pre || n_chunks <= c->pre_cap) return SDRT_OK;
+    (void) hipFree(c->d_pre);
+    (void) hipFree(c->d_pre_exp);
+    c->d_pre = nullptr;
+    c->d_pre_exp = nullptr;
+    c->pre_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_pre, n_chunks * (size_t) c->cfg.n_samples * 2 * sizeof(float)));
+    HIP_TRY(hipMalloc((void **) &c->d_pre_exp, n_chunks * 4 * sizeof(int)));
+    c->pre_cap = n_chunks;
+    return SDRT_OK;
+}
+
+// the scratch pair of the wide kernel's four-tile chunks (a single chunk is doubled into a pair)
+int ensure_pairbufs(sdrt_ctx *c) {
+    if (c->d_pair_raw || !(c->use_i8w && c->cfg.n_samples == 4 * SDRT_TB * SDRT_WIDE_LC)) return SDRT_OK;
+    const size_t cb = (size_t) c->cfg.n_samples * 2 * kItemSize[c->cfg.dtype];
+    HIP_TRY(hipMalloc(&c->d_pair_raw, 2 * cb));
+    HIP_TRY(hipMalloc((void **) &c->d_pair_y, (size_t) c->rows * 2 * (size_t) c->m * 2 * sizeof(double)));
+    return SDRT_OK;
+}
+
 // unpack .. decimate (feedBuffers' per-sample steps, shiftFreq, decimate: read_file.py:100-103, dsp_processor.py:144-147)
 // fix_later: the share of the IQ offset at each chunk's start (wide-column kernel, fused form) is subtracted by the post
 // kernel while it loads the decimated samples (enqueue_post), not by a pass of its own
@@ -744,18 +806,8 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
     memset(&iq_after, 0, sizeof(iq_after));
     if (c->iq) {
         const int gs = c->iq_gs;
-        if (n_chunks > c->iq_cap_chunks) {
-            (void) hipFree(c->d_iq_group);
-            (void) hipFree(c->d_iq_agg);
-            (void) hipFree(c->d_iq_chunk);
-            c->d_iq_group = c->d_iq_agg = c->d_iq_chunk = nullptr;
-            c->iq_cap_chunks = 0;
-            if (!(c->use_i8w && c->iq_fused))
-                HIP_TRY(hipMalloc((void **) &c->d_iq_group, n_chunks * (size_t) (c->cfg.n_samples / gs) * 2 * sizeof(double)));
-            HIP_TRY(hipMalloc((void **) &c->d_iq_agg, n_chunks * 2 * sizeof(double)));
-            HIP_TRY(hipMalloc((void **) &c->d_iq_chunk, (n_chunks + 1) * 2 * sizeof(double)));
-            c->iq_cap_chunks = n_chunks;
-        }
+        int rcq = ensure_iqbufs(c, n_chunks);
+        if (rcq != SDRT_OK) return rcq;
         IqArgs ia;
         ia.raw = raw_dev;
         ia.group_off = c->d_iq_group;
@@ -803,6 +855,8 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
     da.c_im = c->x_offset;
     da.iq_gs = c->iq_gs;
     da.rs = c->use_i8w && c->wide_rs;
+    da.raw_orig = nullptr;
+    da.f32_exp = nullptr;
     da.sched = c->sched;
     if (c->use_i8) {
         da.tab = c->d_tab8;
@@ -819,10 +873,8 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
             // same twice); a single chunk is doubled into a scratch pair
             const size_t cb = (size_t) c->cfg.n_samples * 2 * kItemSize[c->cfg.dtype], yb = (size_t) c->m * (pair_out ? 1 : 2);
             if (n_chunks == 1) {
-                if (!c->d_pair_raw) {
-                    HIP_TRY(hipMalloc(&c->d_pair_raw, 2 * cb));
-                    HIP_TRY(hipMalloc((void **) &c->d_pair_y, (size_t) c->rows * 2 * (size_t) c->m * 2 * sizeof(double)));
-                }
+                int rcp = ensure_pairbufs(c);
+                if (rcp != SDRT_OK) return rcp;
                 HIP_TRY(hipMemcpyAsync(c->d_pair_raw, raw_dev, cb, hipMemcpyDeviceToDevice, s));
                 HIP_TRY(hipMemcpyAsync((char *) c->d_pair_raw + cb, raw_dev, cb, hipMemcpyDeviceToDevice, s));
                 DecimArgs d2 = da;
@@ -833,11 +885,20 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
                 HIP_TRY(hipMemcpy2DAsync(ybuf, yb * sizeof(double), c->d_pair_y, 2 * yb * sizeof(double), yb * sizeof(double), (size_t) c->rows,
                                          hipMemcpyDeviceToDevice, s));
             } else {
+                if (c->f32_pre) {
+                    int rcp = ensure_prebufs(c, n_chunks);
+                    if (rcp != SDRT_OK) return rcp;
+                    HIP_TRY(launch_f32_preslice(raw_dev, c->d_pre, c->d_pre_exp, n_chunks * 4, da.swap, s));
+                    da.raw = c->d_pre;
+                    da.raw_orig = raw_dev;
+                    da.f32_exp = c->d_pre_exp;
+                }
                 da.n_count = n_chunks & ~(size_t) 1;
                 HIP_TRY(launch_chain_i8w(da, c->cfg.decimation, c->cfg.dtype, da.n_count, n_cus, s));
                 if (n_chunks & 1) {
                     DecimArgs d2 = da;
-                    d2.raw = (const char *) raw_dev + (n_chunks - 2) * cb;
+                    d2.raw = (const char *) da.raw + (n_chunks - 2) * cb;
+                    if (da.f32_exp) { d2.raw_orig = (const char *) raw_dev + (n_chunks - 2) * cb; d2.f32_exp = da.f32_exp + (n_chunks - 2) * 4; }
                     d2.ydec = ybuf + (n_chunks - 2) * yb;
                     d2.n_count = 2;
                     HIP_TRY(launch_chain_i8w(d2, c->cfg.decimation, c->cfg.dtype, 2, n_cus, s));
@@ -957,6 +1018,18 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     rc = enqueue_chain(c, raw_dev, n_chunks, ybuf, s, c->n_cus, later, pairs);
     if (rc != SDRT_OK) return rc;
     return enqueue_post(c, ybuf, n_chunks, out_dev, s, later, pairs);
+}
+
+int sdrt_reserve(sdrt_ctx *c, size_t max_chunks) {
+    if (!c) return fail(SDRT_EINVAL, "null context");
+    if (max_chunks == 0) return SDRT_OK;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    int rc = ensure_ybuf(c, max_chunks);
+    if (rc == SDRT_OK) rc = ensure_iqbufs(c, max_chunks);
+    if (rc == SDRT_OK && c->iq) rc = ensure_iqrange(c, max_chunks);
+    if (rc == SDRT_OK) rc = ensure_pairbufs(c);
+    if (rc == SDRT_OK) rc = ensure_prebufs(c, max_chunks);
+    return rc;
 }
 
 int sdrt_process_device(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *out_dev, void *stream) {
@@ -1091,8 +1164,9 @@ int sdrt_iq_range_device(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, doub
     double v[2] = {0.0, 0.0};
     if (n_chunks) {
         // chunk aggregates from a zero start (no group table), chained from a zero state: the end value is b
-        double *d_tmp = nullptr;                               // [n_chunks] aggregates, [n_chunks + 1] offsets, [1] state
-        HIP_TRY(hipMalloc((void **) &d_tmp, (2 * n_chunks + 2) * 2 * sizeof(double)));
+        int rcr = ensure_iqrange(c, n_chunks);                 // [n_chunks] aggregates, [n_chunks + 1] offsets, [1] state
+        if (rcr != SDRT_OK) return rcr;
+        double *d_tmp = c->d_iq_range;
         IqArgs ia;
         memset(&ia, 0, sizeof(ia));
         ia.raw = raw_dev;
@@ -1115,7 +1189,6 @@ int sdrt_iq_range_device(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, doub
         if (e == hipSuccess) e = launch_iq_scan(ia, s);
         if (e == hipSuccess) e = hipMemcpyAsync(v, ia.state, sizeof(v), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        (void) hipFree(d_tmp);
         if (e != hipSuccess) return fail(SDRT_EHIP, "offset range kernels failed: %s", hipGetErrorString(e));
     }
     if (a) *a = exp((double) n_chunks * (double) c->cfg.n_samples * log1p(-c->cfg.iq_inductance));
@@ -1281,15 +1354,33 @@ int sdrt_demodulate_host(int mode, const double *y_host, int rows, int m, double
 
 namespace {
 
-// device buffers of one tap call, freed on every path
-struct TapBufs {
-    void *raw = nullptr;
-    double *u = nullptr, *scratch = nullptr, *out = nullptr, *tw = nullptr, *tile = nullptr, *phase = nullptr, *win = nullptr;
-    ~TapBufs() {
-        (void) hipFree(raw); (void) hipFree(u); (void) hipFree(scratch); (void) hipFree(out);
-        (void) hipFree(tw); (void) hipFree(tile); (void) hipFree(phase); (void) hipFree(win);
+// device buffers of the tap entry points: kept from call to call and only ever grown (the plots call once per frame,
+// plots/abstract_plot.py: every 17 ms), per calling thread and device; sdrt_taps_release frees them
+struct TapSlot {
+    void *p = nullptr;
+    size_t cap = 0;
+    int need(size_t bytes) {
+        if (bytes <= cap) return SDRT_OK;
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        cap = 0;
+        HIP_TRY(hipMalloc(&p, bytes));
+        cap = bytes;
+        return SDRT_OK;
     }
+    int put(const void *src, size_t bytes) {
+        int rc = need(bytes);
+        if (rc != SDRT_OK) return rc;
+        HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        return SDRT_OK;
+    }
+    void drop() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
 };
+struct TapBufs {
+    TapSlot raw, u, scratch, out, tw, tile, phase, win;
+    int dev = -1;
+};
+thread_local TapBufs g_taps;
 
 int tap_common(int dtype, int swap, const void *raw_host, int n, int chunks, double shift_hz, double fs, int normalize, double norm_xmin,
                double norm_inv_range, TapBufs &b, TapArgs &ta) {
@@ -1298,12 +1389,18 @@ int tap_common(int dtype, int swap, const void *raw_host, int n, int chunks, dou
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(SDRT_ENODEVICE, "no HIP device available");
     const size_t in_bytes = (size_t) chunks * n * 2 * kItemSize[dtype], cbytes = (size_t) chunks * n * 2 * sizeof(double);
-    HIP_TRY(hipMalloc(&b.raw, in_bytes));
-    HIP_TRY(hipMalloc((void **) &b.u, cbytes));
-    HIP_TRY(hipMemcpy(b.raw, raw_host, in_bytes, hipMemcpyHostToDevice));
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (b.dev != dev) {                     // buffers belong to the device they were allocated on
+        for (TapSlot *t : {&b.raw, &b.u, &b.scratch, &b.out, &b.tw, &b.tile, &b.phase, &b.win}) t->drop();
+        b.dev = dev;
+    }
+    int rc0 = b.raw.put(raw_host, in_bytes);
+    if (rc0 == SDRT_OK) rc0 = b.u.need(cbytes);
+    if (rc0 != SDRT_OK) return rc0;
     memset(&ta, 0, sizeof(ta));
-    ta.raw = b.raw;
-    ta.u = b.u;
+    ta.raw = b.raw.p;
+    ta.u = (double *) b.u.p;
     ta.chunks = (size_t) chunks;
     ta.n = n;
     ta.swap = swap && kItemSize[dtype] > 1;
@@ -1315,11 +1412,11 @@ int tap_common(int dtype, int swap, const void *raw_host, int n, int chunks, dou
     if (shift_hz != 0.0) {
         std::vector<double> tile(64 * 2), phase((size_t) (n / 64) * 2);
         sdrt_build_nco(shift_hz, fs, 64, n / 64, tile.data(), phase.data());
-        int rc = upload(&b.tile, tile.data(), tile.size() * sizeof(double));
-        if (rc == SDRT_OK) rc = upload(&b.phase, phase.data(), phase.size() * sizeof(double));
+        int rc = b.tile.put(tile.data(), tile.size() * sizeof(double));
+        if (rc == SDRT_OK) rc = b.phase.put(phase.data(), phase.size() * sizeof(double));
         if (rc != SDRT_OK) return rc;
-        ta.nco_tile = b.tile;
-        ta.nco_phase = b.phase;
+        ta.nco_tile = (const double *) b.tile.p;
+        ta.nco_phase = (const double *) b.phase.p;
     }
     HIP_TRY(launch_tap_decode(ta, dtype, nullptr));
     return SDRT_OK;
@@ -1328,7 +1425,7 @@ int tap_common(int dtype, int swap, const void *raw_host, int n, int chunks, dou
 int tap_twiddles(int N, TapBufs &b) {
     std::vector<double> tw((size_t) N * 2), unused((size_t) N * 2);
     sdrt_build_fft_resample(N, tw.data(), unused.data());
-    return upload(&b.tw, tw.data(), tw.size() * sizeof(double));
+    return b.tw.put(tw.data(), tw.size() * sizeof(double));
 }
 
 }  // namespace
@@ -1336,20 +1433,20 @@ int tap_twiddles(int N, TapBufs &b) {
 int sdrt_spectrum_host(int dtype, int swap_endianness, const void *raw_host, int n_samples, int n_chunks, double shift_hz, double fs,
                        int normalize, double norm_xmin, double norm_inv_range, double *out_host) {
     if (!out_host) return fail(SDRT_EINVAL, "null buffer");
-    TapBufs b;
+    TapBufs &b = g_taps;
     TapArgs ta;
     int rc = tap_common(dtype, swap_endianness, raw_host, n_samples, n_chunks, shift_hz, fs, normalize, norm_xmin, norm_inv_range, b, ta);
     if (rc != SDRT_OK) return rc;
     const size_t cbytes = (size_t) n_chunks * n_samples * 2 * sizeof(double), obytes = (size_t) n_chunks * n_samples * sizeof(double);
-    HIP_TRY(hipMalloc((void **) &b.scratch, cbytes));
-    HIP_TRY(hipMalloc((void **) &b.out, obytes));
-    rc = tap_twiddles(n_samples, b);
+    rc = b.scratch.need(cbytes);
+    if (rc == SDRT_OK) rc = b.out.need(obytes);
+    if (rc == SDRT_OK) rc = tap_twiddles(n_samples, b);
     if (rc != SDRT_OK) return rc;
-    ta.scratch = b.scratch;
-    ta.out = b.out;
-    ta.tw = b.tw;
+    ta.scratch = (double *) b.scratch.p;
+    ta.out = (double *) b.out.p;
+    ta.tw = (const double *) b.tw.p;
     HIP_TRY(launch_tap_fft(ta, nullptr));
-    HIP_TRY(hipMemcpy(out_host, b.out, obytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_host, b.out.p, obytes, hipMemcpyDeviceToHost));
     return SDRT_OK;
 }
 
@@ -1359,22 +1456,29 @@ int sdrt_stft_host(int dtype, int swap_endianness, const void *raw_host, int n_s
     if (!out_host || !window) return fail(SDRT_EINVAL, "null buffer");
     if (mfft != 1024 || nperseg < 2 || nperseg > 256 || hop < 1 || n_samples % hop)
         return fail(SDRT_EINVAL, "supported: mfft 1024, nperseg <= 256, hop dividing the chunk (the waterfall plot's 256 / 128 / 1024)");
-    TapBufs b;
+    TapBufs &b = g_taps;
     TapArgs ta;
     int rc = tap_common(dtype, swap_endianness, raw_host, n_samples, n_chunks, shift_hz, fs, normalize, norm_xmin, norm_inv_range, b, ta);
     if (rc != SDRT_OK) return rc;
     const size_t obytes = (size_t) n_chunks * mfft * (size_t) (n_samples / hop + 1) * sizeof(double);
-    HIP_TRY(hipMalloc((void **) &b.out, obytes));
-    rc = tap_twiddles(mfft, b);
-    if (rc == SDRT_OK) rc = upload(&b.win, window, (size_t) nperseg * sizeof(double));
+    rc = b.out.need(obytes);
+    if (rc == SDRT_OK) rc = tap_twiddles(mfft, b);
+    if (rc == SDRT_OK) rc = b.win.put(window, (size_t) nperseg * sizeof(double));
     if (rc != SDRT_OK) return rc;
-    ta.out = b.out;
-    ta.tw = b.tw;
-    ta.window = b.win;
+    ta.out = (double *) b.out.p;
+    ta.tw = (const double *) b.tw.p;
+    ta.window = (const double *) b.win.p;
     ta.nperseg = nperseg;
     ta.hop = hop;
     HIP_TRY(launch_tap_stft(ta, nullptr));
-    HIP_TRY(hipMemcpy(out_host, b.out, obytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_host, b.out.p, obytes, hipMemcpyDeviceToHost));
+    return SDRT_OK;
+}
+
+int sdrt_taps_release(void) {
+    TapBufs &b = g_taps;
+    for (TapSlot *t : {&b.raw, &b.u, &b.scratch, &b.out, &b.tw, &b.tile, &b.phase, &b.win}) t->drop();
+    b.dev = -1;
     return SDRT_OK;
 }
 

@@ -48,6 +48,8 @@ struct DecimArgs {
     const double *iq_consts;    //   IQ: [SDRT_IQROW_CONSTS]
     double iq_combine;          //   IQ: combine factor of the offset rows
     double *iq_chunk_agg;       //   IQ out: [chunk][2] offset at the chunk's end when it starts from zero
+    const void *raw_orig;       //   float32, pre-sliced input (f32_exp != NULL): the records themselves, for the edge operators
+    const int *f32_exp;         //   float32, pre-sliced input: [chunk][4] tile exponents; raw then holds the slices (launch_f32_preslice)
     int sched;                  //   diagnostic builds only (-DSDRT_SCHED_EXP): wave priority assignment, SDRTERM_SCHED
     int rs;                     //   real-stream form (no shift, no IQ correction): w8 / w8mid hold sdrt_build_i8_weights_wide_rs planes
 };
@@ -141,6 +143,8 @@ bool chain_i8w_supported(int q, int dt, int n, bool iq);
 bool chain_i8w_rs_supported(int dt, int n);       // its real-stream form (no shift, no IQ correction)
 size_t chain_i8w_lds_bytes(int q, int n, int iq);      // iq: 0 none, 1 prefix tables, 2 fused (chain_i8w_kernel)
 hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, int n_cus, hipStream_t s);
+// float32 records of `tiles` tiles (4096 samples each) -> their four byte slices in place + the tile exponents (many-row contexts)
+hipError_t launch_f32_preslice(const void *raw, void *out, int *exps, size_t tiles, int swap, hipStream_t s);
 // per-sample modal form for decimation < 8 and the workgroup-per-item demodulation stage for m > 4096 (kernels_seq.hip)
 bool chain_seq_supported(int q, int n);
 hipError_t launch_chain_seq(const DecimArgs &a, int q, int dt, bool nco, bool iq, size_t n_chunks, hipStream_t s);

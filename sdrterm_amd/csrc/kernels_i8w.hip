@@ -62,6 +62,26 @@ __device__ __forceinline__ double swap16_add(double x, double y) {
     return __hiloint2double((int) hi[0], (int) lo[0]) + __hiloint2double((int) hi[1], (int) lo[1]);
 }
 
+// float32 -> block fixed point: 16 values (8 complex samples, one lane's k-step) against the exponent e of their tile,
+// i = trunc(x 2^(30 - e)), and the four bytes of every i into four slices (dword w of slice s: byte s of values 4w .. 4w+3; the
+// lower three made signed by the XOR).  One definition for the chain kernel and for the pre-slicing pass: the same bits.
+__device__ __forceinline__ void f32_slices(const uint32_t *cur, const int sh, v4i (&bsl)[4]) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        unsigned q_[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q_[u] = (unsigned) (int) ldexpf(__uint_as_float(cur[4 * w + u]), sh);
+        const unsigned a01 = __builtin_amdgcn_perm(q_[1], q_[0], 0x05010400u), a23 = __builtin_amdgcn_perm(q_[3], q_[2], 0x05010400u);
+        const unsigned c01 = __builtin_amdgcn_perm(q_[1], q_[0], 0x07030602u), c23 = __builtin_amdgcn_perm(q_[3], q_[2], 0x07030602u);
+        bsl[0][w] = (int) (__builtin_amdgcn_perm(a23, a01, 0x05040100u) ^ 0x80808080u);
+        bsl[1][w] = (int) (__builtin_amdgcn_perm(a23, a01, 0x07060302u) ^ 0x80808080u);
+        bsl[2][w] = (int) (__builtin_amdgcn_perm(c23, c01, 0x05040100u) ^ 0x80808080u);
+        bsl[3][w] = (int) __builtin_amdgcn_perm(c23, c01, 0x07060302u);
+    }
+}
+// the exponent a tile is sliced against: that of its largest magnitude, rounded up to a multiple of four
+__device__ __forceinline__ int f32_tile_exponent(unsigned max_abs_bits) { return (((int) (max_abs_bits >> 23) - 126) + 3) & ~3; }
+
 struct WideLds {        // byte offsets
     int wmain, wloc, cF, cG, bp, mup, tpw, tailF, tailFc, psi, gv, pq, cpow, wiq, buf, buf_stride, total;
     // per buffer (offsets in 16-byte units from its start): carF [SLOTS*8], carG [SLOTS*8], F0 [8 SEG], Gu [8 SEG], IQ: tile totals of
@@ -101,7 +121,10 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int
 // over the input, shared by all rows); 2 offsets from two more matrix rows of this kernel (no second pass; one row: see api.hip)
 // NTC: tiles per chunk.  The workgroup's eight waves take eight (or sixteen) tiles per item: chunks of four tiles (float32
 // records, or half-size chunks) go two to an item, SEG = 2, with carries, edge operators and column phasors per chunk.
-template <int DT, int NOUT, int NTC, int S, int IQ, bool RS>
+// PRE (float32, many rows): the records arrive sliced already (f32_preslice_kernel: same bytes per lane and k-step, the four
+// slices in place of the sixteen floats; tile exponents in a.f32_exp) -- every row of a chunk used to slice the same samples
+// again, the larger part of this form's vector work.  The edge operators read the records themselves (a.raw_orig).
+template <int DT, int NOUT, int NTC, int S, int IQ, bool RS, bool PRE = false>
 __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     constexpr int NT = NTC < 8 ? 8 : NTC, SEG = NT / NTC, SLOTS = SEG * (NTC + 1);
     static_assert(SEG == 1 || (IQ == 0 && !RS), "two chunks per item: plain form only");
@@ -111,6 +134,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     constexpr int NSL = W8Enc<DT>::slices;
     constexpr bool F32 = DT == SDRT_F32;
     static_assert(!F32 || (IQ == 0 && !RS), "float32: plain form only");
+    static_assert(!PRE || F32, "pre-sliced input: float32 only");
     // digit d x slice s adds to level d + s; levels below LMIN lie under the accuracy of the planes (integers) or of the slices
     // themselves (float32) and are not computed; accumulator index = level - LMIN
     constexpr int LMIN = F32 ? 3 : (NSL == 2 ? 1 : 0);
@@ -359,7 +383,12 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             // small global loads first: everything issued later (the raw stream) is younger, so waiting for these never
             // waits for the prefetch ring
             const unsigned char *chunk_raw = (const unsigned char *) a.raw + (size_t) chunk_of(HAVE_K ? it : 0) * chunk_bytes;
+            const unsigned char *edge_raw = PRE ? (const unsigned char *) a.raw_orig + (size_t) chunk_of(HAVE_K ? it : 0) * chunk_bytes : chunk_raw;
             if constexpr (F32) { e_A = e_ab[0]; e_B = e_ab[1]; }
+            if constexpr (PRE && HAVE_K) {
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) e_cur[j] = a.f32_exp[(size_t) chunk_of(it) * NT + wave + 8 * j];
+            }
             raw_t e_re[SEG], e_im[SEG];              // raw edge sample of E(it) per chunk of the item (lanes beyond the pad read sample 27, weight 0)
 #pragma unroll
             for (int sg = 0; sg < SEG; ++sg) {
@@ -368,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     // (a 32-bit lane offset on the chunk pointer: a 64-bit one is a loop invariant the register allocator spills and
                     // reloads in the loop's preheader, and its first use inside the loop then waits with s_waitcnt vmcnt(0) in EVERY
                     // iteration -- a drain of the prefetch ring at the top of each one)
-                    const raw_t *rp = (const raw_t *) (chunk_raw + (unsigned) (2 * (e_idx + sg * n)) * (unsigned) sizeof(raw_t));
+                    const raw_t *rp = (const raw_t *) (edge_raw + (unsigned) (2 * (e_idx + sg * n)) * (unsigned) sizeof(raw_t));
                     e_re[sg] = rp[0];
                     e_im[sg] = rp[1];
                 }
@@ -856,7 +885,13 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                 if constexpr (rt == 0) {
                                     // slices of this k-step's 8 complex samples; then its raw registers take the k-step PF ahead
                                     const uint32_t *cur = raw[stg % NSLOT];
-                                    if constexpr (F32) {
+                                    if constexpr (PRE) {
+                                        // sliced already: dword w of slice sl sits at word 4 sl + w of the lane's k-step
+#pragma unroll
+                                        for (int sl_ = 0; sl_ < 4; ++sl_)
+#pragma unroll
+                                            for (int w = 0; w < 4; ++w) bsl[sl_][w] = (int) cur[4 * sl_ + w];
+                                    } else if constexpr (F32) {
                                         // 16 values (8 samples) -> fixed point against the tile's exponent -> 4 x 4 byte transposes
                                         const int sh = 30 - e_cur[j];
                                         uint32_t *curw = raw[stg % NSLOT];
@@ -869,18 +904,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                                         for (int w = 0; w < 16; w += 2)
                                             asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mxf) : "v"(curw[w]), "v"(curw[w + 1]));
                                         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                        for (int w = 0; w < 4; ++w) {
-                                            unsigned q_[4];
-#pragma unroll
-                                            for (int u = 0; u < 4; ++u) q_[u] = (unsigned) (int) ldexpf(__uint_as_float(cur[4 * w + u]), sh);
-                                            const unsigned a01 = __builtin_amdgcn_perm(q_[1], q_[0], 0x05010400u), a23 = __builtin_amdgcn_perm(q_[3], q_[2], 0x05010400u);
-                                            const unsigned c01 = __builtin_amdgcn_perm(q_[1], q_[0], 0x07030602u), c23 = __builtin_amdgcn_perm(q_[3], q_[2], 0x07030602u);
-                                            bsl[0][w] = (int) (__builtin_amdgcn_perm(a23, a01, 0x05040100u) ^ 0x80808080u);
-                                            bsl[1][w] = (int) (__builtin_amdgcn_perm(a23, a01, 0x07060302u) ^ 0x80808080u);
-                                            bsl[2][w] = (int) (__builtin_amdgcn_perm(c23, c01, 0x05040100u) ^ 0x80808080u);
-                                            bsl[3][w] = (int) __builtin_amdgcn_perm(c23, c01, 0x07060302u);
-                                        }
+                                        f32_slices(cur, sh, bsl);
                                     } else if constexpr (ITEM == 2) {
                                         const unsigned sel_lo = swap ? 0x07050301u : 0x06040200u, sel_hi = swap ? 0x06040200u : 0x07050301u;
     #pragma unroll
@@ -969,10 +993,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     };
                     kpass(std::true_type{});
                     int e_true = 0;
-                    if constexpr (F32 && HAVE_K) {
+                    if constexpr (F32 && HAVE_K && !PRE) {
                         // the exponent in use is a function of the tile's own samples (its exponent rounded up to a multiple of
                         // four), never of the guess: an item's bits do not depend on what the workgroup saw before it
-                        e_true = (__builtin_amdgcn_readfirstlane((int) (wave_max(__float_as_uint(mxf)) >> 23) - 126) + 3) & ~3;
+                        e_true = f32_tile_exponent((unsigned) __builtin_amdgcn_readfirstlane((int) wave_max(__float_as_uint(mxf))));
                         if (e_true != e_cur[j]) {
                             e_cur[j] = e_true;
                             static_for<0, PF>([&](auto pc) { issue(chunk_raw, std::integral_constant<int, j * KS + decltype(pc)::value>{}); });
@@ -1055,8 +1079,18 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         unsigned long long *clk = nullptr;
 #endif
         if (clk) { clk[10] = __builtin_amdgcn_s_memtime(); clk[11] = __builtin_amdgcn_s_memrealtime(); }
-        for (int it = 0; it < cnt && it < 3; ++it) iteration(std::true_type{}, std::false_type{}, it);
-        for (int it = 3; it < cnt; ++it) iteration(std::true_type{}, std::true_type{}, it);
+        // The steady state as a copy of its own (no branch on which phases have an item) where the register allocator copes with a
+        // second loop -- the forms with four outputs per column, eight tiles per chunk and no IQ correction, the headline one among
+        // them: no spill and no vmcnt(0) in either loop (tools/loop_scratch.sh).  The others (eight outputs per column, IQ
+        // correction, float32, sixteen tiles) answer a second loop with 3 to 4 times the spills, reloads inside the loop included:
+        // they keep the one general loop.
+        constexpr bool SPLIT = NOUT == 4 && NTC == 8 && IQ == 0 && !F32;
+        if constexpr (SPLIT) {
+            for (int it = 0; it < cnt && it < 3; ++it) iteration(std::true_type{}, std::false_type{}, it);
+            for (int it = 3; it < cnt; ++it) iteration(std::true_type{}, std::true_type{}, it);
+        } else {
+            for (int it = 0; it < cnt; ++it) iteration(std::true_type{}, std::false_type{}, it);
+        }
         if (clk) { clk[12] = __builtin_amdgcn_s_memtime(); clk[13] = __builtin_amdgcn_s_memrealtime(); clk[14] = (unsigned long long) cnt; }
         for (int it = cnt; it < cnt + 3; ++it) iteration(std::false_type{}, std::false_type{}, it);
     }
@@ -1076,19 +1110,19 @@ hipError_t launch_chain_i8w_bytes(const DecimArgs &a, int nout, int nt, int dt, 
 hipError_t launch_chain_i8w_u16(const DecimArgs &a, int nout, int nt, dim3 grid, size_t lds, hipStream_t s);
 hipError_t launch_chain_i8w_f32(const DecimArgs &a, int nout, int nt, dim3 grid, size_t lds, hipStream_t s);
 
-template <int DT, int NOUT, int NTC, int IQ, bool RS>
+template <int DT, int NOUT, int NTC, int IQ, bool RS, bool PRE = false>
 static hipError_t launch_i8w_q(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     // once per device and instantiation (a driver call per launch costs more than the gap between two kernels)
     static thread_local int done_dev = -1;
     int dev = 0;
     (void) hipGetDevice(&dev);
     if (done_dev != dev) {
-        hipError_t e = hipFuncSetAttribute((const void *) chain_i8w_kernel<DT, NOUT, NTC, SDRT_I8_DIGITS, IQ, RS>,
+        hipError_t e = hipFuncSetAttribute((const void *) chain_i8w_kernel<DT, NOUT, NTC, SDRT_I8_DIGITS, IQ, RS, PRE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
         done_dev = dev;
     }
-    hipLaunchKernelGGL((chain_i8w_kernel<DT, NOUT, NTC, SDRT_I8_DIGITS, IQ, RS>), grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((chain_i8w_kernel<DT, NOUT, NTC, SDRT_I8_DIGITS, IQ, RS, PRE>), grid, dim3(512), lds, s, a);
     return hipGetLastError();
 }
 template <int DT, int NOUT, int NT>
@@ -1096,6 +1130,9 @@ static hipError_t launch_i8w_k(const DecimArgs &a, dim3 grid, size_t lds, hipStr
     // four tiles per chunk (two chunks per item): the plain form only
     if constexpr (NT == 4) {
         if (a.rs || a.w8iq || a.iq_group_off) return hipErrorInvalidValue;
+        if constexpr (DT == SDRT_F32) {
+            if (a.f32_exp) return launch_i8w_q<DT, NOUT, 4, 0, false, true>(a, grid, lds, s);
+        }
         return launch_i8w_q<DT, NOUT, 4, 0, false>(a, grid, lds, s);
     } else {
         // no shift, no IQ correction: real streams (instantiated for the 16-bit encodings at 8 tiles per chunk only)
@@ -1134,6 +1171,56 @@ hipError_t launch_chain_i8w_u16(const DecimArgs &a, int nout, int nt, dim3 grid,
 #elif defined(SDRT_I8W_F32)
 hipError_t launch_chain_i8w_f32(const DecimArgs &a, int nout, int nt, dim3 grid, size_t lds, hipStream_t s) {
     return launch_i8w_d<SDRT_F32>(a, nout, nt, grid, lds, s);
+}
+
+// Pre-slicing pass for many-row float32 contexts: one workgroup per tile of 4096 samples (32 KiB).  A lane's k-step of the chain
+// kernel is an aligned 64-byte piece of the stream (eight complex samples); here every piece is replaced, in a buffer of the same
+// shape, by its four slices against the tile's exponent -- computed as the chain kernel computes it (f32_tile_exponent of the
+// largest magnitude, f32_slices).  Reads 8 B and writes 8 B per sample, once per chunk instead of once per (chunk, row).
+__global__ __launch_bounds__(256) void f32_preslice_kernel(const uint32_t *__restrict__ raw, uint32_t *__restrict__ out, int *__restrict__ exps, int swap) {
+    __shared__ unsigned wmax[4];
+    const size_t tile = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint4 *src = (const uint4 *) (raw + tile * (size_t) (SDRT_TB * SDRT_WIDE_LC * 2));
+    uint32_t w0[16], w1[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint4 p = src[(size_t) tid * 4 + i], r = src[(size_t) (tid + 256) * 4 + i];
+        w0[4 * i] = p.x; w0[4 * i + 1] = p.y; w0[4 * i + 2] = p.z; w0[4 * i + 3] = p.w;
+        w1[4 * i] = r.x; w1[4 * i + 1] = r.y; w1[4 * i + 2] = r.z; w1[4 * i + 3] = r.w;
+    }
+    if (swap) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { w0[i] = __builtin_bswap32(w0[i]); w1[i] = __builtin_bswap32(w1[i]); }
+    }
+    float mxf = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mxf) : "v"(w0[i]), "v"(w0[i + 1]));
+        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mxf) : "v"(w1[i]), "v"(w1[i + 1]));
+    }
+    unsigned v = __float_as_uint(mxf);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (unsigned) __shfl_xor((int) v, d));
+    if ((tid & 63) == 0) wmax[tid >> 6] = v;
+    __syncthreads();
+    v = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    const int e = f32_tile_exponent(v);
+    if (tid == 0) exps[tile] = e;
+    v4i b0[4], b1[4];
+    f32_slices(w0, 30 - e, b0);
+    f32_slices(w1, 30 - e, b1);
+    uint4 *dst = (uint4 *) (out + tile * (size_t) (SDRT_TB * SDRT_WIDE_LC * 2));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dst[(size_t) tid * 4 + i] = make_uint4((unsigned) b0[i][0], (unsigned) b0[i][1], (unsigned) b0[i][2], (unsigned) b0[i][3]);
+        dst[(size_t) (tid + 256) * 4 + i] = make_uint4((unsigned) b1[i][0], (unsigned) b1[i][1], (unsigned) b1[i][2], (unsigned) b1[i][3]);
+    }
+}
+
+hipError_t launch_f32_preslice(const void *raw, void *out, int *exps, size_t tiles, int swap, hipStream_t s) {
+    hipLaunchKernelGGL(f32_preslice_kernel, dim3((unsigned) tiles), dim3(256), 0, s, (const uint32_t *) raw, (uint32_t *) out, exps, swap);
+    return hipGetLastError();
 }
 #else
 // permlane swap self-test: out[0][l] = swap32_add(x[l], y[l]), out[1][l] = swap16_add(x[l], y[l])

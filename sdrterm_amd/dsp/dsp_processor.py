@@ -181,7 +181,7 @@ class DspProcessor(DataProcessor):
         sos = np.asarray(self._outputFilters, dtype=np.float64).reshape(-1, 6) if len(self._outputFilters) else None
         self._engine = Engine(self._fs, self._decimationFactor, mode, code, n_samples=n, row_freqs=self._rowFreqs(),
                               apply_shift=self._applyShift(), out_sos=sos, device=self._device, smooth=window,
-                              row_modes=self._rowModes(), **reader)
+                              row_modes=self._rowModes(), reserve_chunks=self.MAX_BATCH, **reader)
         self._engineReader = reader
         return self._engine
 

@@ -72,6 +72,9 @@ class VfoProcessor(DspProcessor):
         self._channel = None
         self._helpers = []
         self._stream, self._slots, self._moreComing = None, [None, None], False
+        # diagnostics / tests: the block channel with a single rank too (a 1-GPU box then runs the whole multi-GPU data path:
+        # header, upload + broadcast into two buffers, kernels behind events, bounded waits)
+        self._forceChannel = bool(kwargs.get('forceChannel') or os.environ.get('SDRTERM_SIMO_CHANNEL') == '1')
 
     # ---- this rank's share -------------------------------------------------------------------------------------
     def _enterRank(self, rank: int, world: int, uid=None) -> None:
@@ -133,7 +136,7 @@ class VfoProcessor(DspProcessor):
     def _takeBatch(self, buffer):
         """Rank 0 takes the batch from the reader's Queue as the single-GPU processor does and sends it on; the other
         ranks receive it.  Blocks travel as raw bytes + what the engine needs to know about them."""
-        if self._world == 1:
+        if not self._channelled():
             return super()._takeBatch(buffer)
         if self._rank == 0:
             chunks, eof = super()._takeBatch(buffer)
@@ -162,11 +165,14 @@ class VfoProcessor(DspProcessor):
             blk.size = self._blockKind['samples']
         return ([blk] if blk.n else []), blk.eof
 
+    def _channelled(self) -> bool:
+        return self._world > 1 or self._forceChannel
+
     def _moreQueued(self, buffer) -> bool:
-        return super()._moreQueued(buffer) if self._world == 1 else self._moreComing
+        return self._moreComing if self._channelled() else super()._moreQueued(buffer)
 
     def _submitBatch(self, chunks):
-        if self._world == 1:
+        if not self._channelled():
             return super()._submitBatch(chunks)
         return None, self._startBlock(chunks[0]), 0
 
@@ -225,7 +231,7 @@ class VfoProcessor(DspProcessor):
     def _releaseRanks(self) -> None:
         """Rank 0 is leaving (end of stream already sent, halt flag, error): the other ranks wait in a collective and need
         an end-of-stream block to leave as well.  Only while they are all there to take it; the wait is bounded either way."""
-        if self._world > 1 and self._rank == 0 and not getattr(self, '_eofSent', False):
+        if self._channelled() and self._rank == 0 and not getattr(self, '_eofSent', False):
             self._eofSent = True
             if not all(p.is_alive() for p in self._helpers):
                 return

@@ -71,7 +71,7 @@ class Engine:
 
     def __init__(self, fs, decimation, mode, code='h', n_samples=None, row_freqs=None, apply_shift=None,
                  out_sos=None, omega_out=12500, normalize=False, correct_iq=False, impedance=50,
-                 big_endian=False, device=0, smooth=0, row_modes=None):
+                 big_endian=False, device=0, smooth=0, row_modes=None, reserve_chunks=0):
         """``row_modes``: None (every row demodulates as ``mode``, as the reference does, io_args.py:118) or one of 'fm' / 'am' per
         row -- FM and AM channels of a --simo run in one pass over the input (BASELINE configs[2])."""
         if mode not in nat.MODES:
@@ -130,6 +130,9 @@ class Engine:
         self.m = nat.lib().sdrt_out_per_chunk(self._ctx)
         self.stage_a = {0: 'f64', 2: 'i8t', 3: 'i8w', 4: 'seq'}[nat.lib().sdrt_stage_a_kind(self._ctx)]   # which stage-A kernel runs
         self.chunk_bytes = self.n * 2 * nat.ITEM_SIZE[code]
+        if reserve_chunks:
+            # device scratch for batches up to this size now, none inside the processing calls (include/sdrterm_hip.h: sdrt_reserve)
+            nat.check(nat.lib().sdrt_reserve(self._ctx, int(reserve_chunks)))
         self.smooth = int(smooth) if smooth else 0
         if smooth:
             taps, first, n_edge, left, right = savgol_operator(int(smooth))

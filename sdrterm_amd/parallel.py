@@ -158,6 +158,8 @@ class RcclTransport:
 
     @staticmethod
     def _exchange_uid(rank: int, world: int) -> bytes:
+        if world == 1:
+            return RcclTransport.unique_id()
         addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
         port = int(os.environ.get('SDRTERM_UID_PORT', int(os.environ.get('MASTER_PORT', '29500')) + 17))
         if rank == 0:

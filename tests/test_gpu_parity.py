@@ -426,3 +426,29 @@ def test_per_row_modes_on_the_bench_configuration(golden, monkeypatch):
     for r, md in enumerate(modes):
         e = exp[:, r, :] if md == 'fm' else am[:, r, :]
         assert np.abs(got[r] - e).max() <= tol_for(e, md), f'row {r} ({md})'
+
+
+@pytest.mark.parametrize('big_endian,nch', [(False, 5), (True, 2), (False, 4)])
+def test_float32_rows_sliced_once_per_chunk_give_the_same_bits(big_endian, nch, monkeypatch):
+    """float32 records with several rows: from four rows up the records are sliced into their int8 planes once per chunk
+    (f32_preslice_kernel) instead of once per (chunk, row) inside the chain kernel.  Same exponent rule, same slicing code:
+    the outputs must be bit-identical to the per-row form (odd and even chunk counts, either byte order), and meet the oracle."""
+    from sdrterm_amd.engine import Engine
+    from tests.golden import prng
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    fs, q, n = 1024000, 64, 16384
+    freqs = [15700.0, -203300.0, 100100.0, 5.0, -77000.0]
+    raw = prng.raw_bytes('f', n * nch, seed=300 + nch, amp=3000, big_endian=big_endian)
+    outs = {}
+    for pre in ('0', '1'):
+        monkeypatch.setenv('SDRTERM_F32_PRE', pre)
+        eng = Engine(fs, q, 'fm', 'f', row_freqs=freqs, apply_shift=True, omega_out=5000, big_endian=big_endian)
+        assert eng.stage_a == 'i8w'
+        outs[pre] = eng.process(raw)
+    assert np.array_equal(outs['0'], outs['1'])
+    monkeypatch.delenv('SDRTERM_F32_PRE')
+    auto = Engine(fs, q, 'fm', 'f', row_freqs=freqs, apply_shift=True, omega_out=5000, big_endian=big_endian).process(raw)
+    assert np.array_equal(auto, outs['1'])                       # five rows: the pre-sliced form is the default
+    if not big_endian:
+        exp = _oracle_rows(raw, 'f', n, q, 'fm', freqs, fs, 5000, range(nch), range(5))
+        assert np.abs(outs['1'].reshape(5, nch, n // q).transpose(1, 0, 2) - exp).max() <= 1e-6

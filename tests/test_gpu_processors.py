@@ -375,13 +375,20 @@ def test_rccl_transport_single_rank_roundtrip():
         data = np.arange(4096, dtype=np.uint8).tobytes() * 3
         assert t.bcast_bytes(data, len(data)) == data
         ch = parallel.BlockChannel(t, chunk_bytes=4096)
-        blk = ch.exchange(data, 3, False)
-        assert (blk.n, blk.eof) == (3, False) and blk.dev_ptr
+        blk = ch.exchange(data, 3, False, more=True)
+        assert (blk.n, blk.eof, blk.more, blk.seq, blk.slot) == (3, False, True, 0, 0) and blk.dev_ptr
+        t.block_ready(blk.slot, 0)                       # the block is only queued: the reading stream waits for it
         back = np.empty(len(data), dtype=np.uint8)
         nat.check(nat.lib().sdrt_memcpy_d2h(back.ctypes.data, blk.dev_ptr, len(data)))
         assert back.tobytes() == data
+        t.block_consumed(blk.slot, 0)
+        nxt = ch.exchange(data[::-1], 3, False)
+        assert (nxt.seq, nxt.slot, nxt.more) == (1, 1, False) and nxt.dev_ptr != blk.dev_ptr      # the other buffer
+        t.block_ready(nxt.slot, 0)
+        nat.check(nat.lib().sdrt_memcpy_d2h(back.ctypes.data, nxt.dev_ptr, len(data)))
+        assert back.tobytes() == data[::-1]
         end = ch.exchange(b'', 0, True)
-        assert (end.n, end.eof) == (0, True)
+        assert (end.n, end.eof, end.seq) == (0, True, 2)
         src = nat.DeviceBuffer(1024).upload(np.full(1024, 7, dtype=np.uint8))
         dst = nat.DeviceBuffer(1024)
         t.allgather_device(src.ptr, dst.ptr, 1024)
@@ -389,6 +396,86 @@ def test_rccl_transport_single_rank_roundtrip():
         assert (dst.download(np.empty(1024, dtype=np.uint8)) == 7).all()
     finally:
         t.close()
+
+
+def test_simo_block_channel_path_on_one_gpu():
+    """The multi-GPU --simo data path with a world of one (all a 1-GPU box can run): every raw block goes through the header
+    exchange, the page-locked upload and the RCCL broadcast into one of two device buffers on the communication stream, the
+    kernels wait for it behind an event on the processor's stream, the next broadcast into the same buffer waits for them, the
+    copy-out is collected with a bounded wait.  Five blocks (batches of two chunks, so that several are in flight), three rows,
+    three socket clients: every row's stream must equal the oracle's, in order."""
+    import queue
+    import socket
+    import threading
+    import time
+    from oracle import c_chain, ref_chain
+    from sdrterm_amd.dsp.vfo_processor import VfoProcessor
+    from sdrterm_amd.misc.general_util import findPort
+    from sdrterm_amd.misc.read_file import RawChunk
+    from tests.golden import prng
+    fs, q, n, nch = 1024000, 64, 32768, 9
+    raw = prng.raw_bytes('h', n * nch, seed=33, amp=4000)
+    port = findPort('127.0.0.1')
+    p = VfoProcessor(fs, vfoHost=f'127.0.0.1:{port}', vfos='-100000,50000', center=15700, dec=q, omegaOut=5000, forceChannel=True)
+    p.selectOutputFm()
+    p.MAX_BATCH = 2
+    buf = queue.Queue()
+    for c in range(nch):
+        buf.put(RawChunk(raw[c * n * 4:(c + 1) * n * 4], 'h', False, False, False, 50))
+    buf.put(b'')
+    buf.close = lambda: None
+    buf.join_thread = lambda: None
+    m = n // q
+    box = [None] * 3
+
+    def client(k):
+        deadline = time.time() + 60
+        while True:
+            try:
+                s = socket.create_connection(('127.0.0.1', port), timeout=30)
+                break
+            except OSError:
+                if time.time() > deadline:
+                    raise
+                time.sleep(0.05)
+        data = b''
+        with s:
+            while len(data) < nch * m * 8:
+                part = s.recv(nch * m * 8 - len(data))
+                if not part:
+                    break
+                data += part
+        box[k] = np.frombuffer(data, dtype='>f8').astype(np.float64)
+
+    def connect_all():
+        for k in range(3):
+            threading.Thread(target=client, args=(k,), daemon=True).start()
+            time.sleep(0.3)
+    threading.Thread(target=connect_all, daemon=True).start()
+
+    class _Flag:
+        value = 0
+    seen = []
+    take = p._takeBatch
+
+    def spy(b):
+        chunks, eof = take(b)
+        seen.append((sum(c.n for c in chunks), [c.slot for c in chunks], p._moreComing, eof))
+        return chunks, eof
+    p._takeBatch = spy
+    p.processData(_Flag(), buf)
+    deadline = time.time() + 30
+    while any(b is None for b in box) and time.time() < deadline:
+        time.sleep(0.05)
+    assert sum(s[0] for s in seen) == nch and len(seen) >= 5 and seen[-1][3]
+    assert [s[1] for s in seen if s[1]] == [[k % 2] for k in range(len([s for s in seen if s[1]]))]      # the two buffers in turn
+    assert any(s[2] for s in seen)                                                                  # blocks kept in flight
+    rows = ref_chain.vfo_rows(15700, '-100000,50000')
+    shift = c_chain.shift_table(rows, fs, n)
+    exp, _ = c_chain.process_stream(raw, 'h', n, q, 'fm', shift, ref_chain.cheby_sos(q), ref_chain.ellip_sos(fs // q, 5000), threads=4)
+    for k in range(3):
+        assert box[k] is not None and box[k].size == nch * m
+        assert np.abs(box[k] - exp[:, k, :].reshape(-1)).max() <= 1e-6, f'row {k}'
 
 
 @pytest.mark.parametrize('mode', ['re', 'im'])
