@@ -74,6 +74,7 @@ struct sdrt_ctx {
     double *d_fft_tw = nullptr, *d_fft_shift = nullptr;
     double *d_fft8 = nullptr;         // eight-lanes-per-item demodulation stage (kernels_post8.hip): transform tables ...
     Post8Tables *d_p8tab = nullptr;   // ... and its lowpass constants
+    int p8_lpi = 0;
     double *d_smooth = nullptr;       // taps | left | right of --smooth-output (sdrt_set_smoothing)
     int sm_window = 0, sm_ntaps = 0, sm_first = 0, sm_edge = 0;
     bool fft_ok = false, out_modal = false;
@@ -579,12 +580,14 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         // FM with 512 outputs per chunk (decimation 64 of 16-bit records, 32 of float32 records) and the usual output lowpass
         // (one complex pole pair + one real pole): eight lanes per item (diagnostics: SDRTERM_POST=wave keeps one wave per item)
         const char *pk = getenv("SDRTERM_POST");
-        if (rc == SDRT_OK && c->fft_ok && m == 512 && !(pk && strcmp(pk, "wave") == 0)) {
+        if (rc == SDRT_OK && c->fft_ok && (m == 512 || m == 1024) && !(pk && strcmp(pk, "wave") == 0)) {
+            const int lpi = m == 512 ? 8 : 16;
             Post8Tables p8;
-            std::vector<double> ft((size_t) (4 * SDRT_P8_PPL * 8 + 8 * 8) * 2);
-            if (sdrt_build_post8_tables(cfg->out_sos, cfg->out_sections, N, 8, &p8, ft.data()) == 0) {
+            std::vector<double> ft((size_t) (4 * SDRT_P8_PPL * lpi + 8 * lpi) * 2);
+            if (sdrt_build_post8_tables(cfg->out_sos, cfg->out_sections, N, lpi, &p8, ft.data()) == 0) {
                 rc = upload(&c->d_fft8, ft.data(), ft.size() * sizeof(double));
                 if (rc == SDRT_OK) rc = upload(&c->d_p8tab, &p8, sizeof(p8));
+                c->p8_lpi = lpi;
             }
         }
     }
@@ -944,6 +947,7 @@ PostArgs post_args(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out
     pa.row_map = nullptr;
     pa.fft8_tab = c->d_fft8;
     pa.p8tab = c->d_p8tab;
+    pa.p8_lpi = c->p8_lpi;
     return pa;
 }
 

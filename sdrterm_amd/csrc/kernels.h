@@ -92,9 +92,10 @@ struct PostArgs {
     const int *row_map;         // per-row demodulation modes: work item w = (k, chunk) stands for item (row_map[k], chunk) of the
                                 // batch; items = (rows of this mode) * n_chunks.  NULL: every row, item w is item w
     int pairs;                  // FM: y holds [items][m/2] products y[2i] conj(y[2i+1]) (DecimArgs.pair_out)
-    // eight-lanes-per-item form (kernels_post8.hip; FM, m = 512, lowpass = one complex pole pair + one real pole), or NULL
-    const double *fft8_tab;     // [4][128][2] + [8][8][2]: sdrt_build_post8_tables
+    // eight / sixteen lanes per item (kernels_post8.hip; FM, m = 512 / 1024, lowpass = one complex pole pair + one real pole), or NULL
+    const double *fft8_tab;     // [4][16 LPI][2] + [8][LPI][2]: sdrt_build_post8_tables
     const Post8Tables *p8tab;
+    int p8_lpi;                 // lanes per item the tables were built for: 8 (m = 512) or 16 (m = 1024)
 };
 bool post_fft8_supported(const PostArgs &a);
 hipError_t launch_post_fft8(const PostArgs &a, hipStream_t s);

@@ -143,26 +143,30 @@ __device__ __forceinline__ void wave_lds_fence() {
 #ifndef SDRT_P8_BLOCKS_AHEAD
 #define SDRT_P8_BLOCKS_AHEAD 16
 #endif
-#define SDRT_P8_SO 136          // 16-byte slots of one item's exchange image (8 x 17, and = 8 mod 16)
 
-template <int WPB, bool PAIRS>
-__global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 8) void post_fft8_kernel(PostArgs a) {
-    constexpr int LPI = 8, P = SDRT_P8_PPL, H = P * LPI, N = 2 * H, M = 2 * N, IPW = 64 / LPI, TAB = P * LPI, SO = SDRT_P8_SO;
+// LPI lanes per item: 8 (N = 256 pair angles, 512 outputs per chunk) or 16 (N = 512, 1024 outputs per chunk: a DPP row of
+// lanes is one item).  16-byte slots of an item's exchange image: 17 per n2 (8 x 17 = 136 = 8 mod 16, 16 x 17 = 272 = 0 mod 16:
+// what keeps the four lane groups of a ds_read_b128 on sixteen different slots in either form, tools/lds_banks.py).
+template <int LPI, int WPB, bool PAIRS>
+__global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_fft8_kernel(PostArgs a) {
+    constexpr int P = SDRT_P8_PPL, H = P * LPI, N = 2 * H, M = 2 * N, IPW = 64 / LPI, TAB = P * LPI, SO = 17 * LPI, NC = P / LPI;
+    static_assert(LPI == 8 || LPI == 16, "8 or 16 lanes per item");
     extern __shared__ __align__(16) unsigned char smem[];
-    cd *tabL = (cd *) smem;                                        // tw1 | tw2 | alpha | beta
+    cd *tabL = (cd *) smem;                                        // tw1 | tw2 | alpha | beta | lane rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, o = lane / LPI, l = lane % LPI;
     cd *X = tabL + 4 * TAB + 8 * LPI + (size_t) wave * (IPW * SO) + o * SO;  // this item's exchange image
     for (int i = tid; i < 4 * TAB + 8 * LPI; i += 64 * WPB) tabL[i] = ((const cd *) a.fft8_tab)[i];
     __syncthreads();
     const cd *tw1L = tabL, *tw2L = tabL + TAB, *alL = tabL + 2 * TAB, *beL = tabL + 3 * TAB, *lpL = tabL + 4 * TAB;
-    const int c0 = l, c1 = l ? 16 - l : 8;                         // the bins k1 this lane finishes: S_l
+    // the bins k1 this lane finishes (S_l): 8 lanes: l and 16 - l (lane 0: 0 and 8); 16 lanes: l
+    const int c0 = l, c1 = LPI == 8 ? (l ? 16 - l : 8) : 0;
     const bool l0 = l == 0;
 
     const size_t ngroups = (a.items + IPW - 1) / IPW;
     for (size_t grp = (size_t) blockIdx.x * WPB + wave; grp < ngroups; grp += (size_t) gridDim.x * WPB) {
         // (lane groups beyond the last item redo it: the same values to the same places, no branch anywhere in the loop)
         const size_t item = grp * IPW + o, it = post_item(a, item < a.items ? item : a.items - 1);
-        // ---- pair angles: x[k] = a[2n] + i a[2n+1], n = l + 8 k (demodulation.py:25-32) ---------------------------------
+        // ---- pair angles: x[k] = a[2n] + i a[2n+1], n = l + LPI k (demodulation.py:25-32) -------------------------------
         cd x[P];
         if constexpr (PAIRS) {
             const cd *y = (const cd *) a.y + it * (size_t) N;      // d[2i] conj(d[2i+1]) from the chain kernel
@@ -176,13 +180,21 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 8) void post_fft8_kernel(P
             const cd *y = (const cd *) a.y + it * (size_t) M;
             const cd *R = a.iq_R ? (const cd *) a.iq_R + (it / a.n_chunks) * (size_t) M : nullptr;
             const cd h = a.iq_R ? ((const cd *) a.iq_off)[it % a.n_chunks] : mk(0.0, 0.0);
+            // four bins at a time: sixteen samples (and their offset shares) in flight, then their eight angles
+            static_for<0, P / 4>([&](auto gc) {
+                constexpr int k0 = 4 * decltype(gc)::value;
+                cd d[4][4];
 #pragma unroll
-            for (int k = 0; k < P; ++k) {
-                const int i0 = 4 * (l + LPI * k);
-                const cd d0 = load_y(y, R, h, i0), d1 = load_y(y, R, h, i0 + 1), d2 = load_y(y, R, h, i0 + 2), d3 = load_y(y, R, h, i0 + 3);
-                x[k] = mk(atan2_pi(d0.im * d1.re - d0.re * d1.im, d0.re * d1.re + d0.im * d1.im),
-                          atan2_pi(d2.im * d3.re - d2.re * d3.im, d2.re * d3.re + d2.im * d3.im));
-            }
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) d[k][u] = load_y(y, R, h, 4 * (l + LPI * (k0 + k)) + u);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    x[k0 + k] = mk(atan2_pi(d[k][0].im * d[k][1].re - d[k][0].re * d[k][1].im, d[k][0].re * d[k][1].re + d[k][0].im * d[k][1].im),
+                                   atan2_pi(d[k][2].im * d[k][3].re - d[k][2].re * d[k][3].im, d[k][2].re * d[k][3].re + d[k][2].im * d[k][3].im));
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
         // The angles are half of the output samples (before the lowpass) and nothing else needs them after the first transform
         // step: they wait in the item's own place in the output buffer (every lane re-reads what it wrote itself, in one go at
@@ -191,37 +203,49 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 8) void post_fft8_kernel(P
         cd *stash = (cd *) (a.out + it * (size_t) M) + l;
 #pragma unroll
         for (int k = 0; k < P; ++k) stash[LPI * k] = x[k];
-        // ---- forward: 16 points in the lane, twiddle, exchange, 8 points ----------------------------------------------------
-        cd Z[2][LPI];
+        // ---- forward: 16 points in the lane, twiddle, exchange, LPI points ---------------------------------------------------
+        cd Z[NC][LPI];
         {
             cd X1[P];
             reg_fft<P, false>(x, X1);
             static_for<1, P>([&](auto kc) { constexpr int k1 = decltype(kc)::value; X1[k1] = cmul(X1[k1], tw1L[k1 * LPI + l]); });
             static_for<0, P>([&](auto kc) { constexpr int k1 = decltype(kc)::value; X[17 * l + k1] = X1[k1]; });
             wave_lds_fence();
-            cd V[2][LPI];
+            cd V[NC][LPI];
 #pragma unroll
-            for (int j = 0; j < LPI; ++j) { V[0][j] = X[17 * j + c0]; V[1][j] = X[17 * j + c1]; }
+            for (int j = 0; j < LPI; ++j) {
+                V[0][j] = X[17 * j + c0];
+                if constexpr (NC == 2) V[1][j] = X[17 * j + c1];
+            }
             reg_fft<LPI, false>(V[0], Z[0]);
-            reg_fft<LPI, false>(V[1], Z[1]);
+            if constexpr (NC == 2) reg_fft<LPI, false>(V[1], Z[1]);
         }
         // ---- packed spectrum of the angles -> packed spectrum of the half-sample shifted sequence ----------------------------
-        // bin k = c + 16 k2 pairs with H - k = (16 - c) + 16 (7 - k2): the lane's other bin series -- except in lane 0,
-        // whose series c = 0 and c = 8 each pair with themselves
-        cd U[2][LPI];
+        // Y[k] = alpha_k Z[k] + beta_k conj(Z[H - k]).  8 lanes: bin k = c + 16 k2 pairs with H - k = (16 - c) + 16 (7 - k2), the
+        // lane's other bin series -- except in lane 0, whose series c = 0 and c = 8 each pair with themselves.  16 lanes: the
+        // partner (16 - c) + 16 (15 - k2) sits in lane 16 - l of the item's row of lanes (row_mirror, then row_ror:1); lane 0
+        // pairs with itself, k2 with 16 - k2.
+        cd U[NC][LPI];
         {
-            cd Y[2][LPI];
+            cd Y[NC][LPI];
             static_for<0, LPI>([&](auto kc) {
                 constexpr int k2 = decltype(kc)::value;
-                const cd q0 = Z[1][7 - k2], q0s = Z[0][(8 - k2) % 8], q1 = Z[0][7 - k2], q1s = Z[1][7 - k2];
-                const cd p0 = mk(l0 ? q0s.re : q0.re, l0 ? q0s.im : q0.im), p1 = mk(l0 ? q1s.re : q1.re, l0 ? q1s.im : q1.im);
-                const cd a0 = alL[(0 * LPI + k2) * LPI + l], b0 = beL[(0 * LPI + k2) * LPI + l];
-                const cd a1 = alL[(1 * LPI + k2) * LPI + l], b1 = beL[(1 * LPI + k2) * LPI + l];
-                Y[0][k2] = cfma(b0, mk(p0.re, -p0.im), cmul(a0, Z[0][k2]));
-                Y[1][k2] = cfma(b1, mk(p1.re, -p1.im), cmul(a1, Z[1][k2]));
+                if constexpr (LPI == 8) {
+                    const cd q0 = Z[1][7 - k2], q0s = Z[0][(8 - k2) % 8], q1 = Z[0][7 - k2], q1s = Z[1][7 - k2];
+                    const cd p0 = mk(l0 ? q0s.re : q0.re, l0 ? q0s.im : q0.im), p1 = mk(l0 ? q1s.re : q1.re, l0 ? q1s.im : q1.im);
+                    const cd a0 = alL[(0 * LPI + k2) * LPI + l], b0 = beL[(0 * LPI + k2) * LPI + l];
+                    const cd a1 = alL[(1 * LPI + k2) * LPI + l], b1 = beL[(1 * LPI + k2) * LPI + l];
+                    Y[0][k2] = cfma(b0, mk(p0.re, -p0.im), cmul(a0, Z[0][k2]));
+                    Y[1][k2] = cfma(b1, mk(p1.re, -p1.im), cmul(a1, Z[1][k2]));
+                } else {
+                    const cd far = dpp_row<0x121>(dpp_row<0x140>(Z[0][15 - k2])), own = Z[0][(16 - k2) % 16];
+                    const cd p0 = mk(l0 ? own.re : far.re, l0 ? own.im : far.im);
+                    const cd a0 = alL[k2 * LPI + l], b0 = beL[k2 * LPI + l];
+                    Y[0][k2] = cfma(b0, mk(p0.re, -p0.im), cmul(a0, Z[0][k2]));
+                }
             });
             reg_fft<LPI, true>(Y[0], U[0]);
-            reg_fft<LPI, true>(Y[1], U[1]);
+            if constexpr (NC == 2) reg_fft<LPI, true>(Y[1], U[1]);
         }
         // ---- back: twiddle, exchange, 16 points in the lane -------------------------------------------------------------------
         cd zz[P];
@@ -229,17 +253,20 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 8) void post_fft8_kernel(P
             static_for<1, LPI>([&](auto kc) {
                 constexpr int n2 = decltype(kc)::value;
                 U[0][n2] = cmul(U[0][n2], tw2L[(0 * LPI + n2) * LPI + l]);
-                U[1][n2] = cmul(U[1][n2], tw2L[(1 * LPI + n2) * LPI + l]);
+                if constexpr (NC == 2) U[1][n2] = cmul(U[1][n2], tw2L[(1 * LPI + n2) * LPI + l]);
             });
             wave_lds_fence();                                      // the forward step's reads are done
 #pragma unroll
-            for (int n2 = 0; n2 < LPI; ++n2) { X[17 * n2 + c0] = U[0][n2]; X[17 * n2 + c1] = U[1][n2]; }
+            for (int n2 = 0; n2 < LPI; ++n2) {
+                X[17 * n2 + c0] = U[0][n2];
+                if constexpr (NC == 2) X[17 * n2 + c1] = U[1][n2];
+            }
             wave_lds_fence();
             cd Rr[P];
 #pragma unroll
             for (int c = 0; c < P; ++c) Rr[c] = X[17 * l + c];
             wave_lds_fence();                                      // ... before the next group's writes
-            reg_fft<P, true>(Rr, zz);                              // zz[n1] = b[2n] + i b[2n+1], n = l + 8 n1
+            reg_fft<P, true>(Rr, zz);                              // zz[n1] = b[2n] + i b[2n+1], n = l + LPI n1
         }
         // ---- output samples 4n .. 4n+3 = a[2n], b[2n], a[2n+1], b[2n+1]; lowpass; store ------------------------------------------
         double *out = a.out + it * (size_t) M + 4 * l;
@@ -263,6 +290,9 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 8) void post_fft8_kernel(P
         const cd mA1 = lpL[0 * LPI + l], mA2 = lpL[1 * LPI + l], nA = lpL[2 * LPI + l], mB = lpL[3 * LPI + l], mE = lpL[4 * LPI + l];
         const cd nBE = lpL[5 * LPI + l], plc = lpL[6 * LPI + l], plq = lpL[7 * LPI + l];
         const double nA1 = nA.re, nA2 = nA.im, nB = nBE.re, nE = nBE.im, plr = plq.re, q1 = plq.im;
+        // 16 lanes: the scan runs over the item's whole row of lanes, multipliers p^4, p^8, p^16, p^32
+        const cd s1 = mk(pu->pc4[0], pu->pc4[1]), s2 = mk(pu->pc8[0], pu->pc8[1]), s4 = mk(pu->pc_q[3][0], pu->pc_q[3][1]), s8 = mk(pu->pc32[0], pu->pc32[1]);
+        const double t1 = pu->pr4, t2 = pu->pr8, t4 = pu->pr_q[3], t8 = pu->pr32;
         cd Cc = mk(0.0, 0.0);                                      // state at the start of the block
         double Cr = 0.0;
         static_for<0, P>([&](auto nc) {
@@ -273,26 +303,42 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 8) void post_fft8_kernel(P
             const double y03 = fma(h0, x3, fma(h1, x2, fma(h2, x1, h3 * x0)));
             const cd se = mk(fma(p3.re, x0, fma(p2.re, x1, fma(p1.re, x2, x3))), fma(p3.im, x0, fma(p2.im, x1, p1.im * x2)));
             const double te = fma(r3, x0, fma(r2, x1, fma(r1, x2, x3)));
-            // inclusive scan of the end states over the item's eight lanes: inside the quads (quad permutations never leave the
-            // item) ...
-            cd sc = cfma(mA1, dpp_quad<0x90>(se), se);                  // [0,0,1,2]: lane q takes lane q-1
-            double sr = fma(nA1, dpp_quad<0x90>(te), te);
-            sc = cfma(mA2, dpp_quad<0x40>(sc), sc);                    // [0,0,0,1]: lane q takes lane q-2
-            sr = fma(nA2, dpp_quad<0x40>(sr), sr);
-            // ... then the first quad's total into the second: row_shr:4 written to banks 1 and 3 only (lanes 4-7, 12-15; the
-            // others keep 0: nothing crosses from the neighbouring item), its lane 3 broadcast over the quad
-            const cd cq = dpp_quad<0xFF>(dpp_shr4_banks13(sc));
-            const double cqr = dpp_quad<0xFF>(dpp_shr4_banks13(sr));
-            // state before the lane's first sample: the lanes before it in its quad, the quad before, the block's starting state
-            const cd eq = dpp_quad<0x90>(sc);
-            const double eqr = dpp_quad<0x90>(sr);
-            cd s = cfma(plc, Cc, cfma(mE, cq, mk(q1 * eq.re, q1 * eq.im)));
-            double t = fma(plr, Cr, fma(nE, cqr, q1 * eqr));
-            sc = cfma(mB, cq, sc);
-            sr = fma(nB, cqr, sr);
-            // the next block starts from this block's end state (lane 7 of the item)
-            const cd Tc = mk(swz_bcast_last8(sc.re), swz_bcast_last8(sc.im));
-            const double Tr = swz_bcast_last8(sr);
+            cd sc, s;
+            double sr, t;
+            if constexpr (LPI == 8) {
+                // inclusive scan of the end states over the item's eight lanes: inside the quads (quad permutations never leave
+                // the item) ...
+                sc = cfma(mA1, dpp_quad<0x90>(se), se);                // [0,0,1,2]: lane q takes lane q-1
+                sr = fma(nA1, dpp_quad<0x90>(te), te);
+                sc = cfma(mA2, dpp_quad<0x40>(sc), sc);                // [0,0,0,1]: lane q takes lane q-2
+                sr = fma(nA2, dpp_quad<0x40>(sr), sr);
+                // ... then the first quad's total into the second: row_shr:4 written to banks 1 and 3 only (lanes 4-7, 12-15; the
+                // others keep 0: nothing crosses from the neighbouring item), its lane 3 broadcast over the quad
+                const cd cq = dpp_quad<0xFF>(dpp_shr4_banks13(sc));
+                const double cqr = dpp_quad<0xFF>(dpp_shr4_banks13(sr));
+                // state before the lane's first sample: the lanes before it in its quad, the quad before, the block's starting state
+                const cd eq = dpp_quad<0x90>(sc);
+                const double eqr = dpp_quad<0x90>(sr);
+                s = cfma(plc, Cc, cfma(mE, cq, mk(q1 * eq.re, q1 * eq.im)));
+                t = fma(plr, Cr, fma(nE, cqr, q1 * eqr));
+                sc = cfma(mB, cq, sc);
+                sr = fma(nB, cqr, sr);
+            } else {
+                // the item is a whole row of lanes: shifts inside the row fill with zeros at its start and never leave it
+                sc = cfma(s1, dpp_row<0x111>(se), se);
+                sr = fma(t1, dpp_row<0x111>(te), te);
+                sc = cfma(s2, dpp_row<0x112>(sc), sc);
+                sr = fma(t2, dpp_row<0x112>(sr), sr);
+                sc = cfma(s4, dpp_row<0x114>(sc), sc);
+                sr = fma(t4, dpp_row<0x114>(sr), sr);
+                sc = cfma(s8, dpp_row<0x118>(sc), sc);
+                sr = fma(t8, dpp_row<0x118>(sr), sr);
+                s = cfma(plc, Cc, dpp_row<0x111>(sc));
+                t = fma(plr, Cr, dpp_row<0x111>(sr));
+            }
+            // the next block starts from this block's end state (the item's last lane)
+            const cd Tc = LPI == 8 ? mk(swz_bcast_last8(sc.re), swz_bcast_last8(sc.im)) : dpp_row<0x15F>(sc);
+            const double Tr = LPI == 8 ? swz_bcast_last8(sr) : dpp_row<0x15F>(sr);
             Cc = cfma(pbc, Cc, Tc);
             Cr = fma(pbr, Cr, Tr);
             // what the starting state adds to the four outputs (dsp_processor.py:32-36: sosfilt, zero state per chunk)
@@ -302,40 +348,50 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 8) void post_fft8_kernel(P
             const double y3 = fma(g3.re, s.re, fma(-g3.im, s.im, fma(gr3, t, y03)));
             *(double2 *) (out + 4 * LPI * n1) = make_double2(y0, y1);
             *(double2 *) (out + 4 * LPI * n1 + 2) = make_double2(y2, y3);
-            // four blocks at a time: enough independent work for the pipeline, few enough intermediate values for the registers
-            // (left alone, the scheduler starts all sixteen blocks at once and spills)
+            // a few blocks at a time: enough independent work for the pipeline, few enough intermediate values for the registers
             if constexpr (n1 % SDRT_P8_BLOCKS_AHEAD == SDRT_P8_BLOCKS_AHEAD - 1) __builtin_amdgcn_sched_barrier(0);
         });
     }
 }
 
-size_t post_fft8_lds_bytes(int wpb) { return ((size_t) 4 * SDRT_P8_PPL * 8 + 8 * 8 + (size_t) wpb * 8 * SDRT_P8_SO) * 16; }
+size_t post_fft8_lds_bytes(int lpi, int wpb) {
+    return ((size_t) 4 * SDRT_P8_PPL * lpi + 8 * lpi + (size_t) wpb * (64 / lpi) * 17 * lpi) * 16;
+}
 
-template <int WPB, bool PAIRS>
+template <int LPI, int WPB, bool PAIRS>
 static hipError_t launch_post_fft8_p(const PostArgs &a, hipStream_t s) {
-    const size_t lds = post_fft8_lds_bytes(WPB);
+    const size_t lds = post_fft8_lds_bytes(LPI, WPB);
     static thread_local int done_dev = -1;                      // once per device and instantiation
     int dev = 0;
     (void) hipGetDevice(&dev);
     if (done_dev != dev) {
-        hipError_t e = hipFuncSetAttribute((const void *) post_fft8_kernel<WPB, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        hipError_t e = hipFuncSetAttribute((const void *) post_fft8_kernel<LPI, WPB, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
         done_dev = dev;
     }
-    const size_t groups = (a.items + 7) / 8;
+    constexpr size_t IPW = 64 / LPI;
+    const size_t groups = (a.items + IPW - 1) / IPW;
     size_t wgs = (groups + WPB - 1) / WPB;
-    const size_t cap = 256 * 4;                                  // a few workgroups per CU; waves walk over the rest
+    const size_t cap = 256 * (LPI == 16 ? 2 : 4);               // a few workgroups per CU; waves walk over the rest
     if (wgs > cap) wgs = cap;
-    hipLaunchKernelGGL((post_fft8_kernel<WPB, PAIRS>), dim3((unsigned) wgs), dim3(64 * WPB), lds, s, a);
+    hipLaunchKernelGGL((post_fft8_kernel<LPI, WPB, PAIRS>), dim3((unsigned) wgs), dim3(64 * WPB), lds, s, a);
     return hipGetLastError();
 }
 
 bool post_fft8_supported(const PostArgs &a) {
-    return a.mode == SDRT_FM && a.fft8_tab && a.p8tab && a.m == 512;
+    // (with the IQ offset share still to subtract every angle takes four samples and four table entries: the one-wave-per-item
+    // kernel holds those loads better -- 0.54 against 0.63 ms per 2^32 samples, profiles/r03_experiments.txt)
+    if (a.iq_R) return false;
+    return a.mode == SDRT_FM && a.fft8_tab && a.p8tab && ((a.m == 512 && a.p8_lpi == 8) || (a.m == 1024 && a.p8_lpi == 16));
 }
 
 hipError_t launch_post_fft8(const PostArgs &a, hipStream_t s) {
+    if (a.p8_lpi == 16) {
+        // the tables take 18 KiB, a wave's exchange image 17: eight waves share one copy of the tables
+        if (a.items <= 4 * 256) return a.pairs ? launch_post_fft8_p<16, 1, true>(a, s) : launch_post_fft8_p<16, 1, false>(a, s);
+        return a.pairs ? launch_post_fft8_p<16, 8, true>(a, s) : launch_post_fft8_p<16, 8, false>(a, s);
+    }
     // few items: one wave per workgroup spreads them over more compute units
-    if (a.items <= 8 * 256) return a.pairs ? launch_post_fft8_p<1, true>(a, s) : launch_post_fft8_p<1, false>(a, s);
-    return a.pairs ? launch_post_fft8_p<4, true>(a, s) : launch_post_fft8_p<4, false>(a, s);
+    if (a.items <= 8 * 256) return a.pairs ? launch_post_fft8_p<8, 1, true>(a, s) : launch_post_fft8_p<8, 1, false>(a, s);
+    return a.pairs ? launch_post_fft8_p<8, 4, true>(a, s) : launch_post_fft8_p<8, 4, false>(a, s);
 }

@@ -340,6 +340,8 @@ extern "C" int sdrt_build_post8_tables(const double *out_sos, int sections, int 
     out->pr4 = (double) cpow(prc, 4).re;
     put(out->pc8, cpow(pc, 8));
     out->pr8 = (double) cpow(prc, 8).re;
+    put(out->pc32, cpow(pc, 32));
+    out->pr32 = (double) cpow(prc, 32).re;
     for (int q = 0; q < 4; ++q) {
         put(out->pc_q[q], cpow(pc, 4 * (q + 1)));
         out->pr_q[q] = (double) cpow(prc, 4 * (q + 1)).re;

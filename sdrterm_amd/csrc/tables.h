@@ -90,6 +90,7 @@ struct Post8Tables {
     double pcp[3][2], prp[3];               // pc^1..3, pr^1..3: the run's end state x3 + p x2 + p^2 x1 + p^3 x0
     double g[4][2], gr[4];                  // rc pc^j, rr pr^j: what the state at the run's start adds to y[j]
     double pc4[2], pr4, pc8[2], pr8;        // p^4, p^8: scan inside a quad of lanes
+    double pc32[2], pr32;                   // p^32 (with pc_q[3] = p^16: the scan over a row of sixteen lanes)
     double pc_q[4][2], pr_q[4];             // p^(4 (q+1)): the quads before -> lane q of a quad
     double pc_lane[16][2], pr_lane[16];     // p^(4 l):   block start -> first sample of lane l
     double pc_blk[2], pr_blk;               // p^(4 LPI): block to block

@@ -19,6 +19,7 @@ class Post8Tables(C.Structure):
                 ('h', C.c_double * 4), ('pcp', C.c_double * 6), ('prp', C.c_double * 3),
                 ('g', C.c_double * 8), ('gr', C.c_double * 4),
                 ('pc4', C.c_double * 2), ('pr4', C.c_double), ('pc8', C.c_double * 2), ('pr8', C.c_double),
+                ('pc32', C.c_double * 2), ('pr32', C.c_double),
                 ('pc_q', C.c_double * 8), ('pr_q', C.c_double * 4),
                 ('pc_lane', C.c_double * 32), ('pr_lane', C.c_double * 16),
                 ('pc_blk', C.c_double * 2), ('pr_blk', C.c_double)]
@@ -105,7 +106,7 @@ def test_exchange_image_is_conflict_free():
     SO, LPI = 136, 8
     lanes = [(lane >> 3, lane & 7) for lane in range(64)]
     S = lambda l, ci: l if ci == 0 else (16 - l if l else 8)
-    slot = lambda o, n2, k1: 16 * (o * SO + 17 * n2 + k1)
+    slot = lambda o, n2, k1: 16 * (o * SO + 17 * n2 + k1)          # (SO is looked up when called: the second half redefines it)
     for k1 in range(16):                                     # forward: lane writes (n2 = l, k1); back: lane reads (n2 = l, c = k1)
         assert cycles('write_b128', [slot(o, l, k1) for o, l in lanes]) == 8
         assert cycles('read_b128', [slot(o, l, k1) for o, l in lanes]) == 4
@@ -116,3 +117,12 @@ def test_exchange_image_is_conflict_free():
     # the tables: every lane group reads the same eight consecutive entries
     for row in range(16):
         assert cycles('read_b128', [16 * (row * LPI + l) for _o, l in lanes]) == 4
+    # sixteen lanes per item (1024 outputs per chunk): an item's image is 16 x 17 = 272 slots, one bin series per lane
+    SO, LPI = 272, 16
+    lanes = [(lane >> 4, lane & 15) for lane in range(64)]
+    for k1 in range(16):
+        assert cycles('write_b128', [slot(o, l, k1) for o, l in lanes]) == 8
+        assert cycles('read_b128', [slot(o, l, k1) for o, l in lanes]) == 4
+    for j in range(16):
+        assert cycles('read_b128', [slot(o, j, l) for o, l in lanes]) == 4
+        assert cycles('write_b128', [slot(o, j, l) for o, l in lanes]) == 8
