@@ -180,6 +180,7 @@ def main():
     ap.add_argument('--no-kernel-events', action='store_true', help='diagnostic: no per-kernel HIP events in the timed region')
     ap.add_argument('--feed', choices=('bcast', 'allgather'), default='bcast', help='many-row workloads: how a block reaches the ranks')
     ap.add_argument('--no-same-arithmetic', action='store_true', help="skip the fp64 kernel's side figure")
+    ap.add_argument('--force-comm', action='store_true', help='diagnostic: the RCCL communicator with a single rank too (barrier / maximum / block exchange path on one GPU)')
     ap.add_argument('--dry-run', action='store_true', help='with --gpus N > 1 and no launcher: print the ranks that would be started')
     args = ap.parse_args()
 
@@ -200,7 +201,7 @@ def main():
     from sdrterm_amd.engine import Engine
     # one communicator for everything the ranks say to each other (barrier, maximum, block exchange): RCCL behind the C ABI
     comm = None
-    if world > 1:
+    if world > 1 or args.force_comm:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         comm = parallel.RcclTransport(rank, world, local_rank)        # the id travels over TCP at MASTER_ADDR:MASTER_PORT+17
     q, rows_total, default_chunks, scaling, code, FS = WORKLOADS[args.workload]
@@ -220,7 +221,7 @@ def main():
         # two block buffers per rank: block k+1 arrives beside the kernels of block k.  bcast: the stream lives on rank 0 (where
         # the reader's Queue ends).  allgather: every rank holds the same 1/N of every block (the whole stream is synthesised
         # everywhere from one seed, a rank keeps its slice)
-        allg = args.feed == 'allgather' and world > 1
+        allg = args.feed == 'allgather' and comm is not None
         if n_samples % world and allg:
             raise SystemExit('--feed allgather needs a block that divides by the number of ranks')
         src = synth_iq_torch(2 * n_samples, seed=1234, device=device, code=code, fs=FS) if (rank == 0 or allg) else None

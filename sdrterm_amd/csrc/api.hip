@@ -75,6 +75,8 @@ struct sdrt_ctx {
     double *d_fft8 = nullptr;         // eight-lanes-per-item demodulation stage (kernels_post8.hip): transform tables ...
     Post8Tables *d_p8tab = nullptr;   // ... and its lowpass constants
     int p8_lpi = 0;
+    double *d_stash = nullptr;        // ... and the angles of the items in flight (grow-only)
+    size_t stash_cap = 0;
     double *d_smooth = nullptr;       // taps | left | right of --smooth-output (sdrt_set_smoothing)
     int sm_window = 0, sm_ntaps = 0, sm_first = 0, sm_edge = 0;
     bool fft_ok = false, out_modal = false;
@@ -642,6 +644,7 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_fft_shift);
     (void) hipFree(c->d_fft8);
     (void) hipFree(c->d_p8tab);
+    (void) hipFree(c->d_stash);
     (void) hipFree(c->d_rows_of[0]);
     (void) hipFree(c->d_rows_of[1]);
     (void) hipFree(c->d_out_sos);
@@ -948,11 +951,30 @@ PostArgs post_args(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out
     pa.fft8_tab = c->d_fft8;
     pa.p8tab = c->d_p8tab;
     pa.p8_lpi = c->p8_lpi;
+    pa.stash = nullptr;
+    pa.stash_bytes = 0;
     return pa;
 }
 
+// the angle stash of the eight / sixteen-lanes-per-item demodulation stage for a batch of this size
+int ensure_stash(sdrt_ctx *c, PostArgs &pa) {
+    const char *e = getenv("SDRTERM_POST_STASH");              // diagnostics: "out" keeps the angles in the output buffer
+    if (e && strcmp(e, "out") == 0) return SDRT_OK;
+    const size_t need = post_fft8_stash_bytes(pa);
+    if (need > c->stash_cap) {
+        (void) hipFree(c->d_stash);
+        c->d_stash = nullptr;
+        c->stash_cap = 0;
+        HIP_TRY(hipMalloc((void **) &c->d_stash, need));
+        c->stash_cap = need;
+    }
+    if (need) { pa.stash = c->d_stash; pa.stash_bytes = c->stash_cap; }
+    return SDRT_OK;
+}
+
 int enqueue_post(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out_dev, hipStream_t s, bool iq_share = false, bool pairs = false) {
-    const PostArgs pa = post_args(c, ybuf, n_chunks, out_dev, iq_share, pairs);
+    PostArgs pa = post_args(c, ybuf, n_chunks, out_dev, iq_share, pairs);
+    if (!c->mixed) { int rcs = ensure_stash(c, pa); if (rcs != SDRT_OK) return rcs; }
     {
         Timed t(c, s, 1);
         if (c->mixed) {
@@ -1033,6 +1055,10 @@ int sdrt_reserve(sdrt_ctx *c, size_t max_chunks) {
     if (rc == SDRT_OK && c->iq) rc = ensure_iqrange(c, max_chunks);
     if (rc == SDRT_OK) rc = ensure_pairbufs(c);
     if (rc == SDRT_OK) rc = ensure_prebufs(c, max_chunks);
+    if (rc == SDRT_OK && !c->mixed) {
+        PostArgs pa = post_args(c, nullptr, max_chunks, nullptr, false, true);
+        rc = ensure_stash(c, pa);
+    }
     return rc;
 }
 

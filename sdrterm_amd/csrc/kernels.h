@@ -96,8 +96,11 @@ struct PostArgs {
     const double *fft8_tab;     // [4][16 LPI][2] + [8][LPI][2]: sdrt_build_post8_tables
     const Post8Tables *p8tab;
     int p8_lpi;                 // lanes per item the tables were built for: 8 (m = 512) or 16 (m = 1024)
+    double *stash;              // scratch of post_fft8_stash_bytes() bytes: the pair angles of the items in flight (or NULL: they wait in `out`)
+    size_t stash_bytes;
 };
 bool post_fft8_supported(const PostArgs &a);
+size_t post_fft8_stash_bytes(const PostArgs &a);
 hipError_t launch_post_fft8(const PostArgs &a, hipStream_t s);
 // does launch_post pick a kernel that reads pair products (PostArgs.pairs)?
 bool post_takes_pairs(const PostArgs &a);

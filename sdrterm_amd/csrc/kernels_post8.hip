@@ -200,7 +200,10 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
         // step: they wait in the item's own place in the output buffer (every lane re-reads what it wrote itself, in one go at
         // the start of the lowpass; the final stores overwrite them while the lines are still in L2) instead of sitting in 64
         // registers through the transforms -- that, not the arithmetic, is what the register allocator spilled for.
-        cd *stash = (cd *) (a.out + it * (size_t) M) + l;
+        // (a.stash: a region per resident wave instead, rewritten by every group the wave works through: the same few megabytes
+        // stay in L2 / the Infinity Cache, where the item's own place in the output buffer is new memory every time)
+        cd *stash = a.stash ? (cd *) a.stash + ((size_t) blockIdx.x * WPB + wave) * (size_t) (IPW * H) + (size_t) o * H + l
+                            : (cd *) (a.out + it * (size_t) M) + l;
 #pragma unroll
         for (int k = 0; k < P; ++k) stash[LPI * k] = x[k];
         // ---- forward: 16 points in the lane, twiddle, exchange, LPI points ---------------------------------------------------
@@ -354,6 +357,8 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
     }
 }
 
+bool post_fft8_supported(const PostArgs &a);
+
 size_t post_fft8_lds_bytes(int lpi, int wpb) {
     return ((size_t) 4 * SDRT_P8_PPL * lpi + 8 * lpi + (size_t) wpb * (64 / lpi) * 17 * lpi) * 16;
 }
@@ -374,8 +379,20 @@ static hipError_t launch_post_fft8_p(const PostArgs &a, hipStream_t s) {
     size_t wgs = (groups + WPB - 1) / WPB;
     const size_t cap = 256 * (LPI == 16 ? 2 : 4);               // a few workgroups per CU; waves walk over the rest
     if (wgs > cap) wgs = cap;
+    if (a.stash && a.stash_bytes < wgs * WPB * 8 * 128 * 16) return hipErrorInvalidValue;      // 8 x 128 (4 x 256) complex angles per wave
     hipLaunchKernelGGL((post_fft8_kernel<LPI, WPB, PAIRS>), dim3((unsigned) wgs), dim3(64 * WPB), lds, s, a);
     return hipGetLastError();
+}
+
+// bytes of the per-wave angle stash a launch over `items` items takes (PostArgs.stash), 0: none needed (not this kernel)
+size_t post_fft8_stash_bytes(const PostArgs &a) {
+    if (!post_fft8_supported(a)) return 0;
+    const size_t ipw = 64 / a.p8_lpi, groups = (a.items + ipw - 1) / ipw;
+    const bool small = a.items <= (a.p8_lpi == 16 ? 4 * 256 : 8 * 256);
+    const size_t wpb = small ? 1 : (a.p8_lpi == 16 ? 8 : 4), cap = 256 * (a.p8_lpi == 16 ? 2 : 4);
+    size_t wgs = (groups + wpb - 1) / wpb;
+    if (wgs > cap) wgs = cap;
+    return wgs * wpb * 8 * 128 * 16;
 }
 
 bool post_fft8_supported(const PostArgs &a) {

@@ -597,3 +597,29 @@ def test_iq_offset_of_a_chunk_range_and_a_stream_processed_in_two_parts(code, fu
     for c in range(nch):
         chain.process(raw[c * cb:(c + 1) * cb])
     assert abs(chain.off - end_whole) <= 1e-9 * abs(end_whole)
+
+
+@pytest.mark.parametrize('argv', [['--workload', 'simo64', '--feed', 'bcast', '--chunks', '32'],
+                                  ['--workload', 'simo64', '--feed', 'allgather', '--chunks', '32'],
+                                  ['--workload', 'fm64', '--chunks', '256']])
+def test_bench_rank_plumbing_on_one_gpu(argv):
+    """bench.py's multi-rank plumbing with a single rank (--force-comm): the RCCL communicator behind the C ABI comes up inside
+    the bench process (torch loaded first, one HIP runtime), barrier and maximum over ranks go through it, blocks reach the
+    rank by broadcast or all-gather on the communication stream beside the kernels -- and the line it prints carries what the
+    contract asks for, every number measured by that run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--force-comm', '--steps', '3', '--warmup', '1', '--settle-seconds', '0.2',
+                          '--long-seconds', '0', '--no-cpu-baseline'] + argv, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and d['unit'] == 'MSamples/s' and d['higher_is_better'] is True
+    assert d['roofline']['bound'] in ('hbm', 'mfma') and 0 < d['roofline']['frac'] < 1 and d['roofline']['traffic'] is None
+    assert d['vs_baseline'] is None and d['data'] == 'synthetic' and 'workload' in d['config']
+    if argv[1] == 'fm64':
+        assert d['roofline']['from_profile'] is None            # another batch size than the committed counter record's
+        assert d['same_arithmetic']['stage_a'] == 'f64' and 0 < d['same_arithmetic']['path_frac'] < 1      # (tiny batch: no ranking of the two)
+        assert 0 < d['roofline']['read_frac'] < d['roofline']['path_frac']

@@ -1,0 +1,27 @@
+#!/bin/bash
+# The round's measurement set on one GPU box -> gpurun_out/prof_<tag>/ (copy what is to be judged into profiles/):
+#   bench line, bench line under rocprofv3 with the kernel-trace statistics, counter passes + record, phase stamps
+#   (diagnostic build libsdrterm_hip_exp.so made with EXTRA=-DSDRT_STAMPS), determinism.
+# usage: tools/profile_round.sh r03
+tag=${1:-rXX}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/prof_$tag
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+python3 "$ROOT/bench.py" > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" || exit 1
+echo "bench done"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 300 --warmup 20 --no-cpu-baseline --no-same-arithmetic > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof.err" || exit 1
+f=$(find "$OUT/stats" -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv"
+rm -rf "$OUT/stats"
+echo "rocprof stats done"
+bash "$ROOT/tools/pmc.sh" > "$OUT/pmc.log" 2>&1
+cp "$ROOT/gpurun_out/pmc/summary.txt" "$OUT/pmc_summary.txt" 2>/dev/null
+cp "$ROOT/gpurun_out/pmc/pmc_record.json" "$OUT/pmc_record.json" 2>/dev/null
+echo "pmc done"
+if [ -f "$ROOT/sdrterm_amd/libsdrterm_hip_exp.so" ]; then
+    SDRTERM_HIP_LIB=$ROOT/sdrterm_amd/libsdrterm_hip_exp.so python3 "$ROOT/tools/stamps_wide.py" 131072 15000 450 > "$OUT/i8w_phase_stamps_after_2s_load.txt" 2>&1
+    echo "stamps done"
+fi
+python3 "$ROOT/tools/determinism.py" > "$OUT/determinism.txt" 2>&1
+tail -2 "$OUT/determinism.txt"
