@@ -71,7 +71,7 @@ class VfoProcessor(DspProcessor):
         self.rowModes = list(modes) if modes is not None else None
         self._channel = None
         self._helpers = []
-        self._stream, self._slots, self._moreComing = None, [None, None], False
+        self._stream, self._slots, self._moreComing, self._announced = None, [None, None], False, False
         # diagnostics / tests: the block channel with a single rank too (a 1-GPU box then runs the whole multi-GPU data path:
         # header, upload + broadcast into two buffers, kernels behind events, bounded waits)
         self._forceChannel = bool(kwargs.get('forceChannel') or os.environ.get('SDRTERM_SIMO_CHANNEL') == '1')
@@ -221,11 +221,17 @@ class VfoProcessor(DspProcessor):
         return sl['host'][:self._nFreq * n * m * 8].view(np.float64).reshape(self._nFreq, n, m).copy()
 
     def _announce(self, first_chunk) -> None:
-        """Rank 0, once: open the channel (collective) and tell the others what the blocks hold (None: nothing will come)."""
-        if self._channel is not None:
+        """Rank 0, once: tell the others what the blocks hold (None: nothing will come).  The channel itself is opened when the
+        ranks start (processData): joining the communicator is collective and bounded in time, the first chunk of a live source
+        may be long in coming -- the others wait for THIS message for as long as the job lives."""
+        if self._announced:
             return
+        self._announced = True
         self._blockKind = self._describe(first_chunk) if first_chunk is not None else None
-        self._openChannel(self._blockKind['chunk_bytes'] if self._blockKind else 1)
+        if self._channel is None:
+            self._openChannel(1)
+        if self._blockKind:
+            self._channel.chunk_bytes = self._blockKind['chunk_bytes']
         self._channel.t.bcast_bytes(repr(self._blockKind).encode().ljust(512), 512)
 
     def _releaseRanks(self) -> None:
@@ -288,6 +294,8 @@ class VfoProcessor(DspProcessor):
             self._nFreq = sh.rows
             self._fanout = RowFanOut(self.host, sh.port(self.port), sh.rows)
             self._fanout.start()
+            if self._world > 1 and self._rank == 0 and self._transportKind == 'rccl':
+                self._openChannel(1)               # every rank joins the communicator now (the helpers are in theirs already)
             self._processData(isDead, buffer)
         except (KeyboardInterrupt, _EndOfStream):
             pass

@@ -156,38 +156,76 @@ class RcclTransport:
         nat.check(nat.lib().sdrt_comm_unique_id(buf))
         return buf.raw
 
+    UID_MAGIC = b'SDRTuid1'
+    UID_PORTS = 16            # rank 0 listens on the first free one of this many ports from the base on
+
     @staticmethod
     def _exchange_uid(rank: int, world: int) -> bytes:
+        """The 128-byte id from rank 0 to the others over TCP at MASTER_ADDR, ports MASTER_PORT + 17 .. + 32 (or from
+        SDRTERM_UID_PORT on): rank 0 takes the first free one, the others knock until one of them answers with the magic word
+        and this world size (a launcher's own store or a stranger's service on one of the ports is passed over)."""
         if world == 1:
             return RcclTransport.unique_id()
         addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
-        port = int(os.environ.get('SDRTERM_UID_PORT', int(os.environ.get('MASTER_PORT', '29500')) + 17))
+        base = int(os.environ.get('SDRTERM_UID_PORT', int(os.environ.get('MASTER_PORT', '29500')) + 17))
+        hello = RcclTransport.UID_MAGIC + struct.pack('<q', world)
         if rank == 0:
             uid = RcclTransport.unique_id()
-            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
-                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                srv.bind((addr, port))
+            srv = None
+            for port in range(base, base + RcclTransport.UID_PORTS):
+                s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    s.bind((addr, port))
+                except OSError:
+                    s.close()
+                    continue
+                srv = s
+                break
+            if srv is None:
+                raise OSError(f'no free port for the communicator id in {addr}:{base}..{base + RcclTransport.UID_PORTS - 1}')
+            with srv:
                 srv.listen(world)
-                for _ in range(world - 1):
+                srv.settimeout(float(os.environ.get('SDRTERM_COMM_INIT_TIMEOUT', '180')))
+                served = 0
+                while served < world - 1:
                     conn, _peer = srv.accept()
                     with conn:
-                        conn.sendall(uid)
+                        conn.settimeout(10)
+                        try:
+                            got = b''
+                            while len(got) < len(hello):
+                                part = conn.recv(len(hello) - len(got))
+                                if not part:
+                                    break
+                                got += part
+                            if got != hello:
+                                continue                     # not one of ours
+                            conn.sendall(hello + uid)
+                            served += 1
+                        except OSError:
+                            continue
             return uid
-        deadline = time.time() + 120
+        deadline = time.time() + float(os.environ.get('SDRTERM_COMM_INIT_TIMEOUT', '180'))
         while True:
-            try:
-                with socket.create_connection((addr, port), timeout=5) as s:
-                    uid = b''
-                    while len(uid) < 128:
-                        part = s.recv(128 - len(uid))
-                        if not part:
-                            raise ConnectionError('short unique id')
-                        uid += part
-                    return uid
-            except OSError:
-                if time.time() > deadline:
-                    raise
-                time.sleep(0.1)
+            for port in range(base, base + RcclTransport.UID_PORTS):
+                try:
+                    with socket.create_connection((addr, port), timeout=2) as s:
+                        s.settimeout(5)
+                        s.sendall(hello)
+                        got = b''
+                        while len(got) < len(hello) + 128:
+                            part = s.recv(len(hello) + 128 - len(got))
+                            if not part:
+                                break
+                            got += part
+                        if len(got) == len(hello) + 128 and got[:len(hello)] == hello:
+                            return got[len(hello):]
+                except OSError:
+                    pass
+            if time.time() > deadline:
+                raise PeerLost('communicator id: rank 0 did not answer')
+            time.sleep(0.1)
 
     def bcast_device(self, dev_ptr: int, nbytes: int, root: int = 0, stream: int = 0) -> None:
         """In place on device memory, asynchronous on ``stream``."""

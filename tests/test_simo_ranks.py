@@ -223,3 +223,29 @@ def test_ports_of_every_rank_are_probed_before_helpers_start():
         with pytest.raises(OSError, match='rank 1'):
             p._startHelpers(_Flag())
         assert p._helpers == []
+
+
+def test_communicator_id_exchange_passes_over_busy_ports(monkeypatch):
+    """The 128-byte id travels from rank 0 to the others over TCP near MASTER_PORT; a port in that range that is taken (the
+    launcher's own store, somebody else's service) must neither stop rank 0 nor fool the others."""
+    import socket
+    from sdrterm_amd import parallel
+    from sdrterm_amd.misc.general_util import findPort
+    base = findPort('127.0.0.1')
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('SDRTERM_UID_PORT', str(base))
+    monkeypatch.setattr(parallel.RcclTransport, 'unique_id', staticmethod(lambda: bytes(range(128))))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as stranger:
+        stranger.bind(('127.0.0.1', base))           # the first port of the range belongs to somebody who answers nothing useful
+        stranger.listen(4)
+        got = {}
+
+        def run(rank):
+            got[rank] = parallel.RcclTransport._exchange_uid(rank, 3)
+        ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in (1, 0, 2)]
+        for t in ts:
+            t.start()
+            time.sleep(0.2)
+        for t in ts:
+            t.join(60)
+        assert got == {0: bytes(range(128)), 1: bytes(range(128)), 2: bytes(range(128))}
