@@ -1279,6 +1279,13 @@ int sdrt_memcpy_d2d(void *d, const void *s, size_t b) {
     HIP_TRY(hipMemcpy(d, s, b, hipMemcpyDeviceToDevice));
     return SDRT_OK;
 }
+int sdrt_mem_info(size_t *free_bytes, size_t *total_bytes) {
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return SDRT_OK;
+}
 int sdrt_device_synchronize(void) {
     HIP_TRY(hipDeviceSynchronize());
     return SDRT_OK;

@@ -124,7 +124,7 @@ class RcclTransport:
                 box['exc'] = e
         th = threading.Thread(target=join_comm, daemon=True)
         th.start()
-        deadline = time.monotonic() + float(os.environ.get('SDRTERM_COMM_INIT_TIMEOUT', '180'))
+        deadline = time.monotonic() + float(os.environ.get('SDRTERM_COMM_INIT_TIMEOUT', '600'))
         while th.is_alive():
             th.join(0.05)
             if th.is_alive() and ((alive is not None and not alive()) or time.monotonic() > deadline):
@@ -134,7 +134,7 @@ class RcclTransport:
         if box.get('rc'):
             raise nat.SdrtError(box['rc'], box['err'])
         nat.check(nat.lib().sdrt_set_device(device))         # (the communicator was joined on another thread: bind this one too)
-        self.timeout = float(os.environ.get('SDRTERM_COMM_TIMEOUT', '60'))      # seconds a collective may take
+        self.timeout = float(os.environ.get('SDRTERM_COMM_TIMEOUT', '300'))      # seconds a collective may take
         self.alive = alive          # callable: False once the job is going down (halt flag, a dead helper process)
         p = C.c_void_p()
         nat.check(nat.lib().sdrt_stream_create(C.byref(p)))
@@ -186,7 +186,7 @@ class RcclTransport:
                 raise OSError(f'no free port for the communicator id in {addr}:{base}..{base + RcclTransport.UID_PORTS - 1}')
             with srv:
                 srv.listen(world)
-                srv.settimeout(float(os.environ.get('SDRTERM_COMM_INIT_TIMEOUT', '180')))
+                srv.settimeout(float(os.environ.get('SDRTERM_COMM_INIT_TIMEOUT', '600')))
                 served = 0
                 while served < world - 1:
                     conn, _peer = srv.accept()
@@ -206,7 +206,7 @@ class RcclTransport:
                         except OSError:
                             continue
             return uid
-        deadline = time.time() + float(os.environ.get('SDRTERM_COMM_INIT_TIMEOUT', '180'))
+        deadline = time.time() + float(os.environ.get('SDRTERM_COMM_INIT_TIMEOUT', '600'))
         while True:
             for port in range(base, base + RcclTransport.UID_PORTS):
                 try:

@@ -623,3 +623,48 @@ def test_bench_rank_plumbing_on_one_gpu(argv):
         assert d['roofline']['from_profile'] is None            # another batch size than the committed counter record's
         assert d['same_arithmetic']['stage_a'] == 'f64' and 0 < d['same_arithmetic']['path_frac'] < 1      # (tiny batch: no ranking of the two)
         assert 0 < d['roofline']['read_frac'] < d['roofline']['path_frac']
+
+
+def test_reserve_and_error_paths_of_the_abi():
+    """sdrt_reserve: every scratch buffer a batch of that size needs exists afterwards, and a processing call of that size leaves the
+    device's free memory where it was (no allocation inside sdrt_process_*); row_modes outside FM / AM are refused with a message;
+    the tap entry points keep their buffers until sdrt_taps_release."""
+    import ctypes as C
+    from sdrterm_amd import _native as nat
+    from sdrterm_amd.engine import Engine
+    from tests.golden import prng
+    fs, q, n, nch = 1024000, 64, 32768, 48
+    raw = prng.raw_bytes('h', n * nch, seed=12, amp=3000)
+    eng = Engine(fs, q, 'fm', 'h', row_freqs=[15700.0, -1000.0], apply_shift=True, omega_out=5000, correct_iq=True, reserve_chunks=nch)
+    d_raw = nat.DeviceBuffer(len(raw)).upload(np.frombuffer(raw, dtype=np.uint8))
+    d_out = nat.DeviceBuffer(2 * nch * eng.m * 8)
+    lib = nat.lib()
+    lib.sdrt_mem_info.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    free0, free1, tot = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    nat.check(lib.sdrt_device_synchronize())
+    nat.check(lib.sdrt_mem_info(C.byref(free0), C.byref(tot)))
+    eng.process_device(d_raw.ptr, nch, d_out.ptr)
+    a, b = eng.iq_range_device(d_raw.ptr, nch)
+    nat.check(lib.sdrt_device_synchronize())
+    nat.check(lib.sdrt_mem_info(C.byref(free1), C.byref(tot)))
+    assert free1.value == free0.value, 'a processing call within the reserved size allocated device memory'
+    assert 0 < a < 1 and np.isfinite(b.real)
+    with pytest.raises(ValueError):
+        Engine(fs, q, 'fm', 'h', row_freqs=[0.0, 1.0], row_modes=['fm', 're'])
+    # at the ABI itself: a real / imaginary entry among the row modes is refused with a message
+    good = Engine(fs, q, 'fm', 'h', row_freqs=[0.0, 1.0], row_modes=['fm', 'am'])
+    assert good.row_modes == ['fm', 'am']
+    bad = np.ascontiguousarray([0, 3], dtype=np.int32)
+    import scipy.signal as sg
+    dec = np.ascontiguousarray(sg.cheby1(8, 0.05, 0.8 / q, output='sos'))
+    outs = np.ascontiguousarray(sg.ellip(3, 1, 30, 5000, output='sos', fs=fs // q))
+    freqs = np.ascontiguousarray([0.0, 1.0])
+    cfg = nat.Config(struct_size=C.sizeof(nat.Config), device=0, fs=float(fs), decimation=q, mode=0, dtype=2, n_samples=n, n_rows=2,
+                     apply_shift=1, dec_sections=4, out_sections=outs.shape[0])
+    cfg.row_freqs = freqs.ctypes.data_as(C.POINTER(C.c_double))
+    cfg.dec_sos = dec.ctypes.data_as(C.POINTER(C.c_double))
+    cfg.out_sos = outs.ctypes.data_as(C.POINTER(C.c_double))
+    cfg.row_modes = bad.ctypes.data_as(C.POINTER(C.c_int32))
+    ctx = C.c_void_p()
+    assert lib.sdrt_create(C.byref(cfg), C.byref(ctx)) == nat.EINVAL and b'row_modes[1]' in lib.sdrt_last_error()
+    assert lib.sdrt_taps_release() == 0
