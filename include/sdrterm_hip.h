@@ -174,7 +174,9 @@ int sdrt_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int sdrt_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes);
 int sdrt_device_synchronize(void);
 int sdrt_set_device(int device);
-int sdrt_mem_info(size_t *free_bytes, size_t *total_bytes);     /* of the current device (sizing batches; the reserve test) */
+int sdrt_mem_info(size_t *free_bytes, size_t *total_bytes);     /* of the current device (sizing batches) */
+unsigned long long sdrt_alloc_count(void);                      /* device allocations the library has made so far: constant across
+                                                                   the processing calls of a reserved context (sdrt_reserve) */
 
 /*
  * Streams and pinned host memory, for hosts that overlap transfers with computation themselves (the multi-GPU --simo

@@ -31,7 +31,7 @@ EXPORTS = (
     'sdrt_comm_unique_id', 'sdrt_comm_init', 'sdrt_comm_bcast', 'sdrt_comm_allgather', 'sdrt_comm_world', 'sdrt_comm_rank',
     'sdrt_comm_destroy', 'sdrt_submit_host', 'sdrt_wait', 'sdrt_spectrum_host', 'sdrt_stft_host', 'sdrt_iq_range_device',
     'sdrt_event_create', 'sdrt_event_destroy', 'sdrt_event_record', 'sdrt_stream_wait_event', 'sdrt_event_query',
-    'sdrt_event_synchronize', 'sdrt_reserve', 'sdrt_taps_release', 'sdrt_mem_info',
+    'sdrt_event_synchronize', 'sdrt_reserve', 'sdrt_taps_release', 'sdrt_mem_info', 'sdrt_alloc_count',
 )
 
 

@@ -13,7 +13,18 @@
 
 #include "kernels.h"
 
+#include <atomic>
+
 namespace {
+
+// every device allocation of this file goes through here: sdrt_alloc_count() lets a caller (and the tests) check that the
+// steady state allocates nothing (sdrt_reserve)
+std::atomic<unsigned long long> g_dev_allocs{0};
+template <typename T> hipError_t counted_malloc(T **p, size_t bytes) {
+    g_dev_allocs.fetch_add(1, std::memory_order_relaxed);
+    return ::hipMalloc(p, bytes);
+}
+#define hipMalloc(p, bytes) counted_malloc((p), (bytes))
 
 thread_local char g_err[512] = "";
 
@@ -186,7 +197,7 @@ struct Timed {
 
 template <class T>
 int upload(T **dst, const void *src, size_t bytes) {
-    HIP_TRY(hipMalloc((void **) dst, bytes));
+    HIP_TRY(hipMalloc(dst, bytes));
     HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
     return SDRT_OK;
 }
@@ -264,7 +275,7 @@ int setup_wide(sdrt_ctx *c, const sdrt_config *cfg, ScaleFn &) {
         for (int i = 0; i < n; ++i) gz[2 * i] = pw[i];
         double *d_gz = nullptr;
         if (rc == SDRT_OK) rc = upload(&d_gz, gz.data(), gz.size() * sizeof(double));
-        if (rc == SDRT_OK && hipMalloc((void **) &c->d_iq_R, (size_t) c->rows * c->m * 2 * sizeof(double)) != hipSuccess)
+        if (rc == SDRT_OK && hipMalloc(&c->d_iq_R, (size_t) c->rows * c->m * 2 * sizeof(double)) != hipSuccess)
             rc = fail(SDRT_ENOMEM, "hipMalloc failed");
         if (rc == SDRT_OK) {
             DecimArgs da;
@@ -357,7 +368,7 @@ int setup_ybias(sdrt_ctx *c, const sdrt_config *cfg) {
         for (int i = 0; i < n; ++i) { cz[2 * i] = cre; cz[2 * i + 1] = cim; }
         double *d_cz = nullptr;
         int rc = upload(&d_cz, cz.data(), cz.size() * sizeof(double));
-        if (rc == SDRT_OK && hipMalloc((void **) &c->d_ybias, bytes) != hipSuccess) rc = fail(SDRT_ENOMEM, "hipMalloc failed");
+        if (rc == SDRT_OK && hipMalloc(&c->d_ybias, bytes) != hipSuccess) rc = fail(SDRT_ENOMEM, "hipMalloc failed");
         if (rc == SDRT_OK) {
             DecimArgs da;
             memset(&da, 0, sizeof(da));
@@ -380,7 +391,7 @@ int setup_ybias(sdrt_ctx *c, const sdrt_config *cfg) {
     }
     if (c->use_i8w) {
         // the wide-column kernel always adds its ybias operand (no branch in its inner loop): zeros here
-        if (hipMalloc((void **) &c->d_ybias, bytes) != hipSuccess) return fail(SDRT_ENOMEM, "hipMalloc failed");
+        if (hipMalloc(&c->d_ybias, bytes) != hipSuccess) return fail(SDRT_ENOMEM, "hipMalloc failed");
         if (hipMemset(c->d_ybias, 0, bytes) != hipSuccess) return fail(SDRT_EHIP, "hipMemset failed");
     }
     return SDRT_OK;
@@ -727,7 +738,7 @@ int ensure_ybuf(sdrt_ctx *c, size_t n_chunks) {
         (void) hipFree(c->d_y);
         c->d_y = nullptr;
         c->y_cap_chunks = 0;
-        HIP_TRY(hipMalloc((void **) &c->d_y, n_chunks * (size_t) c->rows * c->m * 2 * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_y, n_chunks * (size_t) c->rows * c->m * 2 * sizeof(double)));
         c->y_cap_chunks = n_chunks;
     }
     return SDRT_OK;
@@ -742,9 +753,9 @@ int ensure_iqbufs(sdrt_ctx *c, size_t n_chunks) {
     c->d_iq_group = c->d_iq_agg = c->d_iq_chunk = nullptr;
     c->iq_cap_chunks = 0;
     if (!(c->use_i8w && c->iq_fused))
-        HIP_TRY(hipMalloc((void **) &c->d_iq_group, n_chunks * (size_t) (c->cfg.n_samples / c->iq_gs) * 2 * sizeof(double)));
-    HIP_TRY(hipMalloc((void **) &c->d_iq_agg, n_chunks * 2 * sizeof(double)));
-    HIP_TRY(hipMalloc((void **) &c->d_iq_chunk, (n_chunks + 1) * 2 * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_iq_group, n_chunks * (size_t) (c->cfg.n_samples / c->iq_gs) * 2 * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_iq_agg, n_chunks * 2 * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_iq_chunk, (n_chunks + 1) * 2 * sizeof(double)));
     c->iq_cap_chunks = n_chunks;
     return SDRT_OK;
 }
@@ -754,7 +765,7 @@ int ensure_iqrange(sdrt_ctx *c, size_t n_chunks) {
     (void) hipFree(c->d_iq_range);
     c->d_iq_range = nullptr;
     c->iq_range_cap = 0;
-    HIP_TRY(hipMalloc((void **) &c->d_iq_range, (2 * n_chunks + 2) * 2 * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_iq_range, (2 * n_chunks + 2) * 2 * sizeof(double)));
     c->iq_range_cap = n_chunks;
     return SDRT_OK;
 }
@@ -768,7 +779,7 @@ int ensure_prebufs(sdrt_ctx *c, size_t n_chunks) {
     c->d_pre_exp = nullptr;
     c->pre_cap = 0;
     HIP_TRY(hipMalloc(&c->d_pre, n_chunks * (size_t) c->cfg.n_samples * 2 * sizeof(float)));
-    HIP_TRY(hipMalloc((void **) &c->d_pre_exp, n_chunks * 4 * sizeof(int)));
+    HIP_TRY(hipMalloc(&c->d_pre_exp, n_chunks * 4 * sizeof(int)));
     c->pre_cap = n_chunks;
     return SDRT_OK;
 }
@@ -778,7 +789,7 @@ int ensure_pairbufs(sdrt_ctx *c) {
     if (c->d_pair_raw || !(c->use_i8w && c->cfg.n_samples == 4 * SDRT_TB * SDRT_WIDE_LC)) return SDRT_OK;
     const size_t cb = (size_t) c->cfg.n_samples * 2 * kItemSize[c->cfg.dtype];
     HIP_TRY(hipMalloc(&c->d_pair_raw, 2 * cb));
-    HIP_TRY(hipMalloc((void **) &c->d_pair_y, (size_t) c->rows * 2 * (size_t) c->m * 2 * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_pair_y, (size_t) c->rows * 2 * (size_t) c->m * 2 * sizeof(double)));
     return SDRT_OK;
 }
 
@@ -965,7 +976,7 @@ int ensure_stash(sdrt_ctx *c, PostArgs &pa) {
         (void) hipFree(c->d_stash);
         c->d_stash = nullptr;
         c->stash_cap = 0;
-        HIP_TRY(hipMalloc((void **) &c->d_stash, need));
+        HIP_TRY(hipMalloc(&c->d_stash, need));
         c->stash_cap = need;
     }
     if (need) { pa.stash = c->d_stash; pa.stash_bytes = c->stash_cap; }
@@ -1091,7 +1102,7 @@ int host_slot_prepare(sdrt_ctx *c, HostSlot &sl, size_t n_chunks, size_t in_byte
         if (sl.h_out) HIP_TRY(hipHostFree(sl.h_out));
         sl.d_raw = nullptr; sl.d_out = nullptr; sl.h_out = nullptr; sl.cap_chunks = 0;
         HIP_TRY(hipMalloc(&sl.d_raw, n_chunks * in_bytes));
-        HIP_TRY(hipMalloc((void **) &sl.d_out, n_chunks * out_bytes));
+        HIP_TRY(hipMalloc(&sl.d_out, n_chunks * out_bytes));
         HIP_TRY(hipHostMalloc((void **) &sl.h_out, n_chunks * out_bytes, hipHostMallocDefault));
         sl.cap_chunks = n_chunks;
     }
@@ -1279,6 +1290,7 @@ int sdrt_memcpy_d2d(void *d, const void *s, size_t b) {
     HIP_TRY(hipMemcpy(d, s, b, hipMemcpyDeviceToDevice));
     return SDRT_OK;
 }
+unsigned long long sdrt_alloc_count(void) { return g_dev_allocs.load(std::memory_order_relaxed); }
 int sdrt_mem_info(size_t *free_bytes, size_t *total_bytes) {
     size_t f = 0, t = 0;
     HIP_TRY(hipMemGetInfo(&f, &t));
@@ -1371,13 +1383,13 @@ int sdrt_demodulate_host(int mode, const double *y_host, int rows, int m, double
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(SDRT_ENODEVICE, "no HIP device available");
     double *dy = nullptr, *dout = nullptr, *dh = nullptr;
     const size_t ybytes = (size_t) rows * m * 2 * sizeof(double), obytes = (size_t) rows * m * sizeof(double);
-    HIP_TRY(hipMalloc((void **) &dy, ybytes));
-    HIP_TRY(hipMalloc((void **) &dout, obytes));
+    HIP_TRY(hipMalloc(&dy, ybytes));
+    HIP_TRY(hipMalloc(&dout, obytes));
     HIP_TRY(hipMemcpy(dy, y_host, ybytes, hipMemcpyHostToDevice));
     if (mode == 0) {
         std::vector<double> h((size_t) m / 2);
         sdrt_build_resample_odd(m / 2, h.data());
-        HIP_TRY(hipMalloc((void **) &dh, h.size() * sizeof(double)));
+        HIP_TRY(hipMalloc(&dh, h.size() * sizeof(double)));
         HIP_TRY(hipMemcpy(dh, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     hipError_t e = launch_demod(dy, dout, dh, rows, m, mode, nullptr);
@@ -1524,7 +1536,7 @@ int sdrt_debug_stamps(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double 
     if (!c || !stamps_host || n_wgs < 1) return fail(SDRT_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(c->cfg.device));
     const size_t bytes = (size_t) n_wgs * 4 * 16 * sizeof(unsigned long long);
-    HIP_TRY(hipMalloc((void **) &c->stamps_dev, bytes));
+    HIP_TRY(hipMalloc(&c->stamps_dev, bytes));
     HIP_TRY(hipMemset(c->stamps_dev, 0, bytes));
     c->stamp_wgs = n_wgs;
     int rc = sdrt_process_device(c, raw_dev, n_chunks, out_dev, nullptr);
@@ -1550,9 +1562,9 @@ int sdrt_selftest_mfma_i8(int *mismatches) {
                 A2[i * 64 + k] = ((i * 11 + k * 3) % 29) - 14;
                 B2[k * 16 + i] = ((k * 7 - i * 5 + 128) % 23) - 11;
             }
-        HIP_TRY(hipMalloc((void **) &eA, sizeof(A2)));
-        HIP_TRY(hipMalloc((void **) &eB, sizeof(B2)));
-        HIP_TRY(hipMalloc((void **) &eD, sizeof(D2)));
+        HIP_TRY(hipMalloc(&eA, sizeof(A2)));
+        HIP_TRY(hipMalloc(&eB, sizeof(B2)));
+        HIP_TRY(hipMalloc(&eD, sizeof(D2)));
         HIP_TRY(hipMemcpy(eA, A2, sizeof(A2), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(eB, B2, sizeof(B2), hipMemcpyHostToDevice));
         HIP_TRY(launch_i8t_selftest(eA, eB, eD, nullptr));
@@ -1571,9 +1583,9 @@ int sdrt_selftest_mfma_i8(int *mismatches) {
     {
         double X[64], Y[64], O[128], *dX = nullptr, *dY = nullptr, *dO = nullptr;
         for (int l = 0; l < 64; ++l) { X[l] = 1.0 + l; Y[l] = 1000.0 + 3.0 * l; }
-        HIP_TRY(hipMalloc((void **) &dX, sizeof(X)));
-        HIP_TRY(hipMalloc((void **) &dY, sizeof(Y)));
-        HIP_TRY(hipMalloc((void **) &dO, sizeof(O)));
+        HIP_TRY(hipMalloc(&dX, sizeof(X)));
+        HIP_TRY(hipMalloc(&dY, sizeof(Y)));
+        HIP_TRY(hipMalloc(&dO, sizeof(O)));
         HIP_TRY(hipMemcpy(dX, X, sizeof(X), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(dY, Y, sizeof(Y), hipMemcpyHostToDevice));
         HIP_TRY(launch_swap_selftest(dX, dY, dO, nullptr));
@@ -1599,9 +1611,9 @@ int sdrt_selftest_mfma(double *max_abs_err) {
         for (int k = 0; k < 4; ++k) A[i * 4 + k] = (double) (1 + i * 5 + k * 3);     // asymmetric integer data
     for (int k = 0; k < 4; ++k)
         for (int j = 0; j < 16; ++j) B[k * 16 + j] = (double) (2 + k * 7 - j * 2);
-    HIP_TRY(hipMalloc((void **) &dA, sizeof(A)));
-    HIP_TRY(hipMalloc((void **) &dB, sizeof(B)));
-    HIP_TRY(hipMalloc((void **) &dD, sizeof(D)));
+    HIP_TRY(hipMalloc(&dA, sizeof(A)));
+    HIP_TRY(hipMalloc(&dB, sizeof(B)));
+    HIP_TRY(hipMalloc(&dD, sizeof(D)));
     HIP_TRY(hipMemcpy(dA, A, sizeof(A), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dB, B, sizeof(B), hipMemcpyHostToDevice));
     HIP_TRY(launch_mfma_selftest(dA, dB, dD, nullptr));

@@ -87,6 +87,8 @@ struct WideLds {        // byte offsets
     // per buffer (offsets in 16-byte units from its start): carF [SLOTS*8], carG [SLOTS*8], F0 [8 SEG], Gu [8 SEG], IQ: tile totals of
     // the offset [NT] and the weighted sum of the last 32 samples [1]
 };
+// sixteen tiles per chunk, two per wave: the forms in which Q trails K by one TILE PASS instead of one iteration (see the kernel)
+__host__ __device__ constexpr bool wide_shq(int nout, int ntc, int iq) { return ntc == 16 && nout == 4 && iq == 0; }
 __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int ntc) {
     WideLds l;
     int p = 0;
@@ -107,7 +109,7 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int
     l.buf = p;
     const int seg = nt / ntc, slots = seg * (ntc + 1);          // carry slots: ntc + 1 per chunk of the item
     l.buf_stride = (2 * slots * 8 + 16 * seg + nt + 1) * 16;
-    p += 3 * l.buf_stride;
+    p += (wide_shq(nout, ntc, iq) ? 4 : 3) * l.buf_stride;
     l.total = p;
     return l;
 }
@@ -142,6 +144,15 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     constexpr int NR = 2 * NOUT;                     // rows of the local tile
     constexpr int OPL = NOUT / 4;                    // outputs a lane finishes per tile
     constexpr int TPW = NT / 8;                      // tiles per wave and item
+    // Two tiles per wave (8-bit records: a chunk is sixteen tiles).  With Q(it-1) of both tiles inside iteration it, the states K
+    // leaves behind (dC, dA, dl: 24 registers per tile) wait half an iteration for their turn, and with the second set of them
+    // the steady-state loop carried 40-80 scratch accesses and 20-45 full vmcnt(0) waits.  SHQ: Q trails K by one tile PASS -- the
+    // pass over tile j of item `it` runs Q on the tile the previous pass finished (j = 0: tile 1 of item it-1; j = 1: tile 0 of
+    // item it) -- so that what K leaves is consumed at once and only one set is alive at any time, as with one tile per wave.
+    // P2 and P3 keep their places; the column-local outputs wait five passes for P3 in a queue of their own; the carry buffers
+    // become four (Q of item it writes into its buffer while P3 of item it-3 still reads the one three back).
+    constexpr bool SHQ = wide_shq(NOUT, NTC, IQ);
+    constexpr int NBUF = SHQ ? 4 : 3;
     constexpr int WPK = (RS ? 8 : 4) * ITEM;         // 32-bit words per lane and k-step (8 complex samples; RS: 16)
     constexpr int TILE = SDRT_TB * LC;               // samples per tile
     constexpr int NSTEP = KS * TPW;                  // k-steps per wave and item
@@ -163,6 +174,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     const bool swap = a.swap != 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, nb = lane & 15;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);     // the same in scalar registers
 #ifdef SDRT_SCHED_EXP
     const int young = __builtin_amdgcn_readfirstlane(wave) >= 4, sched = a.sched;
     //            sched:  0 production   1 young waves' groups at 2   2 young waves one level up throughout   3 only the young waves raise
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     }
     if (tid >= 32 && tid < 48) mupL[tid - 32] = mk(wt->mu_pow[(tid - 32) >> 2][tid & 3][0], wt->mu_pow[(tid - 32) >> 2][tid & 3][1]);
     // edge operator of this thread: output o16 = tid >> 5 (kind: 0 head -> F0, 1 tail -> Gu; chain o = mode*2 + stream), sample l
-    const int e_o16 = tid >> 5, e_l = tid & 31, e_kind = e_o16 >> 3, e_o = e_o16 & 7;
+    const int e_o16 = tid >> 5, e_l = tid & 31, e_kind = e_o16 >> 3;
     // sample l of the 32-sample window of the output: the chunk's first / last 32 samples (the operator spans 28 of them)
     const int e_idx = e_kind ? n - 32 + e_l : e_l;
     const double e_off_re = a.e_off_re, e_off_im = a.e_off_im;   // what the edge operators subtract from the decoded components
@@ -300,8 +312,15 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         auto issue = [&](const unsigned char *chunk_raw, auto sc) {
             // k-step st (0 .. NSTEP-1) of the item: tile wave + 8 (st / KS), k-step st % KS
             constexpr int st = decltype(sc)::value;
+            if constexpr (SHQ) {
+                // a scalar base and a 32-bit lane offset (as one 64-bit value per lane the address is a loop invariant the register
+                // allocator spills; its reload waits with vmcnt(0))
+                const unsigned char *p = chunk_raw + ((size_t) (wave_s + 8 * (st / KS)) * TILE + (size_t) (st % KS) * SPK) * 2 * ITEM;
+                load_words<WPK * 4, SDRT_RAW_NT != 0>(p + (unsigned) lane_off, raw[st % NSLOT]);
+            } else {
             const unsigned char *p = chunk_raw + ((size_t) (wave + 8 * (st / KS)) * TILE + (size_t) (st % KS) * SPK) * 2 * ITEM + lane_off;
             load_words<WPK * 4, SDRT_RAW_NT != 0>(p, raw[st % NSLOT]);
+            }
         };
         // float32: the exponent of a tile (|x| < 2^e for all of its samples) is not known before the tile has been read, and a
         // scan ahead of the matrix phase would read the stream twice (measured: the fabric, not the CU, then sets the rate).
@@ -334,6 +353,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         // Q, P3 and E are cut into short pieces that run between the groups of matrix instructions of K, so that the wave
         // sharing the SIMD finds the matrix pipe free meanwhile (and vice versa).  LDS carry buffers: item k uses k % 3.
         cd yq[2][TPW][OPL], ynew[TPW][OPL];          // column-local outputs: [0] two iterations old (P3 finishes them now)
+        cd yqs[SHQ ? 5 : 1][OPL];                    // SHQ: the same as a queue over tile passes ([0]: five passes old)
         cd dC[TPW][2], dA[TPW][2];                   // [stream]: causal / anticausal states of (mode g, column nb) of the tile
         double dli[RS ? TPW : 1][4];                 // RS: local rows of the imaginary stream (dl: of the real stream)
         double dl[TPW][4];                           // local rows of this lane: 8 outputs per column: its own outputs g + 4e,
@@ -347,6 +367,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         for (int j = 0; j < TPW; ++j) {
 #pragma unroll
             for (int e = 0; e < OPL; ++e) yq[0][j][e] = yq[1][j][e] = ynew[j][e] = pv[j][e] = mk(0.0, 0.0);
+#pragma unroll
+            for (int e = 0; e < OPL; ++e)
+#pragma unroll
+                for (int d = 0; d < (SHQ ? 5 : 1); ++d) yqs[d][e] = mk(0.0, 0.0);
             dC[j][0] = dC[j][1] = dA[j][0] = dA[j][1] = mk(0.0, 0.0);
             oex[j] = mk(0.0, 0.0);
             ccon[j] = 0.0;
@@ -360,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) part[b][0] = part[b][1] = 0.0;
 
-        int bcur = 0;                                // it % 3
+        int bcur = 0;                                // it % NBUF
         // One iteration; HAVE_K = there is an item whose matrix-core phase runs now (false only in the three drain iterations).
         // With HAVE_K every global load and store below is issued unconditionally, so that the compiler can count them and
         // wait for exactly the k-step it needs (s_waitcnt vmcnt(N)) instead of draining the whole prefetch ring.
@@ -370,7 +394,9 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         auto iteration = [&](auto hk, auto fullc, const int it) {
             constexpr bool HAVE_K = decltype(hk)::value, FULL = decltype(fullc)::value;
             static_assert(HAVE_K || !FULL, "the steady state has a matrix-core phase");
-            const int bQ = bcur == 0 ? 2 : bcur - 1, bP2 = bcur == 2 ? 0 : bcur + 1, bP3 = bcur;   // (it-1)%3, (it-2)%3, (it-3)%3
+            // (it-1), (it-2), (it-3) % NBUF
+            const int bQ = NBUF == 3 ? (bcur == 0 ? 2 : bcur - 1) : ((bcur + 3) & 3), bP2 = NBUF == 3 ? (bcur == 2 ? 0 : bcur + 1) : ((bcur + 2) & 3);
+            const int bP3 = NBUF == 3 ? bcur : ((bcur + 1) & 3);
             const bool have_q = FULL || (it >= 1 && it - 1 < cnt), have_p2 = FULL || (it >= 2 && it - 2 < cnt), have_p3 = FULL || it >= 3;
 #ifdef SDRT_STAMPS
             // diagnostic build (tools/stamps_wide.py): phase stamps of iteration 6
@@ -505,75 +531,79 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             auto piece = [&](auto jc, auto ic) {
                 constexpr int j = decltype(jc)::value, i = decltype(ic)::value;
                 const int tile = wave + 8 * j;
-                if (have_q) {
+                // what Q works on in this pass: tile j of item it-1, or (SHQ) the tile the previous pass finished
+                constexpr int jq = SHQ ? (j ^ 1) : j;
+                const int tileq = wave + 8 * jq, bQq = SHQ && j == 1 ? bcur : bQ;
+                const bool have_qq = SHQ && j == 1 ? HAVE_K : have_q;
+                if (have_qq) {
                     if constexpr ((IQA || F32) && i == 0) {
                         // IQ correction, the part that is linear in the offset at the column's first sample:
                         // row value += (c - off).re g_re[row] + (c - off).im g_im[row]
-                        const double cp = IQT ? cpowL[tile * SDRT_TB + nb] : 0.0;        // fused: zero offset at the chunk start
+                        const double cp = IQT ? cpowL[tileq * SDRT_TB + nb] : 0.0;        // fused: zero offset at the chunk start
                         // float32: no offset, only the constant the XOR left out of the three lower slices, in the tile's scale
-                        const double dr = F32 ? ccon[j] : a.c_re - fma(cp, off_q.re, gq[j].re), di = F32 ? ccon[j] : a.c_im - fma(cp, off_q.im, gq[j].im);
+                        const double dr = F32 ? ccon[jq] : a.c_re - fma(cp, off_q.re, gq[jq].re), di = F32 ? ccon[jq] : a.c_im - fma(cp, off_q.im, gq[jq].im);
                         const cd g0 = gvL[4 * g + 0], g1 = gvL[4 * g + 1], g2 = gvL[4 * g + 2], g3 = gvL[4 * g + 3];
-                        dC[j][0] = mk(fma(dr, g0.re, fma(di, g0.im, dC[j][0].re)), fma(dr, g1.re, fma(di, g1.im, dC[j][0].im)));
-                        dC[j][1] = mk(fma(dr, g2.re, fma(di, g2.im, dC[j][1].re)), fma(dr, g3.re, fma(di, g3.im, dC[j][1].im)));
+                        dC[jq][0] = mk(fma(dr, g0.re, fma(di, g0.im, dC[jq][0].re)), fma(dr, g1.re, fma(di, g1.im, dC[jq][0].im)));
+                        dC[jq][1] = mk(fma(dr, g2.re, fma(di, g2.im, dC[jq][1].re)), fma(dr, g3.re, fma(di, g3.im, dC[jq][1].im)));
                         const cd h0 = gvL[16 + 4 * g + 0], h1 = gvL[16 + 4 * g + 1], h2 = gvL[16 + 4 * g + 2], h3 = gvL[16 + 4 * g + 3];
-                        dA[j][0] = mk(fma(dr, h0.re, fma(di, h0.im, dA[j][0].re)), fma(dr, h1.re, fma(di, h1.im, dA[j][0].im)));
-                        dA[j][1] = mk(fma(dr, h2.re, fma(di, h2.im, dA[j][1].re)), fma(dr, h3.re, fma(di, h3.im, dA[j][1].im)));
+                        dA[jq][0] = mk(fma(dr, h0.re, fma(di, h0.im, dA[jq][0].re)), fma(dr, h1.re, fma(di, h1.im, dA[jq][0].im)));
+                        dA[jq][1] = mk(fma(dr, h2.re, fma(di, h2.im, dA[jq][1].re)), fma(dr, h3.re, fma(di, h3.im, dA[jq][1].im)));
                         if constexpr (PACK) {
                             // local values of output 2 (g & 1) + (v >> 1), stream v & 1, split over the lanes g and g + 2: once
                             const double lowhalf = g < 2 ? 1.0 : 0.0, dr2 = dr * lowhalf, di2 = di * lowhalf;
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
                                 const cd l0 = gvL[32 + 4 * (g & 1) + v];
-                                dl[j][v] = fma(dr2, l0.re, fma(di2, l0.im, dl[j][v]));
+                                dl[jq][v] = fma(dr2, l0.re, fma(di2, l0.im, dl[jq][v]));
                             }
                         } else {
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {             // local rows of this lane: output g + 4 (v >> 1), stream v & 1
                                 const cd l0 = gvL[32 + 2 * (g + 4 * (v >> 1)) + (v & 1)];
-                                dl[j][v] = fma(dr, l0.re, fma(di, l0.im, dl[j][v]));
+                                dl[jq][v] = fma(dr, l0.re, fma(di, l0.im, dl[jq][v]));
                             }
                         }
                     } else if constexpr (i == 1 && !RS) {
-                        const cd ps = psiL[tile * SDRT_TB + nb];      // the column's common phasor multiplies the complex DATA
+                        const cd ps = psiL[tileq * SDRT_TB + nb];      // the column's common phasor multiplies the complex DATA
                         // (explicit fma everywhere in the pieces: they exist in two compiled copies, steady state and drain,
                         // and both must round identically -- an item's bits must not depend on the batch it arrived in)
                         cd t;
-                        t = mk(fma(ps.re, dC[j][0].re, -(ps.im * dC[j][1].re)), fma(ps.re, dC[j][0].im, -(ps.im * dC[j][1].im)));
-                        dC[j][1] = mk(fma(ps.im, dC[j][0].re, ps.re * dC[j][1].re), fma(ps.im, dC[j][0].im, ps.re * dC[j][1].im));
-                        dC[j][0] = t;
-                        t = mk(fma(ps.re, dA[j][0].re, -(ps.im * dA[j][1].re)), fma(ps.re, dA[j][0].im, -(ps.im * dA[j][1].im)));
-                        dA[j][1] = mk(fma(ps.im, dA[j][0].re, ps.re * dA[j][1].re), fma(ps.im, dA[j][0].im, ps.re * dA[j][1].im));
-                        dA[j][0] = t;
+                        t = mk(fma(ps.re, dC[jq][0].re, -(ps.im * dC[jq][1].re)), fma(ps.re, dC[jq][0].im, -(ps.im * dC[jq][1].im)));
+                        dC[jq][1] = mk(fma(ps.im, dC[jq][0].re, ps.re * dC[jq][1].re), fma(ps.im, dC[jq][0].im, ps.re * dC[jq][1].im));
+                        dC[jq][0] = t;
+                        t = mk(fma(ps.re, dA[jq][0].re, -(ps.im * dA[jq][1].re)), fma(ps.re, dA[jq][0].im, -(ps.im * dA[jq][1].im)));
+                        dA[jq][1] = mk(fma(ps.im, dA[jq][0].re, ps.re * dA[jq][1].re), fma(ps.im, dA[jq][0].im, ps.re * dA[jq][1].im));
+                        dA[jq][0] = t;
                     } else if constexpr (i == 2 && !RS) {
-                        const cd ps = psiL[tile * SDRT_TB + nb];
+                        const cd ps = psiL[tileq * SDRT_TB + nb];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            const double t2 = fma(ps.re, dl[j][2 * h], -(ps.im * dl[j][2 * h + 1]));
-                            dl[j][2 * h + 1] = fma(ps.im, dl[j][2 * h], ps.re * dl[j][2 * h + 1]);
-                            dl[j][2 * h] = t2;
+                            const double t2 = fma(ps.re, dl[jq][2 * h], -(ps.im * dl[jq][2 * h + 1]));
+                            dl[jq][2 * h + 1] = fma(ps.im, dl[jq][2 * h], ps.re * dl[jq][2 * h + 1]);
+                            dl[jq][2 * h] = t2;
                         }
                     } else if constexpr (i >= 3 && i <= 10) {
                         // inclusive scans over the 16 columns of the tile (lanes of one DPP row): step (i-3)/2, causal then anticausal
                         constexpr int stp_ = (i - 3) / 2;
                         const cd mu = mupL[stp_ * 4 + g];
                         if constexpr (((i - 3) & 1) == 0) {
-                            dC[j][0] = cfma(mu, dpp_row<0x110 + (1 << stp_)>(dC[j][0]), dC[j][0]);
-                            dC[j][1] = cfma(mu, dpp_row<0x110 + (1 << stp_)>(dC[j][1]), dC[j][1]);
+                            dC[jq][0] = cfma(mu, dpp_row<0x110 + (1 << stp_)>(dC[jq][0]), dC[jq][0]);
+                            dC[jq][1] = cfma(mu, dpp_row<0x110 + (1 << stp_)>(dC[jq][1]), dC[jq][1]);
                         } else {
-                            dA[j][0] = cfma(mu, dpp_row<0x100 + (1 << stp_)>(dA[j][0]), dA[j][0]);
-                            dA[j][1] = cfma(mu, dpp_row<0x100 + (1 << stp_)>(dA[j][1]), dA[j][1]);
+                            dA[jq][0] = cfma(mu, dpp_row<0x100 + (1 << stp_)>(dA[jq][0]), dA[jq][0]);
+                            dA[jq][1] = cfma(mu, dpp_row<0x100 + (1 << stp_)>(dA[jq][1]), dA[jq][1]);
                         }
                     } else if constexpr (i == 11) {
                         // tile aggregates: causal inclusive at the last column -> slot tile+1, anticausal inclusive at the first -> slot tile
-                        cd *cf = carF(bQ), *cg = carG(bQ);
-                        const int sl = tile + tile / NTC;            // carry slot of the tile's start (NTC + 1 slots per chunk)
-                        if (nb == 15) { cf[(sl + 1) * 8 + g * 2 + 0] = dC[j][0]; cf[(sl + 1) * 8 + g * 2 + 1] = dC[j][1]; }
-                        if (nb == 0) { cg[sl * 8 + g * 2 + 0] = dA[j][0]; cg[sl * 8 + g * 2 + 1] = dA[j][1]; }
+                        cd *cf = carF(bQq), *cg = carG(bQq);
+                        const int sl = tileq + tileq / NTC;          // carry slot of the tile's start (NTC + 1 slots per chunk)
+                        if (nb == 15) { cf[(sl + 1) * 8 + g * 2 + 0] = dC[jq][0]; cf[(sl + 1) * 8 + g * 2 + 1] = dC[jq][1]; }
+                        if (nb == 0) { cg[sl * 8 + g * 2 + 0] = dA[jq][0]; cg[sl * 8 + g * 2 + 1] = dA[jq][1]; }
                         // from here on: states at the column's edges from inside the tile (causal at its start, anticausal at its end)
-                        dC[j][0] = dpp_row<0x111>(dC[j][0]);
-                        dC[j][1] = dpp_row<0x111>(dC[j][1]);
-                        dA[j][0] = dpp_row<0x101>(dA[j][0]);
-                        dA[j][1] = dpp_row<0x101>(dA[j][1]);
+                        dC[jq][0] = dpp_row<0x111>(dC[jq][0]);
+                        dC[jq][1] = dpp_row<0x111>(dC[jq][1]);
+                        dA[jq][0] = dpp_row<0x101>(dA[jq][0]);
+                        dA[jq][1] = dpp_row<0x101>(dA[jq][1]);
                     } else if constexpr (i >= 12 && i < P3_0) {
                         constexpr int e = (i - 12) / 3, sub = (i - 12) % 3;
                         if constexpr (sub < 2) {
@@ -582,32 +612,32 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                             for (int bb = 2 * sub; bb < 2 * sub + 2; ++bb) {
                                 const int b = 4 * e + bb;
                                 const cd bc = bpL[b * 4 + g], ba = bpL[(NOUT - b) * 4 + g];
-                                part[bb][0] = fma(bc.re, dC[j][0].re, fma(-bc.im, dC[j][0].im, fma(ba.re, dA[j][0].re, -(ba.im * dA[j][0].im))));
-                                part[bb][1] = fma(bc.re, dC[j][1].re, fma(-bc.im, dC[j][1].im, fma(ba.re, dA[j][1].re, -(ba.im * dA[j][1].im))));
+                                part[bb][0] = fma(bc.re, dC[jq][0].re, fma(-bc.im, dC[jq][0].im, fma(ba.re, dA[jq][0].re, -(ba.im * dA[jq][0].im))));
+                                part[bb][1] = fma(bc.re, dC[jq][1].re, fma(-bc.im, dC[jq][1].im, fma(ba.re, dA[jq][1].re, -(ba.im * dA[jq][1].im))));
                                 if constexpr (PACK) {
                                     // the column-local part: lanes g and g + 2 hold its lower and higher levels for outputs
                                     // 2 (g & 1), 2 (g & 1) + 1; the sum over the mode lanes below adds them up
                                     const double mine = ((g & 1) == (b >> 1)) ? 1.0 : 0.0;
-                                    part[bb][0] = fma(mine, dl[j][2 * (b & 1)], part[bb][0]);
-                                    part[bb][1] = fma(mine, dl[j][2 * (b & 1) + 1], part[bb][1]);
+                                    part[bb][0] = fma(mine, dl[jq][2 * (b & 1)], part[bb][0]);
+                                    part[bb][1] = fma(mine, dl[jq][2 * (b & 1) + 1], part[bb][1]);
                                 } else if constexpr (RS && NOUT == 4) {
                                     // every lane holds one level group of all four outputs (dl: real stream, dli: imaginary)
-                                    part[bb][0] += dl[j][bb];
-                                    part[bb][1] += dli[j][bb];
+                                    part[bb][0] += dl[jq][bb];
+                                    part[bb][1] += dli[jq][bb];
                                 } else if constexpr (RS) {
                                     // lanes g hold outputs 4 (g & 1) .. + 3, level groups g >> 1
                                     const double mine = ((g & 1) == e) ? 1.0 : 0.0;
-                                    part[bb][0] = fma(mine, dl[j][bb], part[bb][0]);
-                                    part[bb][1] = fma(mine, dli[j][bb], part[bb][1]);
+                                    part[bb][0] = fma(mine, dl[jq][bb], part[bb][0]);
+                                    part[bb][1] = fma(mine, dli[jq][bb], part[bb][1]);
                                 }
                             }
                         } else {
                             // sum over the four modes (lanes 16 apart) as a reduce-scatter: lane g ends up with output g + 4e
                             const double r0 = swap32_add(part[0][0], part[2][0]), i0 = swap32_add(part[0][1], part[2][1]);
                             const double r1 = swap32_add(part[1][0], part[3][0]), i1 = swap32_add(part[1][1], part[3][1]);
-                            if constexpr (PACK || RS) ynew[j][e] = mk(swap16_add(r0, r1), swap16_add(i0, i1));
+                            if constexpr (PACK || RS) ynew[jq][e] = mk(swap16_add(r0, r1), swap16_add(i0, i1));
                             // ... plus the column-local part, which the matrix cores left in this very lane
-                            else ynew[j][e] = mk(swap16_add(r0, r1) + dl[j][2 * e], swap16_add(i0, i1) + dl[j][2 * e + 1]);
+                            else ynew[jq][e] = mk(swap16_add(r0, r1) + dl[jq][2 * e], swap16_add(i0, i1) + dl[jq][2 * e + 1]);
                         }
                     }
                 }
@@ -621,7 +651,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
 #pragma unroll
                         for (int e = 0; e < OPL; ++e) {
                             const cd f = cFL[(e * 4 + mode) * 64 + lane], gq = cGL[(e * 4 + mode) * 64 + lane];
-                            if constexpr (mode == 0) pv[j][e] = mk(yq[0][j][e].re + yb[j][e].re, yq[0][j][e].im + yb[j][e].im);
+                            if constexpr (mode == 0) {
+                                const cd y0 = SHQ ? yqs[0][e] : yq[0][j][e];
+                                pv[j][e] = mk(y0.re + yb[j][e].re, y0.im + yb[j][e].im);
+                            }
                             pv[j][e].re = fma(f.re, Fa.re, fma(-f.im, Fa.im, fma(gq.re, Ga.re, fma(-gq.im, Ga.im, pv[j][e].re))));
                             pv[j][e].im = fma(f.re, Fb.re, fma(-f.im, Fb.im, fma(gq.re, Gb.re, fma(-gq.im, Gb.im, pv[j][e].im))));
                         }
@@ -694,8 +727,14 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     f = cadd(f, dpp_row<0x118>(f));     // lane 15 of every row: the row's sum
                     const double tot = swap16_add(f.re, f.im);   // even rows: re(row) + re(row+1); odd rows: im(row-1) + im(row)
                     if (nb == 15) {
-                        double *dst = (double *) ((e_kind ? GuL(bcur) : F0L(bcur)) + sg * 8 + e_o);
-                        dst[g & 1] = tot;
+                        // (the lane's share of the address is put together here, from the lane number read on the spot: as a loop
+                        // invariant it -- or the thread id it comes from -- is spilled in the forms that are short of registers, and the
+                        // reload waits with vmcnt(0): a drain of the prefetch ring)
+                        int t2;
+                        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(t2));
+                        t2 |= wave_s << 6;
+                        double *dst = (double *) (((t2 >> 8) ? GuL(bcur) : F0L(bcur)) + sg * 8 + ((t2 >> 5) & 7));
+                        dst[(t2 >> 4) & 1] = tot;
                     }
                     }
                 }
@@ -992,6 +1031,15 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         });
                     };
                     kpass(std::true_type{});
+                    if constexpr (SHQ) {
+                        // the queue of column-local outputs moves on by one pass
+#pragma unroll
+                        for (int e = 0; e < OPL; ++e) {
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) yqs[d][e] = yqs[d + 1][e];
+                            yqs[4][e] = ynew[j ^ 1][e];
+                        }
+                    }
                     int e_true = 0;
                     if constexpr (F32 && HAVE_K && !PRE) {
                         // the exponent in use is a function of the tile's own samples (its exponent rounded up to a multiple of
@@ -1062,15 +1110,17 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                 }
             });
             // the queue of column-local outputs moves on
+            if constexpr (!SHQ) {
 #pragma unroll
-            for (int j = 0; j < TPW; ++j)
+                for (int j = 0; j < TPW; ++j)
 #pragma unroll
-                for (int e = 0; e < OPL; ++e) { yq[0][j][e] = yq[1][j][e]; yq[1][j][e] = ynew[j][e]; }
+                    for (int e = 0; e < OPL; ++e) { yq[0][j][e] = yq[1][j][e]; yq[1][j][e] = ynew[j][e]; }
+            }
             SDRT_STAMP(3);
             __syncthreads();
             SDRT_STAMP(4);
 #undef SDRT_STAMP
-            bcur = bcur == 2 ? 0 : bcur + 1;
+            bcur = bcur == NBUF - 1 ? 0 : bcur + 1;
         };
         // diagnostic: core-clock and 100 MHz real-time stamps around the steady-state iterations -> in-kernel clock
 #ifdef SDRT_STAMPS

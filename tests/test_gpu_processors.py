@@ -627,7 +627,7 @@ def test_bench_rank_plumbing_on_one_gpu(argv):
 
 def test_reserve_and_error_paths_of_the_abi():
     """sdrt_reserve: every scratch buffer a batch of that size needs exists afterwards, and a processing call of that size leaves the
-    device's free memory where it was (no allocation inside sdrt_process_*); row_modes outside FM / AM are refused with a message;
+    library's count of device allocations where it was (no allocation inside sdrt_process_*); row_modes outside FM / AM are refused with a message;
     the tap entry points keep their buffers until sdrt_taps_release."""
     import ctypes as C
     from sdrterm_amd import _native as nat
@@ -639,20 +639,26 @@ def test_reserve_and_error_paths_of_the_abi():
     d_raw = nat.DeviceBuffer(len(raw)).upload(np.frombuffer(raw, dtype=np.uint8))
     d_out = nat.DeviceBuffer(2 * nch * eng.m * 8)
     lib = nat.lib()
+    lib.sdrt_alloc_count.restype = C.c_ulonglong
     lib.sdrt_mem_info.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
-    free0, free1, tot = C.c_size_t(), C.c_size_t(), C.c_size_t()
-    nat.check(lib.sdrt_device_synchronize())
-    nat.check(lib.sdrt_mem_info(C.byref(free0), C.byref(tot)))
+    free, tot = C.c_size_t(), C.c_size_t()
+    nat.check(lib.sdrt_mem_info(C.byref(free), C.byref(tot)))
+    assert 0 < free.value <= tot.value
+    n0 = lib.sdrt_alloc_count()
     eng.process_device(d_raw.ptr, nch, d_out.ptr)
     a, b = eng.iq_range_device(d_raw.ptr, nch)
     nat.check(lib.sdrt_device_synchronize())
-    nat.check(lib.sdrt_mem_info(C.byref(free1), C.byref(tot)))
-    assert free1.value == free0.value, 'a processing call within the reserved size allocated device memory'
+    assert lib.sdrt_alloc_count() == n0, 'a processing call within the reserved size allocated device memory'
+    small = Engine(fs, q, 'fm', 'h', row_freqs=[15700.0, -1000.0], apply_shift=True, omega_out=5000, correct_iq=True)
+    n1 = lib.sdrt_alloc_count()
+    small.process_device(d_raw.ptr, nch, d_out.ptr)
+    nat.check(lib.sdrt_device_synchronize())
+    assert lib.sdrt_alloc_count() > n1                      # (the counter does see what an unreserved context does)
     assert 0 < a < 1 and np.isfinite(b.real)
     with pytest.raises(ValueError):
-        Engine(fs, q, 'fm', 'h', row_freqs=[0.0, 1.0], row_modes=['fm', 're'])
+        Engine(fs, q, 'fm', 'h', row_freqs=[0.0, 1.0], row_modes=['fm', 're'], omega_out=5000)
     # at the ABI itself: a real / imaginary entry among the row modes is refused with a message
-    good = Engine(fs, q, 'fm', 'h', row_freqs=[0.0, 1.0], row_modes=['fm', 'am'])
+    good = Engine(fs, q, 'fm', 'h', row_freqs=[0.0, 1.0], row_modes=['fm', 'am'], omega_out=5000)
     assert good.row_modes == ['fm', 'am']
     bad = np.ascontiguousarray([0, 3], dtype=np.int32)
     import scipy.signal as sg
