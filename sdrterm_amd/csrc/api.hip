@@ -621,7 +621,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         if (const char *e = getenv("SDRTERM_IQ_FUSED")) c->iq_fused = c->iq && atoi(e) != 0;
         if (seq) {
             // nothing to set up: the per-sample form reads DecimTables only
-        } else if (want_i8 && !want_t && chain_i8w_supported(q, cfg->dtype, n, c->iq) && chain_i8w_lds_bytes(q, n, c->iq ? (c->iq_fused ? 2 : 1) : 0) <= 160 * 1024)
+        } else if (want_i8 && !want_t && chain_i8w_supported(q, cfg->dtype, n, c->iq) && chain_i8w_lds_bytes(q, n, c->iq ? (c->iq_fused ? 2 : 1) : 0, cfg->dtype) <= 160 * 1024)
             rc = setup_wide(c, cfg, scale_tables);
         if (rc == SDRT_OK && !seq && !c->use_i8w && want_i8 && !c->iq && want_i8_fallback_t(L, cfg->dtype, n, m))
             rc = setup_i8t(c, cfg, scale_tables);

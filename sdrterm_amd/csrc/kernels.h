@@ -145,7 +145,7 @@ hipError_t launch_i8t_selftest(const int *A, const int *B, int *D, hipStream_t s
 // wide-column persistent int8 kernel (kernels_i8w.hip): q in {32, 64}, 8/16-bit integer encodings, 8 or 16 tiles per chunk
 bool chain_i8w_supported(int q, int dt, int n, bool iq);
 bool chain_i8w_rs_supported(int dt, int n);       // its real-stream form (no shift, no IQ correction)
-size_t chain_i8w_lds_bytes(int q, int n, int iq);      // iq: 0 none, 1 prefix tables, 2 fused (chain_i8w_kernel)
+size_t chain_i8w_lds_bytes(int q, int n, int iq, int dt);      // iq: 0 none, 1 prefix tables, 2 fused (chain_i8w_kernel)
 hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, int n_cus, hipStream_t s);
 // float32 records of `tiles` tiles (4096 samples each) -> their four byte slices in place + the tile exponents (many-row contexts)
 hipError_t launch_f32_preslice(const void *raw, void *out, int *exps, size_t tiles, int swap, hipStream_t s);

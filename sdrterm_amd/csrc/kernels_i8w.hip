@@ -88,12 +88,15 @@ struct WideLds {        // byte offsets
     // the offset [NT] and the weighted sum of the last 32 samples [1]
 };
 // sixteen tiles per chunk, two per wave: the forms in which Q trails K by one TILE PASS instead of one iteration (see the kernel)
-__host__ __device__ constexpr bool wide_shq(int nout, int ntc, int iq) { return ntc == 16 && nout == 4 && iq == 0; }
-__host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int ntc) {
+// (the fused IQ form needs the room of a fourth carry buffer beside its offset rows: 8-bit records only, whose packed local tile is
+// three fragments instead of five)
+__host__ __device__ constexpr bool wide_shq(int nout, int ntc, int iq, int nsl) { return ntc == 16 && nout == 4 && (iq <= 1 || nsl == 1); }
+__host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int ntc, int nsl) {
     WideLds l;
     int p = 0;
     l.wmain = p; p += 2 * S * 8 * 1024;
-    l.wloc = p; p += S * 8 * 1024;                  // local tile padded to 16 rows (rows >= 2 nout are zero)
+    // local tile padded to 16 rows (rows >= 2 nout are zero); four outputs per column and one slice: three packed fragments
+    l.wloc = p; p += (nout == 4 && nsl == 1 ? 3 : S) * 8 * 1024;
     l.cF = p; p += SDRT_TB * nout * 4 * 16;
     l.cG = p; p += SDRT_TB * nout * 4 * 16;
     l.bp = p; p += (nout + 1) * 4 * 16;
@@ -109,7 +112,7 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int
     l.buf = p;
     const int seg = nt / ntc, slots = seg * (ntc + 1);          // carry slots: ntc + 1 per chunk of the item
     l.buf_stride = (2 * slots * 8 + 16 * seg + nt + 1) * 16;
-    p += (wide_shq(nout, ntc, iq) ? 4 : 3) * l.buf_stride;
+    p += (wide_shq(nout, ntc, iq, nsl) ? 4 : 3) * l.buf_stride;
     l.total = p;
     return l;
 }
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     // item it) -- so that what K leaves is consumed at once and only one set is alive at any time, as with one tile per wave.
     // P2 and P3 keep their places; the column-local outputs wait five passes for P3 in a queue of their own; the carry buffers
     // become four (Q of item it writes into its buffer while P3 of item it-3 still reads the one three back).
-    constexpr bool SHQ = wide_shq(NOUT, NTC, IQ);
+    constexpr bool SHQ = wide_shq(NOUT, NTC, IQ, W8Enc<DT>::slices) && !RS;
     constexpr int NBUF = SHQ ? 4 : 3;
     constexpr int WPK = (RS ? 8 : 4) * ITEM;         // 32-bit words per lane and k-step (8 complex samples; RS: 16)
     constexpr int TILE = SDRT_TB * LC;               // samples per tile
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     const int prio_hi = sched == 0 ? 1 : sched == 1 ? (young ? 2 : 1) : sched == 2 ? (young ? 2 : 1) : sched == 3 ? (young ? 1 : 0) : sched == 4 ? 0 : sched == 5 ? (young ? 1 : 2) : (young ? 3 : 1);
     const int prio_lo = sched == 2 ? (young ? 1 : 0) : sched == 6 ? (young ? 1 : 0) : 0;
 #endif
-    const WideLds lo = wide_lds(S, NOUT, NT, IQ, NTC);
+    const WideLds lo = wide_lds(S, NOUT, NT, IQ, NTC, NSL);
     const v4i *wmainL = (const v4i *) (smem + lo.wmain);
     const v4i *wlocL = (const v4i *) (smem + lo.wloc);
     cd *cFL = (cd *) (smem + lo.cF), *cGL = (cd *) (smem + lo.cG), *bpL = (cd *) (smem + lo.bp), *mupL = (cd *) (smem + lo.mup), *tpwL = (cd *) (smem + lo.tpw);
@@ -455,9 +458,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                 off_head = mk(uni(off_head.re), uni(off_head.im));
                 off_tail = mk(uni(off_tail.re), uni(off_tail.im));
                 off_q = mk(uni(off_q.re), uni(off_q.im));
+                // (SHQ: tile slot 1 is tile 1 of item it-1, tile slot 0 is tile 0 of item it)
 #pragma unroll
                 for (int j = 0; j < TPW; ++j)
-                    gq[j] = ((const cd *) a.iq_group_off)[(size_t) cq * ngrp + (size_t) ((wave + 8 * j) * SDRT_TB + nb) * cgs];
+                    gq[j] = ((const cd *) a.iq_group_off)[(size_t) (SHQ && j == 0 ? ck : cq) * ngrp + (size_t) ((wave + 8 * j) * SDRT_TB + nb) * cgs];
             }
             if constexpr (IQF) {
                 // Offsets of item it-1, relative to a zero offset at the start of its chunk (the chunk's true starting offset
@@ -465,13 +469,14 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                 // relative to the tile start (oex) and every tile's total in LDS: chain the tiles before this one.
                 if (have_q) {
                     const cd *ot = OtL(bQ);
+                    // (SHQ: tile slot 1 of item it-1 here; tile slot 0 of item it follows the barrier between the two passes)
 #pragma unroll
-                    for (int j = 0; j < TPW; ++j) {
+                    for (int j = SHQ ? 1 : 0; j < TPW; ++j) {
                         cd ts = mk(0.0, 0.0);
-                        for (int t2 = 0; t2 < wave + 8 * j; ++t2) ts = mk(fma(iq_m16, ts.re, ot[t2].re), fma(iq_m16, ts.im, ot[t2].im));
+                        for (int t2 = 0; t2 < wave_s + 8 * j; ++t2) ts = mk(fma(iq_m16, ts.re, ot[t2].re), fma(iq_m16, ts.im, ot[t2].im));    // (a scalar trip count)
                         gq[j] = mk(fma(iq_mnb, ts.re, oex[j].re), fma(iq_mnb, ts.im, oex[j].im));
                     }
-                    if (wave == 0) {
+                    if (wave_s == 0) {
                         // the offset at the chunk's end -> chunk aggregate (the scan over chunks follows the kernel), and the
                         // offset at the first sample of the tail window, unwound over the window's 32 samples: its share of the
                         // tail edge operators (8 outputs) goes into Gu before P2 reads it
@@ -541,7 +546,8 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         // row value += (c - off).re g_re[row] + (c - off).im g_im[row]
                         const double cp = IQT ? cpowL[tileq * SDRT_TB + nb] : 0.0;        // fused: zero offset at the chunk start
                         // float32: no offset, only the constant the XOR left out of the three lower slices, in the tile's scale
-                        const double dr = F32 ? ccon[jq] : a.c_re - fma(cp, off_q.re, gq[jq].re), di = F32 ? ccon[jq] : a.c_im - fma(cp, off_q.im, gq[jq].im);
+                        const cd offc = SHQ && j == 1 ? off_head : off_q;             // offset at the start of the tile's chunk
+                        const double dr = F32 ? ccon[jq] : a.c_re - fma(cp, offc.re, gq[jq].re), di = F32 ? ccon[jq] : a.c_im - fma(cp, offc.im, gq[jq].im);
                         const cd g0 = gvL[4 * g + 0], g1 = gvL[4 * g + 1], g2 = gvL[4 * g + 2], g3 = gvL[4 * g + 3];
                         dC[jq][0] = mk(fma(dr, g0.re, fma(di, g0.im, dC[jq][0].re)), fma(dr, g1.re, fma(di, g1.im, dC[jq][0].im)));
                         dC[jq][1] = mk(fma(dr, g2.re, fma(di, g2.im, dC[jq][1].re)), fma(dr, g3.re, fma(di, g3.im, dC[jq][1].im)));
@@ -745,6 +751,16 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             const unsigned char *next_raw = (const unsigned char *) a.raw + (size_t) chunk_of(more ? it + 1 : it) * chunk_bytes;
             static_for<0, TPW>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
+                if constexpr (SHQ && IQF && j == 1) {
+                    // Q of tile `wave` of item it comes next: its offset at the tile start chains the totals of the tiles before it,
+                    // which the other waves left at the end of their first pass -- the one place where SHQ needs the workgroup
+                    // to meet in mid-iteration
+                    __syncthreads();
+                    const cd *ot = OtL(bcur);
+                    cd ts = mk(0.0, 0.0);
+                    for (int t2 = 0; t2 < wave_s; ++t2) ts = mk(fma(iq_m16, ts.re, ot[t2].re), fma(iq_m16, ts.im, ot[t2].im));
+                    gq[0] = mk(fma(iq_mnb, ts.re, oex[0].re), fma(iq_mnb, ts.im, oex[0].im));
+                }
                 if constexpr (RS) {
                     v4i accR[S], accI[S], accLR[NHF], accLI[NHF];
                     v4i A[S], L[NLF];
@@ -1295,9 +1311,10 @@ bool chain_i8w_supported(int q, int dt, int n, bool iq) {
     return nt == 8 || nt == 16;
 }
 
-size_t chain_i8w_lds_bytes(int q, int n, int iq) {
+size_t chain_i8w_lds_bytes(int q, int n, int iq, int dt) {
     const int ntc = n / (SDRT_TB * SDRT_WIDE_LC);
-    return (size_t) wide_lds(SDRT_I8_DIGITS, SDRT_WIDE_LC / q, ntc < 8 ? 8 : ntc, iq, ntc).total;
+    const int nsl = dt == SDRT_S8 || dt == SDRT_U8 ? 1 : (dt == SDRT_F32 ? 4 : 2);
+    return (size_t) wide_lds(SDRT_I8_DIGITS, SDRT_WIDE_LC / q, ntc < 8 ? 8 : ntc, iq, ntc, nsl).total;
 }
 
 hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, int n_cus, hipStream_t s) {
@@ -1308,7 +1325,7 @@ hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, 
     if (items < wgs) wgs = items;
     wgs = (wgs + 7) / 8 * 8;
     const dim3 grid((unsigned) wgs);
-    const size_t lds = chain_i8w_lds_bytes(q, a.n, a.w8iq ? 2 : (a.iq_group_off ? 1 : 0));
+    const size_t lds = chain_i8w_lds_bytes(q, a.n, a.w8iq ? 2 : (a.iq_group_off ? 1 : 0), dt);
     switch (dt) {
         case SDRT_S8: case SDRT_U8: return launch_chain_i8w_bytes(a, nout, nt, dt, grid, lds, s);     // kernels_i8w_b.hip
         case SDRT_S16: return launch_i8w_d<SDRT_S16>(a, nout, nt, grid, lds, s);

@@ -452,3 +452,48 @@ def test_float32_rows_sliced_once_per_chunk_give_the_same_bits(big_endian, nch, 
     if not big_endian:
         exp = _oracle_rows(raw, 'f', n, q, 'fm', freqs, fs, 5000, range(nch), range(5))
         assert np.abs(outs['1'].reshape(5, nch, n // q).transpose(1, 0, 2) - exp).max() <= 1e-6
+
+
+@pytest.mark.parametrize('code,rows,iq,fused', [('B', 1, False, None), ('b', 2, False, None), ('B', 1, True, '1'), ('b', 1, True, '0'),
+                                                ('B', 2, True, None), ('h', 1, False, None)])
+def test_sixteen_tiles_per_chunk_on_the_wide_kernel(code, rows, iq, fused, monkeypatch):
+    """Chunks of sixteen tiles (8-bit records; 16-bit records in 65536-sample chunks): two tiles per wave, the column phase of a
+    tile running in the pass after its matrix phase (kernels_i8w.hip, SHQ), with and without --correct-iq in both of its forms.
+    Five chunks against oracle/chain.c, offsets carried; then enough chunks that every workgroup reaches the steady state of its
+    pipeline (more than four items each) against the independently written one-block-per-column kernel."""
+    from sdrterm_amd.engine import Engine
+    from oracle import c_chain, ref_chain
+    from tests.golden import prng
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    if fused is not None:
+        monkeypatch.setenv('SDRTERM_IQ_FUSED', fused)
+    fs, q, n = 1024000, 64, 65536
+    freqs = [15700.0, -203300.0][:rows]
+    amp = 100 if code in 'bB' else 3000
+    kw = dict(n_samples=n, row_freqs=freqs, apply_shift=True, omega_out=5000, correct_iq=iq)
+    raw = prng.raw_bytes(code, n * 5, seed=77, amp=amp, dc=(amp // 6, -amp // 10))
+    eng = Engine(fs, q, 'fm', code, **kw)
+    assert eng.stage_a == 'i8w'
+    out = eng.process(raw)
+    exp, off = c_chain.process_stream(raw, code, n, q, 'fm', c_chain.shift_table(freqs, fs, n), ref_chain.cheby_sos(q),
+                                      ref_chain.ellip_sos(fs // q, 5000), iq_inductance=50 / fs if iq else None, threads=4)
+    got = out.reshape(rows, 5, n // q).transpose(1, 0, 2)
+    err = np.abs(got - exp).max()
+    print(f'{code} x {rows} iq={iq} fused={fused}: 5 chunks vs oracle max abs err {err:.3e}')
+    assert err <= 1e-6
+    if iq:
+        assert abs(eng.iq_offset - off) <= 1e-9 * max(abs(off), 1e-30)
+    # the steady state: 1300 chunks (rows x 1300 items over at most 256 workgroups)
+    nch = 1300
+    big = np.tile(np.frombuffer(prng.raw_bytes(code, n * 50, seed=78, amp=amp, dc=(amp // 5, amp // 9)), dtype=np.uint8), nch // 50)
+    a = Engine(fs, q, 'fm', code, **kw)
+    out_a = a.process(big)
+    monkeypatch.setenv('SDRTERM_STAGE_A', 'i8t')
+    b = Engine(fs, q, 'fm', code, **kw)
+    out_b = b.process(big)
+    assert a.stage_a == 'i8w' and b.stage_a in ('i8t', 'f64')      # (fused --correct-iq exists on the wide and the fp64 kernel)
+    d = np.abs(out_a - out_b).max()
+    print(f'   {nch} chunks: wide against the {b.stage_a} kernel {d:.3e}')
+    assert np.isfinite(out_a).all() and d < 1e-7
+    if iq:
+        assert abs(a.iq_offset - b.iq_offset) <= 1e-9 * max(abs(b.iq_offset), 1e-30)
