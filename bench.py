@@ -194,16 +194,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
-
     from sdrterm_amd import _native as nat, parallel
     from sdrterm_amd.engine import Engine
+    local_dev = parallel.device_for(local_rank)       # = LOCAL_RANK unless SDRTERM_DEVICE_MAP says otherwise
+    torch.cuda.set_device(local_dev)
+    device = torch.device('cuda', local_dev)
+
     # one communicator for everything the ranks say to each other (barrier, maximum, block exchange): RCCL behind the C ABI
     comm = None
     if world > 1 or args.force_comm:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        comm = parallel.RcclTransport(rank, world, local_rank)        # the id travels over TCP at MASTER_ADDR:MASTER_PORT+17
+        comm = parallel.RcclTransport(rank, world, local_dev)        # the id travels over TCP at MASTER_ADDR:MASTER_PORT+17
     q, rows_total, default_chunks, scaling, code, FS = WORKLOADS[args.workload]
     N = 131072 // (2 * ITEM[code])            # complex samples per 131072-byte chunk
     n_chunks = args.chunks or default_chunks
@@ -229,7 +230,7 @@ def main():
             per = n_samples // world
             src = torch.stack([src[b * n_samples + rank * per:b * n_samples + (rank + 1) * per] for b in range(2)]).contiguous()
         bufs = [torch.empty((n_samples, 2), dtype=torch.int16 if code == 'h' else torch.float32, device=device) for _ in range(2)]
-    eng = Engine(FS, q, "fm", code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_rank, correct_iq=args.correct_iq,
+    eng = Engine(FS, q, "fm", code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_dev, correct_iq=args.correct_iq,
                  reserve_chunks=n_chunks)         # no allocation inside the timed calls
     rows = len(freqs)
     out = torch.empty((rows, n_chunks * eng.m), dtype=torch.float64, device=device)
@@ -292,7 +293,9 @@ def main():
     torch.cuda.synchronize()
     t_settle = time.perf_counter()
     settle_steps = 0
-    while time.perf_counter() - t_settle < args.settle_seconds:
+    # (the ranks decide together when the settling is over: with a collective in every step a rank that left the loop one round
+    # before the others would leave them waiting in it)
+    while max(over_ranks(time.perf_counter() - t_settle)) < args.settle_seconds:
         for _ in range(16):
             step()
         torch.cuda.synchronize()
@@ -409,7 +412,7 @@ def main():
         if not args.no_same_arithmetic and eng.stage_a != 'f64':
             os.environ['SDRTERM_STAGE_A'] = 'f64'
             try:
-                e64 = Engine(FS, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_rank, correct_iq=args.correct_iq)
+                e64 = Engine(FS, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_dev, correct_iq=args.correct_iq)
             finally:
                 del os.environ['SDRTERM_STAGE_A']
             n64 = 4 if single else 2

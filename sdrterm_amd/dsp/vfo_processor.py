@@ -80,7 +80,8 @@ class VfoProcessor(DspProcessor):
     def _enterRank(self, rank: int, world: int, uid=None) -> None:
         self._rank, self._world, self._uid = rank, world, uid
         if self._transportKind == 'rccl':
-            self._device = self._deviceBase + rank           # one process per GPU of the node, from ``device=`` upwards
+            from ..parallel import device_for
+            self._device = device_for(rank, self._deviceBase)    # one process per GPU of the node, from ``device=`` upwards
         self._engine = None
 
     def _shard(self):

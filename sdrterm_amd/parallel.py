@@ -42,6 +42,19 @@ def split_range(total: int, world: int, rank: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
+def device_for(local_rank: int, base: int = 0) -> int:
+    """The device a rank of this node runs on: ``base + local_rank`` (one process per GPU), unless SDRTERM_DEVICE_MAP lists the
+    devices rank by rank ("4,5,6,7": GPUs 4-7; "0,0": two ranks on one GPU -- only with a transport that allows it, which RCCL
+    does not: tests/standin_rccl)."""
+    spec = os.environ.get('SDRTERM_DEVICE_MAP')
+    if spec:
+        devs = [int(v) for v in spec.split(',')]
+        if local_rank >= len(devs):
+            raise ValueError(f'SDRTERM_DEVICE_MAP={spec!r} names {len(devs)} device(s), rank {local_rank} has none')
+        return devs[local_rank]
+    return base + local_rank
+
+
 def shard_rows(row_freqs: List[float], world: int, rank: int) -> Tuple[List[float], Tuple[int, int]]:
     """Rows (VFO channels) this rank computes, and their [start, stop) in the reference's row order."""
     lo, hi = split_range(len(row_freqs), world, rank)

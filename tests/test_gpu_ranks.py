@@ -1,0 +1,129 @@
+"""Several rank processes on ONE GPU (all a development box has), with tests/standin_rccl in place of RCCL -- which refuses two
+ranks on one device.  What runs is the real thing otherwise: bench.py's self-launched ranks and VfoProcessor's helper processes,
+the unique-id exchange, communicator set-up, the block exchange on the communication stream beside the kernels, barrier and
+maximum over the ranks, every rank's sequence of collectives, the HIP kernels on every rank's share.  (RCCL itself is exercised
+with a world of one in tests/test_gpu_processors.py; N > 1 on N GPUs is the driver's scaling run.)"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(n_ranks):
+    from tests import standin_rccl
+    env = dict(os.environ, SDRTERM_RCCL_LIB=standin_rccl.library(), SDRTERM_DEVICE_MAP=','.join(['0'] * n_ranks),
+               SDRTERM_COMM_TIMEOUT='120', SDRTERM_COMM_INIT_TIMEOUT='120', SDRT_STANDIN_TIMEOUT='120')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    return env
+
+
+def _bench(n_ranks, *flags):
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', str(n_ranks), '--steps', '5', '--warmup', '2', '--settle-seconds', '0.4',
+           '--long-seconds', '0.3', '--no-cpu-baseline', '--no-same-arithmetic', *flags]
+    r = subprocess.run(cmd, env=_env(n_ranks), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 prints the one line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize('n_ranks,flags', [(2, ('--workload', 'simo64', '--chunks', '64')),
+                                           (3, ('--workload', 'simo64', '--chunks', '48', '--feed', 'allgather')),
+                                           (2, ('--workload', 'f32x256', '--chunks', '32')),
+                                           (2, ('--workload', 'fm64', '--chunks', '1024'))],
+                         ids=['simo64-bcast-2', 'simo64-allgather-3', 'f32x256-bcast-2', 'fm64-chunks-2'])
+def test_bench_with_several_ranks_on_one_gpu(n_ranks, flags):
+    """bench.py --gpus N without a launcher: N rank processes, rows (or chunks) sharded, one exchange per step; the line rank 0
+    prints counts every rank's work and the configuration says how the rows were split."""
+    line = _bench(n_ranks, *flags)
+    assert line['n_gpus'] == n_ranks and line['steps'] == 5 and line['value'] > 0 and line['cpu_baseline'] is None
+    wl = flags[1]
+    rows_total = {'simo64': 64, 'f32x256': 256, 'fm64': 1}[wl]
+    if rows_total > 1:
+        assert line['scaling'] == 'strong' and line['config']['rows_per_gpu'] == -(-rows_total // n_ranks)      # rank 0 takes the larger share
+        assert line['config']['parallelism'] == f'rows-sharded x{n_ranks} + ' + ('allgather' if '--feed' in flags else 'bcast')
+        samples = int(flags[3]) * line['config']['samples_per_chunk']
+    else:
+        assert line['scaling'] == 'weak' and line['config']['parallelism'] == f'chunk-sharded x{n_ranks}'
+        samples = int(flags[3]) * line['config']['samples_per_chunk'] * n_ranks
+    assert line['value'] == pytest.approx(samples / (line['ms_per_step'] * 1e-3) / 1e6, rel=1e-3)
+    assert line['steady_state']['steps'] >= 16 and line['kernels_ms']['chain_kernel'] > 0
+
+
+def test_simo_rows_over_two_rank_processes_on_one_gpu(monkeypatch):
+    """VfoProcessor(gpus=2): rank 0 in this process, one helper process, three rows split 2 + 1, each rank serving its own port;
+    nine chunks in batches of two (several blocks in flight), every row's stream against oracle/chain.c, in order."""
+    import multiprocessing as mp
+    import queue
+    import socket
+    import threading
+    import time
+    from oracle import c_chain, ref_chain
+    from sdrterm_amd.dsp.vfo_processor import VfoProcessor
+    from sdrterm_amd.misc.general_util import findPort
+    from sdrterm_amd.misc.read_file import RawChunk
+    from tests.golden import prng
+    for k, v in _env(2).items():
+        if k.startswith('SDRT'):
+            monkeypatch.setenv(k, v)
+    fs, q, n, nch = 1024000, 64, 32768, 9
+    raw = prng.raw_bytes('h', n * nch, seed=34, amp=4000)
+    port = findPort('127.0.0.1')
+    p = VfoProcessor(fs, vfoHost=f'127.0.0.1:{port}', vfos='-100000,50000', center=15700, dec=q, omegaOut=5000, gpus=2)
+    p.selectOutputFm()
+    p.MAX_BATCH = 2
+    buf = queue.Queue()
+    for c in range(nch):
+        buf.put(RawChunk(raw[c * n * 4:(c + 1) * n * 4], 'h', False, False, False, 50))
+    buf.put(b'')
+    buf.close = lambda: None
+    buf.join_thread = lambda: None
+    m = n // q
+    box = [None] * 3
+    where = [(port, 0), (port, 1), (port + 1, 2)]          # rank 0: rows 0, 1 in connection order; rank 1: row 2
+
+    def client(prt, k):
+        deadline = time.time() + 120
+        while True:
+            try:
+                s = socket.create_connection(('127.0.0.1', prt), timeout=60)
+                break
+            except OSError:
+                if time.time() > deadline:
+                    raise
+                time.sleep(0.05)
+        data = b''
+        with s:
+            while len(data) < nch * m * 8:
+                part = s.recv(nch * m * 8 - len(data))
+                if not part:
+                    break
+                data += part
+        box[k] = np.frombuffer(data, dtype='>f8').astype(np.float64)
+
+    def connect_all():
+        for prt, k in where:
+            threading.Thread(target=client, args=(prt, k), daemon=True).start()
+            time.sleep(0.5)
+    threading.Thread(target=connect_all, daemon=True).start()
+    flag = mp.get_context('spawn').Value('b', 0)
+    p.processData(flag, buf)
+    deadline = time.time() + 60
+    while any(b is None for b in box) and time.time() < deadline:
+        time.sleep(0.05)
+    assert flag.value == 0, 'a rank raised the halt flag'
+    rows = ref_chain.vfo_rows(15700, '-100000,50000')
+    exp, _ = c_chain.process_stream(raw, 'h', n, q, 'fm', c_chain.shift_table(rows, fs, n), ref_chain.cheby_sos(q),
+                                    ref_chain.ellip_sos(fs // q, 5000), threads=4)
+    for k in range(3):
+        assert box[k] is not None and box[k].size == nch * m, f'row {k}: {None if box[k] is None else box[k].size} samples'
+        err = np.abs(box[k].reshape(nch, m) - exp[:, k, :]).max()
+        assert err <= 1e-6, f'row {k}: {err:.3e}'

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Secondary workloads (BASELINE.json configs[2] and neighbours) through the C ABI, device-resident buffers, no torch.
-Prints one JSON line per workload: input MSamples/s and the per-kernel HIP-event times."""
+Prints one JSON line per workload: input MSamples/s and the per-kernel HIP-event times.
+usage: tools/bench_extra.py [substring of the workload names to run]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,7 +13,12 @@ FS = 256_000_000
 VFOS8 = [-40e6 + 15000, -30e6 + 15000, -20e6 + 15000, -10e6 + 15000, 10e6 + 15000, 20e6 + 15000, 30e6 + 15000, 15000]
 
 
+ONLY = sys.argv[1] if len(sys.argv) > 1 else None       # substring of the workload names to run
+
+
 def run(name, n_chunks, steps=5, **kw):
+    if ONLY and ONLY not in name:
+        return
     eng = Engine(FS, **kw)
     BLK = 512        # distinct chunks before the stream repeats (a short period keeps every workgroup on the same few L2 lines)
     one = np.frombuffer(prng.raw_bytes(kw.get('code', 'h'), eng.n * BLK, 9, 100 if kw.get('code', 'h') in 'bB' else 8000), dtype=np.uint8)
