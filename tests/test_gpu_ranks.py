@@ -37,9 +37,10 @@ def _bench(n_ranks, *flags):
 
 @pytest.mark.parametrize('n_ranks,flags', [(2, ('--workload', 'simo64', '--chunks', '64')),
                                            (3, ('--workload', 'simo64', '--chunks', '48', '--feed', 'allgather')),
+                                           (4, ('--workload', 'simo64', '--chunks', '64')),
                                            (2, ('--workload', 'f32x256', '--chunks', '32')),
                                            (2, ('--workload', 'fm64', '--chunks', '1024'))],
-                         ids=['simo64-bcast-2', 'simo64-allgather-3', 'f32x256-bcast-2', 'fm64-chunks-2'])
+                         ids=['simo64-bcast-2', 'simo64-allgather-3', 'simo64-bcast-4', 'f32x256-bcast-2', 'fm64-chunks-2'])
 def test_bench_with_several_ranks_on_one_gpu(n_ranks, flags):
     """bench.py --gpus N without a launcher: N rank processes, rows (or chunks) sharded, one exchange per step; the line rank 0
     prints counts every rank's work and the configuration says how the rows were split."""
@@ -127,3 +128,93 @@ def test_simo_rows_over_two_rank_processes_on_one_gpu(monkeypatch):
         assert box[k] is not None and box[k].size == nch * m, f'row {k}: {None if box[k] is None else box[k].size} samples'
         err = np.abs(box[k].reshape(nch, m) - exp[:, k, :]).max()
         assert err <= 1e-6, f'row {k}: {err:.3e}'
+
+
+def test_bench_under_the_distributed_launcher_on_one_gpu():
+    """The driver's own launch line: python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 2 ...: the ranks find RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment and
+    exchange the communicator id beside the launcher's own store on MASTER_PORT."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1',
+           '--workload', 'simo64', '--chunks', '64', '--settle-seconds', '0.3', '--long-seconds', '0.2', '--no-same-arithmetic']
+    r = subprocess.run(cmd, env=_env(2), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 4 and line['warmup'] == 1 and line['config']['rows_per_gpu'] == 32
+    assert line['cpu_baseline'] is None                      # rank 0 at N = 1 only
+
+
+def test_a_helper_rank_that_dies_takes_the_job_down_in_bounded_time(monkeypatch):
+    """a rank that fails must not leave the others in a collective.  Two ranks, a source that trickles; the helper
+    process is killed after the first blocks: rank 0 comes back from processData within the deadlines, with the halt flag up."""
+    import multiprocessing as mp
+    import queue
+    import threading
+    import time
+    from sdrterm_amd.dsp.vfo_processor import VfoProcessor
+    from sdrterm_amd.misc.general_util import findPort
+    from sdrterm_amd.misc.read_file import RawChunk
+    from tests.golden import prng
+    for k, v in _env(2).items():
+        if k.startswith('SDRT'):
+            monkeypatch.setenv(k, v)
+    for k in ('SDRTERM_COMM_TIMEOUT', 'SDRT_STANDIN_TIMEOUT'):
+        monkeypatch.setenv(k, '8')
+    fs, q, n = 1024000, 64, 32768
+    raw = prng.raw_bytes('h', n * 2, seed=35, amp=4000)
+    port = findPort('127.0.0.1')
+    p = VfoProcessor(fs, vfoHost=f'127.0.0.1:{port}', vfos='-100000,50000', center=15700, dec=q, omegaOut=5000, gpus=2)
+    p.selectOutputFm()
+    p.MAX_BATCH = 1
+    buf = queue.Queue()
+    buf.close = lambda: None
+    buf.join_thread = lambda: None
+    stop = threading.Event()
+
+    def feeder():
+        while not stop.is_set():
+            buf.put(RawChunk(raw[:n * 4], 'h', False, False, False, 50))
+            time.sleep(0.2)
+
+    def clients():
+        import socket
+        socks = []
+        for prt in (port, port, port + 1):
+            deadline = time.time() + 60
+            while time.time() < deadline:
+                try:
+                    socks.append(socket.create_connection(('127.0.0.1', prt), timeout=60))
+                    break
+                except OSError:
+                    time.sleep(0.05)
+            time.sleep(0.5)
+        while not stop.is_set():
+            for s in socks:
+                try:
+                    s.settimeout(0.05)
+                    s.recv(1 << 20)
+                except OSError:
+                    pass
+
+    def killer():
+        deadline = time.time() + 60
+        while not p._helpers and time.time() < deadline:
+            time.sleep(0.05)
+        time.sleep(6.0)                                   # clients connected, a few blocks through
+        for h in p._helpers:
+            h.kill()
+    for fn in (feeder, clients, killer):
+        threading.Thread(target=fn, daemon=True).start()
+    flag = mp.get_context('spawn').Value('b', 0)
+    t0 = time.time()
+    p.processData(flag, buf)
+    took = time.time() - t0
+    stop.set()
+    assert flag.value == 1, 'the halt flag stayed down'
+    assert took < 6.0 + 45.0, f'rank 0 took {took:.1f} s to give up'
