@@ -156,6 +156,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     // become four (Q of item it writes into its buffer while P3 of item it-3 still reads the one three back).
     constexpr bool SHQ = wide_shq(NOUT, NTC, IQ, W8Enc<DT>::slices) && !RS;
     constexpr int NBUF = SHQ ? 4 : 3;
+    // the sixteen-tile forms with --correct-iq are the shortest of registers: what they keep out of the loop-invariant lane values
+    // (LDS and output addresses the allocator would spill, each reload a vmcnt(0) drain): the wave number from scalar registers,
+    // the lane number read where an address needs it
+    constexpr bool OPQ = SHQ && IQ != 0;
     constexpr int WPK = (RS ? 8 : 4) * ITEM;         // 32-bit words per lane and k-step (8 complex samples; RS: 16)
     constexpr int TILE = SDRT_TB * LC;               // samples per tile
     constexpr int NSTEP = KS * TPW;                  // k-steps per wave and item
@@ -533,12 +537,22 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
 
             // ---- the pieces of Q(it-1), P3(it-3) and E(it) that run after matrix-instruction group i of tile slot j ------------
             constexpr int P3_0 = 12 + 3 * OPL;       // first P3 piece; the E piece comes after the last one
+            auto lane_id = [&]() -> int {
+                if constexpr (OPQ) {
+                    int l;
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+                    return l;
+                } else {
+                    return lane;
+                }
+            };
             auto piece = [&](auto jc, auto ic) {
                 constexpr int j = decltype(jc)::value, i = decltype(ic)::value;
-                const int tile = wave + 8 * j;
+                const int wv = OPQ ? wave_s : wave;
+                const int tile = wv + 8 * j;
                 // what Q works on in this pass: tile j of item it-1, or (SHQ) the tile the previous pass finished
                 constexpr int jq = SHQ ? (j ^ 1) : j;
-                const int tileq = wave + 8 * jq, bQq = SHQ && j == 1 ? bcur : bQ;
+                const int tileq = wv + 8 * jq, bQq = SHQ && j == 1 ? bcur : bQ;
                 const bool have_qq = SHQ && j == 1 ? HAVE_K : have_q;
                 if (have_qq) {
                     if constexpr ((IQA || F32) && i == 0) {
@@ -603,8 +617,9 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         // tile aggregates: causal inclusive at the last column -> slot tile+1, anticausal inclusive at the first -> slot tile
                         cd *cf = carF(bQq), *cg = carG(bQq);
                         const int sl = tileq + tileq / NTC;          // carry slot of the tile's start (NTC + 1 slots per chunk)
-                        if (nb == 15) { cf[(sl + 1) * 8 + g * 2 + 0] = dC[jq][0]; cf[(sl + 1) * 8 + g * 2 + 1] = dC[jq][1]; }
-                        if (nb == 0) { cg[sl * 8 + g * 2 + 0] = dA[jq][0]; cg[sl * 8 + g * 2 + 1] = dA[jq][1]; }
+                        const int ga = lane_id() >> 4;            // (= g)
+                        if (nb == 15) { cf[(sl + 1) * 8 + ga * 2 + 0] = dC[jq][0]; cf[(sl + 1) * 8 + ga * 2 + 1] = dC[jq][1]; }
+                        if (nb == 0) { cg[sl * 8 + ga * 2 + 0] = dA[jq][0]; cg[sl * 8 + ga * 2 + 1] = dA[jq][1]; }
                         // from here on: states at the column's edges from inside the tile (causal at its start, anticausal at its end)
                         dC[jq][0] = dpp_row<0x111>(dC[jq][0]);
                         dC[jq][1] = dpp_row<0x111>(dC[jq][1]);
@@ -686,7 +701,8 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     gchar *yd = (gchar *) (((uint64_t) (unsigned) __builtin_amdgcn_readfirstlane((int) (ydv >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((int) ydv));
 #pragma unroll
                     for (int e = 0; e < OPL; ++e) {
-                        const int k = (tile * SDRT_TB + nb) * NOUT + g + 4 * e;
+                        const int la = lane_id();
+                        const int k = (tile * SDRT_TB + (la & 15)) * NOUT + (la >> 4) + 4 * e;      // (column nb, output g + 4e)
                         const cd own = pv[j][e];
                         const v2u s0 = __builtin_amdgcn_permlane16_swap((unsigned) __double2loint(own.re), (unsigned) __double2loint(own.re), false, false);
                         const v2u s1 = __builtin_amdgcn_permlane16_swap((unsigned) __double2hiint(own.re), (unsigned) __double2hiint(own.re), false, false);
@@ -725,7 +741,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         tsw = cadd(tsw, dpp_row<0x114>(tsw));
                         tsw = cadd(tsw, dpp_row<0x118>(tsw));
                         const double tot2 = swap16_add(tsw.re, tsw.im);
-                        if (nb == 15 && e_o16 == 8) ((double *) (OtL(bcur) + NT))[g & 1] = tot2;
+                        if (nb == 15 && e_o16 == 8) ((double *) (OtL(bcur) + NT))[(lane_id() >> 4) & 1] = tot2;
                     }
                     f = cadd(f, dpp_row<0x111>(f));
                     f = cadd(f, dpp_row<0x112>(f));
@@ -1119,7 +1135,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                             o = mk(fma(iq_m2, dpp_row<0x112>(o.re), o.re), fma(iq_m2, dpp_row<0x112>(o.im), o.im));
                             o = mk(fma(iq_m4, dpp_row<0x114>(o.re), o.re), fma(iq_m4, dpp_row<0x114>(o.im), o.im));
                             o = mk(fma(iq_m8, dpp_row<0x118>(o.re), o.re), fma(iq_m8, dpp_row<0x118>(o.im), o.im));
-                            if (lane == 15) OtL(bcur)[wave + 8 * j] = o;              // the tile's total
+                            if (lane == 15) OtL(bcur)[(OPQ ? wave_s : wave) + 8 * j] = o;              // the tile's total
                             oex[j] = dpp_row<0x111>(o);                               // offset at the column's first sample
                         }
                     }
