@@ -14,6 +14,8 @@
 //   * the output lowpass never leaves the registers: a lane holds 4 consecutive output samples of each block of 32, the
 //     blocks' states are scanned over the item's 8 lanes with DPP shifts and chained over the 16 blocks in every lane.
 // Every lane group runs the same instructions on its own item only: an item's bits do not depend on its neighbours.
+#include <cstdlib>
+
 #include "kernels_common.hpp"
 
 namespace {
@@ -396,9 +398,13 @@ size_t post_fft8_stash_bytes(const PostArgs &a) {
 }
 
 bool post_fft8_supported(const PostArgs &a) {
-    // (with the IQ offset share still to subtract every angle takes four samples and four table entries: the one-wave-per-item
-    // kernel holds those loads better -- 0.54 against 0.63 ms per 2^32 samples, profiles/r03_experiments.txt)
-    if (a.iq_R) return false;
+    // with the IQ offset share still to subtract every angle takes four samples and four table entries: at 512 outputs per chunk the
+    // one-wave-per-item kernel holds those loads better (0.54 against 0.63 ms per 2^32 samples), at 1024 this one does (0.085
+    // against 0.099 ms per 2^29 8-bit samples; profiles/r03_experiments.txt).  SDRTERM_POST8_IQ=0 / 2: never / at both sizes
+    if (a.iq_R) {
+        static const int with_share = [] { const char *e = getenv("SDRTERM_POST8_IQ"); return e ? atoi(e) : 1; }();
+        if (!(with_share == 2 || (with_share == 1 && a.m == 1024))) return false;
+    }
     return a.mode == SDRT_FM && a.fft8_tab && a.p8tab && ((a.m == 512 && a.p8_lpi == 8) || (a.m == 1024 && a.p8_lpi == 16));
 }
 
