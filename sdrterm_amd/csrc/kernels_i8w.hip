@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     // the sixteen-tile forms with --correct-iq are the shortest of registers: what they keep out of the loop-invariant lane values
     // (LDS and output addresses the allocator would spill, each reload a vmcnt(0) drain): the wave number from scalar registers,
     // the lane number read where an address needs it
-    constexpr bool OPQ = SHQ && IQ != 0;
+    constexpr bool OPQ = (SHQ && IQ != 0) || (NOUT == 8 && IQ == 2);
     constexpr int WPK = (RS ? 8 : 4) * ITEM;         // 32-bit words per lane and k-step (8 complex samples; RS: 16)
     constexpr int TILE = SDRT_TB * LC;               // samples per tile
     constexpr int NSTEP = KS * TPW;                  // k-steps per wave and item

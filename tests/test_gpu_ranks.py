@@ -59,75 +59,16 @@ def test_bench_with_several_ranks_on_one_gpu(n_ranks, flags):
     assert line['steady_state']['steps'] >= 16 and line['kernels_ms']['chain_kernel'] > 0
 
 
-def test_simo_rows_over_two_rank_processes_on_one_gpu(monkeypatch):
-    """VfoProcessor(gpus=2): rank 0 in this process, one helper process, three rows split 2 + 1, each rank serving its own port;
-    nine chunks in batches of two (several blocks in flight), every row's stream against oracle/chain.c, in order."""
-    import multiprocessing as mp
-    import queue
-    import socket
-    import threading
-    import time
-    from oracle import c_chain, ref_chain
-    from sdrterm_amd.dsp.vfo_processor import VfoProcessor
-    from sdrterm_amd.misc.general_util import findPort
-    from sdrterm_amd.misc.read_file import RawChunk
-    from tests.golden import prng
-    for k, v in _env(2).items():
-        if k.startswith('SDRT'):
-            monkeypatch.setenv(k, v)
-    fs, q, n, nch = 1024000, 64, 32768, 9
-    raw = prng.raw_bytes('h', n * nch, seed=34, amp=4000)
-    port = findPort('127.0.0.1')
-    p = VfoProcessor(fs, vfoHost=f'127.0.0.1:{port}', vfos='-100000,50000', center=15700, dec=q, omegaOut=5000, gpus=2)
-    p.selectOutputFm()
-    p.MAX_BATCH = 2
-    buf = queue.Queue()
-    for c in range(nch):
-        buf.put(RawChunk(raw[c * n * 4:(c + 1) * n * 4], 'h', False, False, False, 50))
-    buf.put(b'')
-    buf.close = lambda: None
-    buf.join_thread = lambda: None
-    m = n // q
-    box = [None] * 3
-    where = [(port, 0), (port, 1), (port + 1, 2)]          # rank 0: rows 0, 1 in connection order; rank 1: row 2
+def _scenario(name, **extra):
+    r = subprocess.run([sys.executable, '-m', 'tests.rank_scenarios', name], env=dict(_env(2), **extra), cwd=REPO, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and 'scenario ok' in r.stdout, (r.stdout[-2000:] + r.stderr[-4000:])
 
-    def client(prt, k):
-        deadline = time.time() + 120
-        while True:
-            try:
-                s = socket.create_connection(('127.0.0.1', prt), timeout=60)
-                break
-            except OSError:
-                if time.time() > deadline:
-                    raise
-                time.sleep(0.05)
-        data = b''
-        with s:
-            while len(data) < nch * m * 8:
-                part = s.recv(nch * m * 8 - len(data))
-                if not part:
-                    break
-                data += part
-        box[k] = np.frombuffer(data, dtype='>f8').astype(np.float64)
 
-    def connect_all():
-        for prt, k in where:
-            threading.Thread(target=client, args=(prt, k), daemon=True).start()
-            time.sleep(0.5)
-    threading.Thread(target=connect_all, daemon=True).start()
-    flag = mp.get_context('spawn').Value('b', 0)
-    p.processData(flag, buf)
-    deadline = time.time() + 60
-    while any(b is None for b in box) and time.time() < deadline:
-        time.sleep(0.05)
-    assert flag.value == 0, 'a rank raised the halt flag'
-    rows = ref_chain.vfo_rows(15700, '-100000,50000')
-    exp, _ = c_chain.process_stream(raw, 'h', n, q, 'fm', c_chain.shift_table(rows, fs, n), ref_chain.cheby_sos(q),
-                                    ref_chain.ellip_sos(fs // q, 5000), threads=4)
-    for k in range(3):
-        assert box[k] is not None and box[k].size == nch * m, f'row {k}: {None if box[k] is None else box[k].size} samples'
-        err = np.abs(box[k].reshape(nch, m) - exp[:, k, :]).max()
-        assert err <= 1e-6, f'row {k}: {err:.3e}'
+def test_simo_rows_over_two_rank_processes_on_one_gpu():
+    """VfoProcessor(gpus=2): rank 0 and one helper process, three rows split 2 + 1, each rank serving its own port; nine chunks in
+    batches of two (several blocks in flight), every row's stream against oracle/chain.c, in order (tests/rank_scenarios.py)."""
+    _scenario('rows')
 
 
 def test_bench_under_the_distributed_launcher_on_one_gpu():
@@ -150,71 +91,8 @@ def test_bench_under_the_distributed_launcher_on_one_gpu():
     assert line['cpu_baseline'] is None                      # rank 0 at N = 1 only
 
 
-def test_a_helper_rank_that_dies_takes_the_job_down_in_bounded_time(monkeypatch):
+def test_a_helper_rank_that_dies_takes_the_job_down_in_bounded_time():
     """a rank that fails must not leave the others in a collective.  Two ranks, a source that trickles; the helper
-    process is killed after the first blocks: rank 0 comes back from processData within the deadlines, with the halt flag up."""
-    import multiprocessing as mp
-    import queue
-    import threading
-    import time
-    from sdrterm_amd.dsp.vfo_processor import VfoProcessor
-    from sdrterm_amd.misc.general_util import findPort
-    from sdrterm_amd.misc.read_file import RawChunk
-    from tests.golden import prng
-    for k, v in _env(2).items():
-        if k.startswith('SDRT'):
-            monkeypatch.setenv(k, v)
-    for k in ('SDRTERM_COMM_TIMEOUT', 'SDRT_STANDIN_TIMEOUT'):
-        monkeypatch.setenv(k, '8')
-    fs, q, n = 1024000, 64, 32768
-    raw = prng.raw_bytes('h', n * 2, seed=35, amp=4000)
-    port = findPort('127.0.0.1')
-    p = VfoProcessor(fs, vfoHost=f'127.0.0.1:{port}', vfos='-100000,50000', center=15700, dec=q, omegaOut=5000, gpus=2)
-    p.selectOutputFm()
-    p.MAX_BATCH = 1
-    buf = queue.Queue()
-    buf.close = lambda: None
-    buf.join_thread = lambda: None
-    stop = threading.Event()
-
-    def feeder():
-        while not stop.is_set():
-            buf.put(RawChunk(raw[:n * 4], 'h', False, False, False, 50))
-            time.sleep(0.2)
-
-    def clients():
-        import socket
-        socks = []
-        for prt in (port, port, port + 1):
-            deadline = time.time() + 60
-            while time.time() < deadline:
-                try:
-                    socks.append(socket.create_connection(('127.0.0.1', prt), timeout=60))
-                    break
-                except OSError:
-                    time.sleep(0.05)
-            time.sleep(0.5)
-        while not stop.is_set():
-            for s in socks:
-                try:
-                    s.settimeout(0.05)
-                    s.recv(1 << 20)
-                except OSError:
-                    pass
-
-    def killer():
-        deadline = time.time() + 60
-        while not p._helpers and time.time() < deadline:
-            time.sleep(0.05)
-        time.sleep(6.0)                                   # clients connected, a few blocks through
-        for h in p._helpers:
-            h.kill()
-    for fn in (feeder, clients, killer):
-        threading.Thread(target=fn, daemon=True).start()
-    flag = mp.get_context('spawn').Value('b', 0)
-    t0 = time.time()
-    p.processData(flag, buf)
-    took = time.time() - t0
-    stop.set()
-    assert flag.value == 1, 'the halt flag stayed down'
-    assert took < 6.0 + 45.0, f'rank 0 took {took:.1f} s to give up'
+    process is killed after the first blocks: rank 0 comes back from processData within the deadlines, with the halt flag up
+    (tests/rank_scenarios.py)."""
+    _scenario('kill', SDRTERM_COMM_TIMEOUT='8', SDRT_STANDIN_TIMEOUT='8')
