@@ -52,10 +52,13 @@ WORKLOADS = {
     # name: (decimation, total rows, default chunks per step, scaling, encoding, sample rate)
     'fm64': (64, 1, 131072, 'weak', 'h', 256_000_000),
     'fm64f': (64, 1, 131072, 'weak', 'f', 256_000_000),          # the same stream as float32 records (16384-sample chunks)
+    'fm64b': (64, 1, 65536, 'weak', 'B', 256_000_000),           # the same stream as uint8 records (rtl_tcp's format; 65536-sample chunks)
     'simo64': (32, 64, 512, 'strong', 'h', 256_000_000),
     'f32x256': (64, 256, 128, 'strong', 'f', 1_000_000_000),
 }
-ITEM = {'h': 2, 'f': 4}
+ITEM = {'h': 2, 'f': 4, 'B': 1}
+TORCH_DTYPE = {'h': 'int16', 'f': 'float32', 'B': 'uint8'}
+ENC_NAME = {'h': 'int16', 'f': 'float32', 'B': 'uint8'}
 
 
 def simo_rows(n_rows):
@@ -68,12 +71,12 @@ def simo_rows(n_rows):
 
 def synth_iq_torch(n_samples, seed, device, code='h', fs=FS):
     """FM tone at +CENTER with 1 kHz modulation, amplitude 8000, Gaussian noise sigma 300, int16; float32: the
-    same stream scaled by 2^-15, not rounded."""
+    same stream scaled by 2^-15, not rounded; uint8: scaled by 2^-7 (tone amplitude 62.5, noise sigma 2.3) around 128."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     FS = fs
-    out = torch.empty((n_samples, 2), dtype=torch.int16 if code == 'h' else torch.float32, device=device)
+    out = torch.empty((n_samples, 2), dtype=getattr(torch, TORCH_DTYPE[code]), device=device)
     step = 1 << 24
     fm, dev = 1000.0, 2500.0
     for s in range(0, n_samples, step):
@@ -86,6 +89,9 @@ def synth_iq_torch(n_samples, seed, device, code='h', fs=FS):
         if code == 'h':
             out[s:e, 0] = torch.round(re).clamp_(-32768, 32767).to(torch.int16)
             out[s:e, 1] = torch.round(im).clamp_(-32768, 32767).to(torch.int16)
+        elif code == 'B':
+            out[s:e, 0] = torch.round(re / 128.0 + 128.0).clamp_(0, 255).to(torch.uint8)
+            out[s:e, 1] = torch.round(im / 128.0 + 128.0).clamp_(0, 255).to(torch.uint8)
         else:
             out[s:e, 0] = (re / 32768.0).to(torch.float32)
             out[s:e, 1] = (im / 32768.0).to(torch.float32)
@@ -229,7 +235,7 @@ def main():
         if allg:
             per = n_samples // world
             src = torch.stack([src[b * n_samples + rank * per:b * n_samples + (rank + 1) * per] for b in range(2)]).contiguous()
-        bufs = [torch.empty((n_samples, 2), dtype=torch.int16 if code == 'h' else torch.float32, device=device) for _ in range(2)]
+        bufs = [torch.empty((n_samples, 2), dtype=getattr(torch, TORCH_DTYPE[code]), device=device) for _ in range(2)]
     eng = Engine(FS, q, "fm", code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_dev, correct_iq=args.correct_iq,
                  reserve_chunks=n_chunks)         # no allocation inside the timed calls
     rows = len(freqs)
@@ -350,7 +356,7 @@ def main():
         achieved = alg_bps * n_samples / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms else None
         path_achieved = alg_bps * n_samples / (ms_per_step * 1e-3) / 1e9
         # int8 matrix work of the dominant kernel: matrix instructions per 4096-sample tile x 16*16*64*2 operations
-        mfma_per_tile = (({64: 184, 32: 216} if code == 'h' else {64: 288, 32: 336})[q] + (16 if args.correct_iq and rows == 1 else 0)) if eng.stage_a == 'i8w' else ({'h': 160, 'f': 224}[code] if eng.stage_a == 'i8t' else None)
+        mfma_per_tile = ({'h': {64: 184, 32: 216}, 'f': {64: 288, 32: 336}, 'B': {64: 104, 32: 120}}[code][q] + (16 if args.correct_iq and rows == 1 else 0)) if eng.stage_a == 'i8w' else ({'h': 160, 'f': 224}.get(code) if eng.stage_a == 'i8t' else None)
         i8_ops = mfma_per_tile * 32768.0 * rows * n_samples / 4096 if mfma_per_tile else None
         # hardware counters cannot be read from inside this run: the committed record of rocprofv3 passes over this very workload
         # (tools/pmc.sh) is quoted under "from_profile", with the file it comes from and the commit it was taken at
@@ -383,15 +389,15 @@ def main():
                     'avg_kernel_ms': hbm['avg_kernel_ms'], 'launches': k_n, 'ops': 'int8 multiply-adds x 2 (dense int8 matrix peak)',
                     'hbm': {k: hbm[k] for k in ('achieved', 'frac', 'alg_bytes_per_sample', 'path_achieved', 'path_frac', 'read_frac')}}
         line = {
-            'metric': {'fm64': 'input MSamples/s IQ->FM demod, dec=64', 'fm64f': 'input MSamples/s IQ->FM demod, float32 IQ, dec=64', 'simo64': 'input MSamples/s 64-VFO --simo FM, dec=32',
+            'metric': {'fm64': 'input MSamples/s IQ->FM demod, dec=64', 'fm64f': 'input MSamples/s IQ->FM demod, float32 IQ, dec=64', 'fm64b': 'input MSamples/s IQ->FM demod, uint8 IQ, dec=64', 'simo64': 'input MSamples/s 64-VFO --simo FM, dec=32',
                        'f32x256': 'input MSamples/s 256-VFO --simo FM, float32 IQ, dec=64'}[args.workload],
             'value': round(value, 1), 'unit': 'MSamples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
             'scaling': scaling, 'vs_baseline': None,
             # what the arithmetic is: int8 x int8 -> int32 matrix products of 5 base-256 weight digits x 2 byte slices (exact),
             # recombined and finished in fp64; 'f64' when the fp64 matrix-core kernel runs
-            'dtype': ('i8x5-split+f64' if code == 'h' else 'f32->4 x i8 block fixed point, i8x5-split+f64') if eng.stage_a in ('i8w', 'i8t') else 'f64', 'data': 'synthetic',
-            'config': {'workload': (f'configs[1]{"" if code == "h" else " as float32 records"}: {FS // 1_000_000} MS/s synthetic {"int16" if code == "h" else "float32"} IQ (FM tone + noise), FM demod, dec={q}, single VFO, '
+            'dtype': ('f32->4 x i8 block fixed point, i8x5-split+f64' if code == 'f' else 'i8x5-split+f64') if eng.stage_a in ('i8w', 'i8t') else 'f64', 'data': 'synthetic',
+            'config': {'workload': (f'configs[1]{"" if code == "h" else f" as {ENC_NAME[code]} records"}: {FS // 1_000_000} MS/s synthetic {ENC_NAME[code]} IQ (FM tone + noise), FM demod, dec={q}, single VFO, '
                                     f'center={CENTER} Hz{", --correct-iq" if args.correct_iq else ""}, {n_chunks} chunks x {N} samples per GPU per step, inputs resident in HBM')
                        if single else
                        (f'configs[{3 if code == "h" else 4}]: --simo {rows_total} VFO rows sharded {rows}/GPU, {FS // 1_000_000} MS/s synthetic {"int16" if code == "h" else "float32"} IQ, FM, dec={q}, '
