@@ -488,7 +488,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         for (int t2 = 0; t2 < NT; ++t2) te = mk(fma(iq_m16, te.re, ot[t2].re), fma(iq_m16, te.im, ot[t2].im));
                         const cd tsum = ot[NT];
                         const cd ow = mk((te.re - tsum.re) * a.iq_consts[6], (te.im - tsum.im) * a.iq_consts[6]);
-                        if (tid == 0) ((cd *) a.iq_chunk_agg)[chunk_of(it - 1)] = te;
+                        ((cd *) a.iq_chunk_agg)[chunk_of(it - 1)] = te;        // (every lane of wave 0, the same value: no lane mask around a store)
                         if (lane < 8) {
                             const cd P = pqL[2 * (8 + lane)], Q = pqL[2 * (8 + lane) + 1];
                             cd gu = GuL(bQ)[lane];
