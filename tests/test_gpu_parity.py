@@ -483,17 +483,20 @@ def test_sixteen_tiles_per_chunk_on_the_wide_kernel(code, rows, iq, fused, monke
     assert err <= 1e-6
     if iq:
         assert abs(eng.iq_offset - off) <= 1e-9 * max(abs(off), 1e-30)
-    # the steady state: 1300 chunks (rows x 1300 items over at most 256 workgroups)
-    nch = 1300
-    big = np.tile(np.frombuffer(prng.raw_bytes(code, n * 50, seed=78, amp=amp, dc=(amp // 5, amp // 9)), dtype=np.uint8), nch // 50)
-    a = Engine(fs, q, 'fm', code, **kw)
-    out_a = a.process(big)
-    monkeypatch.setenv('SDRTERM_STAGE_A', 'i8t')
-    b = Engine(fs, q, 'fm', code, **kw)
-    out_b = b.process(big)
-    assert a.stage_a == 'i8w' and b.stage_a in ('i8t', 'f64')      # (fused --correct-iq exists on the wide and the fp64 kernel)
-    d = np.abs(out_a - out_b).max()
-    print(f'   {nch} chunks: wide against the {b.stage_a} kernel {d:.3e}')
-    assert np.isfinite(out_a).all() and d < 1e-7
-    if iq:
-        assert abs(a.iq_offset - b.iq_offset) <= 1e-9 * max(abs(b.iq_offset), 1e-30)
+    # the pipeline at every depth: 300 ... 1300 chunks = one to six items per workgroup (256 of them on an MI355X), the last count
+    # with every workgroup in its steady state
+    block = np.frombuffer(prng.raw_bytes(code, n * 50, seed=78, amp=amp, dc=(amp // 5, amp // 9)), dtype=np.uint8)
+    for nch in (300, 550, 800, 1050, 1300):
+        big = np.tile(block, nch // 50)
+        monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+        a = Engine(fs, q, 'fm', code, **kw)
+        out_a = a.process(big)
+        monkeypatch.setenv('SDRTERM_STAGE_A', 'i8t')
+        b = Engine(fs, q, 'fm', code, **kw)
+        out_b = b.process(big)
+        assert a.stage_a == 'i8w' and b.stage_a in ('i8t', 'f64')      # (fused --correct-iq exists on the wide and the fp64 kernel)
+        d = np.abs(out_a - out_b).max()
+        print(f'   {nch} chunks: wide against the {b.stage_a} kernel {d:.3e}')
+        assert np.isfinite(out_a).all() and d < 1e-7
+        if iq:
+            assert abs(a.iq_offset - b.iq_offset) <= 1e-9 * max(abs(b.iq_offset), 1e-30)
