@@ -184,7 +184,7 @@ def main():
     ap.add_argument('--long-seconds', type=float, default=2.0, help='steady-state run after the timed region (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='diagnostic: no per-kernel HIP events in the timed region')
-    ap.add_argument('--feed', choices=('bcast', 'allgather'), default='bcast', help='many-row workloads: how a block reaches the ranks')
+    ap.add_argument('--feed', choices=('bcast', 'scatter', 'allgather'), default='bcast', help='many-row workloads: how a block reaches the ranks (bcast: ncclBroadcast from rank 0; scatter: from rank 0 as 1/N shards + all-gather; allgather: every rank holds 1/N)')
     ap.add_argument('--no-same-arithmetic', action='store_true', help="skip the fp64 kernel's side figure")
     ap.add_argument('--force-comm', action='store_true', help='diagnostic: the RCCL communicator with a single rank too (barrier / maximum / block exchange path on one GPU)')
     ap.add_argument('--dry-run', action='store_true', help='with --gpus N > 1 and no launcher: print the ranks that would be started')
@@ -267,7 +267,7 @@ def main():
                 dst.copy_(src[(k % 2) * n_samples:(k % 2 + 1) * n_samples], non_blocking=True)
         if s_comm is not None:
             nat.check(lib.sdrt_stream_wait_stream(s_comm, S))        # after the copy above / the kernels still reading dst
-            comm.bcast_device(dst.data_ptr(), block_bytes, 0, s_comm)
+            comm.bcast_device(dst.data_ptr(), block_bytes, 0, s_comm, scatter=args.feed == 'scatter')
 
     run = eng.process_device
 
@@ -401,7 +401,7 @@ def main():
                                     f'center={CENTER} Hz{", --correct-iq" if args.correct_iq else ""}, {n_chunks} chunks x {N} samples per GPU per step, inputs resident in HBM')
                        if single else
                        (f'configs[{3 if code == "h" else 4}]: --simo {rows_total} VFO rows sharded {rows}/GPU, {FS // 1_000_000} MS/s synthetic {"int16" if code == "h" else "float32"} IQ, FM, dec={q}, '
-                        f'{n_chunks} chunks x {N} samples per step ' + ('resident on rank 0, RCCL broadcast per step' if args.feed == 'bcast' else 'resident as 1/N shards per rank, RCCL all-gather per step')),
+                        f'{n_chunks} chunks x {N} samples per step ' + {'bcast': 'resident on rank 0, RCCL broadcast per step', 'scatter': 'resident on rank 0, sent as 1/N shards + RCCL all-gather per step', 'allgather': 'resident as 1/N shards per rank, RCCL all-gather per step'}[args.feed]),
                        'chunks_per_step_per_gpu': n_chunks, 'samples_per_chunk': N, 'rows_per_gpu': rows,
                        'parallelism': f'chunk-sharded x{world}' if single else f'rows-sharded x{world} + {args.feed}',
                        'settle_steps': settle_steps + args.warmup},

@@ -28,7 +28,7 @@ EXPORTS = (
     'sdrt_selftest_mfma', 'sdrt_selftest_mfma_i8', 'sdrt_set_smoothing', 'sdrt_stage_a_kind', 'sdrt_debug_stamps', 'sdrt_demodulate_host',
     'sdrt_stream_create', 'sdrt_stream_destroy', 'sdrt_stream_synchronize', 'sdrt_host_alloc', 'sdrt_host_free',
     'sdrt_memcpy_h2d_async', 'sdrt_memcpy_d2h_async', 'sdrt_stream_wait_stream',
-    'sdrt_comm_unique_id', 'sdrt_comm_init', 'sdrt_comm_bcast', 'sdrt_comm_allgather', 'sdrt_comm_world', 'sdrt_comm_rank',
+    'sdrt_comm_unique_id', 'sdrt_comm_init', 'sdrt_comm_bcast', 'sdrt_comm_bcast_scatter', 'sdrt_comm_allgather', 'sdrt_comm_world', 'sdrt_comm_rank',
     'sdrt_comm_destroy', 'sdrt_submit_host', 'sdrt_wait', 'sdrt_spectrum_host', 'sdrt_stft_host', 'sdrt_iq_range_device',
     'sdrt_event_create', 'sdrt_event_destroy', 'sdrt_event_record', 'sdrt_stream_wait_event', 'sdrt_event_query',
     'sdrt_event_synchronize', 'sdrt_reserve', 'sdrt_taps_release', 'sdrt_mem_info', 'sdrt_alloc_count',
@@ -156,6 +156,7 @@ def lib():
     l.sdrt_comm_unique_id.argtypes = [C.c_void_p]
     l.sdrt_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     l.sdrt_comm_bcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    l.sdrt_comm_bcast_scatter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     l.sdrt_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     l.sdrt_comm_world.argtypes = [C.c_void_p]
     l.sdrt_comm_rank.argtypes = [C.c_void_p]

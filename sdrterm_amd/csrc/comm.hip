@@ -30,6 +30,11 @@ struct Rccl {
     ncclResult_t (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // optional (the scatter + all-gather form of the block broadcast)
+    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
 };
 
 Rccl g_rccl;
@@ -52,6 +57,10 @@ int load_rccl() {
     r.Broadcast = (decltype(r.Broadcast)) dlsym(h, "ncclBroadcast");
     r.AllGather = (decltype(r.AllGather)) dlsym(h, "ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString)) dlsym(h, "ncclGetErrorString");
+    r.Send = (decltype(r.Send)) dlsym(h, "ncclSend");
+    r.Recv = (decltype(r.Recv)) dlsym(h, "ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart)) dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd)) dlsym(h, "ncclGroupEnd");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.AllGather || !r.GetErrorString) {
         dlclose(h);
         return sdrt_set_error(SDRT_EINVAL, "librccl lacks an expected entry point");
@@ -109,6 +118,34 @@ int sdrt_comm_bcast(sdrt_comm *c, void *dev_buf, size_t bytes, int root, void *s
     if (bytes == 0) return SDRT_OK;
     const ncclResult_t e = g_rccl.Broadcast(dev_buf, dev_buf, bytes, kNcclUint8, root, c->comm, (hipStream_t) stream);
     return e == 0 ? SDRT_OK : rccl_fail("ncclBroadcast", e);
+}
+
+// The same result as sdrt_comm_bcast, built for point-to-point links: the root sends every rank ITS 1/world of the block (all of
+// the root's links at once, each carrying one shard), then the ranks all-gather the shards in place (every link of every rank
+// carries one shard).  A ring broadcast moves the whole block over every hop instead.  Needs bytes % world == 0 (a chunked block
+// always divides by the GPU counts of a node); otherwise, and with a single rank, this is sdrt_comm_bcast.
+int sdrt_comm_bcast_scatter(sdrt_comm *c, void *dev_buf, size_t bytes, int root, void *stream) {
+    if (!c || (!dev_buf && bytes) || root < 0 || root >= c->world) return sdrt_set_error(SDRT_EINVAL, "bad argument");
+    if (bytes == 0) return SDRT_OK;
+    if (c->world == 1 || bytes % (size_t) c->world) return sdrt_comm_bcast(c, dev_buf, bytes, root, stream);
+    if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+        return sdrt_set_error(SDRT_EINVAL, "this librccl has no ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+    const size_t shard = bytes / (size_t) c->world;
+    char *buf = (char *) dev_buf;
+    ncclResult_t e = g_rccl.GroupStart();
+    if (e != 0) return rccl_fail("ncclGroupStart", e);
+    if (c->rank == root) {
+        for (int r = 0; r < c->world && e == 0; ++r)
+            if (r != root) e = g_rccl.Send(buf + (size_t) r * shard, shard, kNcclUint8, r, c->comm, (hipStream_t) stream);
+    } else {
+        e = g_rccl.Recv(buf + (size_t) c->rank * shard, shard, kNcclUint8, root, c->comm, (hipStream_t) stream);
+    }
+    const ncclResult_t e2 = g_rccl.GroupEnd();
+    if (e != 0) return rccl_fail("ncclSend / ncclRecv", e);
+    if (e2 != 0) return rccl_fail("ncclGroupEnd", e2);
+    // in place: every rank's shard sits where the gathered block wants it
+    e = g_rccl.AllGather(buf + (size_t) c->rank * shard, buf, shard, kNcclUint8, c->comm, (hipStream_t) stream);
+    return e == 0 ? SDRT_OK : rccl_fail("ncclAllGather", e);
 }
 
 int sdrt_comm_allgather(sdrt_comm *c, const void *send_dev, void *recv_dev, size_t bytes_per_rank, void *stream) {

@@ -240,9 +240,14 @@ class RcclTransport:
                 raise PeerLost('communicator id: rank 0 did not answer')
             time.sleep(0.1)
 
-    def bcast_device(self, dev_ptr: int, nbytes: int, root: int = 0, stream: int = 0) -> None:
-        """In place on device memory, asynchronous on ``stream``."""
-        self._nat.check(self._nat.lib().sdrt_comm_bcast(self._comm, dev_ptr, nbytes, root, stream or None))
+    def bcast_device(self, dev_ptr: int, nbytes: int, root: int = 0, stream: int = 0, scatter: Optional[bool] = None) -> None:
+        """In place on device memory, asynchronous on ``stream``.  ``scatter`` (default: SDRTERM_BCAST=scatter in the environment):
+        the root sends every rank its 1/world of the block and the ranks all-gather the shards -- every xGMI link carries one shard
+        instead of every hop of a ring the whole block (sdrt_comm_bcast_scatter; opt-in: this builder could not time it on N GPUs)."""
+        if scatter is None:
+            scatter = os.environ.get('SDRTERM_BCAST') == 'scatter'
+        fn = self._nat.lib().sdrt_comm_bcast_scatter if scatter else self._nat.lib().sdrt_comm_bcast
+        self._nat.check(fn(self._comm, dev_ptr, nbytes, root, stream or None))
 
     def allgather_device(self, send_ptr: int, recv_ptr: int, bytes_per_rank: int, stream: int = 0) -> None:
         self._nat.check(self._nat.lib().sdrt_comm_allgather(self._comm, send_ptr, recv_ptr, bytes_per_rank, stream or None))
@@ -289,7 +294,7 @@ class RcclTransport:
         if self.rank == root:
             self._stage_host[:nbytes] = np.frombuffer(data, dtype=np.uint8)
             nat.check(nat.lib().sdrt_memcpy_h2d_async(self._stage.ptr, self._stage_host.ctypes.data, nbytes, self._s_comm))
-        self.bcast_device(self._stage.ptr, nbytes, root, self._s_comm)
+        self.bcast_device(self._stage.ptr, nbytes, root, self._s_comm, scatter=False)      # (a header: one small message)
         if self.rank != root:
             nat.check(nat.lib().sdrt_memcpy_d2h_async(self._stage_host.ctypes.data, self._stage.ptr, nbytes, self._s_comm))
         self._finish('header broadcast', None if timeout is None else (timeout or 1e18))

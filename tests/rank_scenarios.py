@@ -6,7 +6,7 @@ import sys
 import numpy as np
 
 
-def simo_rows_over_two_rank_processes():
+def simo_rows_over_rank_processes(gpus=2):
     """VfoProcessor(gpus=2): rank 0 in this process, one helper process, three rows split 2 + 1, each rank serving its own port;
     nine chunks in batches of two (several blocks in flight), every row's stream against oracle/chain.c, in order."""
     import multiprocessing as mp
@@ -22,7 +22,8 @@ def simo_rows_over_two_rank_processes():
     fs, q, n, nch = 1024000, 64, 32768, 9
     raw = prng.raw_bytes('h', n * nch, seed=34, amp=4000)
     port = findPort('127.0.0.1')
-    p = VfoProcessor(fs, vfoHost=f'127.0.0.1:{port}', vfos='-100000,50000', center=15700, dec=q, omegaOut=5000, gpus=2)
+    vfos = '-100000,50000' if gpus == 2 else '-100000,50000,120000,-30000'
+    p = VfoProcessor(fs, vfoHost=f'127.0.0.1:{port}', vfos=vfos, center=15700, dec=q, omegaOut=5000, gpus=gpus)
     p.selectOutputFm()
     p.MAX_BATCH = 2
     buf = queue.Queue()
@@ -32,8 +33,9 @@ def simo_rows_over_two_rank_processes():
     buf.close = lambda: None
     buf.join_thread = lambda: None
     m = n // q
-    box = [None] * 3
-    where = [(port, 0), (port, 1), (port + 1, 2)]          # rank 0: rows 0, 1 in connection order; rank 1: row 2
+    # rank 0: rows 0, 1 in connection order; the other ranks one row each
+    where = [(port, 0), (port, 1)] + [(port + r, r + 1) for r in range(1, gpus)]
+    box = [None] * len(where)
 
     def client(prt, k):
         deadline = time.time() + 120
@@ -65,10 +67,10 @@ def simo_rows_over_two_rank_processes():
     while any(b is None for b in box) and time.time() < deadline:
         time.sleep(0.05)
     assert flag.value == 0, 'a rank raised the halt flag'
-    rows = ref_chain.vfo_rows(15700, '-100000,50000')
+    rows = ref_chain.vfo_rows(15700, vfos)
     exp, _ = c_chain.process_stream(raw, 'h', n, q, 'fm', c_chain.shift_table(rows, fs, n), ref_chain.cheby_sos(q),
                                     ref_chain.ellip_sos(fs // q, 5000), threads=4)
-    for k in range(3):
+    for k in range(len(where)):
         assert box[k] is not None and box[k].size == nch * m, f'row {k}: {None if box[k] is None else box[k].size} samples'
         err = np.abs(box[k].reshape(nch, m) - exp[:, k, :]).max()
         assert err <= 1e-6, f'row {k}: {err:.3e}'
@@ -140,5 +142,5 @@ def a_helper_rank_that_dies():
 
 
 if __name__ == '__main__':
-    {'rows': simo_rows_over_two_rank_processes, 'kill': a_helper_rank_that_dies}[sys.argv[1]]()
+    {'rows': simo_rows_over_rank_processes, 'rows4': lambda: simo_rows_over_rank_processes(4), 'kill': a_helper_rank_that_dies}[sys.argv[1]]()
     print('scenario ok')

@@ -1,5 +1,6 @@
-// TEST INFRASTRUCTURE, not part of the product: a stand-in for the six RCCL entry points sdrterm_amd/csrc/comm.hip binds
-// (ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclBroadcast, ncclAllGather, ncclGetErrorString), for ranks that SHARE
+// TEST INFRASTRUCTURE, not part of the product: a stand-in for the RCCL entry points sdrterm_amd/csrc/comm.hip binds
+// (ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclBroadcast, ncclAllGather, ncclGetErrorString; ncclSend, ncclRecv,
+// ncclGroupStart, ncclGroupEnd for the scatter form of the block broadcast), for ranks that SHARE
 // one GPU.  RCCL refuses two ranks on one device ("Duplicate GPU detected"), and the boxes this build is developed on have one:
 // with SDRTERM_RCCL_LIB pointing here, tests/test_gpu_ranks.py runs bench.py and VfoProcessor with two and three rank
 // processes on that one GPU -- every line of the rank plumbing (unique-id exchange, communicator set-up, block exchange on the
@@ -26,6 +27,7 @@ namespace {
 struct Header {
     std::atomic<unsigned> count, generation;
     std::atomic<int> failed;
+    std::atomic<unsigned long long> p2p_bytes;      // size of the point-to-point message being moved (0: none for this pair)
 };
 constexpr size_t HEADER = 4096;
 }  // namespace
@@ -135,6 +137,62 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, int datat
             if (hipMemcpy((char *) recv + (size_t) r * count + off, c->stage, len, hipMemcpyHostToDevice) != hipSuccess) return fail("stand-in transport: copy failed");
             if (ncclResult_t e = barrier(c)) return e;
         }
+    return 0;
+}
+
+// Point-to-point messages are collected between ncclGroupStart and ncclGroupEnd and moved at ncclGroupEnd: every rank walks over all
+// ordered (sender, receiver) pairs in the same order, the sender announces the size (0: it has nothing for that pair), both sides
+// copy through the staging area.  Every rank of the communicator must reach ncclGroupEnd (comm.hip's scatter does).
+namespace {
+struct P2p { bool send; void *buf; size_t bytes; int peer; ncclComm *comm; hipStream_t stream; };
+thread_local P2p g_ops[64];
+thread_local int g_nops = 0, g_depth = 0;
+
+ncclResult_t run_group() {
+    if (g_nops == 0) return 0;
+    ncclComm *c = g_ops[0].comm;
+    for (int i = 0; i < g_nops; ++i)
+        if (hipStreamSynchronize(g_ops[i].stream) != hipSuccess) return fail("stand-in transport: hipStreamSynchronize failed");
+    for (int src = 0; src < c->world; ++src)
+        for (int dst = 0; dst < c->world; ++dst) {
+            if (src == dst) continue;
+            P2p *mine = nullptr;
+            for (int i = 0; i < g_nops; ++i)
+                if ((c->rank == src && g_ops[i].send && g_ops[i].peer == dst) || (c->rank == dst && !g_ops[i].send && g_ops[i].peer == src)) mine = &g_ops[i];
+            if (c->rank == src) c->h->p2p_bytes.store(mine ? mine->bytes : 0);
+            if (ncclResult_t e = barrier(c)) return e;
+            const size_t total = (size_t) c->h->p2p_bytes.load();
+            if (c->rank == dst && total && (!mine || mine->bytes != total)) { c->h->failed.store(1); return fail("stand-in transport: send without a matching receive"); }
+            for (size_t off = 0; off < total; off += c->stage_bytes) {
+                const size_t len = total - off < c->stage_bytes ? total - off : c->stage_bytes;
+                if (c->rank == src && hipMemcpy(c->stage, (const char *) mine->buf + off, len, hipMemcpyDeviceToHost) != hipSuccess) return fail("stand-in transport: copy failed");
+                if (ncclResult_t e = barrier(c)) return e;
+                if (c->rank == dst && hipMemcpy((char *) mine->buf + off, c->stage, len, hipMemcpyHostToDevice) != hipSuccess) return fail("stand-in transport: copy failed");
+                if (ncclResult_t e = barrier(c)) return e;
+            }
+            if (ncclResult_t e = barrier(c)) return e;      // (the size field is free for the next pair)
+        }
+    g_nops = 0;
+    return 0;
+}
+}  // namespace
+
+ncclResult_t ncclGroupStart() { ++g_depth; return 0; }
+ncclResult_t ncclGroupEnd() {
+    if (--g_depth > 0) return 0;
+    g_depth = 0;
+    const ncclResult_t e = run_group();
+    g_nops = 0;
+    return e;
+}
+ncclResult_t ncclSend(const void *buf, size_t count, int datatype, int peer, ncclComm_t c, hipStream_t stream) {
+    if (datatype != 1 || g_depth == 0 || g_nops == 64) return fail("stand-in transport: bytes, inside a group, at most 64 messages");
+    g_ops[g_nops++] = {true, (void *) buf, count, peer, c, stream};
+    return 0;
+}
+ncclResult_t ncclRecv(void *buf, size_t count, int datatype, int peer, ncclComm_t c, hipStream_t stream) {
+    if (datatype != 1 || g_depth == 0 || g_nops == 64) return fail("stand-in transport: bytes, inside a group, at most 64 messages");
+    g_ops[g_nops++] = {false, buf, count, peer, c, stream};
     return 0;
 }
 

@@ -38,9 +38,11 @@ def _bench(n_ranks, *flags):
 @pytest.mark.parametrize('n_ranks,flags', [(2, ('--workload', 'simo64', '--chunks', '64')),
                                            (3, ('--workload', 'simo64', '--chunks', '48', '--feed', 'allgather')),
                                            (4, ('--workload', 'simo64', '--chunks', '64')),
+                                           (4, ('--workload', 'simo64', '--chunks', '64', '--feed', 'scatter')),
+                                           (3, ('--workload', 'simo64', '--chunks', '64', '--feed', 'scatter')),
                                            (2, ('--workload', 'f32x256', '--chunks', '32')),
                                            (2, ('--workload', 'fm64', '--chunks', '1024'))],
-                         ids=['simo64-bcast-2', 'simo64-allgather-3', 'simo64-bcast-4', 'f32x256-bcast-2', 'fm64-chunks-2'])
+                         ids=['simo64-bcast-2', 'simo64-allgather-3', 'simo64-bcast-4', 'simo64-scatter-4', 'simo64-scatter-3-falls-back', 'f32x256-bcast-2', 'fm64-chunks-2'])
 def test_bench_with_several_ranks_on_one_gpu(n_ranks, flags):
     """bench.py --gpus N without a launcher: N rank processes, rows (or chunks) sharded, one exchange per step; the line rank 0
     prints counts every rank's work and the configuration says how the rows were split."""
@@ -50,7 +52,7 @@ def test_bench_with_several_ranks_on_one_gpu(n_ranks, flags):
     rows_total = {'simo64': 64, 'f32x256': 256, 'fm64': 1}[wl]
     if rows_total > 1:
         assert line['scaling'] == 'strong' and line['config']['rows_per_gpu'] == -(-rows_total // n_ranks)      # rank 0 takes the larger share
-        assert line['config']['parallelism'] == f'rows-sharded x{n_ranks} + ' + ('allgather' if '--feed' in flags else 'bcast')
+        assert line['config']['parallelism'] == f'rows-sharded x{n_ranks} + ' + (flags[flags.index('--feed') + 1] if '--feed' in flags else 'bcast')
         samples = int(flags[3]) * line['config']['samples_per_chunk']
     else:
         assert line['scaling'] == 'weak' and line['config']['parallelism'] == f'chunk-sharded x{n_ranks}'
@@ -59,16 +61,19 @@ def test_bench_with_several_ranks_on_one_gpu(n_ranks, flags):
     assert line['steady_state']['steps'] >= 16 and line['kernels_ms']['chain_kernel'] > 0
 
 
-def _scenario(name, **extra):
-    r = subprocess.run([sys.executable, '-m', 'tests.rank_scenarios', name], env=dict(_env(2), **extra), cwd=REPO, capture_output=True,
+def _scenario(name, n_ranks=2, **extra):
+    r = subprocess.run([sys.executable, '-m', 'tests.rank_scenarios', name], env=dict(_env(n_ranks), **extra), cwd=REPO, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and 'scenario ok' in r.stdout, (r.stdout[-2000:] + r.stderr[-4000:])
 
 
-def test_simo_rows_over_two_rank_processes_on_one_gpu():
-    """VfoProcessor(gpus=2): rank 0 and one helper process, three rows split 2 + 1, each rank serving its own port; nine chunks in
-    batches of two (several blocks in flight), every row's stream against oracle/chain.c, in order (tests/rank_scenarios.py)."""
-    _scenario('rows')
+@pytest.mark.parametrize('name,n_ranks,bcast', [('rows', 2, 'ring'), ('rows', 2, 'scatter'), ('rows4', 4, 'scatter')])
+def test_simo_rows_over_rank_processes_on_one_gpu(name, n_ranks, bcast):
+    """VfoProcessor(gpus=2 / 4): rank 0 and its helper processes, three rows split 2 + 1 (five: 2 + 1 + 1 + 1), each rank serving
+    its own port; nine chunks in batches of two (several blocks in flight), every row's stream against oracle/chain.c, in order
+    (tests/rank_scenarios.py).  The block goes out as one broadcast, or (SDRTERM_BCAST=scatter) as 1/N shards from rank 0 that the
+    ranks all-gather in place (sdrt_comm_bcast_scatter)."""
+    _scenario(name, n_ranks, SDRTERM_BCAST=bcast)
 
 
 def test_bench_under_the_distributed_launcher_on_one_gpu():
