@@ -90,7 +90,14 @@ struct WideLds {        // byte offsets
 // sixteen tiles per chunk, two per wave: the forms in which Q trails K by one TILE PASS instead of one iteration (see the kernel)
 // (the fused IQ form needs the room of a fourth carry buffer beside its offset rows: 8-bit records only, whose packed local tile is
 // three fragments instead of five)
+#ifdef SDRT_NO_SHQ8      // (A/B builds: eight outputs per column on the round-2 form)
 __host__ __device__ constexpr bool wide_shq(int nout, int ntc, int iq, int nsl) { return ntc == 16 && nout == 4 && (iq <= 1 || nsl == 1); }
+#else
+__host__ __device__ constexpr bool wide_shq(int nout, int ntc, int iq, int nsl) { return ntc == 16 && ((nout == 4 && (iq <= 1 || nsl == 1)) || (nout == 8 && iq == 0)); }
+#endif
+// eight outputs per column: the fourth buffer only fits beside the larger output tables if the column phasors are kept as two
+// factors (tile, column in tile: 32 entries instead of 256, one complex product more per use) and the IQ-only areas are left out
+__host__ __device__ constexpr bool wide_psf(int nout, int ntc, int iq) { return wide_shq(nout, ntc, iq, 1) && nout == 8; }
 __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int ntc, int nsl) {
     WideLds l;
     int p = 0;
@@ -104,14 +111,15 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int
     l.tpw = p; p += (SDRT_WIDE_MAXTILES + 1) * 4 * 16;
     l.tailF = p; p += 16 * 16;
     l.tailFc = p; p += 16 * 16;
-    l.psi = p; p += nt * SDRT_TB * 16;              // column phasors of the row
-    l.gv = p; p += 48 * 16;                         // IQ: rank-one vectors {g_re, g_im} per matrix row
-    l.pq = p; p += 16 * 2 * 16;                     // IQ: offset terms of the edge operators
+    const bool psf = wide_psf(nout, ntc, iq);
+    l.psi = p; p += (psf ? nt + SDRT_TB : nt * SDRT_TB) * 16;      // column phasors of the row (psf: per tile, then per column in a tile)
+    l.gv = p; p += psf ? 0 : 48 * 16;               // IQ, float32: rank-one vectors {g_re, g_im} per matrix row
+    l.pq = p; p += psf ? 0 : 16 * 2 * 16;           // IQ: offset terms of the edge operators
     l.cpow = p; p += iq == 1 ? nt * SDRT_TB * 8 : 0;       // IQ from prefix tables: (1-lambda)^(column start)
     l.wiq = p; p += iq == 2 ? (SDRT_WIDE_LC / 32) * 1024 : 0;     // IQ fused: offset rows, one packed fragment per k-step (sdrt_build_i8_offset_rows)
     l.buf = p;
     const int seg = nt / ntc, slots = seg * (ntc + 1);          // carry slots: ntc + 1 per chunk of the item
-    l.buf_stride = (2 * slots * 8 + 16 * seg + nt + 1) * 16;
+    l.buf_stride = (2 * slots * 8 + 16 * seg + (psf ? 0 : nt + 1)) * 16;
     p += (wide_shq(nout, ntc, iq, nsl) ? 4 : 3) * l.buf_stride;
     l.total = p;
     return l;
@@ -156,6 +164,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     // become four (Q of item it writes into its buffer while P3 of item it-3 still reads the one three back).
     constexpr bool SHQ = wide_shq(NOUT, NTC, IQ, W8Enc<DT>::slices) && !RS;
     constexpr int NBUF = SHQ ? 4 : 3;
+    constexpr bool PSF = wide_psf(NOUT, NTC, IQ);
     // the sixteen-tile forms with --correct-iq are the shortest of registers: what they keep out of the loop-invariant lane values
     // (LDS and output addresses the allocator would spill, each reload a vmcnt(0) drain): the wave number from scalar registers,
     // the lane number read where an address needs it
@@ -308,6 +317,10 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             if constexpr (IQT) for (int i = tid; i < NT * SDRT_TB; i += 512) cpowL[i] = a.iq_pow[i * cgs];
             if constexpr (IQF) for (int i = tid; i < KS * 64; i += 512) ((v4i *) (smem + lo.wiq))[i] = ((const v4i *) a.w8iq)[i];
         }
+        if constexpr (PSF) {
+            // phasor of column c = 16 t + nb as the product of the table's entries 16 t and nb
+            if (tid < NT + SDRT_TB) psiL[tid] = nco ? nco_blk_g[tid < NT ? SDRT_TB * tid : tid - NT] : mk(1.0, 0.0);
+        } else
         for (int i = tid; i < NT * SDRT_TB; i += 512) psiL[i] = nco ? nco_blk_g[i % (NTC * SDRT_TB)] : mk(1.0, 0.0);      // the phase restarts with every chunk
         const cd *ybias = (const cd *) a.ybias + (size_t) row * m;      // always present for this kernel (zeros if there is no offset)
         __syncthreads();
@@ -537,6 +550,14 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
 
             // ---- the pieces of Q(it-1), P3(it-3) and E(it) that run after matrix-instruction group i of tile slot j ------------
             constexpr int P3_0 = 12 + 3 * OPL;       // first P3 piece; the E piece comes after the last one
+            auto col_phasor = [&](int t) -> cd {
+                if constexpr (PSF) {
+                    const cd pa = psiL[t], pb = psiL[NT + nb];
+                    return mk(fma(pa.re, pb.re, -(pa.im * pb.im)), fma(pa.re, pb.im, pa.im * pb.re));
+                } else {
+                    return psiL[t * SDRT_TB + nb];
+                }
+            };
             auto lane_id = [&]() -> int {
                 if constexpr (OPQ) {
                     int l;
@@ -584,7 +605,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                             }
                         }
                     } else if constexpr (i == 1 && !RS) {
-                        const cd ps = psiL[tileq * SDRT_TB + nb];      // the column's common phasor multiplies the complex DATA
+                        const cd ps = col_phasor(tileq);               // the column's common phasor multiplies the complex DATA
                         // (explicit fma everywhere in the pieces: they exist in two compiled copies, steady state and drain,
                         // and both must round identically -- an item's bits must not depend on the batch it arrived in)
                         cd t;
@@ -595,7 +616,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         dA[jq][1] = mk(fma(ps.im, dA[jq][0].re, ps.re * dA[jq][1].re), fma(ps.im, dA[jq][0].im, ps.re * dA[jq][1].im));
                         dA[jq][0] = t;
                     } else if constexpr (i == 2 && !RS) {
-                        const cd ps = psiL[tileq * SDRT_TB + nb];
+                        const cd ps = col_phasor(tileq);
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const double t2 = fma(ps.re, dl[jq][2 * h], -(ps.im * dl[jq][2 * h + 1]));

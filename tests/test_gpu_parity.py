@@ -454,11 +454,12 @@ def test_float32_rows_sliced_once_per_chunk_give_the_same_bits(big_endian, nch, 
         assert np.abs(outs['1'].reshape(5, nch, n // q).transpose(1, 0, 2) - exp).max() <= 1e-6
 
 
-@pytest.mark.parametrize('code,rows,iq,fused', [('B', 1, False, None), ('b', 2, False, None), ('B', 1, True, '1'), ('b', 1, True, '0'),
-                                                ('B', 2, True, None), ('h', 1, False, None)])
-def test_sixteen_tiles_per_chunk_on_the_wide_kernel(code, rows, iq, fused, monkeypatch):
+@pytest.mark.parametrize('code,rows,iq,fused,q', [('B', 1, False, None, 64), ('b', 2, False, None, 64), ('B', 1, True, '1', 64), ('b', 1, True, '0', 64),
+                                                  ('B', 2, True, None, 64), ('h', 1, False, None, 64), ('B', 2, False, None, 32), ('b', 2, True, None, 32)])
+def test_sixteen_tiles_per_chunk_on_the_wide_kernel(code, rows, iq, fused, q, monkeypatch):
     """Chunks of sixteen tiles (8-bit records; 16-bit records in 65536-sample chunks): two tiles per wave, the column phase of a
-    tile running in the pass after its matrix phase (kernels_i8w.hip, SHQ), with and without --correct-iq in both of its forms.
+    tile running in the pass after its matrix phase (kernels_i8w.hip, SHQ), with and without --correct-iq in both of its forms,
+    four and eight outputs per column (decimation 64 / 32).
     Five chunks against oracle/chain.c, offsets carried; then enough chunks that every workgroup reaches the steady state of its
     pipeline (more than four items each) against the independently written one-block-per-column kernel."""
     from sdrterm_amd.engine import Engine
@@ -467,7 +468,7 @@ def test_sixteen_tiles_per_chunk_on_the_wide_kernel(code, rows, iq, fused, monke
     monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
     if fused is not None:
         monkeypatch.setenv('SDRTERM_IQ_FUSED', fused)
-    fs, q, n = 1024000, 64, 65536
+    fs, n = 1024000, 65536
     freqs = [15700.0, -203300.0][:rows]
     amp = 100 if code in 'bB' else 3000
     kw = dict(n_samples=n, row_freqs=freqs, apply_shift=True, omega_out=5000, correct_iq=iq)
