@@ -110,6 +110,7 @@ struct sdrt_ctx {
     int *d_rows_of[2] = {nullptr, nullptr};      // [SDRT_FM], [SDRT_AM]
     int n_rows_of[2] = {0, 0};
     int sched = 0;                    // diagnostic builds only (SDRTERM_SCHED, kernels_i8w.hip: SDRT_SCHED_EXP)
+    int dual = 0;                     // wide kernel: one wave per SIMD on two tiles at once (SDRTERM_WIDE_DUAL)
     signed char *d_w8 = nullptr, *d_w8mid = nullptr;
     DecimTables *d_tab8 = nullptr;    // tables for columns of SDRT_I8T_G blocks
     double *d_nco_tile8 = nullptr, *d_nco_phase8 = nullptr;
@@ -611,6 +612,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->n_cus = cus;
         if (const char *e = getenv("SDRTERM_SCHED")) c->sched = atoi(e);
+        if (const char *e = getenv("SDRTERM_WIDE_DUAL")) c->dual = atoi(e);
         if (const char *e = getenv("SDRTERM_WIDE_CUS")) { const int v = atoi(e); if (v >= 8 && v <= c->n_cus) c->n_cus = v / 8 * 8; }   // diagnostics: fewer persistent workgroups
         // int8 matrix-core forms in order of preference; a form that cannot represent this configuration (unequal
         // power-of-two scales between rows, a digit overflow) releases what it uploaded and the next one is tried; the
@@ -875,6 +877,7 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
     da.raw_orig = nullptr;
     da.f32_exp = nullptr;
     da.sched = c->sched;
+    da.dual = c->dual;
     if (c->use_i8) {
         da.tab = c->d_tab8;
         da.n_tiles = c->n_tiles8;

@@ -51,6 +51,7 @@ struct DecimArgs {
     const void *raw_orig;       //   float32, pre-sliced input (f32_exp != NULL): the records themselves, for the edge operators
     const int *f32_exp;         //   float32, pre-sliced input: [chunk][4] tile exponents; raw then holds the slices (launch_f32_preslice)
     int sched;                  //   diagnostic builds only (-DSDRT_SCHED_EXP): wave priority assignment, SDRTERM_SCHED
+    int dual;                   //   chain_i8w_kernel: one wave per SIMD on two tiles at once (DUAL form)
     int rs;                     //   real-stream form (no shift, no IQ correction): w8 / w8mid hold sdrt_build_i8_weights_wide_rs planes
 };
 

@@ -137,8 +137,13 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int
 // PRE (float32, many rows): the records arrive sliced already (f32_preslice_kernel: same bytes per lane and k-step, the four
 // slices in place of the sixteen floats; tile exponents in a.f32_exp) -- every row of a chunk used to slice the same samples
 // again, the larger part of this form's vector work.  The edge operators read the records themselves (a.raw_orig).
-template <int DT, int NOUT, int NTC, int S, int IQ, bool RS, bool PRE = false>
-__global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
+// DUAL: ONE wave per SIMD (256 threads) working on two tiles at once -- every digit-plane fragment is read from LDS once and feeds
+// two matrix instructions (the fragment reads are a quarter of the kernel's energy at one read per instruction:
+// tools/ubench/coexec.hip, modes 10-12), the vector work of both tiles interleaved with them in the one wave's instruction stream.
+template <int DT, int NOUT, int NTC, int S, int IQ, bool RS, bool PRE = false, bool DUAL = false>
+__global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kernel(DecimArgs a) {
+    constexpr int WV = DUAL ? 4 : 8, NTHR = 64 * WV;           // waves, threads per workgroup
+    static_assert(!DUAL || (NTC == 8 && IQ == 0 && !RS && DT != SDRT_F32 && !PRE), "two tiles at once: the plain eight-tile form");
     constexpr int NT = NTC < 8 ? 8 : NTC, SEG = NT / NTC, SLOTS = SEG * (NTC + 1);
     static_assert(SEG == 1 || (IQ == 0 && !RS), "two chunks per item: plain form only");
     static_assert(!(RS && IQ != 0), "the real-stream form has no IQ correction");
@@ -154,7 +159,8 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
     constexpr int ITEM = Enc<DT>::size;
     constexpr int NR = 2 * NOUT;                     // rows of the local tile
     constexpr int OPL = NOUT / 4;                    // outputs a lane finishes per tile
-    constexpr int TPW = NT / 8;                      // tiles per wave and item
+    constexpr int TPW = NT / WV;                     // tiles per wave and item
+    constexpr int TP = DUAL ? TPW : 1;               // tiles a pass of the matrix phase works on at once
     // Two tiles per wave (8-bit records: a chunk is sixteen tiles).  With Q(it-1) of both tiles inside iteration it, the states K
     // leaves behind (dC, dA, dl: 24 registers per tile) wait half an iteration for their turn, and with the second set of them
     // the steady-state loop carried 40-80 scratch accesses and 20-45 full vmcnt(0) waits.  SHQ: Q trails K by one tile PASS -- the
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
 
     // ---- tables that do not depend on the row -> LDS ------------------------------------------------------------------
     // stored in the order P3 reads them, [e][mode][lane]: lane (g, nb) finishes output b = g + 4e of column nb, pos = nb*NOUT + b
-    for (int i = tid; i < OPL * 4 * 64; i += 512) {
+    for (int i = tid; i < OPL * 4 * 64; i += NTHR) {
         const int l = i & 63, md = (i >> 6) & 3, e = i >> 8, pos = (l & 15) * NOUT + (l >> 4) + 4 * e;
         cFL[i] = mk(wt->cF2[pos][md][0], wt->cF2[pos][md][1]);
         cGL[i] = mk(wt->cG2[pos][md][0], wt->cG2[pos][md][1]);
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             constexpr int MT = RS ? 1 : 2, LR = RS ? NOUT : NR;       // aggregate tiles, rows of the compact local planes
             const v4i *wg = (const v4i *) (a.w8 + (size_t) row * (size_t) (MT * S * KS * 1024));
             v4i *dst = (v4i *) (smem + lo.wmain);
-            for (int i = tid; i < MT * S * KS * 64; i += 512) dst[i] = wg[i];
+            for (int i = tid; i < MT * S * KS * 64; i += NTHR) dst[i] = wg[i];
             const v4i *wl = (const v4i *) (a.w8mid + (size_t) row * (size_t) (S * KS * 4 * LR * 16));
             v4i *dl = (v4i *) (smem + lo.wloc);
             // global layout is compact ([digit][kstep][kg][rows]); in LDS every (fragment, kstep, kg) group has 16 rows
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                 // NOUT rows (row b, the same for both streams): PPF = 16 / NOUT digit planes per fragment, row group rg holds
                 // plane base + rg; fragments f < NHF (high / only slice): base = f PPF, the others (low slice): 1 + (f - NHF) PPF.
                 // Accumulator a = fragment a (+ fragment NHF + a): row group rg at level a PPF + rg (+1).
-                for (int i = tid; i < NLF * KS * 64; i += 512) {
+                for (int i = tid; i < NLF * KS * 64; i += NTHR) {
                     const int f = i / (KS * 64), s_ = (i / 64) % KS, ln = i & 63, kg = ln >> 4, rowp = ln & 15;
                     const int d = (f < NHF ? f * PPF : 1 + (f - NHF) * PPF) + rowp / NOUT;
                     dl[i] = d < S ? wl[((d * KS + s_) * 4 + kg) * LR + rowp % NOUT] : (v4i) {0, 0, 0, 0};
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                 // 0..2 = planes (0|1), (2|3), (4|-) for the high slice (16-bit) or the only slice (8-bit); 3, 4 = planes
                 // (1|2), (3|4) for the low slice.  Accumulator a = fragment a (+ fragment 3+a): rows 0-7 hold level 2a(+1),
                 // rows 8-15 the level above it.
-                for (int i = tid; i < NLF * KS * 64; i += 512) {
+                for (int i = tid; i < NLF * KS * 64; i += NTHR) {
                     const int f = i / (KS * 64), s_ = (i / 64) % KS, ln = i & 63, kg = ln >> 4, row = ln & 15;
                     const int lo_pl = f < 3 ? 2 * f : 2 * (f - 3) + 1;
                     const int d = row < 8 ? lo_pl : lo_pl + 1;
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             } else {
                 // 16 local rows, placed so that the matrix result lands in the lane that finishes the output: output
                 // b = g + 4e, stream st <-> row 4g + 2e + st (lane g holds rows 4g .. 4g+3)
-                for (int i = tid; i < S * KS * 64; i += 512) {
+                for (int i = tid; i < S * KS * 64; i += NTHR) {
                     const int pr = i & 15, b = (pr >> 2) + 4 * ((pr >> 1) & 1), st = pr & 1;
                     dl[i] = b < NOUT ? wl[(i >> 4) * NR + 2 * b + st] : (v4i) {0, 0, 0, 0};
                 }
@@ -310,35 +316,45 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         // coefficients of this thread's sample in its edge operator (NCO phasor and IQ correction of the window folded in)
         const cd *e_ab = (const cd *) a.edge_ab + (((size_t) row * 16 + e_o16) * 32 + e_l) * 2;
         cd e_A = e_ab[0], e_B = e_ab[1];             // float32 (registers are short) reloads them in every iteration instead
+        // DUAL: 256 threads for 16 outputs x 32 samples: this thread's second pair, the tail output 8 + (tid >> 5)
+        const cd *e_ab2 = e_ab + (DUAL ? 8 * 32 * 2 : 0);
+        const cd e_A2 = DUAL ? e_ab2[0] : mk(0.0, 0.0), e_B2 = DUAL ? e_ab2[1] : mk(0.0, 0.0);
         if constexpr (F32) { if (tid < 48) gvL[tid] = ((const cd *) a.gvec)[(size_t) row * 48 + tid]; }
         if constexpr (IQA) {
             if (tid < 48) gvL[tid] = ((const cd *) a.gvec)[(size_t) row * 48 + tid];
             if (tid >= 64 && tid < 96) pqL[tid - 64] = ((const cd *) a.edge_pq)[(size_t) row * 32 + (tid - 64)];
-            if constexpr (IQT) for (int i = tid; i < NT * SDRT_TB; i += 512) cpowL[i] = a.iq_pow[i * cgs];
-            if constexpr (IQF) for (int i = tid; i < KS * 64; i += 512) ((v4i *) (smem + lo.wiq))[i] = ((const v4i *) a.w8iq)[i];
+            if constexpr (IQT) for (int i = tid; i < NT * SDRT_TB; i += NTHR) cpowL[i] = a.iq_pow[i * cgs];
+            if constexpr (IQF) for (int i = tid; i < KS * 64; i += NTHR) ((v4i *) (smem + lo.wiq))[i] = ((const v4i *) a.w8iq)[i];
         }
         if constexpr (PSF) {
             // phasor of column c = 16 t + nb as the product of the table's entries 16 t and nb
             if (tid < NT + SDRT_TB) psiL[tid] = nco ? nco_blk_g[tid < NT ? SDRT_TB * tid : tid - NT] : mk(1.0, 0.0);
         } else
-        for (int i = tid; i < NT * SDRT_TB; i += 512) psiL[i] = nco ? nco_blk_g[i % (NTC * SDRT_TB)] : mk(1.0, 0.0);      // the phase restarts with every chunk
+        for (int i = tid; i < NT * SDRT_TB; i += NTHR) psiL[i] = nco ? nco_blk_g[i % (NTC * SDRT_TB)] : mk(1.0, 0.0);      // the phase restarts with every chunk
         const cd *ybias = (const cd *) a.ybias + (size_t) row * m;      // always present for this kernel (zeros if there is no offset)
         __syncthreads();
 
         uint32_t raw[NSLOT][WPK];
+        uint32_t raw2[DUAL ? NSLOT : 1][DUAL ? WPK : 1];      // DUAL: the ring of the wave's second tile
         int e_cur[TPW];                              // float32: exponent K slices this wave's tile against (before K: the guess)
 #pragma unroll
         for (int j = 0; j < TPW; ++j) e_cur[j] = 0;
         auto issue = [&](const unsigned char *chunk_raw, auto sc) {
             // k-step st (0 .. NSTEP-1) of the item: tile wave + 8 (st / KS), k-step st % KS
             constexpr int st = decltype(sc)::value;
+            if constexpr (DUAL) {
+                // both tiles are in the same k-step at the same time: a ring per tile
+                const unsigned char *p = chunk_raw + ((size_t) (wave + WV * (st / KS)) * TILE + (size_t) (st % KS) * SPK) * 2 * ITEM + lane_off;
+                if constexpr (st / KS == 0) load_words<WPK * 4, SDRT_RAW_NT != 0>(p, raw[(st % KS) % NSLOT]);
+                else load_words<WPK * 4, SDRT_RAW_NT != 0>(p, raw2[(st % KS) % NSLOT]);
+            } else
             if constexpr (SHQ) {
                 // a scalar base and a 32-bit lane offset (as one 64-bit value per lane the address is a loop invariant the register
                 // allocator spills; its reload waits with vmcnt(0))
-                const unsigned char *p = chunk_raw + ((size_t) (wave_s + 8 * (st / KS)) * TILE + (size_t) (st % KS) * SPK) * 2 * ITEM;
+                const unsigned char *p = chunk_raw + ((size_t) (wave_s + WV * (st / KS)) * TILE + (size_t) (st % KS) * SPK) * 2 * ITEM;
                 load_words<WPK * 4, SDRT_RAW_NT != 0>(p + (unsigned) lane_off, raw[st % NSLOT]);
             } else {
-            const unsigned char *p = chunk_raw + ((size_t) (wave + 8 * (st / KS)) * TILE + (size_t) (st % KS) * SPK) * 2 * ITEM + lane_off;
+            const unsigned char *p = chunk_raw + ((size_t) (wave + WV * (st / KS)) * TILE + (size_t) (st % KS) * SPK) * 2 * ITEM + lane_off;
             load_words<WPK * 4, SDRT_RAW_NT != 0>(p, raw[st % NSLOT]);
             }
         };
@@ -362,6 +378,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         {
             const unsigned char *c0 = (const unsigned char *) a.raw + (size_t) chunk_of(0) * chunk_bytes;
             static_for<0, PF>([&](auto sc) { issue(c0, sc); });
+            if constexpr (DUAL) static_for<0, PF>([&](auto sc) { issue(c0, std::integral_constant<int, KS + decltype(sc)::value>{}); });
         }
         // Software pipeline over the items k = 0 .. cnt-1 of this workgroup; in iteration `it`:
         //   K(it)     matrix-core phase of item it (all waves; wave w <-> tiles w, w+8): int32 sums -> fp64 column aggregates,
@@ -382,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
         cd pv[TPW][OPL];                             // P3 accumulators
         double ccon[TPW];                            // float32: the constant the slices leave out, in the tile's scale (item of the last K)
         cd oex[TPW];                                 // IQ: offset at this lane's column relative to its tile's start (item of the last K)
-        double part[4][2];
+        double part[DUAL ? 2 : 1][4][2];             // (DUAL: the pieces of both tiles alternate, each tile keeps its own)
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
 #pragma unroll
@@ -402,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) dli[j][v] = 0.0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) part[b][0] = part[b][1] = 0.0;
+        for (int b = 0; b < 4; ++b) part[0][b][0] = part[0][b][1] = part[DUAL ? 1 : 0][b][0] = part[DUAL ? 1 : 0][b][1] = 0.0;
 
         int bcur = 0;                                // it % NBUF
         // One iteration; HAVE_K = there is an item whose matrix-core phase runs now (false only in the three drain iterations).
@@ -433,7 +450,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             if constexpr (F32) { e_A = e_ab[0]; e_B = e_ab[1]; }
             if constexpr (PRE && HAVE_K) {
 #pragma unroll
-                for (int j = 0; j < TPW; ++j) e_cur[j] = a.f32_exp[(size_t) chunk_of(it) * NT + wave + 8 * j];
+                for (int j = 0; j < TPW; ++j) e_cur[j] = a.f32_exp[(size_t) chunk_of(it) * NT + wave + WV * j];
             }
             raw_t e_re[SEG], e_im[SEG];              // raw edge sample of E(it) per chunk of the item (lanes beyond the pad read sample 27, weight 0)
 #pragma unroll
@@ -448,13 +465,19 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     e_im[sg] = rp[1];
                 }
             }
+            raw_t e_re2 = 0, e_im2 = 0;              // DUAL: sample e_l of the tail window
+            if constexpr (DUAL && HAVE_K) {
+                const raw_t *rp = (const raw_t *) (edge_raw + (unsigned) (2 * (n - 32 + e_l)) * (unsigned) sizeof(raw_t));
+                e_re2 = rp[0];
+                e_im2 = rp[1];
+            }
             cd yb[TPW][OPL];
 #pragma unroll
             for (int j = 0; j < TPW; ++j)
 #pragma unroll
                 for (int e = 0; e < OPL; ++e) {
                     if constexpr (IQA || F32) yb[j][e] = mk(0.0, 0.0);          // no constant response: the offset term carries it
-                    else yb[j][e] = ybias[(((wave + 8 * j) % NTC) * SDRT_TB + nb) * NOUT + g + 4 * e];
+                    else yb[j][e] = ybias[(((wave + WV * j) % NTC) * SDRT_TB + nb) * NOUT + g + 4 * e];
                 }
             cd off_head = mk(0.0, 0.0), off_tail = mk(0.0, 0.0), off_q = mk(0.0, 0.0), gq[TPW];
 #pragma unroll
@@ -478,7 +501,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                 // (SHQ: tile slot 1 is tile 1 of item it-1, tile slot 0 is tile 0 of item it)
 #pragma unroll
                 for (int j = 0; j < TPW; ++j)
-                    gq[j] = ((const cd *) a.iq_group_off)[(size_t) (SHQ && j == 0 ? ck : cq) * ngrp + (size_t) ((wave + 8 * j) * SDRT_TB + nb) * cgs];
+                    gq[j] = ((const cd *) a.iq_group_off)[(size_t) (SHQ && j == 0 ? ck : cq) * ngrp + (size_t) ((wave + WV * j) * SDRT_TB + nb) * cgs];
             }
             if constexpr (IQF) {
                 // Offsets of item it-1, relative to a zero offset at the start of its chunk (the chunk's true starting offset
@@ -490,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
 #pragma unroll
                     for (int j = SHQ ? 1 : 0; j < TPW; ++j) {
                         cd ts = mk(0.0, 0.0);
-                        for (int t2 = 0; t2 < wave_s + 8 * j; ++t2) ts = mk(fma(iq_m16, ts.re, ot[t2].re), fma(iq_m16, ts.im, ot[t2].im));    // (a scalar trip count)
+                        for (int t2 = 0; t2 < wave_s + WV * j; ++t2) ts = mk(fma(iq_m16, ts.re, ot[t2].re), fma(iq_m16, ts.im, ot[t2].im));    // (a scalar trip count)
                         gq[j] = mk(fma(iq_mnb, ts.re, oex[j].re), fma(iq_mnb, ts.im, oex[j].im));
                     }
                     if (wave_s == 0) {
@@ -570,10 +593,11 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
             auto piece = [&](auto jc, auto ic) {
                 constexpr int j = decltype(jc)::value, i = decltype(ic)::value;
                 const int wv = OPQ ? wave_s : wave;
-                const int tile = wv + 8 * j;
+                constexpr int pj = DUAL ? j : 0;
+                const int tile = wv + WV * j;
                 // what Q works on in this pass: tile j of item it-1, or (SHQ) the tile the previous pass finished
                 constexpr int jq = SHQ ? (j ^ 1) : j;
-                const int tileq = wv + 8 * jq, bQq = SHQ && j == 1 ? bcur : bQ;
+                const int tileq = wv + WV * jq, bQq = SHQ && j == 1 ? bcur : bQ;
                 const bool have_qq = SHQ && j == 1 ? HAVE_K : have_q;
                 if (have_qq) {
                     if constexpr ((IQA || F32) && i == 0) {
@@ -654,29 +678,29 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                             for (int bb = 2 * sub; bb < 2 * sub + 2; ++bb) {
                                 const int b = 4 * e + bb;
                                 const cd bc = bpL[b * 4 + g], ba = bpL[(NOUT - b) * 4 + g];
-                                part[bb][0] = fma(bc.re, dC[jq][0].re, fma(-bc.im, dC[jq][0].im, fma(ba.re, dA[jq][0].re, -(ba.im * dA[jq][0].im))));
-                                part[bb][1] = fma(bc.re, dC[jq][1].re, fma(-bc.im, dC[jq][1].im, fma(ba.re, dA[jq][1].re, -(ba.im * dA[jq][1].im))));
+                                part[pj][bb][0] = fma(bc.re, dC[jq][0].re, fma(-bc.im, dC[jq][0].im, fma(ba.re, dA[jq][0].re, -(ba.im * dA[jq][0].im))));
+                                part[pj][bb][1] = fma(bc.re, dC[jq][1].re, fma(-bc.im, dC[jq][1].im, fma(ba.re, dA[jq][1].re, -(ba.im * dA[jq][1].im))));
                                 if constexpr (PACK) {
                                     // the column-local part: lanes g and g + 2 hold its lower and higher levels for outputs
                                     // 2 (g & 1), 2 (g & 1) + 1; the sum over the mode lanes below adds them up
                                     const double mine = ((g & 1) == (b >> 1)) ? 1.0 : 0.0;
-                                    part[bb][0] = fma(mine, dl[jq][2 * (b & 1)], part[bb][0]);
-                                    part[bb][1] = fma(mine, dl[jq][2 * (b & 1) + 1], part[bb][1]);
+                                    part[pj][bb][0] = fma(mine, dl[jq][2 * (b & 1)], part[pj][bb][0]);
+                                    part[pj][bb][1] = fma(mine, dl[jq][2 * (b & 1) + 1], part[pj][bb][1]);
                                 } else if constexpr (RS && NOUT == 4) {
                                     // every lane holds one level group of all four outputs (dl: real stream, dli: imaginary)
-                                    part[bb][0] += dl[jq][bb];
-                                    part[bb][1] += dli[jq][bb];
+                                    part[pj][bb][0] += dl[jq][bb];
+                                    part[pj][bb][1] += dli[jq][bb];
                                 } else if constexpr (RS) {
                                     // lanes g hold outputs 4 (g & 1) .. + 3, level groups g >> 1
                                     const double mine = ((g & 1) == e) ? 1.0 : 0.0;
-                                    part[bb][0] = fma(mine, dl[jq][bb], part[bb][0]);
-                                    part[bb][1] = fma(mine, dli[jq][bb], part[bb][1]);
+                                    part[pj][bb][0] = fma(mine, dl[jq][bb], part[pj][bb][0]);
+                                    part[pj][bb][1] = fma(mine, dli[jq][bb], part[pj][bb][1]);
                                 }
                             }
                         } else {
                             // sum over the four modes (lanes 16 apart) as a reduce-scatter: lane g ends up with output g + 4e
-                            const double r0 = swap32_add(part[0][0], part[2][0]), i0 = swap32_add(part[0][1], part[2][1]);
-                            const double r1 = swap32_add(part[1][0], part[3][0]), i1 = swap32_add(part[1][1], part[3][1]);
+                            const double r0 = swap32_add(part[pj][0][0], part[pj][2][0]), i0 = swap32_add(part[pj][0][1], part[pj][2][1]);
+                            const double r1 = swap32_add(part[pj][1][0], part[pj][3][0]), i1 = swap32_add(part[pj][1][1], part[pj][3][1]);
                             if constexpr (PACK || RS) ynew[jq][e] = mk(swap16_add(r0, r1), swap16_add(i0, i1));
                             // ... plus the column-local part, which the matrix cores left in this very lane
                             else ynew[jq][e] = mk(swap16_add(r0, r1) + dl[jq][2 * e], swap16_add(i0, i1) + dl[jq][2 * e + 1]);
@@ -780,13 +804,27 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                         dst[(t2 >> 4) & 1] = tot;
                     }
                     }
+                    if constexpr (DUAL) {
+                        // the tail outputs (with eight waves the threads 256 .. 511 have them)
+                        const double xr = decode<DT>(e_re2, swap) - e_off_re, xi = decode<DT>(e_im2, swap) - e_off_im;
+                        cd f = mk(fma(e_A2.re, xr, e_B2.re * xi), fma(e_A2.im, xr, e_B2.im * xi));
+                        f = cadd(f, dpp_row<0x111>(f));
+                        f = cadd(f, dpp_row<0x112>(f));
+                        f = cadd(f, dpp_row<0x114>(f));
+                        f = cadd(f, dpp_row<0x118>(f));
+                        const double tot = swap16_add(f.re, f.im);
+                        if (nb == 15) {
+                            double *dst = (double *) (GuL(bcur) + e_o16);
+                            dst[g & 1] = tot;
+                        }
+                    }
                 }
             };
 
             // ---- K(it) with the pieces in between ----------------------------------------------------------------------------
             const bool more = it + 1 < cnt;
             const unsigned char *next_raw = (const unsigned char *) a.raw + (size_t) chunk_of(more ? it + 1 : it) * chunk_bytes;
-            static_for<0, TPW>([&](auto jc) {
+            static_for<0, TPW / TP>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 if constexpr (SHQ && IQF && j == 1) {
                     // Q of tile `wave` of item it comes next: its offset at the tile start chains the totals of the tiles before it,
@@ -798,7 +836,95 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                     for (int t2 = 0; t2 < wave_s; ++t2) ts = mk(fma(iq_m16, ts.re, ot[t2].re), fma(iq_m16, ts.im, ot[t2].im));
                     gq[0] = mk(fma(iq_mnb, ts.re, oex[0].re), fma(iq_mnb, ts.im, oex[0].im));
                 }
-                if constexpr (RS) {
+                if constexpr (DUAL) {
+                    // two tiles (slots 0 and 1) through the matrix phase together: a digit-plane fragment is fetched once and multiplies
+                    // the slices of both; the pieces of both tiles follow every group
+                    static_assert(NSL == 2, "16-bit records");
+                    v4i acc[2][3][S];
+                    v4i F[S];
+                    auto frag = [&](auto ic, auto dc) -> v4i {
+                        constexpr int i = decltype(ic)::value, d = decltype(dc)::value, s = i / 3, rt = i % 3;
+                        if constexpr (rt < 2) return wmainL[((rt * S + d) * KS + s) * 64 + lane];
+                        else return wlocL[(d * KS + s) * 64 + lane];
+                    };
+                    v4i blo[2], bhi[2];
+                    if constexpr (HAVE_K) static_for<0, S>([&](auto dc) { F[decltype(dc)::value] = frag(std::integral_constant<int, 0>{}, dc); });
+                    static_for<0, KS * 3>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, s = i / 3, rt = i % 3;
+                        if constexpr (HAVE_K) {
+                            if constexpr (rt == 0) {
+                                const unsigned sel_lo = swap ? 0x07050301u : 0x06040200u, sel_hi = swap ? 0x06040200u : 0x07050301u;
+                                static_for<0, 2>([&](auto tc) {
+                                    constexpr int t = decltype(tc)::value;
+                                    const uint32_t *cur = t == 0 ? raw[s % NSLOT] : raw2[s % NSLOT];
+#pragma unroll
+                                    for (int w = 0; w < 4; ++w) {
+                                        blo[t][w] = (int) (__builtin_amdgcn_perm(cur[2 * w + 1], cur[2 * w], sel_lo) ^ W8Enc<DT>::xlo);
+                                        bhi[t][w] = (int) (__builtin_amdgcn_perm(cur[2 * w + 1], cur[2 * w], sel_hi) ^ W8Enc<DT>::xhi);
+                                    }
+                                    if constexpr (s + PF < KS) issue(chunk_raw, std::integral_constant<int, t * KS + s + PF>{});
+                                    else issue(next_raw, std::integral_constant<int, t * KS + s + PF - KS>{});
+                                });
+                            }
+                            static_for<0, S>([&](auto dc) {
+                                constexpr int d = decltype(dc)::value;
+                                const v4i A = F[d];
+                                static_for<0, 2>([&](auto tc) {
+                                    constexpr int t = decltype(tc)::value;
+                                    if constexpr (PACK && rt == 2) {
+                                        if constexpr (d < 3) {
+                                            if constexpr (s == 0) acc[t][2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi[t], (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                            else acc[t][2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi[t], acc[t][2][d], 0, 0, 0);
+                                        } else if constexpr (d < NLF) {
+                                            acc[t][2][d - 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo[t], acc[t][2][d - 3], 0, 0, 0);
+                                        }
+                                    } else {
+                                        if constexpr (s == 0) acc[t][rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi[t], (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                        else acc[t][rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi[t], acc[t][rt][d], 0, 0, 0);
+                                        if constexpr (d >= 1) acc[t][rt][d - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo[t], acc[t][rt][d - 1], 0, 0, 0);
+                                    }
+                                });
+                                if constexpr (i + 1 < KS * 3) {
+                                    if constexpr (!(PACK && (i + 1) % 3 == 2 && d >= NLF)) F[d] = frag(std::integral_constant<int, i + 1>{}, dc);
+                                }
+                            });
+                        }
+                        piece(std::integral_constant<int, 0>{}, ic);
+                        piece(std::integral_constant<int, 1>{}, ic);
+                    });
+                    SDRT_STAMP(2);
+                    if constexpr (HAVE_K) {
+                        static_for<0, 2>([&](auto tc) {
+                            constexpr int t = decltype(tc)::value;
+                            double val[8];
+                            static_for<0, 3>([&](auto rc) {
+                                constexpr int rt = decltype(rc)::value;
+                                if constexpr (PACK && rt == 2) {
+                                    const double csl = g >= 2 ? cs_loc0 * 256.0 : cs_loc0;
+#pragma unroll
+                                    for (int v = 0; v < 4; ++v) {
+                                        double dsum = (double) acc[t][2][2][v];
+                                        dsum = fma(dsum, 65536.0, (double) acc[t][2][1][v]);
+                                        dsum = fma(dsum, 65536.0, (double) acc[t][2][0][v]);
+                                        dl[t][v] = dsum * csl;
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int v = 0; v < 4; ++v) {
+                                        double dsum = (double) acc[t][rt][S - 1][v];
+#pragma unroll
+                                        for (int q = S - 2; q >= 0; --q) dsum = fma(dsum, 256.0, (double) acc[t][rt][q][v]);
+                                        if constexpr (rt < 2) val[4 * rt + v] = dsum * cs_main0; else dl[t][v] = dsum * cs_loc0;
+                                    }
+                                }
+                            });
+                            dC[t][0] = mk(val[0], val[1]);
+                            dC[t][1] = mk(val[2], val[3]);
+                            dA[t][0] = mk(val[4], val[5]);
+                            dA[t][1] = mk(val[6], val[7]);
+                        });
+                    }
+                } else if constexpr (RS) {
                     v4i accR[S], accI[S], accLR[NHF], accLI[NHF];
                     v4i A[S], L[NLF];
                     auto fragA = [&](auto sc, auto dc) -> v4i {
@@ -1156,7 +1282,7 @@ __global__ __launch_bounds__(512, 2) void chain_i8w_kernel(DecimArgs a) {
                             o = mk(fma(iq_m2, dpp_row<0x112>(o.re), o.re), fma(iq_m2, dpp_row<0x112>(o.im), o.im));
                             o = mk(fma(iq_m4, dpp_row<0x114>(o.re), o.re), fma(iq_m4, dpp_row<0x114>(o.im), o.im));
                             o = mk(fma(iq_m8, dpp_row<0x118>(o.re), o.re), fma(iq_m8, dpp_row<0x118>(o.im), o.im));
-                            if (lane == 15) OtL(bcur)[(OPQ ? wave_s : wave) + 8 * j] = o;              // the tile's total
+                            if (lane == 15) OtL(bcur)[(OPQ ? wave_s : wave) + WV * j] = o;              // the tile's total
                             oex[j] = dpp_row<0x111>(o);                               // offset at the column's first sample
                         }
                     }
@@ -1213,19 +1339,19 @@ hipError_t launch_chain_i8w_bytes(const DecimArgs &a, int nout, int nt, int dt, 
 hipError_t launch_chain_i8w_u16(const DecimArgs &a, int nout, int nt, dim3 grid, size_t lds, hipStream_t s);
 hipError_t launch_chain_i8w_f32(const DecimArgs &a, int nout, int nt, dim3 grid, size_t lds, hipStream_t s);
 
-template <int DT, int NOUT, int NTC, int IQ, bool RS, bool PRE = false>
+template <int DT, int NOUT, int NTC, int IQ, bool RS, bool PRE = false, bool DUAL = false>
 static hipError_t launch_i8w_q(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
     // once per device and instantiation (a driver call per launch costs more than the gap between two kernels)
     static thread_local int done_dev = -1;
     int dev = 0;
     (void) hipGetDevice(&dev);
     if (done_dev != dev) {
-        hipError_t e = hipFuncSetAttribute((const void *) chain_i8w_kernel<DT, NOUT, NTC, SDRT_I8_DIGITS, IQ, RS, PRE>,
+        hipError_t e = hipFuncSetAttribute((const void *) chain_i8w_kernel<DT, NOUT, NTC, SDRT_I8_DIGITS, IQ, RS, PRE, DUAL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
         done_dev = dev;
     }
-    hipLaunchKernelGGL((chain_i8w_kernel<DT, NOUT, NTC, SDRT_I8_DIGITS, IQ, RS, PRE>), grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((chain_i8w_kernel<DT, NOUT, NTC, SDRT_I8_DIGITS, IQ, RS, PRE, DUAL>), grid, dim3(DUAL ? 256 : 512), lds, s, a);
     return hipGetLastError();
 }
 template <int DT, int NOUT, int NT>
@@ -1243,6 +1369,10 @@ static hipError_t launch_i8w_k(const DecimArgs &a, dim3 grid, size_t lds, hipStr
             if (a.rs) return launch_i8w_q<DT, NOUT, NT, 0, true>(a, grid, lds, s);
         } else if (a.rs) return hipErrorInvalidValue;
         if (a.w8iq) return launch_i8w_q<DT, NOUT, NT, 2, false>(a, grid, lds, s);
+        // one wave per SIMD on two tiles at once (signed 16-bit records, four outputs per column, no IQ correction)
+        if constexpr (DT == SDRT_S16 && NT == 8 && NOUT == 4) {
+            if (a.dual && !a.iq_group_off) return launch_i8w_q<DT, NOUT, NT, 0, false, false, true>(a, grid, lds, s);
+        }
         return a.iq_group_off ? launch_i8w_q<DT, NOUT, NT, 1, false>(a, grid, lds, s) : launch_i8w_q<DT, NOUT, NT, 0, false>(a, grid, lds, s);
     }
 }

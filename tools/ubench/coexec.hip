@@ -14,6 +14,10 @@
 //   mode 7  as 2 on v_mfma_i32_32x32x32_i8 (groups of [4][NV/23])
 //   mode 8  as 3, the matrix waves fetch every A fragment from LDS (ds_read_b128 per matrix instruction)
 //   mode 9  as 0 with LDS fragments
+//   mode 10 as 2 with LDS fragments: groups of [8 x (ds_read_b128, matrix instruction)][NV/23 FMAs]   (the shipped kernel with its fetches)
+//   mode 11 ONE wave per SIMD (256 threads) working on two tiles: every fragment is read once and feeds two matrix instructions,
+//           the FMAs of both tiles interleaved between them at instruction granularity
+//   mode 12 as 11, but every matrix instruction fetches its own fragment (what sharing the fragment is worth on its own)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -35,20 +39,20 @@ __device__ __forceinline__ void fmas(double (&x)[8], double c1, double c2) {
 }
 
 template <int MODE, int NV>
-__global__ __launch_bounds__(512, 2) void k(const int *__restrict__ src, double *out, unsigned long long *st, int iters) {
+__global__ __launch_bounds__(512, 1) void k(const int *__restrict__ src, double *out, unsigned long long *st, int iters) {
     __shared__ v4i lds[64 * 40];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 64 * 40; i += 512) lds[i] = ((const v4i *) src)[(i * 7 + blockIdx.x) & 4095];
+    for (int i = tid; i < 64 * 40; i += (int) blockDim.x) lds[i] = ((const v4i *) src)[(i * 7 + blockIdx.x) & 4095];
     __syncthreads();
     v4i a[8], b[2];
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = ((const v4i *) src)[(lane + 64 * i + wave * 17) & 4095];
     b[0] = ((const v4i *) src)[(lane * 3 + 1) & 4095];
     b[1] = ((const v4i *) src)[(lane * 5 + 2) & 4095];
-    v4i acc[8];
+    v4i acc[8], accB[8];
     v16i acc32[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = (v4i) {0, 0, 0, 0};
+    for (int i = 0; i < 8; ++i) acc[i] = accB[i] = (v4i) {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -57,14 +61,27 @@ __global__ __launch_bounds__(512, 2) void k(const int *__restrict__ src, double 
 #pragma unroll
     for (int i = 0; i < 8; ++i) x[i] = 1.0 + 1e-3 * lane + i;
     const double c1 = 0.999999 + 1e-9 * lane, c2 = 1e-7 * (wave + 1);
+    v4i F[8], G[8];
+    int fi = 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { F[i] = lds[i * 64 + lane]; G[i] = lds[(i + 20) * 64 + lane]; }
     constexpr bool M32 = MODE == 5 || MODE == 6 || MODE == 7;
     constexpr bool SPLIT = MODE == 3 || MODE == 6 || MODE == 8;
-    constexpr bool LDSF = MODE == 8 || MODE == 9;
+    constexpr bool LDSF = MODE == 8 || MODE == 9 || MODE == 10;
     auto mm = [&](auto nc) {                       // n 16x16x64 instructions (or n/2 32x32x32)
         constexpr int n = decltype(nc)::value;
         if constexpr (M32) {
 #pragma unroll
             for (int i = 0; i < n / 2; ++i) acc32[i & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i & 7], b[i & 1], acc32[i & 3], 0, 0, 0);
+        } else if constexpr (MODE == 10) {
+            // as the shipped kernel fetches them: a ring of eight fragment registers, each reloaded for the next group as soon as
+            // its matrix instruction has been issued
+#pragma unroll
+            for (int i = 0; i < n; ++i) {
+                acc[i & 7] = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[i & 7], b[i & 1], acc[i & 7], 0, 0, 0);
+                F[i & 7] = lds[((i + fi) % 40) * 64 + lane];
+            }
+            fi = (fi + 8) % 40;
         } else if constexpr (LDSF) {
 #pragma unroll
             for (int i = 0; i < n; ++i) {
@@ -87,6 +104,29 @@ __global__ __launch_bounds__(512, 2) void k(const int *__restrict__ src, double 
             for (int it = 0; it < iters; ++it) {
 #pragma unroll
                 for (int g = 0; g < 2 * GROUPS; ++g) { fmas<NV / GROUPS>(x, c1, c2); __builtin_amdgcn_sched_barrier(0); }
+            }
+        }
+    } else if constexpr (MODE == 11 || MODE == 12) {
+        // one wave per SIMD, two tiles: per group 8 fragments x 2 matrix instructions and 2 x NV/23 FMAs, interleaved
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[i], b[0], acc[i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fmas<3>(x, c1, c2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    accB[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(MODE == 12 ? G[i] : F[i], b[1], accB[i], 0, 0, 0);
+                    // the registers take the next group's fragments (mode 12: one fetch per matrix instruction)
+                    F[i] = lds[((g * 8 + i + 8) % 40) * 64 + lane];
+                    if constexpr (MODE == 12) G[i] = lds[((g * 8 + i + 28) % 40) * 64 + lane];
+                    __builtin_amdgcn_sched_barrier(0);
+                    fmas<2>(x, c1, c2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                fmas<2 * (NV / GROUPS) - 40>(x, c1, c2);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     } else if constexpr (MODE == 0 || MODE == 5 || MODE == 9) {
@@ -116,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void k(const int *__restrict__ src, double 
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     double s = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += x[i] + (double) (acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3]);
+    for (int i = 0; i < 8; ++i) s += x[i] + (double) (acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3]) + (double) (accB[i][0] + accB[i][3]);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -131,26 +171,29 @@ __global__ __launch_bounds__(512, 2) void k(const int *__restrict__ src, double 
 
 template <int MODE, int NV>
 void run(const char *name, const int *src, double *out, unsigned long long *st, int iters, double seconds) {
+    const int threads = (MODE == 11 || MODE == 12) ? 256 : 512, nwaves = threads / 64;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int wgs = 256;
     // load the chip for `seconds` with back-to-back launches, then time 20 more
-    k<MODE, NV><<<wgs, 512>>>(src, out, st, iters);
+    k<MODE, NV><<<wgs, threads>>>(src, out, st, iters);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    k<MODE, NV><<<wgs, 512>>>(src, out, st, iters);
+    k<MODE, NV><<<wgs, threads>>>(src, out, st, iters);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms1 = 0; CK(hipEventElapsedTime(&ms1, e0, e1));
     int warm = std::max(1, (int) (seconds * 1e3 / ms1));
-    for (int i = 0; i < warm; ++i) k<MODE, NV><<<wgs, 512>>>(src, out, st, iters);
+    for (int i = 0; i < warm; ++i) k<MODE, NV><<<wgs, threads>>>(src, out, st, iters);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < 20; ++i) k<MODE, NV><<<wgs, 512>>>(src, out, st, iters);
+    for (int i = 0; i < 20; ++i) k<MODE, NV><<<wgs, threads>>>(src, out, st, iters);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<unsigned long long> h(wgs * 8 * 2);
     CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
     std::vector<double> clk, cyc_lo, cyc_hi;
     for (int w = 0; w < wgs * 8; ++w) {
+        if ((w & 7) >= nwaves) continue;
+        if (nwaves == 4) cyc_hi.push_back((double) h[2 * w] / iters);
         clk.push_back((double) h[2 * w] / (double) h[2 * w + 1] * 100.0);
         ((w & 7) < 4 ? cyc_lo : cyc_hi).push_back((double) h[2 * w] / iters);
     }
@@ -183,5 +226,10 @@ int main(int argc, char **argv) {
     run<6, NV>("6 roles, 32x32x32", src, out, st, iters, seconds);
     run<9, NV>("9 matrix only, A fragments from LDS", src, out, st, iters, seconds);
     run<8, NV>("8 roles, A fragments from LDS", src, out, st, iters, seconds);
+    run<10, NV>("10 as 2 + a fragment fetch per matrix instr.", src, out, st, iters, seconds);
+    run<11, NV>("11 one wave/SIMD, 2 tiles share a fragment", src, out, st, iters, seconds);
+    run<12, NV>("12 one wave/SIMD, a fetch per matrix instr.", src, out, st, iters, seconds);
+    run<10, NV>("10 again", src, out, st, iters, seconds);
+    run<11, NV>("11 again", src, out, st, iters, seconds);
     return 0;
 }
