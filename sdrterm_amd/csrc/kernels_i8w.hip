@@ -21,6 +21,12 @@
 // is below the quantisation step of the planes.
 #include "kernels_common.hpp"
 
+#ifndef SDRT_DUAL_PF
+#define SDRT_DUAL_PF 3           // DUAL form: k-steps of raw samples in flight per tile
+#endif
+#ifndef SDRT_DUAL_VPM
+#define SDRT_DUAL_VPM 3          // DUAL form: vector instructions requested after every matrix instruction
+#endif
 #ifndef SDRT_RAW_NT
 #define SDRT_RAW_NT 0          // 1: non-temporal loads of the raw sample stream (measured: see DESIGN.md section 4)
 #endif
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
     constexpr int NHF = (S + PPF - 1) / PPF;                      // fragments used with the high (or only) slice
     constexpr int NLF = (PACK || RS) ? NHF + (NSL >= 2 ? (S - 1 + PPF - 1) / PPF : 0) : S;   // local-tile fragments per k-step (both plane pairings)
     constexpr int NSLOT = (RS || F32) ? 1 : 4;                             // raw-sample register ring (RS: reloaded in place once sliced)
-    constexpr int PF = (NOUT == 8 || RS || F32) ? 1 : 2;            // k-steps of raw samples in flight (registers are scarcer with 8 outputs per column)
+    constexpr int PF = (NOUT == 8 || RS || F32) ? 1 : (DUAL ? SDRT_DUAL_PF : 2);            // k-steps of raw samples in flight (registers are scarcer with 8 outputs per column)
     static_assert(NOUT == 4 || NOUT == 8, "4 or 8 outputs per column");
     static_assert(NTC == 4 || NTC == 8 || NTC == 16, "4, 8 or 16 tiles per chunk");
     typedef typename Enc<DT>::raw raw_t;
@@ -891,6 +897,20 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
                         }
                         piece(std::integral_constant<int, 0>{}, ic);
                         piece(std::integral_constant<int, 1>{}, ic);
+                        // (-DSDRT_DUAL_PACE: ask the scheduler for one matrix instruction, three vector instructions, ... over each group
+                        // and its pieces -- measured slower, 4.62 against 4.34 ms: the pieces' operands are not there yet when their
+                        // turn comes and the matrix instructions bunch up; profiles/r03_experiments.txt)
+#ifdef SDRT_DUAL_PACE
+                        if constexpr (HAVE_K) {
+                            constexpr int NMG = 2 * ((PACK && rt == 2) ? NLF : 2 * S - 1);
+                            static_for<0, NMG>([&](auto mc) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, SDRT_DUAL_VPM, 0);
+                                if constexpr (decltype(mc)::value % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            });
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
                     });
                     SDRT_STAMP(2);
                     if constexpr (HAVE_K) {
