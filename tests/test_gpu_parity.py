@@ -501,3 +501,25 @@ def test_sixteen_tiles_per_chunk_on_the_wide_kernel(code, rows, iq, fused, q, mo
         assert np.isfinite(out_a).all() and d < 1e-7
         if iq:
             assert abs(a.iq_offset - b.iq_offset) <= 1e-9 * max(abs(b.iq_offset), 1e-30)
+
+
+@pytest.mark.parametrize('name', ['h_q64_fm_c', 'h_q64_fm_bench', 'h_q64_fm_vfo9', 'h_q64_am_norm_c'])
+def test_one_wave_per_simd_form_of_the_wide_kernel(name, golden, monkeypatch):
+    """SDRTERM_WIDE_DUAL=1: the experimental form of chain_i8w_kernel with one wave per SIMD working on two tiles at once (every
+    digit-plane fragment read once for two matrix instructions) meets the reference's vectors like the shipped
+    form, and agrees with it to rounding."""
+    z, _ = golden
+    if name not in BY_NAME:
+        pytest.skip('no such golden case')
+    case = BY_NAME[name]
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    ref_out, _ = _engine(case).process_debug(case_raw(case))
+    monkeypatch.setenv('SDRTERM_WIDE_DUAL', '1')
+    eng = _engine(case)
+    assert eng.stage_a == 'i8w'
+    out, _ = eng.process_debug(case_raw(case))
+    exp = z[f'{name}/z']
+    nch, rows, m = exp.shape
+    got = out.reshape(rows, nch, m).transpose(1, 0, 2)
+    assert np.abs(got - exp).max() <= ref_tol(case, exp)
+    assert np.abs(out - ref_out).max() < 1e-9
