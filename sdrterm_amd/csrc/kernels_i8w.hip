@@ -857,6 +857,7 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
                     if constexpr (HAVE_K) static_for<0, S>([&](auto dc) { F[decltype(dc)::value] = frag(std::integral_constant<int, 0>{}, dc); });
                     static_for<0, KS * 3>([&](auto ic) {
                         constexpr int i = decltype(ic)::value, s = i / 3, rt = i % 3;
+                        if constexpr (rt == 0 && s % 2 == 0) SDRT_STAMP(5 + s / 2);      // (diagnostic builds: k-steps 0, 2, 4, 6 -> slots 5 .. 8)
                         if constexpr (HAVE_K) {
                             if constexpr (rt == 0) {
                                 const unsigned sel_lo = swap ? 0x07050301u : 0x06040200u, sel_hi = swap ? 0x06040200u : 0x07050301u;
