@@ -193,7 +193,6 @@ def main():
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args, sys.argv[1:], dry_run=args.dry_run))
 
-    import numpy as np
     import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

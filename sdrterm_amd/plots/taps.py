@@ -5,7 +5,6 @@ Both plots receive the reader's chunks, shift them by ``center`` (AbstractPlot: 
 shiftFreq, abstract_plot.py:73-76) and transform them.  Chunks may be the reference reader's complex arrays or this
 package's ``RawChunk`` (raw bytes: decode and --normalize-input run on the GPU as well).
 """
-import ctypes as C
 import sys
 
 import numpy as np

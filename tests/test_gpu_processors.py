@@ -1,5 +1,4 @@
 """GPU end-to-end tests of the processor mirrors, the stand-alone discriminators and stream-level properties."""
-import multiprocessing as mp
 import os
 import socket
 import tempfile

@@ -8,7 +8,6 @@ import os
 import subprocess
 import sys
 
-import numpy as np
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,5 @@
 """CPU-only tests of the reader side (sdrterm_amd/misc/file_util.py, read_file.py), modelled on the reference's
 test/misc/file_util_test.py and read_file_test.py; the header byte strings are that test module's fixtures (data)."""
-import os
 import pickle
 from string import ascii_letters
 

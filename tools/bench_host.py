@@ -2,7 +2,7 @@
 """PCIe-inclusive rate of the host entry points: sdrt_process_host one batch at a time (pageable buffers) and
 sdrt_submit_host / sdrt_wait with batches in flight (pageable and page-locked buffers), next to the plain host-to-device copy
 rate of this box (the ceiling of the path: 4 bytes in per sample)."""
-import ctypes as C, json, os, sys, time
+import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from sdrterm_amd import _native as nat
