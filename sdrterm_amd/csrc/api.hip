@@ -594,8 +594,9 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         // FM with 512 outputs per chunk (decimation 64 of 16-bit records, 32 of float32 records) and the usual output lowpass
         // (one complex pole pair + one real pole): eight lanes per item (diagnostics: SDRTERM_POST=wave keeps one wave per item)
         const char *pk = getenv("SDRTERM_POST");
-        if (rc == SDRT_OK && c->fft_ok && (m == 512 || m == 1024) && !(pk && strcmp(pk, "wave") == 0)) {
-            const int lpi = m == 512 ? 8 : 16;
+        const bool fft_wanted = !(pf && strcmp(pf, "direct") == 0);      // (256 outputs per chunk: this kernel only, the one-wave FFT form starts at 512)
+        if (rc == SDRT_OK && fft_wanted && (m == 256 || m == 512 || m == 1024) && !(pk && strcmp(pk, "wave") == 0)) {
+            const int lpi = m / 64;                            // 4, 8 or 16 lanes per item
             Post8Tables p8;
             std::vector<double> ft((size_t) (4 * SDRT_P8_PPL * lpi + 8 * lpi) * 2);
             if (sdrt_build_post8_tables(cfg->out_sos, cfg->out_sections, N, lpi, &p8, ft.data()) == 0) {

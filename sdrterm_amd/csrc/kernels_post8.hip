@@ -152,7 +152,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <int LPI, int WPB, bool PAIRS>
 __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_fft8_kernel(PostArgs a) {
     constexpr int P = SDRT_P8_PPL, H = P * LPI, N = 2 * H, M = 2 * N, IPW = 64 / LPI, TAB = P * LPI, SO = 17 * LPI, NC = P / LPI;
-    static_assert(LPI == 8 || LPI == 16, "8 or 16 lanes per item");
+    static_assert(LPI == 4 || LPI == 8 || LPI == 16, "4, 8 or 16 lanes per item");
     extern __shared__ __align__(16) unsigned char smem[];
     cd *tabL = (cd *) smem;                                        // tw1 | tw2 | alpha | beta | lane rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, o = lane / LPI, l = lane % LPI;
@@ -160,8 +160,8 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
     for (int i = tid; i < 4 * TAB + 8 * LPI; i += 64 * WPB) tabL[i] = ((const cd *) a.fft8_tab)[i];
     __syncthreads();
     const cd *tw1L = tabL, *tw2L = tabL + TAB, *alL = tabL + 2 * TAB, *beL = tabL + 3 * TAB, *lpL = tabL + 4 * TAB;
-    // the bins k1 this lane finishes (S_l): 8 lanes: l and 16 - l (lane 0: 0 and 8); 16 lanes: l
-    const int c0 = l, c1 = LPI == 8 ? (l ? 16 - l : 8) : 0;
+    // the bins k1 this lane finishes (S_l): 16 lanes: l; 8 lanes: l and 16 - l (lane 0: 0 and 8); 4 lanes: those and 4 + l, 12 - l
+    const int cs[4] = {l, LPI <= 8 ? (l ? 16 - l : 8) : 0, 4 + l, 12 - l};
     const bool l0 = l == 0;
 
     const size_t ngroups = (a.items + IPW - 1) / IPW;
@@ -218,12 +218,10 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
             wave_lds_fence();
             cd V[NC][LPI];
 #pragma unroll
-            for (int j = 0; j < LPI; ++j) {
-                V[0][j] = X[17 * j + c0];
-                if constexpr (NC == 2) V[1][j] = X[17 * j + c1];
-            }
-            reg_fft<LPI, false>(V[0], Z[0]);
-            if constexpr (NC == 2) reg_fft<LPI, false>(V[1], Z[1]);
+            for (int j = 0; j < LPI; ++j)
+#pragma unroll
+                for (int ci = 0; ci < NC; ++ci) V[ci][j] = X[17 * j + cs[ci]];
+            static_for<0, NC>([&](auto cc) { reg_fft<LPI, false>(V[decltype(cc)::value], Z[decltype(cc)::value]); });
         }
         // ---- packed spectrum of the angles -> packed spectrum of the half-sample shifted sequence ----------------------------
         // Y[k] = alpha_k Z[k] + beta_k conj(Z[H - k]).  8 lanes: bin k = c + 16 k2 pairs with H - k = (16 - c) + 16 (7 - k2), the
@@ -235,13 +233,21 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
             cd Y[NC][LPI];
             static_for<0, LPI>([&](auto kc) {
                 constexpr int k2 = decltype(kc)::value;
-                if constexpr (LPI == 8) {
-                    const cd q0 = Z[1][7 - k2], q0s = Z[0][(8 - k2) % 8], q1 = Z[0][7 - k2], q1s = Z[1][7 - k2];
+                if constexpr (LPI <= 8) {
+                    const cd q0 = Z[1][LPI - 1 - k2], q0s = Z[0][(LPI - k2) % LPI], q1 = Z[0][LPI - 1 - k2], q1s = Z[1][LPI - 1 - k2];
                     const cd p0 = mk(l0 ? q0s.re : q0.re, l0 ? q0s.im : q0.im), p1 = mk(l0 ? q1s.re : q1.re, l0 ? q1s.im : q1.im);
                     const cd a0 = alL[(0 * LPI + k2) * LPI + l], b0 = beL[(0 * LPI + k2) * LPI + l];
                     const cd a1 = alL[(1 * LPI + k2) * LPI + l], b1 = beL[(1 * LPI + k2) * LPI + l];
                     Y[0][k2] = cfma(b0, mk(p0.re, -p0.im), cmul(a0, Z[0][k2]));
                     Y[1][k2] = cfma(b1, mk(p1.re, -p1.im), cmul(a1, Z[1][k2]));
+                    if constexpr (LPI == 4) {
+                        // the second pair of series, 4 + l and 12 - l: partners in every lane
+                        const cd p2 = Z[3][LPI - 1 - k2], p3 = Z[2][LPI - 1 - k2];
+                        const cd a2 = alL[(2 * LPI + k2) * LPI + l], b2 = beL[(2 * LPI + k2) * LPI + l];
+                        const cd a3 = alL[(3 * LPI + k2) * LPI + l], b3 = beL[(3 * LPI + k2) * LPI + l];
+                        Y[2][k2] = cfma(b2, mk(p2.re, -p2.im), cmul(a2, Z[2][k2]));
+                        Y[3][k2] = cfma(b3, mk(p3.re, -p3.im), cmul(a3, Z[3][k2]));
+                    }
                 } else {
                     const cd far = dpp_row<0x121>(dpp_row<0x140>(Z[0][15 - k2])), own = Z[0][(16 - k2) % 16];
                     const cd p0 = mk(l0 ? own.re : far.re, l0 ? own.im : far.im);
@@ -249,23 +255,21 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
                     Y[0][k2] = cfma(b0, mk(p0.re, -p0.im), cmul(a0, Z[0][k2]));
                 }
             });
-            reg_fft<LPI, true>(Y[0], U[0]);
-            if constexpr (NC == 2) reg_fft<LPI, true>(Y[1], U[1]);
+            static_for<0, NC>([&](auto cc) { reg_fft<LPI, true>(Y[decltype(cc)::value], U[decltype(cc)::value]); });
         }
         // ---- back: twiddle, exchange, 16 points in the lane -------------------------------------------------------------------
         cd zz[P];
         {
             static_for<1, LPI>([&](auto kc) {
                 constexpr int n2 = decltype(kc)::value;
-                U[0][n2] = cmul(U[0][n2], tw2L[(0 * LPI + n2) * LPI + l]);
-                if constexpr (NC == 2) U[1][n2] = cmul(U[1][n2], tw2L[(1 * LPI + n2) * LPI + l]);
+#pragma unroll
+                for (int ci = 0; ci < NC; ++ci) U[ci][n2] = cmul(U[ci][n2], tw2L[(ci * LPI + n2) * LPI + l]);
             });
             wave_lds_fence();                                      // the forward step's reads are done
 #pragma unroll
-            for (int n2 = 0; n2 < LPI; ++n2) {
-                X[17 * n2 + c0] = U[0][n2];
-                if constexpr (NC == 2) X[17 * n2 + c1] = U[1][n2];
-            }
+            for (int n2 = 0; n2 < LPI; ++n2)
+#pragma unroll
+                for (int ci = 0; ci < NC; ++ci) X[17 * n2 + cs[ci]] = U[ci][n2];
             wave_lds_fence();
             cd Rr[P];
 #pragma unroll
@@ -310,7 +314,17 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
             const double te = fma(r3, x0, fma(r2, x1, fma(r1, x2, x3)));
             cd sc, s;
             double sr, t;
-            if constexpr (LPI == 8) {
+            if constexpr (LPI == 4) {
+                // the item is one quad: the two quad steps are the whole scan
+                sc = cfma(mA1, dpp_quad<0x90>(se), se);
+                sr = fma(nA1, dpp_quad<0x90>(te), te);
+                sc = cfma(mA2, dpp_quad<0x40>(sc), sc);
+                sr = fma(nA2, dpp_quad<0x40>(sr), sr);
+                const cd eq = dpp_quad<0x90>(sc);
+                const double eqr = dpp_quad<0x90>(sr);
+                s = cfma(plc, Cc, mk(q1 * eq.re, q1 * eq.im));
+                t = fma(plr, Cr, q1 * eqr);
+            } else if constexpr (LPI == 8) {
                 // inclusive scan of the end states over the item's eight lanes: inside the quads (quad permutations never leave
                 // the item) ...
                 sc = cfma(mA1, dpp_quad<0x90>(se), se);                // [0,0,1,2]: lane q takes lane q-1
@@ -342,8 +356,8 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
                 t = fma(plr, Cr, dpp_row<0x111>(sr));
             }
             // the next block starts from this block's end state (the item's last lane)
-            const cd Tc = LPI == 8 ? mk(swz_bcast_last8(sc.re), swz_bcast_last8(sc.im)) : dpp_row<0x15F>(sc);
-            const double Tr = LPI == 8 ? swz_bcast_last8(sr) : dpp_row<0x15F>(sr);
+            const cd Tc = LPI == 4 ? dpp_quad<0xFF>(sc) : (LPI == 8 ? mk(swz_bcast_last8(sc.re), swz_bcast_last8(sc.im)) : dpp_row<0x15F>(sc));
+            const double Tr = LPI == 4 ? dpp_quad<0xFF>(sr) : (LPI == 8 ? swz_bcast_last8(sr) : dpp_row<0x15F>(sr));
             Cc = cfma(pbc, Cc, Tc);
             Cr = fma(pbr, Cr, Tr);
             // what the starting state adds to the four outputs (dsp_processor.py:32-36: sosfilt, zero state per chunk)
@@ -390,7 +404,7 @@ static hipError_t launch_post_fft8_p(const PostArgs &a, hipStream_t s) {
 size_t post_fft8_stash_bytes(const PostArgs &a) {
     if (!post_fft8_supported(a)) return 0;
     const size_t ipw = 64 / a.p8_lpi, groups = (a.items + ipw - 1) / ipw;
-    const bool small = a.items <= (a.p8_lpi == 16 ? 4 * 256 : 8 * 256);
+    const bool small = a.items <= (size_t) (64 / a.p8_lpi) * 256;
     const size_t wpb = small ? 1 : (a.p8_lpi == 16 ? 8 : 4), cap = 256 * (a.p8_lpi == 16 ? 2 : 4);
     size_t wgs = (groups + wpb - 1) / wpb;
     if (wgs > cap) wgs = cap;
@@ -405,7 +419,7 @@ bool post_fft8_supported(const PostArgs &a) {
         static const int with_share = [] { const char *e = getenv("SDRTERM_POST8_IQ"); return e ? atoi(e) : 1; }();
         if (!(with_share == 2 || (with_share == 1 && a.m == 1024))) return false;
     }
-    return a.mode == SDRT_FM && a.fft8_tab && a.p8tab && ((a.m == 512 && a.p8_lpi == 8) || (a.m == 1024 && a.p8_lpi == 16));
+    return a.mode == SDRT_FM && a.fft8_tab && a.p8tab && ((a.m == 256 && a.p8_lpi == 4) || (a.m == 512 && a.p8_lpi == 8) || (a.m == 1024 && a.p8_lpi == 16));
 }
 
 hipError_t launch_post_fft8(const PostArgs &a, hipStream_t s) {
@@ -413,6 +427,10 @@ hipError_t launch_post_fft8(const PostArgs &a, hipStream_t s) {
         // the tables take 18 KiB, a wave's exchange image 17: eight waves share one copy of the tables
         if (a.items <= 4 * 256) return a.pairs ? launch_post_fft8_p<16, 1, true>(a, s) : launch_post_fft8_p<16, 1, false>(a, s);
         return a.pairs ? launch_post_fft8_p<16, 8, true>(a, s) : launch_post_fft8_p<16, 8, false>(a, s);
+    }
+    if (a.p8_lpi == 4) {
+        if (a.items <= 16 * 256) return a.pairs ? launch_post_fft8_p<4, 1, true>(a, s) : launch_post_fft8_p<4, 1, false>(a, s);
+        return a.pairs ? launch_post_fft8_p<4, 4, true>(a, s) : launch_post_fft8_p<4, 4, false>(a, s);
     }
     // few items: one wave per workgroup spreads them over more compute units
     if (a.items <= 8 * 256) return a.pairs ? launch_post_fft8_p<8, 1, true>(a, s) : launch_post_fft8_p<8, 1, false>(a, s);

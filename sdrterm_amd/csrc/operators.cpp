@@ -318,7 +318,7 @@ extern "C" int sdrt_build_out_tables(const double *sos, int sections, int m, Out
 }
 
 extern "C" int sdrt_build_post8_tables(const double *out_sos, int sections, int N, int LPI, Post8Tables *out, double *fft_tab) {
-    if (!(LPI == 8 || LPI == 16) || N != 2 * SDRT_P8_PPL * LPI) return -1;
+    if (!(LPI == 4 || LPI == 8 || LPI == 16) || N != 2 * SDRT_P8_PPL * LPI) return -1;
     OutModes om;
     if (!out_modes(out_sos, sections, om) || om.nm != 2 || om.ncomplex != 1) return -2;
     std::memset(out, 0, sizeof(*out));
@@ -362,7 +362,8 @@ extern "C" int sdrt_build_post8_tables(const double *out_sos, int sections, int 
         dst[0] = (double) cosl(ang);
         dst[1] = (double) (conj_ ? sinl(ang) : -sinl(ang));
     };
-    auto S = [&](int l, int ci) { return LPI == 16 ? l : (ci == 0 ? l : (l ? 16 - l : 8)); };
+    // the bin series lane l finishes (closed under k1 -> 16 - k1): 16 lanes: l; 8: l, 16 - l (lane 0: 0, 8); 4: those and 4 + l, 12 - l
+    auto S = [&](int l, int ci) { return LPI == 16 ? l : (ci == 0 ? l : (ci == 1 ? (l ? 16 - l : 8) : (ci == 2 ? 4 + l : 12 - l))); };
     double *tw1 = fft_tab, *tw2 = fft_tab + 2 * T, *al = fft_tab + 4 * T, *be = fft_tab + 6 * T, *lp = fft_tab + 8 * T;
     // the lowpass constants that depend on the lane, [8][LPI] complex slots: scan multipliers inside the quad (zero where the quad
     // permutation hands a lane its own or an earlier lane's value), from the quad before, from the block's start

@@ -36,7 +36,7 @@ def _build(N, LPI, sos):
     return rc, pt, tab[:4 * 16 * LPI].reshape(4, 16 * LPI), tab[4 * 16 * LPI:].reshape(8, LPI)
 
 
-@pytest.mark.parametrize('N,LPI', [(256, 8), (512, 16)])
+@pytest.mark.parametrize('N,LPI', [(128, 4), (256, 8), (512, 16)])
 def test_transform_tables_match_the_model(N, LPI):
     import model_post8
     from sdrterm_amd.engine import output_sos
@@ -126,3 +126,14 @@ def test_exchange_image_is_conflict_free():
     for j in range(16):
         assert cycles('read_b128', [slot(o, j, l) for o, l in lanes]) == 4
         assert cycles('write_b128', [slot(o, j, l) for o, l in lanes]) == 8
+    # four lanes per item (256 outputs per chunk): 4 x 17 = 68 slots, four bin series per lane
+    SO, LPI = 68, 4
+    lanes = [(lane >> 2, lane & 3) for lane in range(64)]
+    S4 = lambda l, ci: [l, (16 - l) if l else 8, 4 + l, 12 - l][ci]
+    for k1 in range(16):
+        assert cycles('write_b128', [slot(o, l, k1) for o, l in lanes]) == 8
+        assert cycles('read_b128', [slot(o, l, k1) for o, l in lanes]) == 4
+    for ci in range(4):
+        for j in range(4):
+            assert cycles('read_b128', [slot(o, j, S4(l, ci)) for o, l in lanes]) == 4
+            assert cycles('write_b128', [slot(o, j, S4(l, ci)) for o, l in lanes]) == 8

@@ -13,6 +13,8 @@ def lane_sets(LPI):
     Z[H - k] of every Z[k] the lane holds sits in the same lane (LPI = 8: two values per lane; 16: one, partner in lane 16 - l)."""
     if LPI == 8:
         return [[0, 8]] + [[l, 16 - l] for l in range(1, 8)]
+    if LPI == 4:      # four values per lane: the pairs (l, 16 - l) and (4 + l, 12 - l); lane 0: 0 and 8 pair with themselves
+        return [[l, (16 - l) if l else 8, 4 + l, 12 - l] for l in range(4)]
     return [[l] for l in range(16)]
 
 
@@ -75,7 +77,7 @@ def resample_odd(a, LPI):
 if __name__ == '__main__':
     from scipy.signal import resample
     rng = np.random.default_rng(1)
-    for N, LPI in ((256, 8), (512, 16)):
+    for N, LPI in ((128, 4), (256, 8), (512, 16)):
         a = rng.uniform(-np.pi, np.pi, N)
         ref = resample(a, 2 * N)
         b = resample_odd(a, LPI)
