@@ -839,6 +839,9 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
         ia.gs = gs;
         ia.dt = c->cfg.dtype;
         ia.swap = da.swap;
+        // wide-column kernel: offsets at the starts of its 256-sample columns and at the tail window
+        ia.wmask = c->use_i8w ? SDRT_WIDE_LC / gs - 1 : 0;
+        ia.wtail = (c->cfg.n_samples - 32) / gs;
         ia.norm_bias = c->norm_bias;
         ia.lambda = c->cfg.iq_inductance;
         ia.pow_tab = c->d_iq_pow;

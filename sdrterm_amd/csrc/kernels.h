@@ -63,6 +63,7 @@ struct IqArgs {
     double *state;              // [2] carried offset (in/out, scan kernel)
     size_t n_chunks;
     int n, gs, dt, swap;
+    int wmask, wtail;           // groups the consumer reads: those with (group & wmask) == 0 and group wtail (wmask 0: all of them)
     const double *pow_tab;      // [n/GS + 1] (1-lambda)^(GS k)  (same table the chain kernel uses)
     double norm_bias, lambda, pow_g /* (1-lambda)^GS */, pow_n /* (1-lambda)^n */;
 };

@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256) void iq_local_kernel(IqArgs a) {
         for (int wv = 0; wv < wave; ++wv) wp = mk(fma(ag64, wp.re, wtot[wv].re), fma(ag64, wp.im, wtot[wv].im));
         // offset at this group's first sample = (carry propagated over tid groups) + (wave start propagated over lane groups) + ex
         const cd off = mk(fma(ptid, carry.re, fma(plane, wp.re, ex.re)), fma(ptid, carry.im, fma(plane, wp.im, ex.im)));
-        if (gout && grp < ngroups) gout[grp] = off;
+        // (the wide-column kernel reads the offsets at column starts and at the tail window only: the rest is not written)
+        if (gout && grp < ngroups && ((grp & a.wmask) == 0 || grp == a.wtail)) gout[grp] = off;
         // carry to the next sweep: everything of this sweep + the old carry over 256 groups
         cd tot = mk(0.0, 0.0);
         for (int wv = 0; wv < 4; ++wv) tot = mk(fma(ag64, tot.re, wtot[wv].re), fma(ag64, tot.im, wtot[wv].im));
