@@ -108,6 +108,7 @@ struct sdrt_ctx {
     // per-row demodulation modes (sdrt_config.row_modes): the rows of each mode, on the device, for the demodulation stage
     bool mixed = false;
     int *d_rows_of[2] = {nullptr, nullptr};      // [SDRT_FM], [SDRT_AM]
+    int *d_row_pair = nullptr;                   // per-row modes: [rows] 1 = FM row (its items can leave the chain kernel as pair products)
     int n_rows_of[2] = {0, 0};
     int sched = 0;                    // diagnostic builds only (SDRTERM_SCHED, kernels_i8w.hip: SDRT_SCHED_EXP)
     int dual = 0;                     // wide kernel: one wave per SIMD on two tiles at once (SDRTERM_WIDE_DUAL)
@@ -577,6 +578,11 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
             c->n_rows_of[md] = (int) rows.size();
             rc = upload(&c->d_rows_of[md], rows.data(), rows.size() * sizeof(int));
         }
+        if (rc == SDRT_OK) {
+            std::vector<int> rp((size_t) cfg->n_rows);
+            for (int r = 0; r < cfg->n_rows; ++r) rp[r] = cfg->row_modes[r] == SDRT_FM ? 1 : 0;
+            rc = upload(&c->d_row_pair, rp.data(), rp.size() * sizeof(int));
+        }
     }
     if (rc == SDRT_OK && any_fm) {
         std::vector<double> h((size_t) m / 2);
@@ -661,6 +667,7 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_stash);
     (void) hipFree(c->d_rows_of[0]);
     (void) hipFree(c->d_rows_of[1]);
+    (void) hipFree(c->d_row_pair);
     (void) hipFree(c->d_out_sos);
     (void) hipFree(c->d_otab);
     (void) hipFree(c->d_y);
@@ -800,8 +807,10 @@ int ensure_pairbufs(sdrt_ctx *c) {
 // fix_later: the share of the IQ offset at each chunk's start (wide-column kernel, fused form) is subtracted by the post
 // kernel while it loads the decimated samples (enqueue_post), not by a pass of its own
 // pair_out: the wide-column kernel writes the products y[2i] conj(y[2i+1]) instead of the samples (FM, PostArgs.pairs)
-int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybuf, hipStream_t s, int n_cus, bool fix_later = false, bool pair_out = false) {
+int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybuf, hipStream_t s, int n_cus, bool fix_later = false, bool pair_out = false,
+                  bool row_pairs = false) {
     DecimArgs da;
+    memset(&da, 0, sizeof(da));
     da.raw = raw_dev;
     da.n_count = 0;
     da.tab = c->d_tab;
@@ -811,6 +820,8 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
     da.stamps = c->stamps_dev;
     da.stamp_wgs = c->stamp_wgs;
     da.pair_out = pair_out ? 1 : 0;
+    da.row_pair = row_pairs ? c->d_row_pair : nullptr;      // per-row modes: FM rows leave as pair products, each item in its samples' place
+    da.pair_wide = row_pairs ? 1 : 0;
     da.n_chunks = n_chunks;
     da.n = c->cfg.n_samples;
     da.m = c->m;
@@ -949,6 +960,7 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
 // the demodulation stage's arguments; iq_share: it also subtracts the offset share the fused IQ form leaves to it
 PostArgs post_args(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out_dev, bool iq_share, bool pairs = false) {
     PostArgs pa;
+    memset(&pa, 0, sizeof(pa));
     pa.y = ybuf;
     pa.resample_odd = c->d_resample;
     pa.fft_tw = c->d_fft_tw;
@@ -990,7 +1002,8 @@ int ensure_stash(sdrt_ctx *c, PostArgs &pa) {
     return SDRT_OK;
 }
 
-int enqueue_post(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out_dev, hipStream_t s, bool iq_share = false, bool pairs = false) {
+int enqueue_post(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out_dev, hipStream_t s, bool iq_share = false, bool pairs = false,
+                 bool row_pairs = false) {
     PostArgs pa = post_args(c, ybuf, n_chunks, out_dev, iq_share, pairs);
     if (!c->mixed) { int rcs = ensure_stash(c, pa); if (rcs != SDRT_OK) return rcs; }
     {
@@ -1002,6 +1015,11 @@ int enqueue_post(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out_d
                 pm.mode = md;
                 pm.row_map = c->d_rows_of[md];
                 pm.items = n_chunks * (size_t) c->n_rows_of[md];
+                if (md == SDRT_FM) {
+                    if (row_pairs) { pm.pairs = 1; pm.pairs_wide = 1; }
+                    int rcs = ensure_stash(c, pm);
+                    if (rcs != SDRT_OK) return rcs;
+                }
                 HIP_TRY(launch_post(pm, s));
             }
         } else
@@ -1059,9 +1077,18 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     // FM on the wide-column kernel, likewise without a debug buffer: the pair products instead of the samples (half the bytes
     // between the two stages); not with the offset share still to come
     const bool pairs = !ydec_dev && c->use_i8w && !c->stamps_dev && !later && !c->mixed && post_takes_pairs(post_args(c, ybuf, n_chunks, out_dev, false, true));
-    rc = enqueue_chain(c, raw_dev, n_chunks, ybuf, s, c->n_cus, later, pairs);
+    // per-row modes: the FM rows' items as pair products, every item in the place its samples would take (eight- and sixteen-tile
+    // chunks; the two-chunks-per-item forms keep samples)
+    bool row_pairs = false;
+    if (!ydec_dev && c->use_i8w && !c->stamps_dev && !later && c->mixed && c->d_row_pair && c->n_rows_of[SDRT_FM] > 0
+        && c->cfg.n_samples != 4 * SDRT_TB * SDRT_WIDE_LC) {
+        PostArgs pm = post_args(c, ybuf, n_chunks, out_dev, false, true);
+        pm.mode = SDRT_FM;
+        row_pairs = post_takes_pairs(pm);
+    }
+    rc = enqueue_chain(c, raw_dev, n_chunks, ybuf, s, c->n_cus, later, pairs, row_pairs);
     if (rc != SDRT_OK) return rc;
-    return enqueue_post(c, ybuf, n_chunks, out_dev, s, later, pairs);
+    return enqueue_post(c, ybuf, n_chunks, out_dev, s, later, pairs, row_pairs);
 }
 
 int sdrt_reserve(sdrt_ctx *c, size_t max_chunks) {

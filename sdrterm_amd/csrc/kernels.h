@@ -18,6 +18,8 @@ struct DecimArgs {
     unsigned long long *stamps; // optional diagnostic: [wg < stamp_wgs][wave][8] s_memtime at phase boundaries
     int stamp_wgs;
     int pair_out;               // wide-column kernel: ydec takes [row][chunk][m/2] products y[2i] conj(y[2i+1]) instead of the samples
+    const int *row_pair;        //   per-row modes: [rows] 1 = this row's items leave as pair products (FM), 0 = as samples (AM); NULL: pair_out for all
+    int pair_wide;              //   with row_pair: every item keeps the place the samples would take (products fill its first half)
     size_t n_chunks;            // chunks in the batch = row stride of ydec
     size_t n_count;             // wide-column kernel: chunks to process (0 = n_chunks); raw / ydec then point at the first of them
     int n, m, n_tiles, rows, swap;
@@ -94,6 +96,7 @@ struct PostArgs {
     const int *row_map;         // per-row demodulation modes: work item w = (k, chunk) stands for item (row_map[k], chunk) of the
                                 // batch; items = (rows of this mode) * n_chunks.  NULL: every row, item w is item w
     int pairs;                  // FM: y holds [items][m/2] products y[2i] conj(y[2i+1]) (DecimArgs.pair_out)
+    int pairs_wide;             //   ... each item in the place its m samples would take (DecimArgs.pair_wide: per-row modes)
     // eight / sixteen lanes per item (kernels_post8.hip; FM, m = 512 / 1024, lowpass = one complex pole pair + one real pole), or NULL
     const double *fft8_tab;     // [4][16 LPI][2] + [8][LPI][2]: sdrt_build_post8_tables
     const Post8Tables *p8tab;

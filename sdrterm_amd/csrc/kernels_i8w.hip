@@ -280,6 +280,8 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
 
     for (unsigned row = row0; row < (unsigned) a.rows; row += rstep) {
         __syncthreads();                             // nobody still reads the previous row's planes
+        // this row's items leave as samples or as pair products (per-row modes: FM rows products, AM rows samples)
+        const bool pr_row = a.row_pair ? a.row_pair[row] != 0 : a.pair_out != 0;
         {
             constexpr int MT = RS ? 1 : 2, LR = RS ? NOUT : NR;       // aggregate tiles, rows of the compact local planes
             const v4i *wg = (const v4i *) (a.w8 + (size_t) row * (size_t) (MT * S * KS * 1024));
@@ -738,13 +740,13 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
                     // one store instruction either way, and no lane masked off: for pairs the lanes of odd g form the same product
                     // from the same operands as their partners and write it to the same place (a store under a branch costs the
                     // exact vmcnt accounting of everything after it)
-                    const bool pr = a.pair_out != 0;
+                    const bool pr = pr_row;
                     // outputs of item it-3 (the first three iterations store to item 0's place, which P3(0) rewrites in iteration 3).
                     // The address is put together here, from scalars, where it is used: held from the top of the iteration it is
                     // a 64-bit value the register allocator spills, and its reload waits with vmcnt(0) -- a drain of the raw-sample
                     // prefetch ring in every iteration
                     // (and it is the same in every lane: in scalar registers, the lanes add 32-bit byte offsets)
-                    const uint64_t ydv = (uint64_t) (a.ydec + ((size_t) row * a.n_chunks + (size_t) chunk_of(have_p3 ? it - 3 : 0) * SEG) * (size_t) m * (pr ? 1 : 2));
+                    const uint64_t ydv = (uint64_t) (a.ydec + ((size_t) row * a.n_chunks + (size_t) chunk_of(have_p3 ? it - 3 : 0) * SEG) * (size_t) m * ((pr && !a.pair_wide) ? 1 : 2));
                     // (an address built from integers must say that it is global memory, or the store becomes a flat one)
                     typedef __attribute__((address_space(1))) char gchar;
                     typedef double v2d_ __attribute__((ext_vector_type(2)));

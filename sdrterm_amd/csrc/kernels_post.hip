@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
     const size_t witem = (size_t) blockIdx.x * wpb + wave;
     if (witem >= a.items) return;
     const size_t item = post_item(a, witem);
-    const cd *y = (const cd *) a.y + item * (size_t) (a.pairs ? N : m);
+    const cd *y = (const cd *) a.y + item * (size_t) ((a.pairs && !a.pairs_wide) ? N : m);
     const cd *R = a.iq_R ? (const cd *) a.iq_R + (item / a.n_chunks) * (size_t) m : nullptr;
     const cd h = a.iq_R ? ((const cd *) a.iq_off)[item % a.n_chunks] : mk(0.0, 0.0);
 
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
     // into one complex transform would make the last bits of one depend on the other)
     for (size_t witem = (size_t) blockIdx.x * WPB + wave; witem < a.items; witem += (size_t) gridDim.x * WPB) {
         const size_t item = post_item(a, witem);
-        const cd *y = (const cd *) a.y + item * (size_t) (PAIRS ? N : M);
+        const cd *y = (const cd *) a.y + item * (size_t) ((PAIRS && !a.pairs_wide) ? N : M);
         const cd *R = a.iq_R ? (const cd *) a.iq_R + (item / a.n_chunks) * (size_t) M : nullptr;
         const cd h = a.iq_R ? ((const cd *) a.iq_off)[item % a.n_chunks] : mk(0.0, 0.0);
         cd x[B][4];

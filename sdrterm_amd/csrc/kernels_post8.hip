@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
         // ---- pair angles: x[k] = a[2n] + i a[2n+1], n = l + LPI k (demodulation.py:25-32) -------------------------------
         cd x[P];
         if constexpr (PAIRS) {
-            const cd *y = (const cd *) a.y + it * (size_t) N;      // d[2i] conj(d[2i+1]) from the chain kernel
+            const cd *y = (const cd *) a.y + it * (size_t) (a.pairs_wide ? M : N);      // d[2i] conj(d[2i+1]) from the chain kernel
             cd pp[P][2];                                           // every load of the item in flight before the first angle
 #pragma unroll
             for (int k = 0; k < P; ++k) { pp[k][0] = y[2 * (l + LPI * k)]; pp[k][1] = y[2 * (l + LPI * k) + 1]; }

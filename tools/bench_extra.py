@@ -52,6 +52,8 @@ if __name__ == '__main__':
     run('configs[1] variant center=0 (no shift)', 16384, decimation=64, mode='fm', code='h', row_freqs=[0], apply_shift=False, omega_out=12500)
     run('configs[2]-like 8 VFOs FM dec=32 int16', 4096, decimation=32, mode='fm', code='h', row_freqs=VFOS8, omega_out=12500)
     run('configs[2] 8 VFOs FM dec=32 int16 --correct-iq', 4096, decimation=32, mode='fm', code='h', row_freqs=VFOS8, omega_out=12500, correct_iq=True)
+    run('configs[2] 8 VFOs FM+AM mixed dec=32 int16 --correct-iq', 4096, decimation=32, mode='fm', code='h', row_freqs=VFOS8, omega_out=12500, correct_iq=True,
+        row_modes=['fm', 'am'] * 4)
     run('configs[2] 8 VFOs AM dec=32 int16 --correct-iq --normalize', 4096, decimation=32, mode='am', code='h', row_freqs=VFOS8, omega_out=12500, correct_iq=True, normalize=True)
     run('single VFO FM dec=64 uint8', 8192, decimation=64, mode='fm', code='B', row_freqs=[15000], omega_out=12500)
     run('single VFO FM dec=32 uint8', 8192, decimation=32, mode='fm', code='B', row_freqs=[15000], omega_out=12500)
