@@ -590,7 +590,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         rc = upload(&c->d_resample, h.data(), h.size() * sizeof(double));
         const int N = m / 2;
         const char *pf = getenv("SDRTERM_RESAMPLE");             // diagnostics: "direct" forces the circulant product
-        if (rc == SDRT_OK && (N == 256 || N == 512 || N == 1024 || N == 2048) && !(pf && strcmp(pf, "direct") == 0)) {
+        if (rc == SDRT_OK && (N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096 || N == 8192) && !(pf && strcmp(pf, "direct") == 0)) {
             std::vector<double> tw((size_t) N * 2), sh((size_t) N * 2);
             sdrt_build_fft_resample(N, tw.data(), sh.data());
             rc = upload(&c->d_fft_tw, tw.data(), tw.size() * sizeof(double));

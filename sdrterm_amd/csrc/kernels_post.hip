@@ -561,6 +561,7 @@ hipError_t launch_post(const PostArgs &a, hipStream_t s) {
             case 4096: return launch_post_fft<8, 1>(a, s);
         }
     }
+    if (post_bigfft_supported(a)) return launch_post_bigfft(a, s);                            // kernels_seq.hip
     if (a.m >= 8192 && post_big_supported(a.m, a.mode)) return launch_post_big(a, s);       // kernels_seq.hip
     const int wpb = post_waves_per_block(a.m, a.mode);
     if (wpb == 0) return hipErrorInvalidValue;                      // sdrt_create refuses such a configuration

@@ -322,62 +322,9 @@ hipError_t launch_chain_seq(const DecimArgs &a, int q, int dt, bool nco, bool iq
     return hipErrorInvalidValue;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// post_big_kernel: FM pair angle (demodulation.py:25-32) + resample m/2 -> m (demodulation.py:35-38: even outputs are the
-// angles, odd outputs the circulant product with the half-sample kernel) or AM (demodulation.py:41-48), then the output
-// lowpass (dsp_processor.py:32-36,149) as a modal scan.  One workgroup of 256 threads per (chunk, row) item; the item's m
-// samples live in the output buffer itself between the steps.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void post_big_kernel(PostArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ cd ptot[SDRT_OUT_MAXMODES][4];
+// output lowpass of an item's m samples in place (dsp_processor.py:32-36,149), 256 threads: a modal scan over the workgroup
+__device__ __forceinline__ void workgroup_lowpass(const PostArgs &a, double *out, cd (&ptot)[SDRT_OUT_MAXMODES][4]) {
     const int m = a.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t item = post_item(a, blockIdx.x);
-    const cd *y = (const cd *) a.y + item * (size_t) m;
-    double *out = a.out + item * (size_t) m;
-    if (a.mode == SDRT_FM) {
-        const int N = m >> 1, msk = N - 1;
-        constexpr int AT = 2048, R = 16;                    // angles per LDS tile; outputs per thread and turn
-        double *hr = (double *) smem;                       // [N]: hr[i] = h[(-i) mod N]
-        double *at = hr + N;                                // [AT]
-        for (int i = tid; i < N; i += 256) hr[i] = a.resample_odd[i == 0 ? 0 : N - i];
-        for (int j = tid; j < N; j += 256) {
-            const cd pa = y[2 * j], c = y[2 * j + 1];
-            out[2 * j] = atan2(pa.im * c.re - pa.re * c.im, pa.re * c.re + pa.im * c.im);    // angle(d[i] * conj(d[i+1]))
-        }
-        __syncthreads();
-        // z_odd[j] = sum_k a[k] hr[(k - j) mod N]: thread owns R consecutive outputs per turn; a sliding register window
-        // feeds them from one new value of hr per k (as resample_wave does for one wave)
-        for (int j0 = R * tid; j0 < N; j0 += R * 256) {
-            double acc[R], B[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) { acc[r] = 0.0; B[r] = 0.0; }
-            for (int k0 = 0; k0 < N; k0 += AT) {
-                __syncthreads();
-                for (int i = tid; i < AT; i += 256) at[i] = out[2 * (k0 + i)];
-                __syncthreads();
-#pragma unroll
-                for (int r = 1; r < R; ++r) B[r] = hr[(k0 - j0 - r) & msk];
-                for (int k = 0; k < AT; k += R) {
-#pragma unroll
-                    for (int u = 0; u < R; ++u) {
-                        B[(R - u) % R] = hr[(k0 + k + u - j0) & msk];
-                        const double ak = at[k + u];
-#pragma unroll
-                        for (int r = 0; r < R; ++r) acc[r] = fma(ak, B[(r - u + R) % R], acc[r]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) out[2 * (j0 + r) + 1] = acc[r];
-        }
-    } else {
-        for (int k = tid; k < m; k += 256) {
-            const cd v = y[k];
-            out[k] = v.re * v.re + v.im * v.im;
-        }
-    }
-    __syncthreads();
     // ---- output lowpass: y[t] = D x[t] + sum_k Re(r_k s_k(t)), s_k(t+1) = p_k s_k(t) + x[t], s_k(0) = 0 --------------------
     const OutTables *__restrict__ ot = a.otab;
     const int nm = ot->nmodes;
@@ -433,6 +380,205 @@ __global__ __launch_bounds__(256) void post_big_kernel(PostArgs a) {
         }
         out[t0 + e] = yv;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// post_big_kernel: FM pair angle (demodulation.py:25-32) + resample m/2 -> m (demodulation.py:35-38: even outputs are the
+// angles, odd outputs the circulant product with the half-sample kernel) or AM (demodulation.py:41-48), then the output
+// lowpass (dsp_processor.py:32-36,149) as a modal scan.  One workgroup of 256 threads per (chunk, row) item; the item's m
+// samples live in the output buffer itself between the steps.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void post_big_kernel(PostArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ cd ptot[SDRT_OUT_MAXMODES][4];
+    const int m = a.m, tid = threadIdx.x;
+    const size_t item = post_item(a, blockIdx.x);
+    const cd *y = (const cd *) a.y + item * (size_t) m;
+    double *out = a.out + item * (size_t) m;
+    if (a.mode == SDRT_FM) {
+        const int N = m >> 1, msk = N - 1;
+        constexpr int AT = 2048, R = 16;                    // angles per LDS tile; outputs per thread and turn
+        double *hr = (double *) smem;                       // [N]: hr[i] = h[(-i) mod N]
+        double *at = hr + N;                                // [AT]
+        for (int i = tid; i < N; i += 256) hr[i] = a.resample_odd[i == 0 ? 0 : N - i];
+        for (int j = tid; j < N; j += 256) {
+            const cd pa = y[2 * j], c = y[2 * j + 1];
+            out[2 * j] = atan2(pa.im * c.re - pa.re * c.im, pa.re * c.re + pa.im * c.im);    // angle(d[i] * conj(d[i+1]))
+        }
+        __syncthreads();
+        // z_odd[j] = sum_k a[k] hr[(k - j) mod N]: thread owns R consecutive outputs per turn; a sliding register window
+        // feeds them from one new value of hr per k (as resample_wave does for one wave)
+        for (int j0 = R * tid; j0 < N; j0 += R * 256) {
+            double acc[R], B[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { acc[r] = 0.0; B[r] = 0.0; }
+            for (int k0 = 0; k0 < N; k0 += AT) {
+                __syncthreads();
+                for (int i = tid; i < AT; i += 256) at[i] = out[2 * (k0 + i)];
+                __syncthreads();
+#pragma unroll
+                for (int r = 1; r < R; ++r) B[r] = hr[(k0 - j0 - r) & msk];
+                for (int k = 0; k < AT; k += R) {
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        B[(R - u) % R] = hr[(k0 + k + u - j0) & msk];
+                        const double ak = at[k + u];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r] = fma(ak, B[(r - u + R) % R], acc[r]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) out[2 * (j0 + r) + 1] = acc[r];
+        }
+    } else {
+        for (int k = tid; k < m; k += 256) {
+            const cd v = y[k];
+            out[k] = v.re * v.re + v.im * v.im;
+        }
+    }
+    __syncthreads();
+    workgroup_lowpass(a, out, ptot);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// post_bigfft_kernel: the same stage with scipy.signal.resample as the reference computes it (rfft, zero-pad, irfft;
+// demodulation.py:35-38) for the sizes the decimation factors 2 and 4 -- the CLI's default among them -- produce: N = m/2 = 4096 or
+// 8192 pair angles per chunk.  One workgroup of 256 threads per item; Stockham radix-4 passes (+ one radix-2 pass for 8192 = 2 x 4^6)
+// through one LDS image of the sequence, in place: every pass loads all of its points into registers, the workgroup meets, then
+// stores.  O(N log N) where post_big_kernel's circulant product is O(N^2): 4.5 -> 0.3 ms per 1024 chunks at decimation 2.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ int xq(int i) { return i + (i >> 4); }       // one pad element per sixteen (8192 points: 136 KB)
+__device__ __forceinline__ cd csub_(cd a, cd b) { return mk(a.re - b.re, a.im - b.im); }
+template <bool INV> __device__ __forceinline__ cd cmul_tw_(cd v, cd w) {     // v * w (forward) or v * conj(w) (inverse)
+    if constexpr (INV) return mk(fma(v.re, w.re, v.im * w.im), fma(v.im, w.re, -(v.re * w.im)));
+    else return mk(fma(v.re, w.re, -(v.im * w.im)), fma(v.re, w.im, v.im * w.re));
+}
+// one radix-4 Stockham pass over N = 1024 B points held as x[b][k] = X[t + k N/4], t = tid + 256 b; sub-transform length N / S_
+template <int B, int S_, bool INV, class Store>
+__device__ __forceinline__ void radix4_pass_wg(cd (&x)[B][4], const cd *__restrict__ tw, const int tid, Store store) {
+    constexpr int N = 1024 * B, n = N / S_;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const int t = tid + 256 * b, p = t / S_, q = t % S_;
+        const cd a0 = x[b][0], a1 = x[b][1], a2 = x[b][2], a3 = x[b][3];
+        const cd t0 = cadd(a0, a2), t1 = csub_(a0, a2), t2 = cadd(a1, a3), t3 = csub_(a1, a3);
+        const cd jt3 = INV ? mk(-t3.im, t3.re) : mk(t3.im, -t3.re);
+        cd y0 = cadd(t0, t2), y1 = cadd(t1, jt3), y2 = csub_(t0, t2), y3 = csub_(t1, jt3);
+        if constexpr (n > 4) {
+            y1 = cmul_tw_<INV>(y1, tw[p * S_]);
+            y2 = cmul_tw_<INV>(y2, tw[2 * p * S_]);
+            y3 = cmul_tw_<INV>(y3, tw[3 * p * S_]);
+        }
+        const int o = q + S_ * 4 * p;
+        store(o, y0);
+        store(o + S_, y1);
+        store(o + 2 * S_, y2);
+        store(o + 3 * S_, y3);
+    }
+}
+// a whole transform: x holds the first pass's input; the result goes to store_last(index, value) in natural order
+template <int B, bool INV, class Store>
+__device__ __forceinline__ void fft_workgroup(cd (&x)[B][4], cd *X, const cd *__restrict__ tw, const int tid, Store store_last) {
+    constexpr int N = 1024 * B;
+    constexpr bool R2 = B == 8;                      // 8192 = 2 x 4^6: a final radix-2 pass; 4096 = 4^6
+    auto stX = [&](int o, cd v) { X[xq(o)] = v; };
+    auto reload = [&]() {
+        __syncthreads();                             // the pass's stores are there
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[b][k] = X[xq(tid + 256 * b + k * (N / 4))];
+        __syncthreads();                             // everybody holds its points: the image may be overwritten
+    };
+    radix4_pass_wg<B, 1, INV>(x, tw, tid, stX);
+    reload();
+    radix4_pass_wg<B, 4, INV>(x, tw, tid, stX);
+    reload();
+    radix4_pass_wg<B, 16, INV>(x, tw, tid, stX);
+    reload();
+    radix4_pass_wg<B, 64, INV>(x, tw, tid, stX);
+    reload();
+    radix4_pass_wg<B, 256, INV>(x, tw, tid, stX);
+    reload();
+    if constexpr (!R2) {
+        radix4_pass_wg<B, 1024, INV>(x, tw, tid, store_last);
+    } else {
+        radix4_pass_wg<B, 1024, INV>(x, tw, tid, stX);
+        __syncthreads();
+        // n = 2: y[q] = a + b, y[q + N/2] = a - b, q < N/2
+#pragma unroll
+        for (int c = 0; c < N / 512; ++c) {
+            const int q = tid + 256 * c;
+            const cd u = X[xq(q)], v = X[xq(q + N / 2)];
+            store_last(q, cadd(u, v));
+            store_last(q + N / 2, csub_(u, v));
+        }
+    }
+}
+}  // namespace
+
+template <int B>
+__global__ __launch_bounds__(256) void post_bigfft_kernel(PostArgs a) {
+    constexpr int N = 1024 * B, M = 2 * N;
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ cd ptot[SDRT_OUT_MAXMODES][4];
+    cd *X = (cd *) smem;                                        // [N + N/16]
+    const cd *__restrict__ tw = (const cd *) a.fft_tw;          // [N] exp(-2 pi i k/N), from L2
+    const cd *__restrict__ sh = (const cd *) a.fft_shift;       // [N] half-sample shift / N
+    const int tid = threadIdx.x;
+    const size_t item = post_item(a, blockIdx.x);
+    const cd *y = (const cd *) a.y + item * (size_t) M;
+    double *out = a.out + item * (size_t) M;
+    cd x[B][4];
+    // pair angles (demodulation.py:25-32): the even output samples, and the real input of the transform
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = tid + 256 * b + k * (N / 4);
+            const cd pa = y[2 * j], c = y[2 * j + 1];
+            const double an = atan2(pa.im * c.re - pa.re * c.im, pa.re * c.re + pa.im * c.im);
+            out[2 * j] = an;
+            x[b][k] = mk(an, 0.0);
+        }
+    fft_workgroup<B, false>(x, X, tw, tid, [&](int o, cd v) { X[xq(o)] = v; });
+    __syncthreads();
+    // spectrum x half-sample shift, inverse transform: the odd output samples (imaginary parts are rounding noise)
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int f = tid + 256 * b + k * (N / 4);
+            x[b][k] = cmul(X[xq(f)], sh[f]);
+        }
+    __syncthreads();
+    fft_workgroup<B, true>(x, X, tw, tid, [&](int o, cd v) { out[2 * o + 1] = v.re; });
+    __syncthreads();
+    workgroup_lowpass(a, out, ptot);
+}
+
+bool post_bigfft_supported(const PostArgs &a) {
+    return a.mode == SDRT_FM && a.fft_tw && a.fft_shift && (a.m == 8192 || a.m == 16384) && !a.pairs && !a.iq_R;
+}
+
+hipError_t launch_post_bigfft(const PostArgs &a, hipStream_t s) {
+    const int N = a.m / 2;
+    const size_t lds = (size_t) (N + N / 16) * 16;
+    static thread_local int done_dev[2] = {-1, -1};
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    const int which = a.m == 16384 ? 1 : 0;
+    if (done_dev[which] != dev) {
+        hipError_t e = which ? hipFuncSetAttribute((const void *) post_bigfft_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)
+                             : hipFuncSetAttribute((const void *) post_bigfft_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+        done_dev[which] = dev;
+    }
+    if (which) hipLaunchKernelGGL(post_bigfft_kernel<8>, dim3((unsigned) a.items), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(post_bigfft_kernel<4>, dim3((unsigned) a.items), dim3(256), lds, s, a);
+    return hipGetLastError();
 }
 
 bool post_big_supported(int m, int mode) {
