@@ -552,6 +552,7 @@ hipError_t launch_post(const PostArgs &a, hipStream_t s) {
         return hipGetLastError();
     }
     if (post_fft8_supported(a)) return launch_post_fft8(a, s);                                // kernels_post8.hip
+    if (post_bigfft_supported(a)) return launch_post_bigfft(a, s);                            // kernels_seq.hip: a workgroup per item, 2048 outputs and up
     // FFT form of the resampler where it applies: FM, N = m/2 in {256, 512, 1024}, output lowpass in modal form
     if (a.mode == SDRT_FM && a.fft_tw && a.fft_shift && a.fft_ok) {
         switch (a.m) {
@@ -561,7 +562,6 @@ hipError_t launch_post(const PostArgs &a, hipStream_t s) {
             case 4096: return launch_post_fft<8, 1>(a, s);
         }
     }
-    if (post_bigfft_supported(a)) return launch_post_bigfft(a, s);                            // kernels_seq.hip
     if (a.m >= 8192 && post_big_supported(a.m, a.mode)) return launch_post_big(a, s);       // kernels_seq.hip
     const int wpb = post_waves_per_block(a.m, a.mode);
     if (wpb == 0) return hipErrorInvalidValue;                      // sdrt_create refuses such a configuration

@@ -14,6 +14,8 @@
 // post_big_kernel: the demodulation stage for chunks whose m outputs do not fit one wave's LDS share (m > 4096): one
 // workgroup per item, FM resampler as the circulant product with the half-sample kernel (O(N^2), LDS-tiled), output
 // lowpass as a modal scan over the workgroup.
+#include <cstdlib>
+
 #include "kernels_common.hpp"
 
 namespace {
@@ -478,11 +480,12 @@ __device__ __forceinline__ void radix4_pass_wg(cd (&x)[B][4], const cd *__restri
         store(o + 3 * S_, y3);
     }
 }
-// a whole transform: x holds the first pass's input; the result goes to store_last(index, value) in natural order
+// a whole transform: x holds the first pass's input; the result goes to store_last(index, value) in natural order.
+// N = 1024 B = 4^5 (B = 1), 2 x 4^5 (2), 4^6 (4), 2 x 4^6 (8): five or six radix-4 passes, then a radix-2 pass where a factor 2 is left
 template <int B, bool INV, class Store>
 __device__ __forceinline__ void fft_workgroup(cd (&x)[B][4], cd *X, const cd *__restrict__ tw, const int tid, Store store_last) {
     constexpr int N = 1024 * B;
-    constexpr bool R2 = B == 8;                      // 8192 = 2 x 4^6: a final radix-2 pass; 4096 = 4^6
+    constexpr bool R2 = B == 2 || B == 8, SIX = B >= 4;
     auto stX = [&](int o, cd v) { X[xq(o)] = v; };
     auto reload = [&]() {
         __syncthreads();                             // the pass's stores are there
@@ -500,12 +503,15 @@ __device__ __forceinline__ void fft_workgroup(cd (&x)[B][4], cd *X, const cd *__
     reload();
     radix4_pass_wg<B, 64, INV>(x, tw, tid, stX);
     reload();
-    radix4_pass_wg<B, 256, INV>(x, tw, tid, stX);
-    reload();
+    if constexpr (SIX) {
+        radix4_pass_wg<B, 256, INV>(x, tw, tid, stX);
+        reload();
+    }
+    constexpr int SL = SIX ? 1024 : 256;             // the last radix-4 pass
     if constexpr (!R2) {
-        radix4_pass_wg<B, 1024, INV>(x, tw, tid, store_last);
+        radix4_pass_wg<B, SL, INV>(x, tw, tid, store_last);
     } else {
-        radix4_pass_wg<B, 1024, INV>(x, tw, tid, stX);
+        radix4_pass_wg<B, SL, INV>(x, tw, tid, stX);
         __syncthreads();
         // n = 2: y[q] = a + b, y[q + N/2] = a - b, q < N/2
 #pragma unroll
@@ -519,7 +525,7 @@ __device__ __forceinline__ void fft_workgroup(cd (&x)[B][4], cd *X, const cd *__
 }
 }  // namespace
 
-template <int B>
+template <int B, bool PAIRS>
 __global__ __launch_bounds__(256) void post_bigfft_kernel(PostArgs a) {
     constexpr int N = 1024 * B, M = 2 * N;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(256) void post_bigfft_kernel(PostArgs a) {
     const cd *__restrict__ sh = (const cd *) a.fft_shift;       // [N] half-sample shift / N
     const int tid = threadIdx.x;
     const size_t item = post_item(a, blockIdx.x);
-    const cd *y = (const cd *) a.y + item * (size_t) M;
+    const cd *y = (const cd *) a.y + item * (size_t) ((PAIRS && !a.pairs_wide) ? N : M);
     double *out = a.out + item * (size_t) M;
     cd x[B][4];
     // pair angles (demodulation.py:25-32): the even output samples, and the real input of the transform
@@ -538,8 +544,14 @@ __global__ __launch_bounds__(256) void post_bigfft_kernel(PostArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int j = tid + 256 * b + k * (N / 4);
-            const cd pa = y[2 * j], c = y[2 * j + 1];
-            const double an = atan2(pa.im * c.re - pa.re * c.im, pa.re * c.re + pa.im * c.im);
+            double an;
+            if constexpr (PAIRS) {
+                const cd z = y[j];                              // d[2j] conj(d[2j+1]) from the chain kernel
+                an = atan2(z.im, z.re);
+            } else {
+                const cd pa = y[2 * j], c = y[2 * j + 1];
+                an = atan2(pa.im * c.re - pa.re * c.im, pa.re * c.re + pa.im * c.im);
+            }
             out[2 * j] = an;
             x[b][k] = mk(an, 0.0);
         }
@@ -560,25 +572,32 @@ __global__ __launch_bounds__(256) void post_bigfft_kernel(PostArgs a) {
 }
 
 bool post_bigfft_supported(const PostArgs &a) {
-    return a.mode == SDRT_FM && a.fft_tw && a.fft_shift && (a.m == 8192 || a.m == 16384) && !a.pairs && !a.iq_R;
+    // (2048 / 4096 outputs per chunk stay with the one-wave kernel of kernels_post.hip: a workgroup per item measured 0.289 against
+    // 0.251 ms per 2^29 8-bit samples at decimation 32 there, profiles/r03_experiments.txt)
+    return a.mode == SDRT_FM && a.fft_tw && a.fft_shift && !a.iq_R && !a.pairs && (a.m == 8192 || a.m == 16384);
+}
+
+template <int B, bool PAIRS>
+static hipError_t launch_post_bigfft_b(const PostArgs &a, hipStream_t s) {
+    const size_t lds = (size_t) (1024 * B + 64 * B) * 16;
+    static thread_local int done_dev = -1;
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    if (done_dev != dev) {
+        hipError_t e = hipFuncSetAttribute((const void *) post_bigfft_kernel<B, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+        done_dev = dev;
+    }
+    hipLaunchKernelGGL((post_bigfft_kernel<B, PAIRS>), dim3((unsigned) a.items), dim3(256), lds, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_post_bigfft(const PostArgs &a, hipStream_t s) {
-    const int N = a.m / 2;
-    const size_t lds = (size_t) (N + N / 16) * 16;
-    static thread_local int done_dev[2] = {-1, -1};
-    int dev = 0;
-    (void) hipGetDevice(&dev);
-    const int which = a.m == 16384 ? 1 : 0;
-    if (done_dev[which] != dev) {
-        hipError_t e = which ? hipFuncSetAttribute((const void *) post_bigfft_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)
-                             : hipFuncSetAttribute((const void *) post_bigfft_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        if (e != hipSuccess) return e;
-        done_dev[which] = dev;
+    switch (a.m) {
+        case 8192: return launch_post_bigfft_b<4, false>(a, s);
+        case 16384: return launch_post_bigfft_b<8, false>(a, s);
     }
-    if (which) hipLaunchKernelGGL(post_bigfft_kernel<8>, dim3((unsigned) a.items), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(post_bigfft_kernel<4>, dim3((unsigned) a.items), dim3(256), lds, s, a);
-    return hipGetLastError();
+    return hipErrorInvalidValue;
 }
 
 bool post_big_supported(int m, int mode) {
