@@ -1100,8 +1100,12 @@ int sdrt_reserve(sdrt_ctx *c, size_t max_chunks) {
     if (rc == SDRT_OK && c->iq) rc = ensure_iqrange(c, max_chunks);
     if (rc == SDRT_OK) rc = ensure_pairbufs(c);
     if (rc == SDRT_OK) rc = ensure_prebufs(c, max_chunks);
-    if (rc == SDRT_OK && !c->mixed) {
+    if (rc == SDRT_OK) {
         PostArgs pa = post_args(c, nullptr, max_chunks, nullptr, false, true);
+        if (c->mixed) {                                       // per-row modes: the FM rows' launch is the one that keeps a stash
+            pa.mode = SDRT_FM;
+            pa.items = max_chunks * (size_t) c->n_rows_of[SDRT_FM];
+        }
         rc = ensure_stash(c, pa);
     }
     return rc;

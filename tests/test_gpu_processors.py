@@ -651,6 +651,15 @@ def test_reserve_and_error_paths_of_the_abi():
     a, b = eng.iq_range_device(d_raw.ptr, nch)
     nat.check(lib.sdrt_device_synchronize())
     assert lib.sdrt_alloc_count() == n0, 'a processing call within the reserved size allocated device memory'
+    # ... also with per-row modes (the FM rows' demodulation launch keeps a stash of its own)
+    mixed = Engine(fs, q, 'fm', 'h', row_freqs=[15700.0, -1000.0], row_modes=['fm', 'am'], apply_shift=True, omega_out=5000, correct_iq=True,
+                   reserve_chunks=nch)
+    mixed.process_device(d_raw.ptr, 1, d_out.ptr)
+    nat.check(lib.sdrt_device_synchronize())
+    nm = lib.sdrt_alloc_count()
+    mixed.process_device(d_raw.ptr, nch, d_out.ptr)
+    nat.check(lib.sdrt_device_synchronize())
+    assert lib.sdrt_alloc_count() == nm, 'a reserved context with per-row modes allocated device memory while processing'
     small = Engine(fs, q, 'fm', 'h', row_freqs=[15700.0, -1000.0], apply_shift=True, omega_out=5000, correct_iq=True)
     n1 = lib.sdrt_alloc_count()
     small.process_device(d_raw.ptr, nch, d_out.ptr)
