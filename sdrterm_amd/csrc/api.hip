@@ -358,19 +358,25 @@ int setup_i8t(sdrt_ctx *c, const sdrt_config *cfg, ScaleFn &scale_tables) {
 }
 
 // The int8 kernels filter x - x_offset (the slices' range); the decimator is linear, so its response to the constant the
-// slices leave out (plus the normalisation bias) is one vector per row: run the fp64 kernel once on a constant chunk.
+// slices leave out (plus the normalisation bias) is one vector per row.  Two parts (round 4):
+//  * the normalisation bias (re only): the fp64 kernel once on that constant chunk;
+//  * the slices' offset: MINUS what the int8 kernel itself makes of an all-zero chunk (calibrate_zero_response, below) -- the
+//    reference turns a zero chunk into exact zeros (angle(0) = 0, demodulation.py:30-32), and only the kernel's own response,
+//    quantised weights and rounding included, cancels to the last bit.  (The fp64 response to the constant, used before,
+//    left 128 x 2^-39 of the weights behind: harmless beside any signal, but the FM angle of a silent chunk was noise.)
 int setup_ybias(sdrt_ctx *c, const sdrt_config *cfg) {
     static const double kOff[8] = {0.0, 128.0, 128.0, 32896.0, 0, 0, 0, 0};
     const int n = cfg->n_samples, m = c->m;
     c->x_offset = kOff[cfg->dtype];
     const size_t bytes = (size_t) c->rows * m * 2 * sizeof(double);
     if (!c->iq && (c->x_offset != 0.0 || c->norm_bias != 0.0)) {
-        const double cre = c->x_offset + c->norm_bias, cim = c->x_offset;
-        std::vector<double> cz((size_t) n * 2);
-        for (int i = 0; i < n; ++i) { cz[2 * i] = cre; cz[2 * i + 1] = cim; }
+        if (hipMalloc(&c->d_ybias, bytes) != hipSuccess) return fail(SDRT_ENOMEM, "hipMalloc failed");
+        if (hipMemset(c->d_ybias, 0, bytes) != hipSuccess) return fail(SDRT_EHIP, "hipMemset failed");
+        if (c->norm_bias == 0.0) return SDRT_OK;
+        std::vector<double> cz((size_t) n * 2, 0.0);
+        for (int i = 0; i < n; ++i) cz[2 * i] = c->norm_bias;
         double *d_cz = nullptr;
         int rc = upload(&d_cz, cz.data(), cz.size() * sizeof(double));
-        if (rc == SDRT_OK && hipMalloc(&c->d_ybias, bytes) != hipSuccess) rc = fail(SDRT_ENOMEM, "hipMalloc failed");
         if (rc == SDRT_OK) {
             DecimArgs da;
             memset(&da, 0, sizeof(da));
@@ -398,6 +404,8 @@ int setup_ybias(sdrt_ctx *c, const sdrt_config *cfg) {
     }
     return SDRT_OK;
 }
+
+int calibrate_zero_response(sdrt_ctx *c);       // after enqueue_chain
 
 }  // namespace
 
@@ -641,6 +649,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         if (const char *e = getenv("SDRTERM_F32_PRE")) c->f32_pre = c->use_i8w && cfg->dtype == SDRT_F32 && atoi(e) != 0;
     }
     if (rc == SDRT_OK && c->use_i8) rc = setup_ybias(c, cfg);
+    if (rc == SDRT_OK && c->use_i8) rc = calibrate_zero_response(c);
     if (rc != SDRT_OK) {
         sdrt_destroy(c);
         return rc;
@@ -954,6 +963,33 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
         if (!fix_later) HIP_TRY(launch_iq_fix(ybuf, c->d_iq_R, c->d_iq_chunk, c->rows, n_chunks, c->m, s));
     }
     return SDRT_OK;
+}
+
+// ybias -= (the stage-A kernel this context will run, applied to one all-zero chunk): see setup_ybias.  The kernel's bits for a
+// chunk do not depend on the batch around it (tests: the batch-size and determinism cases, zero chunks scattered over a batch).
+int calibrate_zero_response(sdrt_ctx *c) {
+    // (--correct-iq: the offset term carries the constant and those forms take no ybias)
+    if (!c->use_i8 || c->iq || c->x_offset == 0.0 || !c->d_ybias) return SDRT_OK;
+    const size_t cb = (size_t) c->cfg.n_samples * 2 * kItemSize[c->cfg.dtype];
+    const size_t cnt = (size_t) c->rows * c->m * 2;
+    void *d_zero = nullptr;
+    double *d_r0 = nullptr;
+    int rc = SDRT_OK;
+    if (hipMalloc(&d_zero, cb) != hipSuccess || hipMalloc(&d_r0, cnt * sizeof(double)) != hipSuccess) rc = fail(SDRT_ENOMEM, "hipMalloc failed");
+    std::vector<double> bias(cnt), r0(cnt);
+    if (rc == SDRT_OK && hipMemset(d_zero, 0, cb) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemset failed");
+    if (rc == SDRT_OK && hipMemcpy(bias.data(), c->d_ybias, cnt * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemcpy failed");
+    if (rc == SDRT_OK && hipMemset(c->d_ybias, 0, cnt * sizeof(double)) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemset failed");
+    if (rc == SDRT_OK) rc = enqueue_chain(c, d_zero, 1, d_r0, nullptr, c->n_cus);
+    if (rc == SDRT_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(SDRT_EHIP, "zero-response kernel failed");
+    if (rc == SDRT_OK && hipMemcpy(r0.data(), d_r0, cnt * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemcpy failed");
+    if (rc == SDRT_OK) {
+        for (size_t i = 0; i < cnt; ++i) bias[i] -= r0[i];
+        if (hipMemcpy(c->d_ybias, bias.data(), cnt * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemcpy failed");
+    }
+    (void) hipFree(d_zero);
+    (void) hipFree(d_r0);
+    return rc;
 }
 
 // demodulate, resample, output lowpass, --smooth-output (dsp_processor.py:148-149,159-160)

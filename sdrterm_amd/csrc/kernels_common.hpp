@@ -309,6 +309,7 @@ __device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, cons
             v.im += 2.0 * (f.re * Fb.re - f.im * Fb.im + gq.re * Gb.re - gq.im * Gb.im);
         }
         if (ybias) { v.re += ybias[k].re; v.im += ybias[k].im; }
+        else { v.re += 0.0; v.im += 0.0; }           // -0.0 -> +0.0: angle(-0) would be pi where the reference's exact zeros give 0
         *(double2 *) (yd + 2 * (size_t) k) = make_double2(v.re, v.im);
     }
     SDRT_STAMP(5);

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, (G > 1 || DT == SDRT_F32 ? 2 : 3)) void chain_
             mx = max(mx, (unsigned) __shfl_xor((int) mx, 16));
             mx = max(mx, (unsigned) __shfl_xor((int) mx, 32));
             const int e = (int) (mx >> 23) - 126;    // |x| < 2^e for every sample of the column (e = -126 for an all-zero column)
-            colscale = __hiloint2double((1023 + e - 30) << 20, 0);
+            colscale = mx == 0 ? 0.0 : __hiloint2double((1023 + e - 30) << 20, 0);     // a silent column contributes exact zeros
             u0r = (double) __uint_as_float(cur[0]);
             u0i = (double) __uint_as_float(cur[1]);
 #pragma unroll

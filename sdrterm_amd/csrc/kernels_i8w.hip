@@ -86,7 +86,12 @@ __device__ __forceinline__ void f32_slices(const uint32_t *cur, const int sh, v4
     }
 }
 // the exponent a tile is sliced against: that of its largest magnitude, rounded up to a multiple of four
-__device__ __forceinline__ int f32_tile_exponent(unsigned max_abs_bits) { return (((int) (max_abs_bits >> 23) - 126) + 3) & ~3; }
+// (an all-zero tile: -993, for which the scale 2^(E - 30) below is the double with exponent field 0, i.e. exactly 0.0 -- a silent
+// tile contributes exact zeros, as in the reference, not 2^-154 of rounding residue whose FM angle would be noise)
+#define SDRT_F32_SILENT (-993)
+__device__ __forceinline__ int f32_tile_exponent(unsigned max_abs_bits) {
+    return max_abs_bits == 0 ? SDRT_F32_SILENT : (((int) (max_abs_bits >> 23) - 126) + 3) & ~3;
+}
 
 struct WideLds {        // byte offsets
     int wmain, wloc, cF, cG, bp, mup, tpw, tailF, tailFc, psi, gv, pq, cpow, wiq, buf, buf_stride, total;
@@ -484,7 +489,10 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
             for (int j = 0; j < TPW; ++j)
 #pragma unroll
                 for (int e = 0; e < OPL; ++e) {
-                    if constexpr (IQA || F32) yb[j][e] = mk(0.0, 0.0);          // no constant response: the offset term carries it
+                    // float32: no constant left out; --correct-iq: the offset term carries it (the registers of those forms do not hold a
+                    // ybias besides: their residue for a silent stream with a zero offset, ~2^-39 of the offset, stays -- DESIGN section 1).
+                    // (+0.0 still turns a -0.0 into +0.0: angle(-0) would be pi where the reference's exact zeros give 0)
+                    if constexpr (IQA || F32) yb[j][e] = mk(0.0, 0.0);
                     else yb[j][e] = ybias[(((wave + WV * j) % NTC) * SDRT_TB + nb) * NOUT + g + 4 * e];
                 }
             cd off_head = mk(0.0, 0.0), off_tail = mk(0.0, 0.0), off_q = mk(0.0, 0.0), gq[TPW];
@@ -725,12 +733,12 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
 #pragma unroll
                         for (int e = 0; e < OPL; ++e) {
                             const cd f = cFL[(e * 4 + mode) * 64 + lane], gq = cGL[(e * 4 + mode) * 64 + lane];
-                            if constexpr (mode == 0) {
-                                const cd y0 = SHQ ? yqs[0][e] : yq[0][j][e];
-                                pv[j][e] = mk(y0.re + yb[j][e].re, y0.im + yb[j][e].im);
-                            }
+                            if constexpr (mode == 0) pv[j][e] = SHQ ? yqs[0][e] : yq[0][j][e];
                             pv[j][e].re = fma(f.re, Fa.re, fma(-f.im, Fa.im, fma(gq.re, Ga.re, fma(-gq.im, Ga.im, pv[j][e].re))));
                             pv[j][e].im = fma(f.re, Fb.re, fma(-f.im, Fb.im, fma(gq.re, Gb.re, fma(-gq.im, Gb.im, pv[j][e].im))));
+                            // the response to the constant the slices leave out goes in LAST: it is minus what this very sequence of
+                            // operations makes of an all-zero chunk (api.hip: calibrate_zero_response), so a silent chunk cancels to the bit
+                            if constexpr (mode == 3) pv[j][e] = mk(pv[j][e].re + yb[j][e].re, pv[j][e].im + yb[j][e].im);
                         }
                     }
                 } else if constexpr (i == P3_0 + 4) {

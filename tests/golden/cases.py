@@ -64,6 +64,65 @@ CASES = [
     # the same normalise flag in an FM and an AM run of one 9-row layout: what a context with per-row modes must equal
     _c('h_q32_fm_norm_vfo9_iq', 'h', 32, 'fm', center=15700, vfos=_VFOS8, normalize=True, correct_iq=True,
        n_chunks=3, dc=(500, -300), seed=20),
+    # ---- round 4: classes of input other than moderate white noise (prng.case_ints documents the ``sig`` kinds) ----------------
+    # (i) the encodings' rails and the byte-slice corner values (x = 256 hi + lo' + 128), in every position incl. the 28-sample edges
+    _c('h_q64_fm_rails_c0', 'h', 64, 'fm', n_chunks=3, amp=8000, seed=50, sig=dict(kind='rails', chunks=['corners', 'const', 'edges'])),
+    _c('h_q64_fm_rails_c', 'h', 64, 'fm', center=15700, n_chunks=3, amp=8000, seed=51, sig=dict(kind='rails', chunks=['corners', 'two', 'edges'])),
+    _c('h_q32_am_rails_c', 'h', 32, 'am', center=15700, n_chunks=3, amp=8000, seed=52, sig=dict(kind='rails', chunks=['two', 'corners', 'const'])),
+    _c('B_q64_fm_rails_c', 'B', 64, 'fm', center=15700, n_chunks=3, amp=100, seed=53, sig=dict(kind='rails', chunks=['corners', 'two', 'edges'])),
+    _c('B_q64_fm_rails_c0', 'B', 64, 'fm', n_chunks=3, amp=100, seed=54, sig=dict(kind='rails', chunks=['two', 'const', 'corners'])),
+    _c('H_q64_fm_rails_c', 'H', 64, 'fm', center=15700, n_chunks=3, amp=8000, seed=55, sig=dict(kind='rails', chunks=['corners', 'two', 'edges'])),
+    _c('b_q32_fm_rails_c', 'b', 32, 'fm', center=15700, n_chunks=2, amp=100, seed=56, sig=dict(kind='rails', chunks=['two', 'corners'])),
+    _c('h_q64_fm_rails_iq', 'h', 64, 'fm', center=15700, correct_iq=True, n_chunks=3, amp=8000, seed=57,
+       sig=dict(kind='rails', chunks=['corners', 'two', 'edges'])),
+    _c('h_q16_fm_rails_c', 'h', 16, 'fm', center=15700, omega_out=15000, n_chunks=2, amp=8000, seed=58, sig=dict(kind='rails', chunks=['two', 'edges'])),
+    _c('h_q2_fm_rails_c', 'h', 2, 'fm', center=15700, omega_out=100000, n_chunks=2, amp=8000, seed=59, sig=dict(kind='rails', chunks=['corners', 'edges'])),
+    # (ii) the class of stream bench.py times: an FM tone (1 kHz modulation, 2.5 kHz deviation) of amplitude 8000 + bell noise sigma 300
+    _c('h_q64_fm_tone_bench', 'h', 64, 'fm', center=15000, omega_out=12500, fs=256000000, seed=60,
+       sig=dict(kind='tone', a=8000, f=15000, fm=1000, dev=2500, noise=260)),
+    _c('h_q64_fm_tone_1m', 'h', 64, 'fm', center=15700, seed=61, sig=dict(kind='tone', a=8000, f=15700, fm=1000, dev=2500, noise=260)),
+    _c('B_q64_fm_tone_1m', 'B', 64, 'fm', center=15700, seed=62, amp=100, sig=dict(kind='tone', a=62, f=15700, fm=1000, dev=2500, noise=2)),
+    _c('h_q64_am_tone_norm', 'h', 64, 'am', center=15700, normalize=True, seed=63, sig=dict(kind='tone', a=8000, f=15700, fm=1000, dev=2500, noise=260)),
+    _c('h_q64_fm_tone_iq_dc', 'h', 64, 'fm', center=15700, correct_iq=True, n_chunks=3, dc=(20000, -20000), seed=64,
+       sig=dict(kind='tone', a=8000, f=15700, fm=1000, dev=2500, noise=260)),
+    _c('h_q32_fm_tone_vfo8_iq_dc_bench', 'h', 32, 'fm', center=15000, vfos=_VFOS7_BENCH, omega_out=12500, fs=256000000, correct_iq=True,
+       n_chunks=3, dc=(20000, -20000), seed=65, sig=dict(kind='tone', a=8000, f=15000, fm=1000, dev=2500, noise=260)),
+    # (iii) a weak in-band tone under a full-scale out-of-band one (the worst case of the int8 path's 2^-39 weight image); the row sits
+    # on 15625 Hz = 1000 fs/65536, the weak tone 1 kHz above it, the strong one 200 kHz (far) or 12.5 kHz (transition band) above it
+    _c('h_q64_fm_blk60', 'h', 64, 'fm', center=15625, seed=66, sig=dict(kind='blocker', a1=32000, f1=215625, f2=16625, db=-60)),
+    _c('h_q64_fm_blk80', 'h', 64, 'fm', center=15625, seed=67, sig=dict(kind='blocker', a1=32000, f1=215625, f2=16625, db=-80)),
+    _c('h_q64_fm_blk80_near', 'h', 64, 'fm', center=15625, seed=68, sig=dict(kind='blocker', a1=32000, f1=28125, f2=16625, db=-80)),
+    _c('h_q64_am_blk60', 'h', 64, 'am', center=15625, seed=69, sig=dict(kind='blocker', a1=32000, f1=215625, f2=16625, db=-60)),
+    _c('h_q32_fm_blk60_iq_dc', 'h', 32, 'fm', center=15625, correct_iq=True, n_chunks=3, dc=(20000, -20000), seed=70,
+       sig=dict(kind='blocker', a1=12000, f1=215625, f2=16625, db=-60)),
+    _c('B_q64_fm_blk40', 'B', 64, 'fm', center=15625, amp=100, seed=71, sig=dict(kind='blocker', a1=120, f1=215625, f2=16625, db=-40)),
+    _c('h_q64_fm_blk80_c0', 'h', 64, 'fm', center=0, seed=72, sig=dict(kind='blocker', a1=32000, f1=200000, f2=1000, db=-80)),
+    # (iv) full-scale impulses on the first / last samples of a chunk (scipy's odd extension by 27, dsp_processor.py:147) over noise
+    _c('h_q64_fm_impulse_c', 'h', 64, 'fm', center=15700, amp=1000, seed=73, sig=dict(kind='impulse', at=[0, 26, -27, -1])),
+    _c('h_q64_fm_impulse_c0', 'h', 64, 'fm', amp=1000, seed=74, sig=dict(kind='impulse', at=[0, 26, -27, -1])),
+    _c('h_q16_fm_impulse_c', 'h', 16, 'fm', center=15700, omega_out=15000, amp=1000, seed=75, sig=dict(kind='impulse', at=[0, 26, -27, -1])),
+    _c('h_q2_am_impulse_c', 'h', 2, 'am', center=15700, omega_out=100000, amp=1000, seed=76, sig=dict(kind='impulse', at=[0, 26, -27, -1])),
+    _c('B_q64_fm_impulse_c', 'B', 64, 'fm', center=15700, amp=30, seed=77, sig=dict(kind='impulse', at=[0, 26, -27, -1])),
+    # (v) all-zero chunks between (and before) loud ones: the reference writes exact zeros there (angle(0) = 0)
+    _c('h_q64_fm_zero_c', 'h', 64, 'fm', center=15700, n_chunks=3, amp=8000, seed=78, sig=dict(kind='zero', chunks=[1])),
+    _c('h_q64_fm_zero_c0', 'h', 64, 'fm', n_chunks=3, amp=8000, seed=79, sig=dict(kind='zero', chunks=[0, 2])),
+    _c('h_q32_am_zero_vfo9', 'h', 32, 'am', center=15700, vfos=_VFOS8, n_chunks=3, amp=8000, seed=80, sig=dict(kind='zero', chunks=[1])),
+    _c('h_q32_fm_zero_vfo9', 'h', 32, 'fm', center=15700, vfos=_VFOS8, n_chunks=3, amp=8000, seed=81, sig=dict(kind='zero', chunks=[1])),
+    _c('B_q64_fm_zero_c', 'B', 64, 'fm', center=15700, n_chunks=3, amp=100, seed=82, sig=dict(kind='zero', chunks=[1])),
+    _c('H_q64_fm_zero_c', 'H', 64, 'fm', center=15700, n_chunks=3, amp=8000, seed=83, sig=dict(kind='zero', chunks=[1])),
+    # (--correct-iq: the silent chunk is -offset, a slowly decaying exponential; on the row's own frequency it is the signal.  With the
+    # row 15.7 kHz away it would be 164 dB down in the stop band -- an FM angle of 1e-13 of the input peak, which no arithmetic
+    # other than the reference's own operation order reproduces to 1e-6: DESIGN section 1, "conditioning")
+    _c('h_q64_fm_zero_iq_dc_c0', 'h', 64, 'fm', center=0, correct_iq=True, n_chunks=3, dc=(20000, -20000), amp=8000, seed=84,
+       sig=dict(kind='zero', chunks=[1])),
+    _c('f_q64_fm_zero_c', 'f', 64, 'fm', center=15700, n_chunks=3, amp=8000, seed=85, sig=dict(kind='zero', chunks=[1])),
+    _c('h_q4_fm_zero_c', 'h', 4, 'fm', center=15700, omega_out=60000, n_chunks=3, amp=8000, seed=86, sig=dict(kind='zero', chunks=[1])),
+    _c('h_q16_fm_zero_c', 'h', 16, 'fm', center=15700, omega_out=15000, n_chunks=3, amp=8000, seed=87, sig=dict(kind='zero', chunks=[1])),
+    # a stream that STARTS silent under --correct-iq (offset exactly zero): the reference writes zeros for that chunk.  The int8 forms
+    # with --correct-iq carry the slices' constant in the offset term and leave ~1e-10 of it behind (no ybias in those kernels), so their
+    # FM angle of that chunk is noise: the test compares that chunk through the decimated samples (silent_start), the rest as usual
+    _c('h_q64_fm_zero_iq_start', 'h', 64, 'fm', center=15700, correct_iq=True, n_chunks=3, amp=8000, seed=88, sig=dict(kind='zero', chunks=[0]),
+       silent_start=1),
 ]
 
 BY_NAME = {c['name']: c for c in CASES}

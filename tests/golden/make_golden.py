@@ -79,8 +79,7 @@ def run_reader(case):
     dt = DataType[code].value
     dt = dt.newbyteorder('>' if case.get('big_endian') else '<')
     n = READ_SIZE // (2 * dt.itemsize)
-    data = prng.raw_bytes(code, n * case['n_chunks'], case['seed'], case['amp'], tuple(case.get('dc', (0, 0))),
-                          big_endian=bool(case.get('big_endian')))
+    data = prng.case_bytes(case, n)
     sink = _Sink()
     with tempfile.NamedTemporaryFile(suffix='.raw', delete=False) as f:
         f.write(data)

@@ -37,8 +37,7 @@ def samples_per_chunk(code: str) -> int:
 
 def case_raw(case: dict) -> bytes:
     n = samples_per_chunk(case['code'])
-    return prng.raw_bytes(case['code'], n * case['n_chunks'], case['seed'], case['amp'],
-                          tuple(case.get('dc', (0, 0))), big_endian=bool(case.get('big_endian')))
+    return prng.case_bytes(case, n)
 
 
 # float32 input: the reference itself runs the decimator in complex64 (see oracle/ref_chain.process_chunk),
