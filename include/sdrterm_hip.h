@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SDRT_ABI_VERSION 5
+#define SDRT_ABI_VERSION 6
 
 /* Input encodings: src/misc/file_util.py:44-56 (DataType b,B,h,H,i,I,f,d). */
 enum sdrt_dtype {
@@ -202,6 +202,13 @@ int sdrt_event_record(void *event, void *stream);
 int sdrt_stream_wait_event(void *stream, void *event);
 int sdrt_event_query(void *event, int *done);
 int sdrt_event_synchronize(void *event);
+/* ABI 6: events that carry a time stamp (sdrt_event_create's do not: cheaper to record), the milliseconds between two of them once
+ * both have completed, and a device-to-device copy on a stream -- what a host needs to time steps and to stage blocks without any
+ * other GPU runtime binding (bench.py times its steps with these; the reference has no counterpart, it times with `time`,
+ * example.sh:43,52). */
+int sdrt_event_create_timed(void **event);
+int sdrt_event_elapsed_ms(void *start, void *stop, double *ms);
+int sdrt_memcpy_d2d_async(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 
 /*
  * Multi-GPU --simo: one process per GPU runs VfoProcessor (vfo_processor.py:38-57,80-126) on its

@@ -60,9 +60,11 @@ def correct_iq(z: np.ndarray, off: complex, fs: float, impedance: float = 50):
     Returns (corrected z, carried offset).  Sequential by definition.
     """
     L = impedance / fs
-    out = np.empty_like(z)
-    for i in range(z.shape[0]):
-        v = z[i] - off
+    zz = np.asarray(z, dtype=np.complex128)            # the gufunc's signature is complex128 (read_file.py:66)
+    out = np.empty(zz.shape, dtype=np.complex128)
+    off = complex(off)
+    for i in range(zz.shape[0]):
+        v = complex(zz[i]) - off
         out[i] = v
         off = off + v * L
     return out, off

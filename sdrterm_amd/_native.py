@@ -18,7 +18,7 @@ ITEM_SIZE = {'b': 1, 'B': 1, 'h': 2, 'H': 2, 'i': 4, 'I': 4, 'f': 4, 'd': 8}
 MODES = {'fm': 0, 'am': 1, 're': 2, 'im': 3}
 OK, EINVAL, EHIP, ENOMEM, ENODEVICE = 0, 1, 2, 3, 4
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 EXPORTS = (
     'sdrt_abi_version', 'sdrt_config_size', 'sdrt_device_count', 'sdrt_last_error', 'sdrt_create', 'sdrt_destroy',
     'sdrt_out_per_chunk', 'sdrt_rows', 'sdrt_process_device', 'sdrt_process_host',
@@ -32,6 +32,7 @@ EXPORTS = (
     'sdrt_comm_destroy', 'sdrt_submit_host', 'sdrt_wait', 'sdrt_spectrum_host', 'sdrt_stft_host', 'sdrt_iq_range_device',
     'sdrt_event_create', 'sdrt_event_destroy', 'sdrt_event_record', 'sdrt_stream_wait_event', 'sdrt_event_query',
     'sdrt_event_synchronize', 'sdrt_reserve', 'sdrt_taps_release', 'sdrt_mem_info', 'sdrt_alloc_count',
+    'sdrt_event_create_timed', 'sdrt_event_elapsed_ms', 'sdrt_memcpy_d2d_async',
 )
 
 
@@ -153,6 +154,9 @@ def lib():
     l.sdrt_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p]
     l.sdrt_event_query.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     l.sdrt_event_synchronize.argtypes = [C.c_void_p]
+    l.sdrt_event_create_timed.argtypes = [C.POINTER(C.c_void_p)]
+    l.sdrt_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    l.sdrt_memcpy_d2d_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     l.sdrt_comm_unique_id.argtypes = [C.c_void_p]
     l.sdrt_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     l.sdrt_comm_bcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
@@ -220,6 +224,18 @@ class DeviceBuffer:
     def download(self, out):
         assert out.flags['C_CONTIGUOUS'] and out.nbytes <= self.nbytes
         check(lib().sdrt_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def upload_at(self, offset: int, data) -> 'DeviceBuffer':
+        import numpy as np
+        a = np.ascontiguousarray(data)
+        assert offset + a.nbytes <= self.nbytes
+        check(lib().sdrt_memcpy_h2d(self.ptr + int(offset), a.ctypes.data, a.nbytes))
+        return self
+
+    def download_at(self, offset: int, out):
+        assert out.flags['C_CONTIGUOUS'] and offset + out.nbytes <= self.nbytes
+        check(lib().sdrt_memcpy_d2h(out.ctypes.data, self.ptr + int(offset), out.nbytes))
         return out
 
     def free(self):

@@ -1426,6 +1426,26 @@ int sdrt_event_create(void **event) {
     *event = (void *) e;
     return SDRT_OK;
 }
+int sdrt_event_create_timed(void **event) {
+    if (!event) return fail(SDRT_EINVAL, "null argument");
+    hipEvent_t e = nullptr;
+    HIP_TRY(hipEventCreate(&e));
+    *event = (void *) e;
+    return SDRT_OK;
+}
+int sdrt_event_elapsed_ms(void *start, void *stop, double *ms) {
+    if (!start || !stop || !ms) return fail(SDRT_EINVAL, "null argument");
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, (hipEvent_t) start, (hipEvent_t) stop));
+    *ms = (double) t;
+    return SDRT_OK;
+}
+int sdrt_memcpy_d2d_async(void *dst_dev, const void *src_dev, size_t bytes, void *stream) {
+    if (bytes == 0) return SDRT_OK;
+    if (!dst_dev || !src_dev) return fail(SDRT_EINVAL, "null buffer");
+    HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t) stream));
+    return SDRT_OK;
+}
 int sdrt_event_destroy(void *event) {
     HIP_TRY(hipEventDestroy((hipEvent_t) event));
     return SDRT_OK;

@@ -241,11 +241,13 @@ class RcclTransport:
             time.sleep(0.1)
 
     def bcast_device(self, dev_ptr: int, nbytes: int, root: int = 0, stream: int = 0, scatter: Optional[bool] = None) -> None:
-        """In place on device memory, asynchronous on ``stream``.  ``scatter`` (default: SDRTERM_BCAST=scatter in the environment):
-        the root sends every rank its 1/world of the block and the ranks all-gather the shards -- every xGMI link carries one shard
-        instead of every hop of a ring the whole block (sdrt_comm_bcast_scatter; opt-in: this builder could not time it on N GPUs)."""
+        """In place on device memory, asynchronous on ``stream``.  ``scatter`` (the default whenever the block divides by the number
+        of ranks; SDRTERM_BCAST=ring in the environment or scatter=False selects ncclBroadcast): the root sends every rank its
+        1/world of the block and the ranks all-gather the shards -- every xGMI link carries one shard instead of every hop of a ring
+        the whole block (sdrt_comm_bcast_scatter).  xGMI is point to point: a whole-block broadcast is bound by one link per hop
+        (DESIGN section 5), which is why the form that uses all seven links of the root at once is the default."""
         if scatter is None:
-            scatter = os.environ.get('SDRTERM_BCAST') == 'scatter'
+            scatter = self.world > 1 and nbytes % self.world == 0 and os.environ.get('SDRTERM_BCAST', 'scatter') != 'ring'
         fn = self._nat.lib().sdrt_comm_bcast_scatter if scatter else self._nat.lib().sdrt_comm_bcast
         self._nat.check(fn(self._comm, dev_ptr, nbytes, root, stream or None))
 

@@ -603,12 +603,14 @@ def test_iq_offset_of_a_chunk_range_and_a_stream_processed_in_two_parts(code, fu
 
 @pytest.mark.parametrize('argv', [['--workload', 'simo64', '--feed', 'bcast', '--chunks', '32'],
                                   ['--workload', 'simo64', '--feed', 'allgather', '--chunks', '32'],
-                                  ['--workload', 'fm64', '--chunks', '256']])
+                                  ['--workload', 'simo8', '--chunks', '64'],
+                                  ['--workload', 'fm64', '--chunks', '256'],
+                                  ['--workload', 'fm64', '--chunks', '256', '--correct-iq']])
 def test_bench_rank_plumbing_on_one_gpu(argv):
     """bench.py's multi-rank plumbing with a single rank (--force-comm): the RCCL communicator behind the C ABI comes up inside
-    the bench process (torch loaded first, one HIP runtime), barrier and maximum over ranks go through it, blocks reach the
-    rank by broadcast or all-gather on the communication stream beside the kernels -- and the line it prints carries what the
-    contract asks for, every number measured by that run."""
+    the bench process (no torch in it: buffers, streams and events are the C ABI's), barrier and maximum over ranks go through it,
+    blocks reach the rank by broadcast or all-gather on the communication stream beside the kernels -- and the line it prints
+    carries what the contract asks for, every number measured by that run, with the sampled comparison against the oracle."""
     import json
     import subprocess
     import sys
@@ -619,12 +621,42 @@ def test_bench_rank_plumbing_on_one_gpu(argv):
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and d['unit'] == 'MSamples/s' and d['higher_is_better'] is True
-    assert d['roofline']['bound'] in ('hbm', 'mfma') and 0 < d['roofline']['frac'] < 1 and d['roofline']['traffic'] is None
+    assert d['roofline']['bound'] in ('hbm', 'mfma') and 0 < d['roofline']['frac'] < 1
     assert d['vs_baseline'] is None and d['data'] == 'synthetic' and 'workload' in d['config']
-    if argv[1] == 'fm64':
-        assert d['roofline']['from_profile'] is None            # another batch size than the committed counter record's
+    par = d['parity']
+    print(argv, 'parity:', par)
+    assert par['ok'] is True and par['max_abs_err'] <= 1e-6 and len(par['chunks']) >= 4 and 'oracle/chain.c' in par['checker']
+    if argv[1] == 'simo8':
+        assert d['roofline']['bound'] == 'mfma' and 'hbm' in d['roofline'] and par['am_max_err_rel_to_peak'] <= 1e-6
+        assert 'FM+AM mixed' in d['config']['workload'] and '--correct-iq' in d['config']['workload'] and d['config']['rows_per_gpu'] == 8
+    if argv[1] == 'fm64' and '--correct-iq' not in argv:
+        fp = d['roofline']['from_profile']                      # another batch size than the committed counter record's: quoted scaled, and said so
+        assert fp is None or (fp['traffic_scaled_from_chunks'] == 131072 and d['roofline']['traffic'] == fp['traffic'])
         assert d['same_arithmetic']['stage_a'] == 'f64' and 0 < d['same_arithmetic']['path_frac'] < 1      # (tiny batch: no ranking of the two)
         assert 0 < d['roofline']['read_frac'] < d['roofline']['path_frac']
+
+
+def test_bench_py_uses_no_torch():
+    """north_star: "no PyTorch".  bench.py and everything it imports on the measured path stay clear of torch: a run with an
+    import hook that refuses torch still prints its line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hook = ("import sys, runpy\n"
+            "class _No:\n"
+            "    def find_spec(self, name, path=None, target=None):\n"
+            "        if name == 'torch' or name.startswith('torch.'):\n"
+            "            raise ImportError('torch is not to be imported by bench.py')\n"
+            "sys.meta_path.insert(0, _No())\n"
+            f"sys.argv = ['bench.py', '--steps', '2', '--warmup', '1', '--settle-seconds', '0.1', '--long-seconds', '0', '--no-cpu-baseline', '--no-same-arithmetic', '--chunks', '128']\n"
+            f"runpy.run_path({os.path.join(root, 'bench.py')!r}, run_name='__main__')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env['SDRTERM_SYSTEM_HIP'] = '1'                      # and the library binds the system HIP runtime, not the one a torch wheel bundles
+    out = subprocess.run([sys.executable, '-c', hook], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d['value'] > 0 and d['parity']['ok'] is True
 
 
 def test_reserve_and_error_paths_of_the_abi():

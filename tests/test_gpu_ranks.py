@@ -36,12 +36,12 @@ def _bench(n_ranks, *flags):
 
 @pytest.mark.parametrize('n_ranks,flags', [(2, ('--workload', 'simo64', '--chunks', '64')),
                                            (3, ('--workload', 'simo64', '--chunks', '48', '--feed', 'allgather')),
-                                           (4, ('--workload', 'simo64', '--chunks', '64')),
+                                           (4, ('--workload', 'simo64', '--chunks', '64', '--feed', 'bcast')),
                                            (4, ('--workload', 'simo64', '--chunks', '64', '--feed', 'scatter')),
                                            (3, ('--workload', 'simo64', '--chunks', '64', '--feed', 'scatter')),
                                            (2, ('--workload', 'f32x256', '--chunks', '32')),
                                            (2, ('--workload', 'fm64', '--chunks', '1024'))],
-                         ids=['simo64-bcast-2', 'simo64-allgather-3', 'simo64-bcast-4', 'simo64-scatter-4', 'simo64-scatter-3-falls-back', 'f32x256-bcast-2', 'fm64-chunks-2'])
+                         ids=['simo64-default-2', 'simo64-allgather-3', 'simo64-bcast-4', 'simo64-scatter-4', 'simo64-scatter-3-falls-back', 'f32x256-default-2', 'fm64-chunks-2'])
 def test_bench_with_several_ranks_on_one_gpu(n_ranks, flags):
     """bench.py --gpus N without a launcher: N rank processes, rows (or chunks) sharded, one exchange per step; the line rank 0
     prints counts every rank's work and the configuration says how the rows were split."""
@@ -51,7 +51,9 @@ def test_bench_with_several_ranks_on_one_gpu(n_ranks, flags):
     rows_total = {'simo64': 64, 'f32x256': 256, 'fm64': 1}[wl]
     if rows_total > 1:
         assert line['scaling'] == 'strong' and line['config']['rows_per_gpu'] == -(-rows_total // n_ranks)      # rank 0 takes the larger share
-        assert line['config']['parallelism'] == f'rows-sharded x{n_ranks} + ' + (flags[flags.index('--feed') + 1] if '--feed' in flags else 'bcast')
+        # the default feed: scatter + all-gather whenever the block divides by the number of ranks (else ncclBroadcast)
+        default = 'scatter' if (int(flags[3]) * 131072) % n_ranks == 0 else 'bcast'
+        assert line['config']['parallelism'] == f'rows-sharded x{n_ranks} + ' + (flags[flags.index('--feed') + 1] if '--feed' in flags else default)
         samples = int(flags[3]) * line['config']['samples_per_chunk']
     else:
         assert line['scaling'] == 'weak' and line['config']['parallelism'] == f'chunk-sharded x{n_ranks}'

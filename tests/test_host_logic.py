@@ -116,7 +116,7 @@ def test_shared_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(lib, n), f'{n} declared in the header but not exported'
     assert set(_native.EXPORTS) <= names
-    assert _native.lib().sdrt_abi_version() == _native.ABI_VERSION == 5
+    assert _native.lib().sdrt_abi_version() == _native.ABI_VERSION == 6
     assert ctypes.sizeof(_native.Config) == _native.lib().sdrt_config_size()
 
 
