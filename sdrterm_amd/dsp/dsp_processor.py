@@ -255,6 +255,10 @@ class DspProcessor(DataProcessor):
         except (OSError, ValueError, NotImplementedError, AttributeError):
             return False
 
+    def _halted(self, isDead) -> bool:
+        """The reference's loop condition (dsp_processor.py:168): the processor's own flag or the shared halt flag."""
+        return bool(self._isDead or isDead.value)
+
     def _processData(self, isDead, buffer, file=None) -> None:
         pending = None              # a batch whose kernels run while the next one is taken from the Queue and copied in
 
@@ -266,22 +270,29 @@ class DspProcessor(DataProcessor):
             if p is not None:
                 self._emit(self._collectBatch(p), file)
 
-        while not (self._isDead or isDead.value):
-            chunks, eof = self._takeBatch(buffer)
-            if chunks:
-                if self._shift is None:
-                    self._generateShift(chunks[0].size)
-                started = self._submitBatch(chunks)
-                flush()
-                pending = started
-                if eof or not self._moreQueued(buffer):      # nothing to overlap with: write it out now (latency)
+        try:
+            while not self._halted(isDead):
+                chunks, eof = self._takeBatch(buffer)
+                if chunks:
+                    if self._shift is None:
+                        self._generateShift(chunks[0].size)
+                    started = self._submitBatch(chunks)
                     flush()
-            if eof:
-                flush()             # (the end marker alone in this batch: the one before it is still in flight)
-                # the reference's loop ends on the ValueError numpy raises for ``x[0, :] = b''``
-                # (dsp_processor.py:170, swallowed by processData's finally/return)
-                raise _EndOfStream('end of stream')
-        flush()                     # halt flag: what is in flight still goes out; an exception leaves it behind
+                    pending = started
+                    if eof or not self._moreQueued(buffer):      # nothing to overlap with: write it out now (latency)
+                        flush()
+                if eof:
+                    flush()             # (the end marker alone in this batch: the one before it is still in flight)
+                    # the reference's loop ends on the ValueError numpy raises for ``x[0, :] = b''``
+                    # (dsp_processor.py:170, swallowed by processData's finally/return)
+                    raise _EndOfStream('end of stream')
+        except KeyboardInterrupt:
+            # Ctrl-C while waiting for the Queue (or a halt seen there): the reference has written every chunk it processed
+            # before it leaves (dsp_processor.py:162-183) -- the batch in flight goes out too.  (flush() empties `pending`
+            # first, so an interrupt raised by the write itself does not write it twice.)
+            flush()
+            raise
+        flush()                     # halt flag: what is in flight still goes out; an error leaves it behind
 
     def _generateShift(self, c: int) -> None:
         """Host copy of the NCO row for callers that inspect ``_shift`` (dsp_processor.py:185-187: only when

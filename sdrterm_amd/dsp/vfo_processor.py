@@ -11,9 +11,12 @@ chain kernel (the NCO rows live in the kernel's tables); the socket side is ``fa
 Several GPUs (``gpus=N`` keyword, or ``SDRTERM_GPUS``): the rows are split contiguously over N
 processes, one per GPU.  The process the CLI started (io_args.py:92-95) is rank 0: it owns the reader's Queue, starts
 the N-1 others, and hands every raw block to them (``parallel.BlockChannel``: RCCL broadcast between device buffers).
-Rank r computes rows [lo_r, hi_r) only and serves them on TCP port ``port + r`` -- client k of that port gets row
-lo_r + k -- with the reference's handshake per port (no processing before every row of every rank has its client: the
-block exchange is collective, so one waiting rank holds all of them).  Block k+1 is uploaded and broadcast beside the
+Rank r computes rows [lo_r, hi_r) only.  Every row is served on the ONE port the reference serves it on
+(vfo_processor.py:99-110): rank 0 listens, the k-th connection is row k of the reference's order, and a connection whose row
+belongs to another rank is handed to that process (its file descriptor travels over a Unix socket, ``fanout.py``), which then
+writes to the client directly -- ``example_simo.sh``-style clients work unchanged.  The reference's handshake holds for the job
+as a whole (no processing before every row of every rank has its client: the block exchange is collective, so one waiting rank
+holds all of them).  Block k+1 is uploaded and broadcast beside the
 kernels of block k (two device buffers per rank, a communication stream, events: ``parallel.RcclTransport``), as the
 single-GPU loop overlaps its copy-in.  Every wait on a collective is bounded and watches the halt flag and the helper
 processes: a rank that dies takes the job down (halt flag up, non-zero exit) instead of leaving the others in a collective.
@@ -23,7 +26,7 @@ import os
 import numpy as np
 
 from .dsp_processor import DspProcessor, _EndOfStream
-from .fanout import RowFanOut
+from .fanout import make_fanout
 from ..misc.general_util import eprint, findPort, vprint
 
 
@@ -38,6 +41,7 @@ def _rank_main(processor, rank, world, uid, isDead):
     """Entry point of the helper processes (ranks 1 .. world-1): the same processor, pickled, on another GPU.  A helper that
     cannot go on raises the shared halt flag: rank 0 and the reader watch it."""
     try:
+        processor._parentPid = os.getppid()          # rank 0: while it lives, this rank waits for its blocks
         processor._enterRank(rank, world, uid)
         processor.processData(isDead, None)
     except BaseException:
@@ -129,10 +133,22 @@ class VfoProcessor(DspProcessor):
         self._channel = parallel.BlockChannel(t, chunk_bytes)
 
     def _jobAlive(self) -> bool:
-        """False once the job is going down: the halt flag is up, or (rank 0) a helper process has exited."""
-        if self._isDead or bool(self._halt.value):
+        """False once the job is going down.  Rank 0: the halt flag is up or a helper process has exited.  The other ranks do
+        NOT watch the halt flag: when it goes up (Ctrl-C, the reader's end) rank 0 still sends them an end-of-stream block, and
+        they must be in the collective to take it -- a helper that left on the flag alone would leave rank 0 with a broadcast no
+        peer completes.  They watch rank 0 itself (their parent process) and the transport's timeout."""
+        if self._isDead:
+            return False
+        if self._rank > 0:
+            parent = getattr(self, '_parentPid', None)
+            return parent is None or os.getppid() == parent
+        if bool(self._halt.value):
             return False
         return all(p.is_alive() for p in self._helpers)
+
+    def _halted(self, isDead) -> bool:
+        # ranks 1 .. N-1 leave on the end-of-stream block rank 0 sends them when IT leaves (halt flag included), not on the flag
+        return bool(self._isDead) if (self._channelled() and self._rank > 0) else super()._halted(isDead)
 
     def _takeBatch(self, buffer):
         """Rank 0 takes the batch from the reader's Queue as the single-GPU processor does and sends it on; the other
@@ -241,6 +257,7 @@ class VfoProcessor(DspProcessor):
         if self._channelled() and self._rank == 0 and not getattr(self, '_eofSent', False):
             self._eofSent = True
             if not all(p.is_alive() for p in self._helpers):
+                self._abandon = True             # a collective may still sit in the stream with nobody to complete it
                 return
             try:
                 if self._channel is not None and hasattr(self._channel.t, 'alive'):
@@ -248,7 +265,7 @@ class VfoProcessor(DspProcessor):
                 self._announce(None)
                 self._channel.exchange(b'', 0, True)
             except Exception:
-                pass
+                self._abandon = True             # the end-of-stream block did not get through: nothing behind it may be waited for
 
     @staticmethod
     def _bytesOf(chunk) -> bytes:
@@ -268,15 +285,14 @@ class VfoProcessor(DspProcessor):
         import multiprocessing as mp
         import socket
         from ..parallel import RcclTransport
-        # every rank serves its own port: all of them must be free before anybody starts (a helper that cannot bind would
-        # leave the others in their first collective)
-        for r in range(self._gpus):
-            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as probe:
-                probe.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                try:
-                    probe.bind((self.host, self.port + r))
-                except OSError as e:
-                    raise OSError(f'{self.host}:{self.port + r} (rank {r} of --simo on {self._gpus} GPUs) is not free: {e}') from e
+        # the one port of the job must be free before anybody starts (rank 0 failing to bind after the helpers are up would leave
+        # them in their first collective)
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as probe:
+            probe.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                probe.bind((self.host, self.port))
+            except OSError as e:
+                raise OSError(f'{self.host}:{self.port} (--simo on {self._gpus} GPUs) is not free: {e}') from e
         uid = RcclTransport.unique_id() if self._transportKind == 'rccl' else None
         ctx = mp.get_context('spawn')
         self._helpers = [ctx.Process(target=_rank_main, args=(self, r, self._gpus, uid, isDead), daemon=True)
@@ -293,7 +309,7 @@ class VfoProcessor(DspProcessor):
                 self._startHelpers(isDead)
             sh = self._shard()
             self._nFreq = sh.rows
-            self._fanout = RowFanOut(self.host, sh.port(self.port), sh.rows)
+            self._fanout = make_fanout(self.host, self.port, self._rank, sh.bounds)
             self._fanout.start()
             if self._world > 1 and self._rank == 0 and self._transportKind == 'rccl':
                 self._openChannel(1)               # every rank joins the communicator now (the helpers are in theirs already)
@@ -315,7 +331,8 @@ class VfoProcessor(DspProcessor):
                 self._fanout.close()
             if self._channel is not None:
                 try:
-                    self._channel.t.close(abandon=True) if failed and hasattr(self._channel.t, 'wait_event') else self._channel.t.close()
+                    abandon = failed or getattr(self, '_abandon', False)
+                    self._channel.t.close(abandon=True) if abandon and hasattr(self._channel.t, 'wait_event') else self._channel.t.close()
                 except Exception:
                     pass
             for p in self._helpers:
@@ -334,4 +351,5 @@ class VfoProcessor(DspProcessor):
         state['_stream'], state['_slots'] = None, [None, None]
         state['_helpers'] = []
         state.pop('_halt', None)
+        state.pop('_abandon', None)
         return state

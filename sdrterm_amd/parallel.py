@@ -173,7 +173,7 @@ class RcclTransport:
     UID_PORTS = 16            # rank 0 listens on the first free one of this many ports from the base on
 
     @staticmethod
-    def _exchange_uid(rank: int, world: int) -> bytes:
+    def _exchange_uid(rank: int, world: int, job: Optional[str] = None) -> bytes:
         """The 128-byte id from rank 0 to the others over TCP at MASTER_ADDR, ports MASTER_PORT + 17 .. + 32 (or from
         SDRTERM_UID_PORT on): rank 0 takes the first free one, the others knock until one of them answers with the magic word
         and this world size (a launcher's own store or a stranger's service on one of the ports is passed over)."""
@@ -181,7 +181,12 @@ class RcclTransport:
             return RcclTransport.unique_id()
         addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
         base = int(os.environ.get('SDRTERM_UID_PORT', int(os.environ.get('MASTER_PORT', '29500')) + 17))
-        hello = RcclTransport.UID_MAGIC + struct.pack('<q', world)
+        # the hello names the job as well: two jobs on one host whose port ranges overlap (and whose world sizes agree) must not
+        # take each other's id -- SDRTERM_JOB_ID if the launcher gives one, else MASTER_ADDR:MASTER_PORT, which differ per job
+        import hashlib
+        job = job or os.environ.get('SDRTERM_JOB_ID') or f"{addr}:{os.environ.get('MASTER_PORT', '29500')}"
+        token = hashlib.sha256(job.encode()).digest()[:8]
+        hello = RcclTransport.UID_MAGIC + struct.pack('<q', world) + token
         if rank == 0:
             uid = RcclTransport.unique_id()
             srv = None
@@ -200,22 +205,25 @@ class RcclTransport:
             with srv:
                 srv.listen(world)
                 srv.settimeout(float(os.environ.get('SDRTERM_COMM_INIT_TIMEOUT', '600')))
-                served = 0
-                while served < world - 1:
+                served = set()                               # distinct ranks: a rank that asks twice (a retry) counts once
+                while len(served) < world - 1:
                     conn, _peer = srv.accept()
                     with conn:
                         conn.settimeout(10)
                         try:
                             got = b''
-                            while len(got) < len(hello):
-                                part = conn.recv(len(hello) - len(got))
+                            while len(got) < len(hello) + 4:
+                                part = conn.recv(len(hello) + 4 - len(got))
                                 if not part:
                                     break
                                 got += part
-                            if got != hello:
+                            if len(got) != len(hello) + 4 or got[:len(hello)] != hello:
                                 continue                     # not one of ours
+                            peer_rank = struct.unpack('<i', got[len(hello):])[0]
+                            if not 0 < peer_rank < world:
+                                continue
                             conn.sendall(hello + uid)
-                            served += 1
+                            served.add(peer_rank)
                         except OSError:
                             continue
             return uid
@@ -225,7 +233,7 @@ class RcclTransport:
                 try:
                     with socket.create_connection((addr, port), timeout=2) as s:
                         s.settimeout(5)
-                        s.sendall(hello)
+                        s.sendall(hello + struct.pack('<i', rank))
                         got = b''
                         while len(got) < len(hello) + 128:
                             part = s.recv(len(hello) + 128 - len(got))
@@ -264,8 +272,8 @@ class RcclTransport:
         """Host wait for ``event`` by polling: returns when it has completed, raises ``PeerLost`` after ``timeout`` seconds
         (None: this transport's) or as soon as ``self.alive()`` says the job is going down (halt flag, a dead helper)."""
         nat, done = self._nat, C.c_int(0)
-        deadline = None if (timeout if timeout is not None else self.timeout) is None else \
-            time.monotonic() + (timeout if timeout is not None else self.timeout)
+        limit = timeout if timeout is not None else self.timeout
+        deadline = None if limit is None else time.monotonic() + limit
         pause = 0.0
         while True:
             nat.check(nat.lib().sdrt_event_query(event, C.byref(done)))
@@ -274,7 +282,7 @@ class RcclTransport:
             if self.alive is not None and not self.alive():
                 raise PeerLost(f'{what}: the job is going down')
             if deadline is not None and time.monotonic() > deadline:
-                raise PeerLost(f'{what}: no completion within {self.timeout} s (a peer rank is gone?)')
+                raise PeerLost(f'{what}: no completion within {limit:g} s (a peer rank is gone?)')
             time.sleep(pause)
             pause = min(0.002, pause + 0.0001)              # spin first: a block broadcast takes tens of microseconds
 
@@ -324,7 +332,7 @@ class RcclTransport:
         nat, lib = self._nat, self._nat.lib()
         if nbytes > self._block_cap[slot]:
             if self._block[slot] is not None:
-                nat.check(lib.sdrt_stream_synchronize(self._s_comm))
+                self._finish('block buffer growth')           # bounded, and watching the job: never an open-ended stream wait
                 self._block[slot].free()
             self._block[slot], self._block_cap[slot] = nat.DeviceBuffer(nbytes), nbytes
             if self.rank == root:
@@ -441,19 +449,21 @@ def chain_iq_offsets(transport, a: float, b: complex, off0: complex = 0j) -> Tup
 
 
 class SimoShard:
-    """This rank's share of a --simo processor: rows [lo, hi) of the reference's row order (vfo_processor.py:43-47), served
-    on TCP port ``base_port + rank`` -- client k of that port receives row lo + k."""
+    """This rank's share of a --simo processor: rows [lo, hi) of the reference's row order (vfo_processor.py:43-47).  Every
+    rank's rows are served on the ONE port the reference serves them on (vfo_processor.py:106): rank 0 listens, the k-th
+    connection is row k, and a connection whose row belongs to another rank is handed to that process (dsp/fanout.py)."""
 
     def __init__(self, n_rows: int, rank: int, world: int):
         self.rank, self.world = rank, world
         self.lo, self.hi = split_range(n_rows, world, rank)
+        self.bounds = [split_range(n_rows, world, r) for r in range(world)]
 
     @property
     def rows(self) -> int:
         return self.hi - self.lo
 
     def port(self, base_port: int) -> int:
-        return base_port + self.rank
+        return base_port
 
 
 def max_over_ranks(value: float, device=None) -> float:

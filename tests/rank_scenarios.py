@@ -7,8 +7,9 @@ import numpy as np
 
 
 def simo_rows_over_rank_processes(gpus=2):
-    """VfoProcessor(gpus=2): rank 0 in this process, one helper process, three rows split 2 + 1, each rank serving its own port;
-    nine chunks in batches of two (several blocks in flight), every row's stream against oracle/chain.c, in order."""
+    """VfoProcessor(gpus=2): rank 0 in this process, one helper process, three rows split 2 + 1, every client on the ONE port of
+    the job (the k-th connection is row k; the helper's row reaches it as a handed-over socket); nine chunks in batches of two
+    (several blocks in flight), every row's stream against oracle/chain.c, in order."""
     import multiprocessing as mp
     import queue
     import socket
@@ -33,8 +34,8 @@ def simo_rows_over_rank_processes(gpus=2):
     buf.close = lambda: None
     buf.join_thread = lambda: None
     m = n // q
-    # rank 0: rows 0, 1 in connection order; the other ranks one row each
-    where = [(port, 0), (port, 1)] + [(port + r, r + 1) for r in range(1, gpus)]
+    # one port, as in the reference (vfo_processor.py:106): connection k is row k; rank 0 computes rows 0, 1, the other ranks one each
+    where = [(port, k) for k in range(gpus + 1)]
     box = [None] * len(where)
 
     def client(prt, k):
@@ -106,7 +107,7 @@ def a_helper_rank_that_dies():
     def clients():
         import socket
         socks = []
-        for prt in (port, port, port + 1):
+        for prt in (port, port, port):
             deadline = time.time() + 60
             while time.time() < deadline:
                 try:
@@ -141,6 +142,79 @@ def a_helper_rank_that_dies():
     assert took < 6.0 + 45.0, f'rank 0 took {took:.1f} s to give up'
 
 
+def halt_flag_with_live_helpers():
+    """the halt flag goes up in mid-stream while the helper rank waits in a collective.  The helper must stay for the
+    end-of-stream block rank 0 sends on its way out and exit with code 0; rank 0 must come back promptly (no teardown behind a
+    collective nobody completes)."""
+    import multiprocessing as mp
+    import queue
+    import threading
+    import time
+    from sdrterm_amd.dsp.vfo_processor import VfoProcessor
+    from sdrterm_amd.misc.general_util import findPort
+    from sdrterm_amd.misc.read_file import RawChunk
+    from tests.golden import prng
+    fs, q, n = 1024000, 64, 32768
+    raw = prng.raw_bytes('h', n * 2, seed=36, amp=4000)
+    port = findPort('127.0.0.1')
+    p = VfoProcessor(fs, vfoHost=f'127.0.0.1:{port}', vfos='-100000,50000', center=15700, dec=q, omegaOut=5000, gpus=2)
+    p.selectOutputFm()
+    p.MAX_BATCH = 1
+    buf = queue.Queue()
+    buf.close = lambda: None
+    buf.join_thread = lambda: None
+    stop = threading.Event()
+    flag = mp.get_context('spawn').Value('b', 0)
+    codes = []
+
+    def feeder():
+        while not stop.is_set():
+            buf.put(RawChunk(raw[:n * 4], 'h', False, False, False, 50))
+            time.sleep(0.2)
+
+    def clients():
+        import socket
+        socks = []
+        for _ in range(3):
+            deadline = time.time() + 60
+            while time.time() < deadline:
+                try:
+                    socks.append(socket.create_connection(('127.0.0.1', port), timeout=60))
+                    break
+                except OSError:
+                    time.sleep(0.05)
+            time.sleep(0.5)
+        while not stop.is_set():
+            for s in socks:
+                try:
+                    s.settimeout(0.05)
+                    s.recv(1 << 20)
+                except OSError:
+                    pass
+
+    def halter():
+        deadline = time.time() + 60
+        while not p._helpers and time.time() < deadline:
+            time.sleep(0.05)
+        time.sleep(6.0)                                   # clients connected, a few blocks through
+        helpers = list(p._helpers)
+        flag.value = 1
+        for h in helpers:
+            h.join(40)
+            codes.append(h.exitcode)
+    ths = [threading.Thread(target=fn, daemon=True) for fn in (feeder, clients, halter)]
+    for t in ths:
+        t.start()
+    t0 = time.time()
+    p.processData(flag, buf)
+    took = time.time() - t0
+    stop.set()
+    ths[2].join(60)
+    assert took < 6.0 + 20.0, f'rank 0 took {took:.1f} s to leave'
+    assert codes == [0], f'helper exit codes {codes}: it did not leave on the end-of-stream block'
+
+
 if __name__ == '__main__':
-    {'rows': simo_rows_over_rank_processes, 'rows4': lambda: simo_rows_over_rank_processes(4), 'kill': a_helper_rank_that_dies}[sys.argv[1]]()
+    {'rows': simo_rows_over_rank_processes, 'rows4': lambda: simo_rows_over_rank_processes(4), 'kill': a_helper_rank_that_dies,
+     'halt': halt_flag_with_live_helpers}[sys.argv[1]]()
     print('scenario ok')

@@ -70,10 +70,11 @@ def _scenario(name, n_ranks=2, **extra):
 
 @pytest.mark.parametrize('name,n_ranks,bcast', [('rows', 2, 'ring'), ('rows', 2, 'scatter'), ('rows4', 4, 'scatter')])
 def test_simo_rows_over_rank_processes_on_one_gpu(name, n_ranks, bcast):
-    """VfoProcessor(gpus=2 / 4): rank 0 and its helper processes, three rows split 2 + 1 (five: 2 + 1 + 1 + 1), each rank serving
-    its own port; nine chunks in batches of two (several blocks in flight), every row's stream against oracle/chain.c, in order
-    (tests/rank_scenarios.py).  The block goes out as one broadcast, or (SDRTERM_BCAST=scatter) as 1/N shards from rank 0 that the
-    ranks all-gather in place (sdrt_comm_bcast_scatter)."""
+    """VfoProcessor(gpus=2 / 4): rank 0 and its helper processes, three rows split 2 + 1 (five: 2 + 1 + 1 + 1), every client on the
+    ONE port the reference serves (connection k = row k; the other ranks' sockets are handed to them); nine chunks in batches of
+    two (several blocks in flight), every row's stream against oracle/chain.c, in order (tests/rank_scenarios.py).  The block goes
+    out as 1/N shards from rank 0 that the ranks all-gather in place (sdrt_comm_bcast_scatter, the default) or as one broadcast
+    (SDRTERM_BCAST=ring)."""
     _scenario(name, n_ranks, SDRTERM_BCAST=bcast)
 
 
@@ -102,3 +103,9 @@ def test_a_helper_rank_that_dies_takes_the_job_down_in_bounded_time():
     process is killed after the first blocks: rank 0 comes back from processData within the deadlines, with the halt flag up
     (tests/rank_scenarios.py)."""
     _scenario('kill', SDRTERM_COMM_TIMEOUT='8', SDRT_STANDIN_TIMEOUT='8')
+
+
+def test_halt_flag_with_live_helpers_leaves_in_bounded_time():
+    """the halt flag raised in mid-stream while the helper waits in a collective: the helper stays for rank 0's
+    end-of-stream block and exits 0, rank 0 does not tear down behind a collective nobody completes (tests/rank_scenarios.py)."""
+    _scenario('halt')

@@ -1,7 +1,9 @@
 """CPU test of the multi-GPU --simo driver: two ranks under gloo run the sharded VfoProcessor end to
 end with a stub in place of the GPU engine.  Checked: which rows each rank serves (vfo_processor.py:43-47 order, split
-contiguously), which TCP port, that client k of a rank's port receives row lo + k of every chunk as big-endian doubles
-(vfo_processor.py:83-84), that every rank sees every block in order and that end of stream reaches all of them."""
+contiguously), that ONE port serves them all as in the reference (vfo_processor.py:99-110) -- the k-th client to connect
+receives row k of every chunk as big-endian doubles (vfo_processor.py:83-84) whichever rank computes it, the socket having
+been handed to that rank's process --, that every rank sees every block in order and that end of stream reaches all of them;
+a halt flag raised in mid-stream; the hand-off of client sockets between processes on its own."""
 import os
 import queue
 import socket
@@ -70,7 +72,7 @@ def _client(host, port, nbytes, box, idx):
     box[idx] = data
 
 
-def _rank_worker(rank, world, master_port, base_port, q, feed='all at once'):
+def _rank_worker(rank, world, master_port, base_port, q, feed='all at once', flag=None):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(master_port)
@@ -84,24 +86,29 @@ def _rank_worker(rank, world, master_port, base_port, q, feed='all at once'):
     def spy(buffer):
         chunks, eof = take(buffer)
         seen.append((sum(c.n for c in chunks), eof, p._moreComing))
+        if flag is not None and rank == 0 and len(seen) == 3:
+            flag.value = 1                      # 'halt': the flag goes up in mid-stream, with the other rank waiting for a block
         return chunks, eof
     p._takeBatch = spy
     if feed != 'all at once':
         p.MAX_BATCH = 2
     sh = p._shard()
     m = N // Q
-    box = [None] * sh.rows
-    # clients connect one after the other, so that client k is registered k-th (the reference's mapping follows
-    # connection order too, example_simo.sh:161)
-    def connect_all():
-        for k in range(sh.rows):
-            t = threading.Thread(target=_client, args=('127.0.0.1', sh.port(base_port), CHUNKS * m * 8, box, k), daemon=True)
-            t.start()
-            ts.append(t)
-            time.sleep(0.3)
+    total = sh.bounds[-1][1]
+    box = [None] * total
     ts = []
-    starter = threading.Thread(target=connect_all, daemon=True)
-    starter.start()
+    starter = None
+    if rank == 0:
+        # every client connects to the ONE port, one after the other: the k-th connection is row k (the reference's mapping
+        # follows connection order too, example_simo.sh:161), whichever rank computes that row
+        def connect_all():
+            for k in range(total):
+                t = threading.Thread(target=_client, args=('127.0.0.1', base_port, CHUNKS * m * 8, box, k), daemon=True)
+                t.start()
+                ts.append(t)
+                time.sleep(0.3)
+        starter = threading.Thread(target=connect_all, daemon=True)
+        starter.start()
     buf = None
     if rank == 0:
         buf = queue.Queue()
@@ -109,6 +116,13 @@ def _rank_worker(rank, world, master_port, base_port, q, feed='all at once'):
             for c in chunks_for_test():
                 buf.put(c)
             buf.put(b'')
+        elif feed == 'halt':
+            def forever():
+                cs = chunks_for_test()
+                while not flag.value:
+                    buf.put(cs[0])
+                    time.sleep(0.3)
+            threading.Thread(target=forever, daemon=True).start()
         else:
             # a live source: the first three chunks are there when the clients have connected, the rest trickle in one by
             # one, then the end marker -- several blocks that are not the last one cross the channel, some with more queued
@@ -123,8 +137,9 @@ def _rank_worker(rank, world, master_port, base_port, q, feed='all at once'):
                 time.sleep(0.7)
                 buf.put(b'')
             threading.Thread(target=trickle, daemon=True).start()
-    p.processData(_Flag(), buf)
-    starter.join(30)
+    p.processData(flag if flag is not None else _Flag(), buf)
+    if starter is not None:
+        starter.join(30)
     for t in ts:
         t.join(30)
     q.put((rank, (sh.lo, sh.hi), sh.port(base_port), [np.frombuffer(b, dtype='>f8').astype(np.float64) if b else None for b in box], seen))
@@ -146,7 +161,7 @@ def test_sharded_vfo_processor_under_gloo(feed):
         p.join(60)
         assert p.exitcode == 0
     rows_all = [1100.0, 1200.0, 1300.0, 1400.0, 1000.0]        # csv + center, center LAST
-    assert [g[1] for g in got] == [(0, 3), (3, 5)] and [g[2] for g in got] == [base, base + 1]
+    assert [g[1] for g in got] == [(0, 3), (3, 5)] and [g[2] for g in got] == [base, base]      # one port, as in the reference
     m = N // Q
     check = [int(np.frombuffer(c.tobytes(), dtype=np.uint8).astype(np.int64).sum() % 251) for c in chunks_for_test()]
     blocks = [g[4] for g in got]
@@ -156,12 +171,84 @@ def test_sharded_vfo_processor_under_gloo(feed):
         # the helper rank runs processData(isDead, None): blocks that are not the last one must get through it (round 2: the
         # helper died on None.empty() after the first of them), in order, with and without more queued behind them
         assert len(blocks[0]) >= 4 and any(b[2] for b in blocks[0]) and any(not b[2] and not b[1] for b in blocks[0])
-    for _rank, (lo, hi), _port, streams, _seen in got:
-        assert len(streams) == hi - lo
-        for k, s in enumerate(streams):
-            assert s is not None and s.size == CHUNKS * m
-            exp = np.concatenate([rows_all[lo + k] + check[c] + np.arange(m) / 1024.0 for c in range(CHUNKS)])
-            assert np.array_equal(s, exp), f'row {lo + k}'
+    streams = got[0][3]                                            # the clients all sat in rank 0's process: client k <-> row k
+    assert len(streams) == 5
+    for k, s in enumerate(streams):
+        assert s is not None and s.size == CHUNKS * m, f'row {k}'
+        exp = np.concatenate([rows_all[k] + check[c] + np.arange(m) / 1024.0 for c in range(CHUNKS)])
+        assert np.array_equal(s, exp), f'row {k}'
+
+
+def test_halt_flag_in_mid_stream_releases_the_other_rank():
+    """the halt flag goes up while rank 1 waits for its next block.  Rank 1 must not leave on the flag (rank 0 would
+    then queue an end-of-stream broadcast no peer completes, and hang in its teardown behind it): it stays for the
+    end-of-stream block rank 0 sends on its way out, and both leave with exit code 0."""
+    import torch.multiprocessing as mp
+    from sdrterm_amd.misc.general_util import findPort
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    flag = ctx.Value('b', 0)
+    world, master, base = 2, findPort('127.0.0.1'), findPort('127.0.0.1')
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, master, base, q, 'halt', flag)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    blocks = [g[4] for g in got]
+    assert flag.value == 1
+    assert blocks[1][-1][1] and blocks[1][-1][0] == 0            # the last thing rank 1 took: the end-of-stream block
+    assert [b[:2] for b in blocks[1][:-1]] == [b[:2] for b in blocks[0][:len(blocks[1]) - 1]]
+
+
+def test_client_sockets_are_handed_to_the_rank_that_owns_the_row():
+    """dsp/fanout.py on its own: rank 0 listens on the one port; connections 0, 1 stay with it, 2, 3, 4 belong to rank 1 -- a
+    separate process, which receives the sockets themselves (SCM_RIGHTS) and writes to the clients directly; a sixth client is
+    refused.  The owning process may knock later than its clients connect."""
+    import multiprocessing as mp
+    from sdrterm_amd.dsp import fanout
+    from sdrterm_amd.misc.general_util import findPort
+    port = findPort('127.0.0.1')
+    bounds = [(0, 2), (2, 5)]
+    f0 = fanout.make_fanout('127.0.0.1', port, 0, bounds)
+    f0.start()
+    socks = []
+    for k in range(5):
+        socks.append(socket.create_connection(('127.0.0.1', port), timeout=30))
+        time.sleep(0.1)
+    ctx = mp.get_context('spawn')
+    helper = ctx.Process(target=_handed_rank, args=(port, bounds))
+    helper.start()                                                   # after its clients: rank 0 holds them until it knocks
+    assert f0.wait_for_clients(lambda: False)
+    f0.send_rows(np.array([[10.0, 0.5], [11.0, 0.5]]))
+    for k, s in enumerate(socks):
+        s.settimeout(30)
+        data = b''
+        while len(data) < 16:
+            part = s.recv(16 - len(data))
+            assert part, f'client {k}: connection closed'
+            data += part
+        row, tag = np.frombuffer(data, dtype='>f8')
+        assert (row, tag) == ((10.0 + k, 0.5) if k < 2 else (100.0 + k - 2, float(helper.pid))), f'client {k}'
+    extra = socket.create_connection(('127.0.0.1', port), timeout=30)
+    extra.settimeout(10)
+    assert extra.recv(8) == b''                                      # more clients than rows: refused
+    helper.join(30)
+    assert helper.exitcode == 0
+    f0.close()
+    for s in socks + [extra]:
+        s.close()
+
+
+def _handed_rank(port, bounds):
+    from sdrterm_amd.dsp import fanout
+    f1 = fanout.make_fanout('127.0.0.1', port, 1, bounds)
+    f1.start()
+    assert f1.wait_for_clients(lambda: False)
+    f1.send_rows(np.array([[100.0 + k, float(os.getpid())] for k in range(3)]))
+    time.sleep(0.5)
+    f1.close()
 
 
 def test_rank_zero_releases_the_others_when_halted_before_any_data():
@@ -210,17 +297,18 @@ def test_collective_waits_are_bounded_and_watch_the_job():
     assert len(calls) == 3
 
 
-def test_ports_of_every_rank_are_probed_before_helpers_start():
-    """Rank r serves port + r: a busy one must stop the start-up in rank 0, before any helper waits in a collective."""
+def test_the_port_is_probed_before_helpers_start():
+    """The job serves ONE port (rank 0 listens, the others get their sockets from it): a busy one must stop the start-up in rank 0,
+    before any helper waits in a collective."""
     import socket
     from sdrterm_amd.misc.general_util import findPort
     base = findPort('127.0.0.1')
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as busy:
-        busy.bind(('127.0.0.1', base + 1))
+        busy.bind(('127.0.0.1', base))
         busy.listen(1)
         p = StubVfo(FS, vfoHost=f'127.0.0.1:{base}', vfos=VFOS, dec=Q, omegaOut=5000, gpus=2, device=3)
         assert p._deviceBase == 3
-        with pytest.raises(OSError, match='rank 1'):
+        with pytest.raises(OSError, match='is not free'):
             p._startHelpers(_Flag())
         assert p._helpers == []
 
@@ -249,3 +337,41 @@ def test_communicator_id_exchange_passes_over_busy_ports(monkeypatch):
         for t in ts:
             t.join(60)
         assert got == {0: bytes(range(128)), 1: bytes(range(128)), 2: bytes(range(128))}
+
+
+def test_communicator_id_exchange_keeps_two_jobs_apart(monkeypatch):
+    """two jobs on one host with overlapping port ranges and equal world size.  The hello carries a token of the job
+    (SDRTERM_JOB_ID or MASTER_ADDR:MASTER_PORT) and the asking rank: job B's rank knocking on job A's port is passed over, and a
+    rank that asks twice counts once."""
+    from sdrterm_amd import parallel
+    from sdrterm_amd.misc.general_util import findPort
+    base = findPort('127.0.0.1')
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('SDRTERM_UID_PORT', str(base))
+    ids = {'A': bytes([1] * 128), 'B': bytes([2] * 128)}
+    got = {}
+
+    def run(job, rank):
+        if rank == 0:
+            # (unique_id is looked up when rank 0 runs: give each job's rank 0 its own)
+            uid = ids[job]
+            orig = parallel.RcclTransport.unique_id
+            parallel.RcclTransport.unique_id = staticmethod(lambda: uid)
+            try:
+                got[job, rank] = parallel.RcclTransport._exchange_uid(rank, 2, job=job)
+            finally:
+                parallel.RcclTransport.unique_id = orig
+        else:
+            got[job, rank] = parallel.RcclTransport._exchange_uid(rank, 2, job=job)
+    ta = threading.Thread(target=run, args=('A', 0), daemon=True)
+    ta.start()
+    time.sleep(0.5)                                   # job A's rank 0 holds the first port of the range ...
+    tb = threading.Thread(target=run, args=('B', 0), daemon=True)
+    tb.start()
+    time.sleep(0.5)                                   # ... job B's the second
+    others = [threading.Thread(target=run, args=(j, 1), daemon=True) for j in ('B', 'A')]
+    for t in others:
+        t.start()
+    for t in [ta, tb] + others:
+        t.join(60)
+    assert got == {('A', 0): ids['A'], ('A', 1): ids['A'], ('B', 0): ids['B'], ('B', 1): ids['B']}
