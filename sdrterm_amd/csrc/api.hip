@@ -14,6 +14,7 @@
 #include "kernels.h"
 
 #include <atomic>
+#include <mutex>
 
 namespace {
 
@@ -1519,9 +1520,21 @@ struct TapSlot {
     }
     void drop() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
 };
+// A thread's tap buffers go with the thread (a plot thread that ends must not leave its device memory behind: ADVICE r3) -- but
+// not at process exit, where thread-local destructors can run after the HIP runtime has torn itself down: an atexit handler,
+// registered with the first buffers, raises a flag and the memory is left to the process's end.
+std::atomic<bool> g_process_exiting{false};
 struct TapBufs {
     TapSlot raw, u, scratch, out, tw, tile, phase, win;
     int dev = -1;
+    TapBufs() {
+        static std::once_flag once;
+        std::call_once(once, [] { std::atexit([] { g_process_exiting.store(true); }); });
+    }
+    ~TapBufs() {
+        if (g_process_exiting.load()) return;
+        for (TapSlot *t : {&raw, &u, &scratch, &out, &tw, &tile, &phase, &win}) t->drop();
+    }
 };
 thread_local TapBufs g_taps;
 
