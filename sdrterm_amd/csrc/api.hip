@@ -133,6 +133,7 @@ struct sdrt_ctx {
     bool iq = false;
     double *d_iq_state = nullptr;     // [2] carried offset, lives on the device
     double *d_iq_pow = nullptr;       // [n/GS + 1]
+    double *d_iq_colw = nullptr;      // [259] iq_cols_kernel's column weights (IqArgs.col_w)
     double *d_iq_group = nullptr, *d_iq_agg = nullptr, *d_iq_chunk = nullptr;
     size_t iq_cap_chunks = 0;
     double *d_iq_range = nullptr;     // scratch of sdrt_iq_range_device: [n] aggregates, [n + 1] offsets, [1] state
@@ -558,6 +559,15 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         c->iq_pow_e = tmp[gs];                 // (1-lambda)^GS
         c->iq_pow_n = tmp[n];
         rc = upload(&c->d_iq_pow, pwg.data(), pwg.size() * sizeof(double));
+        if (rc == SDRT_OK && n >= 256) {
+            // the column form of the prefix pass (iq_cols_kernel): weights of a 256-sample column and three powers
+            std::vector<double> cw(259);
+            for (int t = 0; t < 256; ++t) cw[t] = cfg->iq_inductance * tmp[255 - t];
+            cw[256] = 1.0 / tmp[32];
+            cw[257] = tmp[256];
+            cw[258] = tmp[224];
+            rc = upload(&c->d_iq_colw, cw.data(), cw.size() * sizeof(double));
+        }
         if (rc == SDRT_OK) {
             const double zero[2] = {0.0, 0.0};
             rc = upload(&c->d_iq_state, zero, sizeof(zero));
@@ -701,6 +711,7 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_iq_R);
     (void) hipFree(c->d_iq_state);
     (void) hipFree(c->d_iq_pow);
+    (void) hipFree(c->d_iq_colw);
     (void) hipFree(c->d_iq_group);
     (void) hipFree(c->d_iq_agg);
     (void) hipFree(c->d_iq_chunk);
@@ -868,6 +879,8 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
         ia.pow_tab = c->d_iq_pow;
         ia.pow_g = c->iq_pow_e;
         ia.pow_n = c->iq_pow_n;
+        const char *colenv = getenv("SDRTERM_IQ_COLS");            // diagnostics: "0" keeps the per-group prefix kernel
+        ia.col_w = c->use_i8w && !(colenv && strcmp(colenv, "0") == 0) ? c->d_iq_colw : nullptr;
         if (!(c->use_i8w && c->iq_fused)) {
             // prefix pass over the input, then the chunks chained: the kernels below take offsets from these tables
             Timed t(c, s, 2);

@@ -68,6 +68,7 @@ struct IqArgs {
     int wmask, wtail;           // groups the consumer reads: those with (group & wmask) == 0 and group wtail (wmask 0: all of them)
     const double *pow_tab;      // [n/GS + 1] (1-lambda)^(GS k)  (same table the chain kernel uses)
     double norm_bias, lambda, pow_g /* (1-lambda)^GS */, pow_n /* (1-lambda)^n */;
+    const double *col_w;        // [259] column form (iq_cols_kernel): lambda (1-lambda)^(255-t), t < 256; (1-lambda)^-32; ^256; ^224 (or NULL)
 };
 hipError_t launch_iq_local(const IqArgs &a, hipStream_t s);
 hipError_t launch_iq_scan(const IqArgs &a, hipStream_t s);

@@ -279,6 +279,112 @@ __global__ __launch_bounds__(256) void iq_local_kernel(IqArgs a) {
     if (tid == 0) ((cd *) a.chunk_agg)[chunk] = carry;     // offset at the end of the chunk when it starts from zero
 }
 
+// The same prefix pass for the wide-column kernel as consumer (round 4): it reads the offsets at the starts of its 256-sample
+// columns and at the tail window only, so the pass works in columns too.  A wave takes a column with one coalesced load (lane l:
+// samples 4l .. 4l+3), every lane weighs its four samples with lambda (1-lambda)^(255-t) from a table (independent fused
+// multiply-adds: the per-sample recurrence of iq_local_kernel is a dependent chain, and its scan over 8- or 16-sample groups was
+// most of its work), a DPP reduction gives the column's aggregate, and the 128 (64, 256) column aggregates of the chunk are chained
+// by one wave at the end.  One read of the input at streaming rate.
+template <int DT>
+__global__ __launch_bounds__(256) void iq_cols_kernel(IqArgs a) {
+    constexpr int ITEM = Enc<DT>::size, LC = 256;
+    constexpr int BYTES = 4 * 2 * ITEM;                // four complex samples per lane
+    constexpr int NW = BYTES / 4;
+    constexpr int MAXC = 512;                          // columns per chunk this kernel takes (131072 samples)
+    __shared__ cd agg[MAXC + 1];
+    __shared__ cd tail_part;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long chunk = blockIdx.x;
+    const int n = a.n, ncol = n / LC;
+    const unsigned char *chunk_raw = (const unsigned char *) a.raw + (size_t) chunk * (size_t) n * 2 * ITEM;
+    const bool swap = a.swap != 0;
+    const double nbias = a.norm_bias;
+    double w[4];                                       // lambda (1-lambda)^(255 - 4 lane - j)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = a.col_w[4 * lane + j];
+    uint32_t nxt[NW];
+    load_words<BYTES, true>(chunk_raw + ((size_t) wave * LC + 4 * lane) * 2 * ITEM, nxt);
+    for (int c = wave; c < ncol; c += 4) {
+        uint32_t wds[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) wds[k] = nxt[k];
+        const int cn = c + 4 < ncol ? c + 4 : c;
+        load_words<BYTES, true>(chunk_raw + ((size_t) cn * LC + 4 * lane) * 2 * ITEM, nxt);
+        double sr = 0.0, si = 0.0;
+        static_for<0, 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            sr = fma(w[j], decode<DT>(get_item<DT, 2 * j>(wds), swap) + nbias, sr);
+            si = fma(w[j], decode<DT>(get_item<DT, 2 * j + 1>(wds), swap), si);
+        });
+        cd s = mk(sr, si);
+        // sum over the wave: four shifts inside the 16-lane rows (lane 15 of a row ends up with the row's sum), then the rows
+        s = mk(s.re + dpp_row<0x111>(s.re), s.im + dpp_row<0x111>(s.im));
+        s = mk(s.re + dpp_row<0x112>(s.re), s.im + dpp_row<0x112>(s.im));
+        s = mk(s.re + dpp_row<0x114>(s.re), s.im + dpp_row<0x114>(s.im));
+        s = mk(s.re + dpp_row<0x118>(s.re), s.im + dpp_row<0x118>(s.im));
+        auto rl = [](double v, int l) {                 // v_readlane: no trip through the LDS crossbar
+            return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+        };
+        const double r0 = rl(s.re, 15), r1 = rl(s.re, 31), r2 = rl(s.re, 47), r3 = rl(s.re, 63);
+        const double i0 = rl(s.im, 15), i1 = rl(s.im, 31), i2 = rl(s.im, 47), i3 = rl(s.im, 63);
+        if (lane == 0) {
+            agg[c] = mk((r0 + r1) + (r2 + r3), (i0 + i1) + (i2 + i3));
+            // the tail window starts 224 samples into the last column: lanes 0 .. 55 = rows 0 .. 2 and lanes 48 .. 55 of row 3;
+            // the weights there are (1-lambda)^32 too small (col_w[256] = (1-lambda)^-32)
+            if (c == ncol - 1) tail_part = mk(r0 + r1 + r2, i0 + i1 + i2);
+        }
+        if (c == ncol - 1) {
+            // row 3, lanes 48 .. 55: the shifted sums hold lanes 48 .. l at lane l
+            const double t7r = rl(s.re, 55), t7i = rl(s.im, 55);
+            if (lane == 0) { agg[MAXC] = mk(t7r, t7i); }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // offsets at the column starts: off[c+1] = mu off[c] + agg[c], mu = (1-lambda)^256; lane l chains columns [l per, (l+1) per)
+        const double mu = a.col_w[257];
+        const int per = (ncol + 63) / 64;
+        cd gout_local[MAXC / 64];
+        cd s = mk(0.0, 0.0);
+        double p = 1.0;
+        for (int k = 0; k < per; ++k) {
+            const int c = lane * per + k;
+            gout_local[k] = s;                                         // relative to the lane's own start
+            if (c < ncol) { s = mk(fma(mu, s.re, agg[c].re), fma(mu, s.im, agg[c].im)); p *= mu; }
+        }
+        // exclusive scan of the lanes' affine maps (p, s) over the wave
+        cd ex = mk(0.0, 0.0);
+        {
+            cd acc = s;
+            double pp = p;
+            for (int d = 1; d < 64; d <<= 1) {
+                const double ore = __shfl_up(acc.re, d), oim = __shfl_up(acc.im, d), op = __shfl_up(pp, d);
+                if (lane >= d) { acc = mk(fma(pp, ore, acc.re), fma(pp, oim, acc.im)); pp *= op; }
+            }
+            const double ere = __shfl_up(acc.re, 1), eim = __shfl_up(acc.im, 1);
+            if (lane > 0) ex = mk(ere, eim);
+            if (lane == 63) ((cd *) a.chunk_agg)[chunk] = acc;         // offset at the end of the chunk when it starts from zero
+        }
+        cd *gout = a.group_off ? (cd *) a.group_off + (size_t) chunk * (size_t) (n / a.gs) : nullptr;
+        double q = 1.0;
+        const int gpc = LC / a.gs;                                     // groups per column
+        for (int k = 0; k < per; ++k) {
+            const int c = lane * per + k;
+            if (c < ncol) {
+                const cd off = mk(fma(q, ex.re, gout_local[k].re), fma(q, ex.im, gout_local[k].im));
+                if (gout) gout[(size_t) c * gpc] = off;
+                if (gout && c == ncol - 1) {
+                    // offset at sample n - 32: the last column's start carried over 224 samples + its first 224 samples' share
+                    const double m224 = a.col_w[258], inv32 = a.col_w[256];
+                    const cd tp = mk((tail_part.re + agg[MAXC].re) * inv32, (tail_part.im + agg[MAXC].im) * inv32);
+                    gout[a.wtail] = mk(fma(m224, off.re, tp.re), fma(m224, off.im, tp.im));
+                }
+                q *= mu;
+            }
+        }
+    }
+}
+
 // one workgroup: chunk offsets off[c+1] = (1-lambda)^n off[c] + agg[c], off[0] = carried state
 constexpr int IQ_SCAN_THREADS = 1024;
 __global__ __launch_bounds__(IQ_SCAN_THREADS) void iq_scan_kernel(IqArgs a) {
@@ -391,6 +497,17 @@ static hipError_t launch_iq_local_dt(const IqArgs &a, dim3 grid, hipStream_t s) 
 
 hipError_t launch_iq_local(const IqArgs &a, hipStream_t s) {
     const dim3 grid((unsigned) a.n_chunks);
+    if (a.col_w && a.wmask && a.n % 256 == 0 && a.n / 256 <= 512 && (256 / a.gs) == a.wmask + 1) {
+        // the wide-column kernel is the consumer: offsets at column starts and at the tail window only
+        switch (a.dt) {
+            case SDRT_S8: hipLaunchKernelGGL((iq_cols_kernel<SDRT_S8>), grid, dim3(256), 0, s, a); return hipGetLastError();
+            case SDRT_U8: hipLaunchKernelGGL((iq_cols_kernel<SDRT_U8>), grid, dim3(256), 0, s, a); return hipGetLastError();
+            case SDRT_S16: hipLaunchKernelGGL((iq_cols_kernel<SDRT_S16>), grid, dim3(256), 0, s, a); return hipGetLastError();
+            case SDRT_U16: hipLaunchKernelGGL((iq_cols_kernel<SDRT_U16>), grid, dim3(256), 0, s, a); return hipGetLastError();
+            case SDRT_F32: hipLaunchKernelGGL((iq_cols_kernel<SDRT_F32>), grid, dim3(256), 0, s, a); return hipGetLastError();
+            default: break;
+        }
+    }
     switch (a.dt) {
         case SDRT_S8: return launch_iq_local_dt<SDRT_S8>(a, grid, s);
         case SDRT_U8: return launch_iq_local_dt<SDRT_U8>(a, grid, s);
