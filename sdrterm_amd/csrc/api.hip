@@ -105,6 +105,12 @@ struct sdrt_ctx {
     WideTables *d_wtab = nullptr;
     double *d_edge_ab = nullptr, *d_edge_pq = nullptr, *d_gvec = nullptr;
     bool wide_rs = false;             // wide kernel in its real-stream form (no shift, no IQ correction)
+    // decimation 8 / 16 on the wide kernel: a column has 32 / 16 outputs, the kernel finishes eight per pass (tables.h:
+    // sdrt_build_wide_tables_pass).  Pass 0 lives in the fields above / below (d_wtab, d_w8mid, d_gvec, d_ybias, w8mid_combine);
+    // further passes here
+    struct WidePass { WideTables *d_wtab = nullptr; signed char *d_w8mid = nullptr; double *d_gvec = nullptr, *d_ybias = nullptr; double w8mid_combine = 0.0; };
+    std::vector<WidePass> more_passes;
+    int nout_pass = 0;                // outputs per column and pass (0: not the wide kernel)
     int n_cus = 256;
     // per-row demodulation modes (sdrt_config.row_modes): the rows of each mode, on the device, for the demodulation stage
     bool mixed = false;
@@ -213,6 +219,9 @@ void free_stage_a(sdrt_ctx *c) {
     drop(c->d_wtab); drop(c->d_edge_ab); drop(c->d_edge_pq); drop(c->d_gvec);
     drop(c->d_w8); drop(c->d_w8mid); drop(c->d_tab8); drop(c->d_nco_tile8); drop(c->d_nco_phase8); drop(c->d_wsum);
     drop(c->d_w8iq); drop(c->d_iq_consts); drop(c->d_iq_R);
+    for (auto &wp : c->more_passes) { drop(wp.d_wtab); drop(wp.d_w8mid); drop(wp.d_gvec); drop(wp.d_ybias); }
+    c->more_passes.clear();
+    c->nout_pass = 0;
     c->use_i8w = c->use_i8t = c->wide_rs = false;
     c->w8_combine = c->w8mid_combine = 0.0;
 }
@@ -222,13 +231,15 @@ void free_stage_a(sdrt_ctx *c) {
 template <class ScaleFn>
 int setup_wide(sdrt_ctx *c, const sdrt_config *cfg, ScaleFn &) {
     const int q = cfg->decimation, n = cfg->n_samples;
-    const int S = SDRT_I8_DIGITS, LC = SDRT_WIDE_LC, KS = LC / 32, NR = 2 * (LC / q);
+    const int S = SDRT_I8_DIGITS, LC = SDRT_WIDE_LC, KS = LC / 32;
+    const int nout_total = LC / q, nout_pass = nout_total > SDRT_WIDE_MAXOUT ? SDRT_WIDE_MAXOUT : nout_total, passes = nout_total / nout_pass;
+    const int NR = 2 * nout_pass;
     const char *msg = nullptr;
     WideTables wtab;
-    if (sdrt_build_wide_tables(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, &wtab, &msg) != 0)
+    if (sdrt_build_wide_tables_pass(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, nout_pass, 0, &wtab, &msg) != 0)
         return fail(SDRT_EINVAL, "wide-column tables: %s", msg ? msg : "failed");
     const char *rsenv = getenv("SDRTERM_WIDE_RS");               // diagnostics: "0" keeps the general form
-    c->wide_rs = !c->nco && !c->iq && chain_i8w_rs_supported(cfg->dtype, n) && !(rsenv && strcmp(rsenv, "0") == 0);
+    c->wide_rs = passes == 1 && !c->nco && !c->iq && chain_i8w_rs_supported(cfg->dtype, n) && !(rsenv && strcmp(rsenv, "0") == 0);
     const size_t per_row = c->wide_rs ? (size_t) S * (LC / 64) * 64 * 16 : (size_t) 2 * S * KS * 64 * 16;
     const size_t per_row_loc = c->wide_rs ? (size_t) S * (LC / 64) * 4 * (NR / 2) * 16 : (size_t) S * KS * 4 * NR * 16;
     std::vector<signed char> w8(per_row * c->rows), w8l(per_row_loc * c->rows);
@@ -243,9 +254,9 @@ int setup_wide(sdrt_ctx *c, const sdrt_config *cfg, ScaleFn &) {
         const int brc = c->wide_rs
             ? sdrt_build_i8_weights_wide_rs(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, S, w8.data() + per_row * r, &comb,
                                             w8l.data() + per_row_loc * r, &combl)
-            : sdrt_build_i8_weights_wide(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, c->nco ? sp : nullptr, S, lam,
-                                         w8.data() + per_row * r, &comb, w8l.data() + per_row_loc * r, &combl,
-                                         &gv[(size_t) r * 96]);
+            : sdrt_build_i8_weights_wide_pass(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, c->nco ? sp : nullptr, S, lam, nout_pass, 0,
+                                              w8.data() + per_row * r, &comb, w8l.data() + per_row_loc * r, &combl,
+                                              &gv[(size_t) r * 96]);
         sdrt_build_wide_edge(&wtab, c->nco ? sp : nullptr, c->nco ? bp : nullptr, n, lam, &eab[(size_t) r * 2048],
                              &epq[(size_t) r * 64]);
         // one power-of-two scale per context (rows differ by a rotation of the weights only); a digit overflow or unequal
@@ -300,6 +311,30 @@ int setup_wide(sdrt_ctx *c, const sdrt_config *cfg, ScaleFn &) {
         }
         (void) hipFree(d_gz);
     }
+    // the further passes of a small decimation: their own tables, local planes and rank-one vectors (the main planes are the same)
+    for (int p = 1; p < passes && rc == SDRT_OK && ok; ++p) {
+        sdrt_ctx::WidePass wp;
+        WideTables wt2;
+        if (sdrt_build_wide_tables_pass(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, nout_pass, p * nout_pass, &wt2, &msg) != 0) { ok = false; break; }
+        std::vector<signed char> w8x(per_row), w8l2(per_row_loc * c->rows);
+        std::vector<double> gv2((size_t) c->rows * 48 * 2);
+        for (int r = 0; r < c->rows && ok; ++r) {
+            double comb = 0.0, combl = 0.0;
+            const double *sp = &samp[(size_t) r * LC * 2];
+            const int brc = sdrt_build_i8_weights_wide_pass(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, c->nco ? sp : nullptr, S, lam, nout_pass,
+                                                            p * nout_pass, w8x.data(), &comb, w8l2.data() + per_row_loc * r, &combl, &gv2[(size_t) r * 96]);
+            if (brc != 0 || combl == 0.0) ok = false;
+            else if (r == 0) wp.w8mid_combine = combl;
+            else if (combl != wp.w8mid_combine) ok = false;
+        }
+        if (!ok) break;
+        rc = upload(&wp.d_wtab, &wt2, sizeof(wt2));
+        if (rc == SDRT_OK) rc = upload(&wp.d_w8mid, w8l2.data(), w8l2.size());
+        if (rc == SDRT_OK) rc = upload(&wp.d_gvec, gv2.data(), gv2.size() * sizeof(double));
+        c->more_passes.push_back(wp);
+    }
+    if (!ok) { free_stage_a(c); return SDRT_OK; }
+    c->nout_pass = nout_pass;
     c->use_i8w = rc == SDRT_OK;
     return rc;
 }
@@ -408,6 +443,16 @@ int setup_ybias(sdrt_ctx *c, const sdrt_config *cfg) {
 }
 
 int calibrate_zero_response(sdrt_ctx *c);       // after enqueue_chain
+
+// several passes (decimation 8 / 16 on the wide kernel): every pass adds its own slice of the constant response, [row][m / passes]
+int setup_pass_ybias(sdrt_ctx *c) {
+    const size_t bytes = (size_t) c->rows * (c->m / (1 + c->more_passes.size())) * 2 * sizeof(double);
+    for (auto &wp : c->more_passes) {
+        if (hipMalloc(&wp.d_ybias, bytes) != hipSuccess) return fail(SDRT_ENOMEM, "hipMalloc failed");
+        if (hipMemset(wp.d_ybias, 0, bytes) != hipSuccess) return fail(SDRT_EHIP, "hipMemset failed");
+    }
+    return SDRT_OK;
+}
 
 }  // namespace
 
@@ -660,6 +705,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         if (const char *e = getenv("SDRTERM_F32_PRE")) c->f32_pre = c->use_i8w && cfg->dtype == SDRT_F32 && atoi(e) != 0;
     }
     if (rc == SDRT_OK && c->use_i8) rc = setup_ybias(c, cfg);
+    if (rc == SDRT_OK && c->use_i8 && !c->more_passes.empty()) rc = setup_pass_ybias(c);
     if (rc == SDRT_OK && c->use_i8) rc = calibrate_zero_response(c);
     if (rc != SDRT_OK) {
         sdrt_destroy(c);
@@ -701,6 +747,7 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_nco_tile8);
     (void) hipFree(c->d_nco_phase8);
     (void) hipFree(c->d_ybias);
+    for (auto &wp : c->more_passes) { (void) hipFree(wp.d_wtab); (void) hipFree(wp.d_w8mid); (void) hipFree(wp.d_gvec); (void) hipFree(wp.d_ybias); }
     (void) hipFree(c->d_wsum);
     (void) hipFree(c->d_pre);
     (void) hipFree(c->d_pre_exp);
@@ -916,6 +963,9 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
     da.f32_exp = nullptr;
     da.sched = c->sched;
     da.dual = c->dual;
+    da.out_mul = c->use_i8w ? SDRT_WIDE_LC / c->cfg.decimation : 0;       // outputs per column (all passes)
+    da.out_off = 0;
+    da.m_local = c->m / (1 + (int) c->more_passes.size());
     if (c->use_i8) {
         da.tab = c->d_tab8;
         da.n_tiles = c->n_tiles8;
@@ -964,6 +1014,18 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
             }
         } else if (c->use_i8w) {
             HIP_TRY(launch_chain_i8w(da, c->cfg.decimation, c->cfg.dtype, n_chunks, n_cus, s));
+            // decimation 8 / 16: the further passes, eight more outputs of every column each
+            for (size_t p = 0; p < c->more_passes.size(); ++p) {
+                const sdrt_ctx::WidePass &wp = c->more_passes[p];
+                DecimArgs dp = da;
+                dp.wtab = wp.d_wtab;
+                dp.w8mid = wp.d_w8mid;
+                dp.gvec = wp.d_gvec;
+                dp.ybias = wp.d_ybias;
+                dp.w8mid_combine = wp.w8mid_combine;
+                dp.out_off = (int) (p + 1) * c->nout_pass;
+                HIP_TRY(launch_chain_i8w(dp, c->cfg.decimation, c->cfg.dtype, n_chunks, n_cus, s));
+            }
         } else if (c->use_i8t) {
             // the int8 kernels feed x - x_offset to the matrix cores; normalisation bias and offset come back via ybias
             HIP_TRY(launch_chain_i8t(da, c->L, c->cfg.dtype, n_chunks, s));
@@ -999,7 +1061,25 @@ int calibrate_zero_response(sdrt_ctx *c) {
     if (rc == SDRT_OK && hipMemcpy(r0.data(), d_r0, cnt * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemcpy failed");
     if (rc == SDRT_OK) {
         for (size_t i = 0; i < cnt; ++i) bias[i] -= r0[i];
-        if (hipMemcpy(c->d_ybias, bias.data(), cnt * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemcpy failed");
+        const size_t np = 1 + c->more_passes.size();
+        if (np == 1) {
+            if (hipMemcpy(c->d_ybias, bias.data(), cnt * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemcpy failed");
+        } else {
+            // output k of the chunk = column k / nout_total, output b = k % nout_total of it: pass b / nout_pass holds it at
+            // column * nout_pass + b % nout_pass of its own slice
+            const size_t mt = (size_t) c->m, ml = mt / np, no = (size_t) c->nout_pass, nt = no * np;
+            std::vector<double> part((size_t) c->rows * ml * 2);
+            for (size_t p = 0; p < np && rc == SDRT_OK; ++p) {
+                for (size_t r = 0; r < (size_t) c->rows; ++r)
+                    for (size_t k = 0; k < ml; ++k) {
+                        const size_t col = k / no, b = k % no, kt = col * nt + p * no + b;
+                        part[(r * ml + k) * 2] = bias[(r * mt + kt) * 2];
+                        part[(r * ml + k) * 2 + 1] = bias[(r * mt + kt) * 2 + 1];
+                    }
+                double *dst = p == 0 ? c->d_ybias : c->more_passes[p - 1].d_ybias;
+                if (hipMemcpy(dst, part.data(), part.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemcpy failed");
+            }
+        }
     }
     (void) hipFree(d_zero);
     (void) hipFree(d_r0);
@@ -1126,11 +1206,11 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     }
     // FM on the wide-column kernel, likewise without a debug buffer: the pair products instead of the samples (half the bytes
     // between the two stages); not with the offset share still to come
-    const bool pairs = !ydec_dev && c->use_i8w && !c->stamps_dev && !later && !c->mixed && post_takes_pairs(post_args(c, ybuf, n_chunks, out_dev, false, true));
+    const bool pairs = !ydec_dev && c->use_i8w && c->more_passes.empty() && !c->stamps_dev && !later && !c->mixed && post_takes_pairs(post_args(c, ybuf, n_chunks, out_dev, false, true));
     // per-row modes: the FM rows' items as pair products, every item in the place its samples would take (eight- and sixteen-tile
     // chunks; the two-chunks-per-item forms keep samples)
     bool row_pairs = false;
-    if (!ydec_dev && c->use_i8w && !c->stamps_dev && !later && c->mixed && c->d_row_pair && c->n_rows_of[SDRT_FM] > 0
+    if (!ydec_dev && c->use_i8w && c->more_passes.empty() && !c->stamps_dev && !later && c->mixed && c->d_row_pair && c->n_rows_of[SDRT_FM] > 0
         && c->cfg.n_samples != 4 * SDRT_TB * SDRT_WIDE_LC) {
         PostArgs pm = post_args(c, ybuf, n_chunks, out_dev, false, true);
         pm.mode = SDRT_FM;

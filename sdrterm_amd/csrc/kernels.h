@@ -54,6 +54,8 @@ struct DecimArgs {
     const int *f32_exp;         //   float32, pre-sliced input: [chunk][4] tile exponents; raw then holds the slices (launch_f32_preslice)
     int sched;                  //   diagnostic builds only (-DSDRT_SCHED_EXP): wave priority assignment, SDRTERM_SCHED
     int dual;                   //   chain_i8w_kernel: one wave per SIMD on two tiles at once (DUAL form)
+    int out_mul, out_off;       //   eight outputs per column: output b of column c goes to index c * out_mul + out_off + b (one pass: 8, 0)
+    int m_local;                //   ... and the pass's ybias holds m_local entries per row (one pass: m)
     int rs;                     //   real-stream form (no shift, no IQ correction): w8 / w8mid hold sdrt_build_i8_weights_wide_rs planes
 };
 

@@ -117,7 +117,7 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int
     l.wloc = p; p += (nout == 4 && nsl == 1 ? 3 : S) * 8 * 1024;
     l.cF = p; p += SDRT_TB * nout * 4 * 16;
     l.cG = p; p += SDRT_TB * nout * 4 * 16;
-    l.bp = p; p += (nout + 1) * 4 * 16;
+    l.bp = p; p += 2 * (nout + 1) * 4 * 16;         // [b]: from the column start, [nout + 1 + b]: from the column end (WideTables.bp2)
     l.mup = p; p += 4 * 4 * 16;
     l.tpw = p; p += (SDRT_WIDE_MAXTILES + 1) * 4 * 16;
     l.tailF = p; p += 16 * 16;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
         cFL[i] = mk(wt->cF2[pos][md][0], wt->cF2[pos][md][1]);
         cGL[i] = mk(wt->cG2[pos][md][0], wt->cG2[pos][md][1]);
     }
-    if (tid < (NOUT + 1) * 4) bpL[tid] = mk(wt->bp2[tid >> 2][tid & 3][0], wt->bp2[tid >> 2][tid & 3][1]);
+    if (tid < 2 * (NOUT + 1) * 4) bpL[tid] = mk(wt->bp2[tid >> 2][tid & 3][0], wt->bp2[tid >> 2][tid & 3][1]);
     if (tid >= 64 && tid < 64 + (SDRT_WIDE_MAXTILES + 1) * 4) {
         const int i = tid - 64;
         tpwL[i] = mk(wt->tile_pow[i >> 2][i & 3][0], wt->tile_pow[i >> 2][i & 3][1]);
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
             if (tid < NT + SDRT_TB) psiL[tid] = nco ? nco_blk_g[tid < NT ? SDRT_TB * tid : tid - NT] : mk(1.0, 0.0);
         } else
         for (int i = tid; i < NT * SDRT_TB; i += NTHR) psiL[i] = nco ? nco_blk_g[i % (NTC * SDRT_TB)] : mk(1.0, 0.0);      // the phase restarts with every chunk
-        const cd *ybias = (const cd *) a.ybias + (size_t) row * m;      // always present for this kernel (zeros if there is no offset)
+        const cd *ybias = (const cd *) a.ybias + (size_t) row * (NOUT == 8 ? a.m_local : m);      // always present for this kernel (zeros if there is no offset)
         __syncthreads();
 
         uint32_t raw[NSLOT][WPK];
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
 #pragma unroll
                             for (int bb = 2 * sub; bb < 2 * sub + 2; ++bb) {
                                 const int b = 4 * e + bb;
-                                const cd bc = bpL[b * 4 + g], ba = bpL[(NOUT - b) * 4 + g];
+                                const cd bc = bpL[b * 4 + g], ba = bpL[(NOUT + 1 + b) * 4 + g];
                                 part[pj][bb][0] = fma(bc.re, dC[jq][0].re, fma(-bc.im, dC[jq][0].im, fma(ba.re, dA[jq][0].re, -(ba.im * dA[jq][0].im))));
                                 part[pj][bb][1] = fma(bc.re, dC[jq][1].re, fma(-bc.im, dC[jq][1].im, fma(ba.re, dA[jq][1].re, -(ba.im * dA[jq][1].im))));
                                 if constexpr (PACK) {
@@ -763,7 +763,10 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
 #pragma unroll
                     for (int e = 0; e < OPL; ++e) {
                         const int la = lane_id();
-                        const int k = (tile * SDRT_TB + (la & 15)) * NOUT + (la >> 4) + 4 * e;      // (column nb, output g + 4e)
+                        // (column nb, output g + 4e); eight outputs per column: possibly one pass of several over the chunk (decimation
+                        // below 32: a column has out_mul = 256 / q outputs, this pass finishes out_off .. out_off + 7 of them)
+                        const int k = NOUT == 8 ? (tile * SDRT_TB + (la & 15)) * a.out_mul + a.out_off + (la >> 4) + 4 * e
+                                                : (tile * SDRT_TB + (la & 15)) * NOUT + (la >> 4) + 4 * e;
                         const cd own = pv[j][e];
                         const v2u s0 = __builtin_amdgcn_permlane16_swap((unsigned) __double2loint(own.re), (unsigned) __double2loint(own.re), false, false);
                         const v2u s1 = __builtin_amdgcn_permlane16_swap((unsigned) __double2hiint(own.re), (unsigned) __double2hiint(own.re), false, false);
@@ -1500,9 +1503,12 @@ bool chain_i8w_rs_supported(int dt, int n) {
 }
 
 bool chain_i8w_supported(int q, int dt, int n, bool iq) {
-    if (!(q == 32 || q == 64)) return false;
     const int nt = n / (SDRT_TB * SDRT_WIDE_LC);
     if (n % (SDRT_TB * SDRT_WIDE_LC)) return false;
+    // decimation 8 and 16 (round 4): 32 / 16 outputs per column, eight per pass -- 4 / 2 passes over the chunk (api.hip: WidePass);
+    // plain integer forms at 8 or 16 tiles per chunk
+    if (q == 8 || q == 16) return !iq && (nt == 8 || nt == 16) && (dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16);
+    if (!(q == 32 || q == 64)) return false;
     // chunks of four tiles go two to an item (float32 records; 16-bit records in half-size chunks): plain form only
     if (nt == 4) return !iq && (dt == SDRT_F32 || dt == SDRT_S16 || dt == SDRT_U16);
     if (!(dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16)) return false;
@@ -1512,11 +1518,12 @@ bool chain_i8w_supported(int q, int dt, int n, bool iq) {
 size_t chain_i8w_lds_bytes(int q, int n, int iq, int dt) {
     const int ntc = n / (SDRT_TB * SDRT_WIDE_LC);
     const int nsl = dt == SDRT_S8 || dt == SDRT_U8 ? 1 : (dt == SDRT_F32 ? 4 : 2);
-    return (size_t) wide_lds(SDRT_I8_DIGITS, SDRT_WIDE_LC / q, ntc < 8 ? 8 : ntc, iq, ntc, nsl).total;
+    const int nout = SDRT_WIDE_LC / q > SDRT_WIDE_MAXOUT ? SDRT_WIDE_MAXOUT : SDRT_WIDE_LC / q;
+    return (size_t) wide_lds(SDRT_I8_DIGITS, nout, ntc < 8 ? 8 : ntc, iq, ntc, nsl).total;
 }
 
 hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, int n_cus, hipStream_t s) {
-    const int nout = SDRT_WIDE_LC / q, nt = a.n / (SDRT_TB * SDRT_WIDE_LC);
+    const int nout = SDRT_WIDE_LC / q > SDRT_WIDE_MAXOUT ? SDRT_WIDE_MAXOUT : SDRT_WIDE_LC / q, nt = a.n / (SDRT_TB * SDRT_WIDE_LC);
     // one workgroup per CU, in multiples of 8 (one per XCD); fewer when there is less work than CUs
     size_t items = n_chunks * (size_t) a.rows;
     size_t wgs = (size_t) (n_cus > 8 ? n_cus : 8);

@@ -568,25 +568,37 @@ extern "C" void sdrt_build_iq_pow(double lambda, int count, double *pw) {
 // ---- wide-column kernel (kernels_i8w.hip) --------------------------------------------------------------------------
 extern "C" int sdrt_build_wide_tables(const double *sos, int sections, int q, double data_scale, WideTables *out,
                                       const char **err) {
+    if (q < SDRT_WIDE_LC / SDRT_WIDE_MAXOUT) { if (err) *err = "wide columns need 32 <= q <= 256"; return -1; }
+    return sdrt_build_wide_tables_pass(sos, sections, q, data_scale, SDRT_WIDE_LC / (q > 0 ? q : 1), 0, out, err);
+}
+
+extern "C" int sdrt_build_wide_tables_pass(const double *sos, int sections, int q, double data_scale, int nout, int boff,
+                                           WideTables *out, const char **err) {
     const int LC = SDRT_WIDE_LC;
-    if (q < LC / SDRT_WIDE_MAXOUT || q > LC || (q & (q - 1))) { if (err) *err = "wide columns need 32 <= q <= 256"; return -1; }
+    if (q < 2 || q > LC || (q & (q - 1))) { if (err) *err = "wide columns need a power-of-two decimation <= 256"; return -1; }
+    if (nout < 1 || nout > SDRT_WIDE_MAXOUT || boff < 0 || (boff + nout) * q > LC) { if (err) *err = "bad output range of the pass"; return -1; }
     Modal m;
     if (!build_modal(sos, sections, m, err)) return -2;
     DecimTables base;
     if (int rc = sdrt_build_decim_tables(sos, sections, q, 1, &base, err)) return rc;
     std::memset(out, 0, sizeof(*out));
     out->q = q;
-    out->nout = LC / q;
-    const int nout = out->nout;
+    out->nout = nout;
+    out->boff = boff;
+    out->nout_total = LC / q;
     for (int i = 0; i < 4; ++i) {
         const C P = m.p[2 * i];
         const C mu = cpow(P, LC);
         for (int k = 0; k < 4; ++k) put(out->mu_pow[k][i], cpow(mu, 1 << k));
         for (int k = 0; k <= SDRT_WIDE_MAXTILES; ++k) put(out->tile_pow[k][i], cpow(mu, SDRT_TB * k));
-        for (int b = 0; b <= nout; ++b) put(out->bp2[b][i], C(2) * cpow(P, b * q));
+        for (int b = 0; b <= nout; ++b) {
+            put(out->bp2[b][i], C(2) * cpow(P, (boff + b) * q));
+            put(out->bp2[nout + 1 + b][i], C(2) * cpow(P, LC - (boff + b) * q));
+        }
         for (int pos = 0; pos < SDRT_TB * nout; ++pos) {
-            put(out->cF2[pos][i], C(2) * cpow(P, pos * q));
-            put(out->cG2[pos][i], C(2) * cpow(P, (SDRT_TB * nout - pos) * q));
+            const int s = (pos / nout) * LC + (boff + pos % nout) * q;      // the output's sample position in the tile
+            put(out->cF2[pos][i], C(2) * cpow(P, s));
+            put(out->cG2[pos][i], C(2) * cpow(P, SDRT_TB * LC - s));
         }
     }
     for (int i = 0; i < SDRT_NMODE; ++i) {
@@ -622,12 +634,20 @@ void fold_iq(double *row, int LC, double lambda, double *g2) {
 extern "C" int sdrt_build_i8_weights_wide(const double *sos, int sections, int q, double data_scale, const double *nco_samp,
                                           int S, double iq_lambda, signed char *main_out, double *main_combine,
                                           signed char *loc_out, double *loc_combine, double *gvec) {
+    if (q < SDRT_WIDE_LC / SDRT_WIDE_MAXOUT) return -3;
+    return sdrt_build_i8_weights_wide_pass(sos, sections, q, data_scale, nco_samp, S, iq_lambda, SDRT_WIDE_LC / (q > 0 ? q : 1), 0, main_out,
+                                           main_combine, loc_out, loc_combine, gvec);
+}
+
+extern "C" int sdrt_build_i8_weights_wide_pass(const double *sos, int sections, int q, double data_scale, const double *nco_samp,
+                                               int S, double iq_lambda, int nout, int boff, signed char *main_out,
+                                               double *main_combine, signed char *loc_out, double *loc_combine, double *gvec) {
     Modal m;
     const char *err = nullptr;
     if (!build_modal(sos, sections, m, &err)) return -2;
     const int LC = SDRT_WIDE_LC, cols = 2 * LC, KS = LC / 32;
-    if (q < LC / SDRT_WIDE_MAXOUT || q > LC || (q & (q - 1))) return -3;
-    const int nout = LC / q, NR = 2 * nout;
+    if (q < 2 || q > LC || (q & (q - 1)) || nout < 1 || nout > SDRT_WIDE_MAXOUT || boff < 0 || (boff + nout) * q > LC) return -3;
+    const int NR = 2 * nout;
     auto tr = [&](int t) { return nco_samp ? nco_samp[2 * t] : 1.0; };
     auto ti = [&](int t) { return nco_samp ? nco_samp[2 * t + 1] : 0.0; };
     auto kpos = [&](int c, int &ks, int &kg, int &j) {
@@ -671,13 +691,14 @@ extern "C" int sdrt_build_i8_weights_wide(const double *sos, int sections, int q
     std::vector<double> Wl((size_t) NR * cols, 0.0);
     for (int b = 0; b < nout; ++b)
         for (int t = 0; t < LC; ++t) {
+            const int so = (boff + b) * q;                   // the output's sample inside the column
             R acc = 0;
             for (int i = 0; i < 4; ++i) {
-                const C w = t < b * q ? ac[i] * cpow(P[i], b * q - 1 - t) : aa[i] * cpow(P[i], t - b * q);
+                const C w = t < so ? ac[i] * cpow(P[i], so - 1 - t) : aa[i] * cpow(P[i], t - so);
                 acc = acc + 2 * w.re;
             }
             double mt = (double) acc * data_scale;
-            if (t == b * q) mt += d0p;
+            if (t == so) mt += d0p;
             Wl[(size_t) (2 * b) * cols + 2 * t] = mt * tr(t);            // stream re: mt (xr tr - xi ti)
             Wl[(size_t) (2 * b) * cols + 2 * t + 1] = -mt * ti(t);
             Wl[(size_t) (2 * b + 1) * cols + 2 * t] = mt * ti(t);        // stream im: mt (xr ti + xi tr)

@@ -42,13 +42,14 @@ struct DecimTables {
 #define SDRT_WIDE_MAXOUT 8
 #define SDRT_WIDE_MAXTILES 16
 struct WideTables {
-    int32_t q, nout, reserved[2];
+    int32_t q, nout, boff, nout_total;                       // outputs boff .. boff + nout - 1 of the nout_total = LC / q of a column
     double mu_pow[4][SDRT_NMODE][2];                         // (p_i^LC)^(1,2,4,8): column-to-column scan inside a tile
     double tile_pow[SDRT_WIDE_MAXTILES + 1][SDRT_NMODE][2];  // (p_i^(16 LC))^k: tile-to-tile carries
-    double bp2[SDRT_WIDE_MAXOUT + 1][SDRT_NMODE][2];         // 2 p_i^(b q): state at the column start -> boundary b;
-                                                             //   state at the column end -> boundary b uses bp2[nout - b]
-    double cF2[SDRT_TB * SDRT_WIDE_MAXOUT][SDRT_NMODE][2];   // 2 p_i^(pos q): causal state at the tile start -> output pos
-    double cG2[SDRT_TB * SDRT_WIDE_MAXOUT][SDRT_NMODE][2];   // 2 p_i^((16 nout - pos) q): anticausal state at the tile end
+    double bp2[2 * (SDRT_WIDE_MAXOUT + 1)][SDRT_NMODE][2];   // [b] 2 p_i^((boff + b) q): state at the column start -> output b of the
+                                                             // pass; [nout + 1 + b] 2 p_i^(LC - (boff + b) q): state at the column end
+    double cF2[SDRT_TB * SDRT_WIDE_MAXOUT][SDRT_NMODE][2];   // 2 p_i^(s): causal state at the tile start -> the output at sample s of the
+                                                             // tile, s = column * LC + (boff + b) q for pos = column * nout + b
+    double cG2[SDRT_TB * SDRT_WIDE_MAXOUT][SDRT_NMODE][2];   // 2 p_i^(16 LC - s): anticausal state at the tile end
     double head[SDRT_NMODE][SDRT_EDGE + 1][2];               // edge operators, as in DecimTables
     double tailF[SDRT_NMODE][SDRT_NMODE][2];
     double tailFc[SDRT_NMODE][SDRT_NMODE][2];
@@ -139,6 +140,12 @@ int sdrt_build_i8_weights16(const double *sos, int sections, const struct DecimT
 // Wide-column kernel: tables for decimation q (32 <= q <= 256, power of two); data_scale multiplies the edge operators
 // (the digit planes take it through sdrt_build_i8_weights_wide).
 int sdrt_build_wide_tables(const double *sos, int sections, int q, double data_scale, struct WideTables *out, const char **err);
+// Decimations below LC / SDRT_WIDE_MAXOUT (round 4): a column has nout_total = LC / q > 8 outputs, the kernel's local tile holds 8 --
+// the chunk goes through the kernel nout_total / 8 times, pass p finishing outputs boff = 8 p .. 8 p + 7 of every column (the column
+// aggregates are the same in every pass; tables and local planes are the pass's own).  nout_pass * k = nout_total, boff a multiple
+// of nout_pass; nout_pass = LC / q, boff = 0 is the single pass above.
+int sdrt_build_wide_tables_pass(const double *sos, int sections, int q, double data_scale, int nout_pass, int boff, struct WideTables *out,
+                                const char **err);
 
 // Digit planes of the wide-column kernel.  Column = SDRT_WIDE_LC samples, KS = 8 k-steps of 64; K position (kstep, kg, j)
 // <-> sample 32*kstep + 8*kg + (j>>1), component j&1.  Row tiles 0/1 (causal / anticausal column aggregates, row =
@@ -154,6 +161,10 @@ int sdrt_build_wide_tables(const double *sos, int sections, int q, double data_s
 int sdrt_build_i8_weights_wide(const double *sos, int sections, int q, double data_scale, const double *nco_samp, int S,
                                double iq_lambda, signed char *main_out, double *main_combine, signed char *loc_out,
                                double *loc_combine, double *gvec /*[48][2]*/);
+// ... of one pass (see sdrt_build_wide_tables_pass): the local rows are outputs boff .. boff + nout_pass - 1 of the column
+int sdrt_build_i8_weights_wide_pass(const double *sos, int sections, int q, double data_scale, const double *nco_samp, int S,
+                                    double iq_lambda, int nout_pass, int boff, signed char *main_out, double *main_combine,
+                                    signed char *loc_out, double *loc_combine, double *gvec /*[48][2]*/);
 
 // Offset rows of the wide-column kernel with IQ correction (iq_lambda > 0): per column the two sums  sum_j w_j x_re[j],
 // sum_j w_j x_im[j], w_j = lambda (1-lambda)^(LC-1-j) -- what the column adds to the carried offset.  All S digit planes of

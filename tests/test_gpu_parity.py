@@ -538,7 +538,8 @@ def test_one_wave_per_simd_form_of_the_wide_kernel(name, golden, monkeypatch):
 
 @pytest.mark.parametrize('code,q,center,rows', [('h', 64, 15700, 1), ('h', 64, 0, 1), ('B', 64, 15700, 1), ('H', 64, 15700, 1),
                                                  ('h', 32, 15700, 3), ('B', 32, 0, 1), ('b', 64, 15700, 1), ('f', 64, 15700, 1),
-                                                 ('f', 64, 15700, 5), ('h', 128, 15700, 1), ('f', 128, 15700, 1)])
+                                                 ('f', 64, 15700, 5), ('h', 128, 15700, 1), ('f', 128, 15700, 1),
+                                                 ('h', 16, 15700, 1), ('h', 8, 0, 2), ('B', 16, 15700, 1)])
 def test_silent_chunks_anywhere_in_a_batch_come_out_as_exact_zeros(code, q, center, rows, monkeypatch):
     """The reference turns an all-zero chunk into exact zeros (sosfiltfilt of zeros, angle(0) = 0: demodulation.py:30-32,
     dsp_processor.py:147).  The int8 forms filter x - offset and add the response to the offset back: that response is taken

@@ -63,6 +63,10 @@ if __name__ == '__main__':
     run('single VFO FM dec=64 int16 --correct-iq', 8192, decimation=64, mode='fm', code='h', row_freqs=[15000], omega_out=12500, correct_iq=True)
     run('single VFO FM dec=32 int16 --correct-iq', 8192, decimation=32, mode='fm', code='h', row_freqs=[15000], omega_out=12500, correct_iq=True)
     run('single VFO FM dec=16 int16', 8192, decimation=16, mode='fm', code='h', row_freqs=[15000], omega_out=12500)
+    run('single VFO FM dec=8 int16', 8192, decimation=8, mode='fm', code='h', row_freqs=[15000], omega_out=12500)
+    run('single VFO FM dec=16 uint8', 4096, decimation=16, mode='fm', code='B', row_freqs=[15000], omega_out=12500)
+    run('8 VFOs FM dec=16 int16', 1024, decimation=16, mode='fm', code='h', row_freqs=VFOS8, omega_out=12500)
+    run('single VFO FM dec=4 int16', 2048, decimation=4, mode='fm', code='h', row_freqs=[15000], omega_out=12500)
     run('single VFO FM dec=2 int16 (the CLI default)', 1024, decimation=2, mode='fm', code='h', row_freqs=[15000], omega_out=12500)
     if os.environ.get('SDRTERM_STAGE_A') is None:
         os.environ['SDRTERM_STAGE_A'] = 'i8t'       # the same int8 workloads on the one-block-per-column kernel, for comparison
