@@ -13,9 +13,9 @@ LC, TB, NM, EDGE = 256, 16, 4, 27
 
 
 class WideTables(C.Structure):
-    _fields_ = [('q', C.c_int32), ('nout', C.c_int32), ('reserved', C.c_int32 * 2),
+    _fields_ = [('q', C.c_int32), ('nout', C.c_int32), ('boff', C.c_int32), ('nout_total', C.c_int32),
                 ('mu_pow', C.c_double * (4 * NM * 2)), ('tile_pow', C.c_double * (17 * NM * 2)),
-                ('bp2', C.c_double * (9 * NM * 2)), ('cF2', C.c_double * (TB * 8 * NM * 2)), ('cG2', C.c_double * (TB * 8 * NM * 2)),
+                ('bp2', C.c_double * (18 * NM * 2)), ('cF2', C.c_double * (TB * 8 * NM * 2)), ('cG2', C.c_double * (TB * 8 * NM * 2)),
                 ('head', C.c_double * (NM * 28 * 2)), ('tailF', C.c_double * (NM * NM * 2)), ('tailFc', C.c_double * (NM * NM * 2)),
                 ('tailU', C.c_double * (NM * 28 * 2))]
 
@@ -96,7 +96,7 @@ def run(q, n, theta, seed=1, S=5, lam=0.0, off0=0j):
     Lv = np.stack([blk.real[:, None] * lr - blk.imag[:, None] * li, blk.imag[:, None] * lr + blk.real[:, None] * li], -1)
     mu = cplx(wt.mu_pow, (4, NM))[0]              # p^LC
     tp = cplx(wt.tile_pow, (17, NM))
-    bp2 = cplx(wt.bp2, (9, NM))
+    bp2 = cplx(wt.bp2, (18, NM))          # [b]: from the column start; [nout + 1 + b]: from the column end
     cF2 = cplx(wt.cF2, (TB * 8, NM))
     cG2 = cplx(wt.cG2, (TB * 8, NM))
     head = cplx(wt.head, (NM, 28))
@@ -119,7 +119,7 @@ def run(q, n, theta, seed=1, S=5, lam=0.0, off0=0j):
     yl = np.zeros((nt, TB, nout, 2))
     for b in range(nout):
         yl[:, :, b, :] = Lv.reshape(nt, TB, nout, 2)[:, :, b, :] + \
-            (bp2[b][None, None, :, None] * Cx + bp2[nout - b][None, None, :, None] * Ax).real.sum(axis=2)
+            (bp2[b][None, None, :, None] * Cx + bp2[nout + 1 + b][None, None, :, None] * Ax).real.sum(axis=2)
     # edge operators: the decimator sees u = z e^{i theta t}
     u = zc * np.exp(1j * theta * np.arange(n))
     blk_ri = np.ascontiguousarray(np.stack([blk.real, blk.imag], -1))
