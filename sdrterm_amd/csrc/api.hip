@@ -84,6 +84,7 @@ struct sdrt_ctx {
     OutTables *d_otab = nullptr;
     double *d_nco_tile = nullptr, *d_nco_phase = nullptr, *d_resample = nullptr, *d_out_sos = nullptr;
     double *d_fft_tw = nullptr, *d_fft_shift = nullptr;
+    double *d_fftp_tw = nullptr, *d_fftp_ab = nullptr;     // packed form of the resampler's transform (post_fftp_kernel)
     double *d_fft8 = nullptr;         // eight-lanes-per-item demodulation stage (kernels_post8.hip): transform tables ...
     Post8Tables *d_p8tab = nullptr;   // ... and its lowpass constants
     int p8_lpi = 0;
@@ -660,6 +661,14 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
             rc = upload(&c->d_fft_tw, tw.data(), tw.size() * sizeof(double));
             if (rc == SDRT_OK) rc = upload(&c->d_fft_shift, sh.data(), sh.size() * sizeof(double));
             c->fft_ok = rc == SDRT_OK;
+            const char *pp = getenv("SDRTERM_POST_PACKED");      // diagnostics: "0" keeps the full-size complex transforms
+            if (rc == SDRT_OK && (N == 1024 || N == 2048) && !(pp && strcmp(pp, "0") == 0)) {
+                // 2048 / 4096 outputs per chunk (decimation 16 / 8 of 16-bit records): the real angles packed two to a complex number
+                std::vector<double> twp((size_t) N), ab((size_t) N * 2);
+                sdrt_build_fft_resample_packed(N, twp.data(), ab.data());
+                rc = upload(&c->d_fftp_tw, twp.data(), twp.size() * sizeof(double));
+                if (rc == SDRT_OK) rc = upload(&c->d_fftp_ab, ab.data(), ab.size() * sizeof(double));
+            }
         }
         // FM with 512 outputs per chunk (decimation 64 of 16-bit records, 32 of float32 records) and the usual output lowpass
         // (one complex pole pair + one real pole): eight lanes per item (diagnostics: SDRTERM_POST=wave keeps one wave per item)
@@ -728,6 +737,8 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_smooth);
     (void) hipFree(c->d_fft_tw);
     (void) hipFree(c->d_fft_shift);
+    (void) hipFree(c->d_fftp_tw);
+    (void) hipFree(c->d_fftp_ab);
     (void) hipFree(c->d_fft8);
     (void) hipFree(c->d_p8tab);
     (void) hipFree(c->d_stash);
@@ -1096,6 +1107,8 @@ PostArgs post_args(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out
     pa.fft_tw = c->d_fft_tw;
     pa.fft_shift = c->d_fft_shift;
     pa.fft_ok = c->fft_ok && c->out_modal;
+    pa.fftp_tw = c->d_fftp_tw;
+    pa.fftp_ab = c->d_fftp_ab;
     pa.otab = c->d_otab;
     pa.out_sos = c->d_out_sos;
     pa.out = out_dev;

@@ -91,6 +91,7 @@ struct PostArgs {
     size_t items;
     int m, mode, out_sections;
     int fft_ok;                 // host check: modal lowpass available (OutTables.nmodes >= 0) and not disabled
+    const double *fftp_tw, *fftp_ab;   // packed form (post_fftp_kernel: 2048 / 4096 outputs per chunk): [m/4][2] twiddles, [m/4][4] alpha / beta (or NULL)
     // --correct-iq computed inside the wide-column kernel: the share of the offset at each chunk's start is still to be
     // subtracted, y[row][chunk][k] -= iq_off[chunk] * iq_R[row][k] (NULL: nothing to subtract); see iq_fix_kernel
     const double *iq_R;         // [rows][m][2]

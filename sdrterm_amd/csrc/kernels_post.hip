@@ -358,6 +358,106 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
     }
 }
 
+// The same stage with the N real pair angles packed two to a complex number (round 4; 2048 / 4096 outputs per chunk: decimation
+// 16 / 8 of 16-bit records): z[n] = a[2n] + i a[2n+1] through ONE transform of H = N/2 = 256 B points each way, the packed
+// spectrum of the half-sample shifted sequence bin by bin from the packed spectrum of the angles (sdrt_build_fft_resample_packed:
+// Wp[k] = alpha_k Z[k] + beta_k conj(Z[H-k])), IDFT_H(Wp) = o[2n] + i o[2n+1] = two odd output samples per point.  Half the
+// transform work and half the LDS of post_fft_kernel: three workgroups per CU instead of one.
+template <int B, int WPB, bool PAIRS>
+__global__ __launch_bounds__(64 * WPB) void post_fftp_kernel(PostArgs a) {
+    constexpr int H = 256 * B, N = 2 * H, M = 2 * N;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cd *tw = (cd *) smem;                                       // [H] exp(-2 pi i k/H)
+    const double4 *__restrict__ ab = (const double4 *) a.fftp_ab;      // [H] alpha, beta: read once per item, from L2
+    // per wave: the padded transform buffer (xpos) and, afterwards, the demodulated samples for the lowpass (zpos) -- M doubles
+    // need more room than H complex numbers: the buffer is sized for them
+    constexpr int ZL = M + (M >> 3) + 1;                        // doubles
+    constexpr int XL = (ZL + 1) / 2;                            // 16-byte elements
+    static_assert(XL >= H + H / 4 + 1, "the transform buffer must fit");
+    cd *X = tw + H + (size_t) wave * XL;
+    double *zb = (double *) X;
+    for (int i = tid; i < H; i += 64 * WPB) tw[i] = ((const cd *) a.fftp_tw)[i];
+    __syncthreads();
+    const OutTables *__restrict__ ot = a.otab;
+    for (size_t witem = (size_t) blockIdx.x * WPB + wave; witem < a.items; witem += (size_t) gridDim.x * WPB) {
+        const size_t item = post_item(a, witem);
+        const cd *y = (const cd *) a.y + item * (size_t) ((PAIRS && !a.pairs_wide) ? N : M);
+        const cd *R = a.iq_R ? (const cd *) a.iq_R + (item / a.n_chunks) * (size_t) M : nullptr;
+        const cd h = a.iq_R ? ((const cd *) a.iq_off)[item % a.n_chunks] : mk(0.0, 0.0);
+        cd x[B][4];
+        cd ev[B][4];                                            // the angles themselves: the even output samples
+        auto angle_of = [&](int j) {
+            // angle(d[i] * conj(d[i+1])) (demodulation.py:25-32); pairs: the product comes from the chain kernel
+            if constexpr (PAIRS) {
+                const cd z = y[j];
+                return atan2(z.im, z.re);
+            } else {
+                const cd p = load_y(y, R, h, 2 * j), c = load_y(y, R, h, 2 * j + 1);
+                return atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);
+            }
+        };
+        auto angles = [&]() {
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int n = lane + 64 * b + k * (H / 4);
+                    x[b][k] = mk(angle_of(2 * n), angle_of(2 * n + 1));
+                    ev[b][k] = x[b][k];
+                }
+        };
+        fft_wave<B, false>(x, X, tw, lane, angles, [&](int o, cd v) { X[xpos(o)] = v; });
+        auto shifted = [&]() {
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int f = lane + 64 * b + k * (H / 4);
+                    const cd Z = X[xpos(f)], Zm = X[xpos((H - f) & (H - 1))];
+                    const double4 c = ab[f];
+                    // alpha Z + beta conj(Zm)
+                    x[b][k] = mk(fma(c.x, Z.re, fma(-c.y, Z.im, fma(c.z, Zm.re, c.w * Zm.im))),
+                                 fma(c.x, Z.im, fma(c.y, Z.re, fma(c.w, Zm.re, -(c.z * Zm.im)))));
+                }
+        };
+        // the last inverse pass has loaded all of X before it stores into zb (same bytes)
+        fft_wave<B, true>(x, X, tw, lane, shifted, [&](int o, cd v) { zb[zpos(4 * o + 1)] = v.re; zb[zpos(4 * o + 3)] = v.im; });
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int n = lane + 64 * b + k * (H / 4);
+                zb[zpos(4 * n)] = ev[b][k].re;
+                zb[zpos(4 * n + 2)] = ev[b][k].im;
+            }
+        modal_lowpass_wave(ot, zb, a.out + item * (size_t) M, M, lane);
+    }
+}
+
+template <int B, int WPB, bool PAIRS>
+static hipError_t launch_post_fftp_p(const PostArgs &a, hipStream_t s) {
+    constexpr int H = 256 * B, M = 4 * H;
+    const size_t lds = (size_t) (H + WPB * ((M + (M >> 3) + 2) / 2)) * 16;
+    static thread_local int done_dev = -1;                      // once per device and instantiation
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    if (done_dev != dev) {
+        hipError_t e = hipFuncSetAttribute((const void *) post_fftp_kernel<B, WPB, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+        done_dev = dev;
+    }
+    size_t wgs = (a.items + WPB - 1) / WPB;
+    const size_t cap = 256 * 8;
+    if (wgs > cap) wgs = cap;
+    hipLaunchKernelGGL((post_fftp_kernel<B, WPB, PAIRS>), dim3((unsigned) wgs), dim3(64 * WPB), lds, s, a);
+    return hipGetLastError();
+}
+template <int B, int WPB>
+static hipError_t launch_post_fftp(const PostArgs &a, hipStream_t s) {
+    return a.pairs ? launch_post_fftp_p<B, WPB, true>(a, s) : launch_post_fftp_p<B, WPB, false>(a, s);
+}
+
 template <int B, int WPB, bool PAIRS>
 static hipError_t launch_post_fft_p(const PostArgs &a, hipStream_t s) {
     constexpr int N = 256 * B;
@@ -554,6 +654,13 @@ hipError_t launch_post(const PostArgs &a, hipStream_t s) {
     if (post_fft8_supported(a)) return launch_post_fft8(a, s);                                // kernels_post8.hip
     if (post_bigfft_supported(a)) return launch_post_bigfft(a, s);                            // kernels_seq.hip: a workgroup per item, 2048 outputs and up
     // FFT form of the resampler where it applies: FM, N = m/2 in {256, 512, 1024}, output lowpass in modal form
+    if (a.mode == SDRT_FM && a.fftp_tw && a.fftp_ab && a.fft_ok) {
+        switch (a.m) {                                         // the real angles packed two to a complex number: half-size transforms
+            // (a wave's share of LDS is its m output samples for the lowpass, 18 / 37 KB: eight / three waves fill a CU)
+            case 2048: return launch_post_fftp<2, 8>(a, s);
+            case 4096: return launch_post_fftp<4, 3>(a, s);
+        }
+    }
     if (a.mode == SDRT_FM && a.fft_tw && a.fft_shift && a.fft_ok) {
         switch (a.m) {
             case 512: return launch_post_fft<1, 4>(a, s);

@@ -15,6 +15,7 @@
 #include "tables.h"
 
 #include <cmath>
+#include <complex>
 #include <cstring>
 #include <vector>
 
@@ -454,6 +455,36 @@ extern "C" void sdrt_build_fft_resample(int N, double *tw, double *shift) {
         const long double a2 = pi * (long double) fs / (long double) N;
         shift[2 * k] = (double) (cosl(a2) / (long double) N);
         shift[2 * k + 1] = (double) (sinl(a2) / (long double) N);
+    }
+}
+
+// Packed form of the same resampler (post_fftp_kernel): the N real pair angles a[n] go two to a complex number, z[n] = a[2n] +
+// i a[2n+1], through ONE transform of H = N/2 points each way.  With Z = DFT_H(z) the packed spectrum of the half-sample shifted
+// sequence o (the odd output samples, demodulation.py:35-38) is  Wp[k] = alpha_k Z[k] + beta_k conj(Z[(H - k) mod H])  and
+// IDFT_H(Wp) (unnormalised) = o[2n] + i o[2n+1].  tw: [H] exp(-2 pi i k / H); ab: [H][4] = alpha (re, im), beta (re, im).
+extern "C" void sdrt_build_fft_resample_packed(int N, double *tw, double *ab) {
+    const long double pi = 3.141592653589793238462643383279502884L;
+    const int H = N / 2;
+    typedef std::complex<long double> CL;
+    auto shift = [&](int k) -> CL {            // as sdrt_build_fft_resample: exp(i pi f / N) / N, zero at the Nyquist bin
+        if (2 * k == N) return CL(0, 0);
+        const int fs = k < N / 2 ? k : k - N;
+        const long double a2 = pi * (long double) fs / (long double) N;
+        return CL(cosl(a2), sinl(a2)) / (long double) N;
+    };
+    for (int k = 0; k < H; ++k) {
+        const long double ang = -2.0L * pi * (long double) k / (long double) H;
+        tw[2 * k] = (double) cosl(ang);
+        tw[2 * k + 1] = (double) sinl(ang);
+        const long double an = -2.0L * pi * (long double) k / (long double) N;
+        const CL w(cosl(an), sinl(an)), iw = CL(0, 1) / w, half(0.5L, 0), wi = w / CL(0, 2);
+        const CL s0 = shift(k), s1 = shift(k + H);
+        const CL cz0 = s0 * (half + wi), cz1 = s1 * (half - wi), cc0 = s0 * (half - wi), cc1 = s1 * (half + wi);
+        const CL al = ((cz0 + cz1) + iw * (cz0 - cz1)), be = ((cc0 + cc1) + iw * (cc0 - cc1));      // (the factor 2 of the packing folded in)
+        ab[4 * k] = (double) al.real();
+        ab[4 * k + 1] = (double) al.imag();
+        ab[4 * k + 2] = (double) be.real();
+        ab[4 * k + 3] = (double) be.imag();
     }
 }
 

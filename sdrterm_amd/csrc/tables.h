@@ -191,6 +191,9 @@ int sdrt_build_i8_weights_wide_rs(const double *sos, int sections, int q, double
 void sdrt_build_wide_edge(const struct WideTables *wt, const double *nco_samp, const double *nco_blk, int n, double iq_lambda,
                           double *ab /*[16][32][4]*/, double *pq /*[16][4]*/);
 
+// Packed (real-input) form of the FM resampler's transform tables: see operators.cpp.  tw [N/2][2], ab [N/2][4].
+void sdrt_build_fft_resample_packed(int N, double *tw, double *ab);
+
 // IQ-correction geometric weights: pw[j] = (1-lambda)^j, j <= count.
 void sdrt_build_iq_pow(double lambda, int count, double *pw);
 #ifdef __cplusplus
