@@ -662,7 +662,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
             if (rc == SDRT_OK) rc = upload(&c->d_fft_shift, sh.data(), sh.size() * sizeof(double));
             c->fft_ok = rc == SDRT_OK;
             const char *pp = getenv("SDRTERM_POST_PACKED");      // diagnostics: "0" keeps the full-size complex transforms
-            if (rc == SDRT_OK && (N == 1024 || N == 2048) && !(pp && strcmp(pp, "0") == 0)) {
+            if (rc == SDRT_OK && (N == 1024 || N == 2048 || N == 4096 || N == 8192) && !(pp && strcmp(pp, "0") == 0)) {
                 // 2048 / 4096 outputs per chunk (decimation 16 / 8 of 16-bit records): the real angles packed two to a complex number
                 std::vector<double> twp((size_t) N), ab((size_t) N * 2);
                 sdrt_build_fft_resample_packed(N, twp.data(), ab.data());
@@ -701,13 +701,14 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         // one prefix pass instead of each recomputing them (diagnostics: SDRTERM_IQ_FUSED=0 / 1 forces either)
         c->iq_fused = c->iq && c->rows == 1;
         if (const char *e = getenv("SDRTERM_IQ_FUSED")) c->iq_fused = c->iq && atoi(e) != 0;
-        if (seq) {
+        if (seq && !(want_i8 && !c->iq && c->norm_bias == 0.0 && chain_i8w_supported(q, cfg->dtype, n, c->iq))) {
             // nothing to set up: the per-sample form reads DecimTables only
         } else if (want_i8 && !want_t && chain_i8w_supported(q, cfg->dtype, n, c->iq) && chain_i8w_lds_bytes(q, n, c->iq ? (c->iq_fused ? 2 : 1) : 0, cfg->dtype) <= 160 * 1024)
             rc = setup_wide(c, cfg, scale_tables);
         if (rc == SDRT_OK && !seq && !c->use_i8w && want_i8 && !c->iq && want_i8_fallback_t(L, cfg->dtype, n, m))
             rc = setup_i8t(c, cfg, scale_tables);
         c->use_i8 = c->use_i8w || c->use_i8t;
+        if (seq && c->use_i8w) c->use_seq = false;               // decimation 4 (and, SDRTERM_WIDE_SMALLQ=1, 2) as 8 (16) passes of the wide kernel
         // float32 on the wide kernel with several rows: every row of a chunk would slice the same records again (the larger part
         // of that form's vector work); from four rows up one pass slices them once (diagnostics: SDRTERM_F32_PRE=0 / 1)
         c->f32_pre = c->use_i8w && cfg->dtype == SDRT_F32 && c->rows >= 4;

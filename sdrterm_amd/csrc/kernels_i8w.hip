@@ -19,6 +19,7 @@
 // Arithmetic: identical to kernels_i8t.hip (error-free int8 slicing, S digit planes, exact int32 sums, one fp64
 // recombination), see DESIGN.md section 3.  The lowest (digit 0 x low slice) product of 16-bit encodings is dropped: it
 // is below the quantisation step of the planes.
+#include <cstdlib>
 #include "kernels_common.hpp"
 
 #ifndef SDRT_DUAL_PF
@@ -109,6 +110,11 @@ __host__ __device__ constexpr bool wide_shq(int nout, int ntc, int iq, int nsl) 
 // eight outputs per column: the fourth buffer only fits beside the larger output tables if the column phasors are kept as two
 // factors (tile, column in tile: 32 entries instead of 256, one complex product more per use) and the IQ-only areas are left out
 __host__ __device__ constexpr bool wide_psf(int nout, int ntc, int iq) { return wide_shq(nout, ntc, iq, 1) && nout == 8; }
+// eight outputs per column without IQ correction -- the forms that may be one of several passes over the chunk (decimation below 32):
+// the shares from the column's END for the pass's outputs come from a second half of the table, WideTables.bp2[nout + 1 + b]; the IQ
+// forms (never one of several passes, and short of LDS) keep the one table and read bp2[nout - b].  A compile-time property of the
+// form: choosing at run time cost these forms 8 % in spills.
+__host__ __device__ constexpr bool wide_sepba(int nout, int iq) { return nout == 8 && iq == 0; }
 __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int ntc, int nsl) {
     WideLds l;
     int p = 0;
@@ -117,7 +123,7 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int
     l.wloc = p; p += (nout == 4 && nsl == 1 ? 3 : S) * 8 * 1024;
     l.cF = p; p += SDRT_TB * nout * 4 * 16;
     l.cG = p; p += SDRT_TB * nout * 4 * 16;
-    l.bp = p; p += 2 * (nout + 1) * 4 * 16;         // [b]: from the column start, [nout + 1 + b]: from the column end (WideTables.bp2)
+    l.bp = p; p += (wide_sepba(nout, iq) ? 2 : 1) * (nout + 1) * 4 * 16;      // WideTables.bp2: [b] from the column start; from its end: [nout - b], or (wide_sepba) [nout + 1 + b]
     l.mup = p; p += 4 * 4 * 16;
     l.tpw = p; p += (SDRT_WIDE_MAXTILES + 1) * 4 * 16;
     l.tailF = p; p += 16 * 16;
@@ -135,6 +141,7 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int
     l.total = p;
     return l;
 }
+
 }  // namespace
 
 // RS ("real streams"): no frequency shift and no IQ correction.  The real and the imaginary sample stream are then filtered by
@@ -255,7 +262,9 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
         cFL[i] = mk(wt->cF2[pos][md][0], wt->cF2[pos][md][1]);
         cGL[i] = mk(wt->cG2[pos][md][0], wt->cG2[pos][md][1]);
     }
-    if (tid < 2 * (NOUT + 1) * 4) bpL[tid] = mk(wt->bp2[tid >> 2][tid & 3][0], wt->bp2[tid >> 2][tid & 3][1]);
+    constexpr bool SEPBA_ = wide_sepba(NOUT, IQ);
+    if (tid < (SEPBA_ ? 2 : 1) * (NOUT + 1) * 4) bpL[tid] = mk(wt->bp2[tid >> 2][tid & 3][0], wt->bp2[tid >> 2][tid & 3][1]);
+    constexpr bool SEPBA = wide_sepba(NOUT, IQ);
     if (tid >= 64 && tid < 64 + (SDRT_WIDE_MAXTILES + 1) * 4) {
         const int i = tid - 64;
         tpwL[i] = mk(wt->tile_pow[i >> 2][i & 3][0], wt->tile_pow[i >> 2][i & 3][1]);
@@ -693,7 +702,7 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
 #pragma unroll
                             for (int bb = 2 * sub; bb < 2 * sub + 2; ++bb) {
                                 const int b = 4 * e + bb;
-                                const cd bc = bpL[b * 4 + g], ba = bpL[(NOUT + 1 + b) * 4 + g];
+                                const cd bc = bpL[b * 4 + g], ba = bpL[(SEPBA ? NOUT + 1 + b : NOUT - b) * 4 + g];
                                 part[pj][bb][0] = fma(bc.re, dC[jq][0].re, fma(-bc.im, dC[jq][0].im, fma(ba.re, dA[jq][0].re, -(ba.im * dA[jq][0].im))));
                                 part[pj][bb][1] = fma(bc.re, dC[jq][1].re, fma(-bc.im, dC[jq][1].im, fma(ba.re, dA[jq][1].re, -(ba.im * dA[jq][1].im))));
                                 if constexpr (PACK) {
@@ -1506,8 +1515,12 @@ bool chain_i8w_supported(int q, int dt, int n, bool iq) {
     const int nt = n / (SDRT_TB * SDRT_WIDE_LC);
     if (n % (SDRT_TB * SDRT_WIDE_LC)) return false;
     // decimation 8 and 16 (round 4): 32 / 16 outputs per column, eight per pass -- 4 / 2 passes over the chunk (api.hip: WidePass);
-    // plain integer forms at 8 or 16 tiles per chunk
-    if (q == 8 || q == 16) return !iq && (nt == 8 || nt == 16) && (dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16);
+    // plain integer forms (no IQ correction, no normalisation bias at decimation 4) at 8 or 16 tiles per chunk
+    // ... and decimation 4 as 8 passes (measured against the per-sample kernel: chain 1.245 -> 0.765 ms per 2^26 samples); decimation 2
+    // would be 16 passes and ties with it (0.78 / 0.80 ms per 2^25): it stays there unless SDRTERM_WIDE_SMALLQ=1 (diagnostics)
+    const char *sq = getenv("SDRTERM_WIDE_SMALLQ");
+    if (q == 4 && sq && atoi(sq) == 0) return false;
+    if (q == 4 || q == 8 || q == 16 || (q == 2 && sq && atoi(sq) != 0)) return !iq && (nt == 8 || nt == 16) && (dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16);
     if (!(q == 32 || q == 64)) return false;
     // chunks of four tiles go two to an item (float32 records; 16-bit records in half-size chunks): plain form only
     if (nt == 4) return !iq && (dt == SDRT_F32 || dt == SDRT_S16 || dt == SDRT_U16);
@@ -1519,7 +1532,7 @@ size_t chain_i8w_lds_bytes(int q, int n, int iq, int dt) {
     const int ntc = n / (SDRT_TB * SDRT_WIDE_LC);
     const int nsl = dt == SDRT_S8 || dt == SDRT_U8 ? 1 : (dt == SDRT_F32 ? 4 : 2);
     const int nout = SDRT_WIDE_LC / q > SDRT_WIDE_MAXOUT ? SDRT_WIDE_MAXOUT : SDRT_WIDE_LC / q;
-    return (size_t) wide_lds(SDRT_I8_DIGITS, nout, ntc < 8 ? 8 : ntc, iq, ntc, nsl).total;
+    return (size_t) wide_lds(SDRT_I8_DIGITS, nout, ntc < 8 ? 8 : ntc, iq, ntc, nsl).total ;
 }
 
 hipError_t launch_chain_i8w(const DecimArgs &a, int q, int dt, size_t n_chunks, int n_cus, hipStream_t s) {

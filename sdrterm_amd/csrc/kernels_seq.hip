@@ -571,6 +571,60 @@ __global__ __launch_bounds__(256) void post_bigfft_kernel(PostArgs a) {
     workgroup_lowpass(a, out, ptot);
 }
 
+// ... and with the pair angles packed two to a complex number (round 4, as post_fftp_kernel in kernels_post.hip): ONE transform of
+// H = N/2 = 1024 B points each way, half the passes' work and half the LDS image (two to four workgroups per CU instead of one or two).
+template <int B, bool PAIRS>
+__global__ __launch_bounds__(256) void post_bigfftp_kernel(PostArgs a) {
+    constexpr int H = 1024 * B, N = 2 * H, M = 2 * N;
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ cd ptot[SDRT_OUT_MAXMODES][4];
+    cd *X = (cd *) smem;                                        // [H + H/16]
+    const cd *__restrict__ tw = (const cd *) a.fftp_tw;         // [H] exp(-2 pi i k/H), from L2
+    const double4 *__restrict__ ab = (const double4 *) a.fftp_ab;      // [H] alpha, beta (sdrt_build_fft_resample_packed)
+    const int tid = threadIdx.x;
+    const size_t item = post_item(a, blockIdx.x);
+    const cd *y = (const cd *) a.y + item * (size_t) ((PAIRS && !a.pairs_wide) ? N : M);
+    double *out = a.out + item * (size_t) M;
+    cd x[B][4];
+    auto angle_of = [&](int j) {
+        if constexpr (PAIRS) {
+            const cd z = y[j];                                  // d[2j] conj(d[2j+1]) from the chain kernel
+            return atan2(z.im, z.re);
+        } else {
+            const cd pa = y[2 * j], c = y[2 * j + 1];
+            return atan2(pa.im * c.re - pa.re * c.im, pa.re * c.re + pa.im * c.im);
+        }
+    };
+    // pair angles (demodulation.py:25-32): the even output samples, and -- two to a point -- the input of the transform
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int n = tid + 256 * b + k * (H / 4);
+            const double a0 = angle_of(2 * n), a1 = angle_of(2 * n + 1);
+            out[4 * n] = a0;
+            out[4 * n + 2] = a1;
+            x[b][k] = mk(a0, a1);
+        }
+    fft_workgroup<B, false>(x, X, tw, tid, [&](int o, cd v) { X[xq(o)] = v; });
+    __syncthreads();
+    // packed spectrum of the half-sample shifted sequence, bin by bin: alpha Z[f] + beta conj(Z[H - f])
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int f = tid + 256 * b + k * (H / 4);
+            const cd Z = X[xq(f)], Zm = X[xq((H - f) & (H - 1))];
+            const double4 c = ab[f];
+            x[b][k] = mk(fma(c.x, Z.re, fma(-c.y, Z.im, fma(c.z, Zm.re, c.w * Zm.im))),
+                         fma(c.x, Z.im, fma(c.y, Z.re, fma(c.w, Zm.re, -(c.z * Zm.im)))));
+        }
+    __syncthreads();
+    fft_workgroup<B, true>(x, X, tw, tid, [&](int o, cd v) { out[4 * o + 1] = v.re; out[4 * o + 3] = v.im; });
+    __syncthreads();
+    workgroup_lowpass(a, out, ptot);
+}
+
 bool post_bigfft_supported(const PostArgs &a) {
     // (2048 / 4096 outputs per chunk stay with the one-wave kernel of kernels_post.hip: a workgroup per item measured 0.289 against
     // 0.251 ms per 2^29 8-bit samples at decimation 32 there, profiles/r03_experiments.txt)
@@ -592,7 +646,28 @@ static hipError_t launch_post_bigfft_b(const PostArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int B>
+static hipError_t launch_post_bigfftp_b(const PostArgs &a, hipStream_t s) {
+    const size_t lds = (size_t) (1024 * B + 64 * B) * 16;
+    static thread_local int done_dev = -1;
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    if (done_dev != dev) {
+        hipError_t e = hipFuncSetAttribute((const void *) post_bigfftp_kernel<B, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+        done_dev = dev;
+    }
+    hipLaunchKernelGGL((post_bigfftp_kernel<B, false>), dim3((unsigned) a.items), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_post_bigfft(const PostArgs &a, hipStream_t s) {
+    if (a.fftp_tw && a.fftp_ab) {                    // the packed form where its tables exist
+        switch (a.m) {
+            case 8192: return launch_post_bigfftp_b<2>(a, s);
+            case 16384: return launch_post_bigfftp_b<4>(a, s);
+        }
+    }
     switch (a.m) {
         case 8192: return launch_post_bigfft_b<4, false>(a, s);
         case 16384: return launch_post_bigfft_b<8, false>(a, s);
