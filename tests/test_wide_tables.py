@@ -17,6 +17,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
     (64, 65536, -1.1, 0.0, 0j),
     (64, 32768, 0.37, 50 / 1024000, 300 - 200j),
     (32, 32768, -0.2, 0.01, -1000 + 50j),
+    # decimation 16 / 8 / 4: 16 / 32 / 64 outputs per column in 2 / 4 / 8 passes of eight (sdrt_build_*_pass)
+    (16, 32768, 0.3, 0.0, 0j),
+    (8, 32768, -0.4, 0.0, 0j),
+    (4, 32768, 0.0, 0.0, 0j),
+    (16, 65536, 0.2, 0.0, 0j),
 ])
 def test_tables_reproduce_scipy_decimate(q, n, theta, lam, off0):
     import emulate_wide

@@ -26,13 +26,27 @@ def cplx(a, shape):
 
 
 def run(q, n, theta, seed=1, S=5, lam=0.0, off0=0j):
+    """Decimations below 32: a column has more than eight outputs and the kernel takes them eight per pass (tables and local planes per
+    pass: sdrt_build_wide_tables_pass, sdrt_build_i8_weights_wide_pass); the passes' outputs interleave to the chunk's."""
+    nout_total = LC // q
+    nout = min(8, nout_total)
+    parts = [run_pass(q, n, theta, seed, S, lam, off0, nout, p * nout) for p in range(nout_total // nout)]
+    ref = parts[0][1]
+    y = np.stack([pt[0] for pt in parts], axis=1).reshape(-1, nout_total // nout, nout)       # [column][pass][b]
+    y = y.reshape(-1)
+    e = np.abs(y - ref).max() / np.abs(ref).max()
+    print(f'q={q} n={n} theta={theta}: max rel err {e:.3e} ({len(parts)} pass(es))')
+    return e
+
+
+def run_pass(q, n, theta, seed, S, lam, off0, nout, boff):
     rng = np.random.default_rng(seed)
     sos = np.ascontiguousarray(cheby1(8, 0.05, 0.8 / q, output='sos'))
     wt = WideTables()
     err = C.c_char_p()
-    rc = lib.sdrt_build_wide_tables(sos.ctypes.data_as(C.c_void_p), 4, q, C.c_double(1.0), C.byref(wt), C.byref(err))
+    rc = lib.sdrt_build_wide_tables_pass(sos.ctypes.data_as(C.c_void_p), 4, q, C.c_double(1.0), nout, boff, C.byref(wt), C.byref(err))
     assert rc == 0, err.value
-    nout = wt.nout
+    assert (wt.nout, wt.boff, wt.nout_total) == (nout, boff, LC // q)
     NR = 2 * nout
     KS = 8
     t = np.arange(LC)
@@ -42,10 +56,10 @@ def run(q, n, theta, seed=1, S=5, lam=0.0, off0=0j):
     loc = np.zeros(S * KS * 4 * NR * 16, np.int8)
     cm, cl = C.c_double(), C.c_double()
     gvec = np.zeros((48, 2))
-    rc = lib.sdrt_build_i8_weights_wide(sos.ctypes.data_as(C.c_void_p), 4, q, C.c_double(1.0),
-                                        samp_ri.ctypes.data_as(C.c_void_p) if theta else None, S, C.c_double(lam),
-                                        main.ctypes.data_as(C.c_void_p), C.byref(cm), loc.ctypes.data_as(C.c_void_p), C.byref(cl),
-                                        gvec.ctypes.data_as(C.c_void_p))
+    rc = lib.sdrt_build_i8_weights_wide_pass(sos.ctypes.data_as(C.c_void_p), 4, q, C.c_double(1.0),
+                                             samp_ri.ctypes.data_as(C.c_void_p) if theta else None, S, C.c_double(lam), nout, boff,
+                                             main.ctypes.data_as(C.c_void_p), C.byref(cm), loc.ctypes.data_as(C.c_void_p), C.byref(cl),
+                                             gvec.ctypes.data_as(C.c_void_p))
     assert rc == 0
     # de-quantise into float weight matrices W[row][2*LC] by K position
     main = main.reshape(2, S, KS, 4, 16, 16)      # tile, digit, kstep, kg, row, j
@@ -154,16 +168,14 @@ def run(q, n, theta, seed=1, S=5, lam=0.0, off0=0j):
         for b in range(nout):
             pos = c * nout + b
             y[:, c, b, :] = yl[:, c, b, :] + (cF2[pos][None, :, None] * F[:-1] + cG2[pos][None, :, None] * G[1:]).real.sum(axis=1)
-    y = (y[..., 0] + 1j * y[..., 1]).reshape(-1)
-    ref = decimate(u, q)
-    e = np.abs(y - ref).max() / np.abs(ref).max()
-    print(f'q={q} n={n} theta={theta}: max rel err {e:.3e}')
-    return e
+    y = (y[..., 0] + 1j * y[..., 1]).reshape(-1, nout)           # [column][b]
+    return y, decimate(u, q)
 
 
 if __name__ == '__main__':
     ok = True
-    for q, n, th in [(64, 32768, 0.0), (64, 32768, 0.37), (32, 32768, 0.1), (64, 65536, -1.1), (128, 32768, 0.2), (256, 32768, 0.0)]:
+    for q, n, th in [(64, 32768, 0.0), (64, 32768, 0.37), (32, 32768, 0.1), (64, 65536, -1.1), (128, 32768, 0.2), (256, 32768, 0.0), (16, 32768, 0.3),
+                     (8, 32768, -0.4), (4, 32768, 0.0)]:
         ok &= run(q, n, th) < 2e-11
     for q, n, th in [(64, 32768, 0.37), (32, 32768, -0.2)]:
         ok &= run(q, n, th, lam=50 / 1024000, off0=300 - 200j) < 2e-11
