@@ -64,15 +64,18 @@ WORKLOADS = {
     'fm64': (64, 1, 131072, 'weak', 'h', 256_000_000, False, None),
     'fm64f': (64, 1, 131072, 'weak', 'f', 256_000_000, False, None),     # the same stream as float32 records (16384-sample chunks)
     'fm64b': (64, 1, 65536, 'weak', 'B', 256_000_000, False, None),      # the same stream as uint8 records (rtl_tcp's format; 65536-sample chunks)
+    'fm16': (16, 1, 16384, 'weak', 'h', 256_000_000, False, None),       # decimation 16: the wide kernel in two passes of eight outputs per column
+    'fm2': (2, 1, 2048, 'weak', 'h', 256_000_000, False, None),          # decimation 2, the CLI's default (src/sdrterm.py:80): the per-sample kernel
     'simo8': (32, 8, 4096, 'strong', 'h', 256_000_000, True, ('fm', 'am', 'fm', 'am', 'fm', 'am', 'am', 'fm')),
     'simo64': (32, 64, 512, 'strong', 'h', 256_000_000, False, None),
     'f32x256': (64, 256, 128, 'strong', 'f', 1_000_000_000, False, None),
 }
 METRIC = {'fm64': 'input MSamples/s IQ->FM demod, dec=64', 'fm64f': 'input MSamples/s IQ->FM demod, float32 IQ, dec=64',
           'fm64b': 'input MSamples/s IQ->FM demod, uint8 IQ, dec=64',
+          'fm16': 'input MSamples/s IQ->FM demod, dec=16', 'fm2': 'input MSamples/s IQ->FM demod, dec=2',
           'simo8': 'input MSamples/s 8-VFO --simo FM+AM mixed, --correct-iq, dec=32',
           'simo64': 'input MSamples/s 64-VFO --simo FM, dec=32', 'f32x256': 'input MSamples/s 256-VFO --simo FM, float32 IQ, dec=64'}
-CONFIG_NO = {'fm64': 1, 'fm64f': 1, 'fm64b': 1, 'simo8': 2, 'simo64': 3, 'f32x256': 4}
+CONFIG_NO = {'fm64': 1, 'fm64f': 1, 'fm64b': 1, 'fm16': 1, 'fm2': 1, 'simo8': 2, 'simo64': 3, 'f32x256': 4}
 ITEM = {'h': 2, 'f': 4, 'B': 1}
 NP_DTYPE = {'h': 'int16', 'f': 'float32', 'B': 'uint8'}
 ENC_NAME = {'h': 'int16', 'f': 'float32', 'B': 'uint8'}
@@ -507,7 +510,9 @@ def main():
         path_achieved = alg_bps * n_samples / (ms_per_step * 1e-3) / 1e9
         # int8 matrix work of the dominant kernel: matrix instructions per 4096-sample tile x 16*16*64*2 operations
         fused_iq = correct_iq and rows == 1
-        mfma_per_tile = ({'h': {64: 184, 32: 216}, 'f': {64: 288, 32: 336}, 'B': {64: 104, 32: 120}}[code][q] + (16 if fused_iq else 0)) if eng.stage_a == 'i8w' else ({'h': 160, 'f': 224}.get(code) if eng.stage_a == 'i8t' else None)
+        # (decimation below 32: 256 / q / 8 passes of the eight-outputs-per-column form)
+        mfma_table = {'h': {64: 184, 32: 216, 16: 2 * 216, 8: 4 * 216, 4: 8 * 216}, 'f': {64: 288, 32: 336}, 'B': {64: 104, 32: 120, 16: 2 * 120, 8: 4 * 120}}
+        mfma_per_tile = (mfma_table[code].get(q, 0) + (16 if fused_iq else 0) or None) if eng.stage_a == 'i8w' else ({'h': 160, 'f': 224}.get(code) if eng.stage_a == 'i8t' else None)
         i8_ops = mfma_per_tile * 32768.0 * rows * n_samples / 4096 if mfma_per_tile else None
         # hardware counters cannot be read from inside this run: the committed record of rocprofv3 passes over this very workload
         # (tools/pmc.sh) is quoted under "from_profile", with the file it comes from and the commit it was taken at; traffic is per
@@ -556,7 +561,7 @@ def main():
             # what the arithmetic is: int8 x int8 -> int32 matrix products of 5 base-256 weight digits x 2 byte slices (exact),
             # recombined and finished in fp64; 'f64' when the fp64 matrix-core kernel runs
             'dtype': ('f32->4 x i8 block fixed point, i8x5-split+f64' if code == 'f' else 'i8x5-split+f64') if eng.stage_a in ('i8w', 'i8t') else 'f64', 'data': 'synthetic',
-            'config': {'workload': (f'configs[1]{"" if code == "h" else f" as {ENC_NAME[code]} records"}: {FS // 1_000_000} MS/s synthetic {ENC_NAME[code]} IQ (FM tone + noise), FM demod, dec={q}, single VFO, '
+            'config': {'workload': (f'configs[1]{"" if code == "h" and q == 64 else (f" as {ENC_NAME[code]} records" if code != "h" else f" at decimation {q}")}: {FS // 1_000_000} MS/s synthetic {ENC_NAME[code]} IQ (FM tone + noise), FM demod, dec={q}, single VFO, '
                                     f'center={CENTER} Hz{", --correct-iq" if correct_iq else ""}, {n_chunks} chunks x {N} samples per GPU per step, inputs resident in HBM')
                        if single else
                        (f'configs[{CONFIG_NO[args.workload]}]: --simo {rows_total} VFO rows sharded {rows}/GPU, {FS // 1_000_000} MS/s synthetic {ENC_NAME[code]} IQ, {mode_txt}, dec={q}'

@@ -51,7 +51,7 @@ for k, cs in sorted(acc.items()):
     rec[e['kernel']] = e
 chain = next((v for k, v in rec.items() if k.startswith('chain')), None)
 if chain:
-    defaults = {'fm64': 131072, 'fm64_iq': 131072, 'fm64f': 131072, 'fm64b': 65536, 'fm64b_iq': 65536, 'simo8': 4096, 'simo64': 512, 'f32x256': 128}
+    defaults = {'fm64': 131072, 'fm64_iq': 131072, 'fm64f': 131072, 'fm64b': 65536, 'fm64b_iq': 65536, 'fm16': 16384, 'fm2': 2048, 'simo8': 4096, 'simo64': 512, 'f32x256': 128}
     wl = os.environ.get('BENCH_WORKLOAD', 'fm64')
     top = dict(chain, workload=wl, chunks_per_step_per_gpu=int(os.environ.get('BENCH_CHUNKS', defaults.get(wl, 131072))), other_kernels={k: v for k, v in rec.items() if v is not chain},
                note='rocprofv3 --pmc, one pass per counter group with --kernel-trace; FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced '
