@@ -48,14 +48,26 @@ __device__ __forceinline__ cd cpow_u(cd b, unsigned e) {
 
 }  // namespace
 
+#ifndef SDRT_SEQ_WAVES
+#define SDRT_SEQ_WAVES 1         // minimum waves per SIMD the register allocation of chain_seq_kernel is held to
+#endif
 template <int DT, bool NCO, bool IQ>
-__global__ __launch_bounds__(256) void chain_seq_kernel(DecimArgs a, int qshift) {
+__global__ __launch_bounds__(256, SDRT_SEQ_WAVES) void chain_seq_kernel(DecimArgs a, int qshift) {
     constexpr int ITEM = Enc<DT>::size;
     constexpr int SPG = ITEM >= 8 ? 1 : 8 / ITEM;          // samples per 16-byte load (f64: one 16-byte sample)
     constexpr int GB = SPG * 2 * ITEM;                     // bytes per load
     __shared__ cd wtot[16][4];
     __shared__ cd tileL[SEQ_NCO_L];
     __shared__ cd edgeL[16];                               // [0..7] F0, [8..15] sample part of G_end; index mode*2 + stream
+    // Outputs travel through LDS in blocks of 16 samples (round 4).  A thread's run is contiguous in time, so its outputs are
+    // contiguous in memory and the 64 runs of a wave lie T / q x 16 bytes apart: written one by one, every store instruction
+    // touched 64 cache lines with 16 bytes each, the second pass read them back the same way and wrote them again (counters of the
+    // round-3 kernel at decimation 2: 2.88 GB written and 1.8 GB fetched per 2^26 samples against 0.54 + 0.27 algorithmic).  Now a
+    // lane drops its outputs of a block into its row of the wave's tile, and the wave moves the tile to or from memory with whole
+    // cache lines per run (decimation 2: eight outputs = 128 bytes per run and block).  Row stride 9 elements: the lanes' rows start on
+    // different banks.
+    constexpr int SEQ_BLK = 16, SEQ_ROW = SEQ_BLK / 2 + 1;
+    __shared__ cd stageL[4][64 * SEQ_ROW];
     const DecimTables *__restrict__ tab = a.tab;
     const int n = a.n, T = n / 256;
     const long qmask = (1L << qshift) - 1;
@@ -238,6 +250,39 @@ __global__ __launch_bounds__(256) void chain_seq_kernel(DecimArgs a, int qshift)
 
     // ---- pass 2a: forward with the causal states: direct + causal part of the run's outputs -----------------------------
     double *yd = a.ydec + ((size_t) row * a.n_chunks + (size_t) chunk) * (size_t) a.m * 2;
+    cd *myrow = &stageL[wave][lane * SEQ_ROW];
+    const int obq = SEQ_BLK >> qshift;                      // outputs per block and run
+    const long kstride = (long) T >> qshift;                // outputs per run
+    // the wave's tile <-> memory: element e = i * 64 + lane of the tile = output e % obq of run e / obq (this block): consecutive
+    // lanes take consecutive outputs of a run, whole 128-byte (decimation 4: 64-byte) pieces per run
+    auto tile_to_memory = [&](long trel) {                  // trel: first sample of the block relative to the run start
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const long k0 = trel >> qshift;
+        for (int i = 0; i < obq; ++i) {
+            const int e = i * 64 + lane, r = e / obq, j = e % obq;
+            const cd v = stageL[wave][r * SEQ_ROW + j];
+            *(double2 *) (yd + 2 * (size_t) ((long) (wave * 64 + r) * kstride + k0 + j)) = make_double2(v.re, v.im);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto memory_to_tile = [&](long trel) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const long k0 = trel >> qshift;
+        for (int i = 0; i < obq; ++i) {
+            const int e = i * 64 + lane, r = e / obq, j = e % obq;
+            const double2 v = *(const double2 *) (yd + 2 * (size_t) ((long) (wave * 64 + r) * kstride + k0 + j));
+            stageL[wave][r * SEQ_ROW + j] = mk(v.x, v.y);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     cd off_end = off0;
     {
         cd off = off0;
@@ -252,13 +297,14 @@ __global__ __launch_bounds__(256) void chain_seq_kernel(DecimArgs a, int qshift)
                 double yr = d0p * ur, yi = d0p * ui;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { yr = fma(2.0, Fs[i][0].re, yr); yi = fma(2.0, Fs[i][1].re, yi); }
-                *(double2 *) (yd + 2 * (size_t) (t >> qshift)) = make_double2(yr, yi);
+                myrow[((t - t0) & (SEQ_BLK - 1)) >> qshift] = mk(yr, yi);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 Fs[i][0] = mk(fma(p[i].re, Fs[i][0].re, fma(-p[i].im, Fs[i][0].im, ac[i].re * ur)), fma(p[i].re, Fs[i][0].im, fma(p[i].im, Fs[i][0].re, ac[i].im * ur)));
                 Fs[i][1] = mk(fma(p[i].re, Fs[i][1].re, fma(-p[i].im, Fs[i][1].im, ac[i].re * ui)), fma(p[i].re, Fs[i][1].im, fma(p[i].im, Fs[i][1].re, ac[i].im * ui)));
             }
+            if (((t - t0) & (SEQ_BLK - 1)) == SEQ_BLK - 1) tile_to_memory((t - t0) - (SEQ_BLK - 1));     // the block is complete (every lane at once)
         });
         off_end = off;
     }
@@ -266,6 +312,7 @@ __global__ __launch_bounds__(256) void chain_seq_kernel(DecimArgs a, int qshift)
     {
         cd off = off_end;                                   // offset at t0 + T
         for_run(std::false_type{}, [&](long t, double xr, double xi) {
+            if (((t - t0) & (SEQ_BLK - 1)) == SEQ_BLK - 1) memory_to_tile((t - t0) - (SEQ_BLK - 1));     // descending: a block begins with its last sample
             if constexpr (IQ) {
                 off.re = (off.re - lam * xr) * rom;          // offset at t
                 off.im = (off.im - lam * xi) * rom;
@@ -279,11 +326,12 @@ __global__ __launch_bounds__(256) void chain_seq_kernel(DecimArgs a, int qshift)
                 Gs[i][1] = mk(fma(p[i].re, Gs[i][1].re, fma(-p[i].im, Gs[i][1].im, aa[i].re * ui)), fma(p[i].re, Gs[i][1].im, fma(p[i].im, Gs[i][1].re, aa[i].im * ui)));
             }
             if ((t & qmask) == 0) {
-                double2 v = *(double2 *) (yd + 2 * (size_t) (t >> qshift));
+                cd v = myrow[((t - t0) & (SEQ_BLK - 1)) >> qshift];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { v.x = fma(2.0, Gs[i][0].re, v.x); v.y = fma(2.0, Gs[i][1].re, v.y); }
-                *(double2 *) (yd + 2 * (size_t) (t >> qshift)) = v;
+                for (int i = 0; i < 4; ++i) { v.re = fma(2.0, Gs[i][0].re, v.re); v.im = fma(2.0, Gs[i][1].re, v.im); }
+                myrow[((t - t0) & (SEQ_BLK - 1)) >> qshift] = v;
             }
+            if (((t - t0) & (SEQ_BLK - 1)) == 0) tile_to_memory(t - t0);            // the block's first sample was its last one to do
         });
     }
 }
