@@ -16,8 +16,8 @@ f=$(find "$OUT/stats" -name "*kernel_stats.csv" | head -1)
 rm -rf "$OUT/stats"
 echo "rocprof stats done"
 bash "$ROOT/tools/pmc.sh" > "$OUT/pmc.log" 2>&1
-cp "$ROOT/gpurun_out/pmc/summary.txt" "$OUT/pmc_summary.txt" 2>/dev/null
-cp "$ROOT/gpurun_out/pmc/pmc_record.json" "$OUT/pmc_record.json" 2>/dev/null
+cp "$ROOT/gpurun_out/pmc/summary_fm64.txt" "$OUT/pmc_summary_fm64.txt" 2>/dev/null
+cp "$ROOT/gpurun_out/pmc/pmc_record_fm64.json" "$OUT/pmc_record_fm64.json" 2>/dev/null
 echo "pmc done"
 if [ -f "$ROOT/sdrterm_amd/libsdrterm_hip_exp.so" ]; then
     SDRTERM_HIP_LIB=$ROOT/sdrterm_amd/libsdrterm_hip_exp.so python3 "$ROOT/tools/stamps_wide.py" 131072 15000 450 > "$OUT/i8w_phase_stamps_after_2s_load.txt" 2>&1
@@ -25,3 +25,10 @@ if [ -f "$ROOT/sdrterm_amd/libsdrterm_hip_exp.so" ]; then
 fi
 python3 "$ROOT/tools/determinism.py" > "$OUT/determinism.txt" 2>&1
 tail -2 "$OUT/determinism.txt"
+# the other bench workloads (one line each) and the secondary workloads of tools/bench_extra.py
+for w in fm64f fm64b fm16 fm2 simo8 simo64 f32x256; do
+    python3 "$ROOT/bench.py" --workload $w --steps 300 > "$OUT/${w}_n1.json" 2> "$OUT/${w}.err" || echo "$w failed"
+done
+python3 "$ROOT/bench.py" --correct-iq --steps 300 > "$OUT/fm64_correct_iq.json" 2> "$OUT/fm64_correct_iq.err" || echo "fm64 --correct-iq failed"
+python3 "$ROOT/tools/bench_extra.py" > "$OUT/secondary_workloads.jsonl" 2> "$OUT/secondary.err"
+echo "workloads done"
