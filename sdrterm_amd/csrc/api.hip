@@ -564,8 +564,12 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     c->iq = cfg->correct_iq != 0;
     c->use_seq = seq;
     c->iq_gs = iq_gs;
+    // the fp64 block kernel keeps a chunk's block states in LDS: too many blocks (8-bit records at decimation 8: 8192 of them) do
+    // not fit.  The wide int8 kernel takes such a chunk where it applies (in passes, section 3c of DESIGN.md) -- without the
+    // normalisation bias, whose response comes from the fp64 kernel; settled after the stage-A form has been chosen
     const size_t lds = seq ? 0 : chain_lds_bytes(n, L, m);
-    if (lds > 160 * 1024) {
+    const bool f64_fits = lds <= 160 * 1024;
+    if (!f64_fits && !(chain_i8w_supported(q, cfg->dtype, n, cfg->correct_iq != 0) && c->norm_bias == 0.0)) {
         delete c;
         return fail(SDRT_EINVAL, "chunk needs %zu bytes of LDS (> 160 KiB): n_samples/decimation combination unsupported", lds);
     }
@@ -714,6 +718,8 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         c->f32_pre = c->use_i8w && cfg->dtype == SDRT_F32 && c->rows >= 4;
         if (const char *e = getenv("SDRTERM_F32_PRE")) c->f32_pre = c->use_i8w && cfg->dtype == SDRT_F32 && atoi(e) != 0;
     }
+    if (rc == SDRT_OK && !f64_fits && !c->use_i8w)
+        rc = fail(SDRT_EINVAL, "chunk needs %zu bytes of LDS (> 160 KiB) on the fp64 kernel and the int8 form does not apply: n_samples/decimation combination unsupported", lds);
     if (rc == SDRT_OK && c->use_i8) rc = setup_ybias(c, cfg);
     if (rc == SDRT_OK && c->use_i8 && !c->more_passes.empty()) rc = setup_pass_ybias(c);
     if (rc == SDRT_OK && c->use_i8) rc = calibrate_zero_response(c);

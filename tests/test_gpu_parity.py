@@ -569,3 +569,42 @@ def test_silent_chunks_anywhere_in_a_batch_come_out_as_exact_zeros(code, q, cent
         ref = eng.process(raw[2:6].tobytes()).reshape(rows, 4, n // q)
         assert np.array_equal(ref[:, :3], out[:, 2:5])
         eng.close()
+
+
+@pytest.mark.parametrize('code,q,mode,rows', [('h', 16, 'fm', 3), ('h', 8, 'am', 2), ('H', 16, 'am', 1), ('B', 16, 'fm', 2), ('b', 8, 'fm', 1), ('h', 4, 'fm', 1)])
+def test_small_decimations_in_passes_of_the_wide_kernel(code, q, mode, rows, monkeypatch):
+    """Decimation 4 / 8 / 16 on the wide-column int8 kernel: a 256-sample column has 64 / 32 / 16 outputs and the kernel finishes eight
+    per pass (8 / 4 / 2 passes over the chunk, tables and local planes per pass: api.hip WidePass).  Against oracle/chain.c (the
+    reference's chain, dsp_processor.py:140-149) on several rows, FM and AM, odd batch sizes; the bits of a chunk must not depend on
+    the batch it arrives in; and the fp64 kernel forced on the same input must agree to the usual 1e-9 of the decimated peak."""
+    from sdrterm_amd.engine import Engine
+    from tests.golden import prng
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    fs, n, nch = 1024000, samples_per_chunk(code), 7
+    freqs = [15700.0, -203300.0, 100100.0][:rows]
+    omega = 60000 if q == 4 else (30000 if q == 8 else 15000)
+    raw = prng.raw_bytes(code, n * nch, seed=400 + q, amp=100 if code in 'bB' else 8000)
+    eng = Engine(fs, q, mode, code, row_freqs=freqs, apply_shift=True, omega_out=omega)
+    assert eng.stage_a == 'i8w'
+    out, y = eng.process_debug(raw)
+    m = n // q
+    exp = _oracle_rows(raw, code, n, q, mode, freqs, fs, omega, range(nch), range(rows))
+    got = out.reshape(rows, nch, m).transpose(1, 0, 2)
+    err = float(np.abs(got - exp).max())
+    tol = tol_for(exp, mode)
+    print(f'{code} q={q} {mode} x {rows}: {256 // q // 8} passes, max abs err {err:.3e} (tol {tol:.1e})')
+    assert err <= tol
+    # the same chunks in another batching: the same bits
+    part = eng.process(raw[2 * eng.chunk_bytes:5 * eng.chunk_bytes]).reshape(rows, 3, m)
+    assert np.array_equal(part, out.reshape(rows, nch, m)[:, 2:5])
+    monkeypatch.setenv('SDRTERM_STAGE_A', 'f64')
+    from sdrterm_amd._native import SdrtError
+    try:
+        e64 = Engine(fs, q, mode, code, row_freqs=freqs, apply_shift=True, omega_out=omega)
+    except SdrtError as e:
+        # 8-bit records at decimation 8: 8192 blocks per chunk do not fit the fp64 kernel's LDS -- only the int8 form takes them
+        assert 'LDS' in str(e) and code in 'bB' and q == 8
+        return
+    assert e64.stage_a in ('f64', 'seq')
+    _o64, y64 = e64.process_debug(raw)
+    assert np.abs(y - y64).max() <= 1e-9 * np.abs(y64).max()
