@@ -245,7 +245,7 @@ int setup_wide(sdrt_ctx *c, const sdrt_config *cfg, ScaleFn &) {
     const size_t per_row_loc = c->wide_rs ? (size_t) S * (LC / 64) * 4 * (NR / 2) * 16 : (size_t) S * KS * 4 * NR * 16;
     std::vector<signed char> w8(per_row * c->rows), w8l(per_row_loc * c->rows);
     std::vector<double> samp((size_t) c->rows * LC * 2), blk((size_t) c->rows * (n / LC) * 2);
-    std::vector<double> eab((size_t) c->rows * 16 * 32 * 4), epq((size_t) c->rows * 16 * 4), gv((size_t) c->rows * 48 * 2);
+    std::vector<double> eab((size_t) c->rows * 16 * 32 * 4), epq((size_t) c->rows * 16 * 4), gv((size_t) c->rows * SDRT_WIDE_GV * 2);
     const double lam = c->iq ? cfg->iq_inductance : 0.0;
     bool ok = true;
     for (int r = 0; r < c->rows && ok; ++r) {
@@ -257,7 +257,7 @@ int setup_wide(sdrt_ctx *c, const sdrt_config *cfg, ScaleFn &) {
                                             w8l.data() + per_row_loc * r, &combl)
             : sdrt_build_i8_weights_wide_pass(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, c->nco ? sp : nullptr, S, lam, nout_pass, 0,
                                               w8.data() + per_row * r, &comb, w8l.data() + per_row_loc * r, &combl,
-                                              &gv[(size_t) r * 96]);
+                                              &gv[(size_t) r * 2 * SDRT_WIDE_GV]);
         sdrt_build_wide_edge(&wtab, c->nco ? sp : nullptr, c->nco ? bp : nullptr, n, lam, &eab[(size_t) r * 2048],
                              &epq[(size_t) r * 64]);
         // one power-of-two scale per context (rows differ by a rotation of the weights only); a digit overflow or unequal
@@ -318,12 +318,12 @@ int setup_wide(sdrt_ctx *c, const sdrt_config *cfg, ScaleFn &) {
         WideTables wt2;
         if (sdrt_build_wide_tables_pass(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, nout_pass, p * nout_pass, &wt2, &msg) != 0) { ok = false; break; }
         std::vector<signed char> w8x(per_row), w8l2(per_row_loc * c->rows);
-        std::vector<double> gv2((size_t) c->rows * 48 * 2);
+        std::vector<double> gv2((size_t) c->rows * SDRT_WIDE_GV * 2);
         for (int r = 0; r < c->rows && ok; ++r) {
             double comb = 0.0, combl = 0.0;
             const double *sp = &samp[(size_t) r * LC * 2];
             const int brc = sdrt_build_i8_weights_wide_pass(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, c->nco ? sp : nullptr, S, lam, nout_pass,
-                                                            p * nout_pass, w8x.data(), &comb, w8l2.data() + per_row_loc * r, &combl, &gv2[(size_t) r * 96]);
+                                                            p * nout_pass, w8x.data(), &comb, w8l2.data() + per_row_loc * r, &combl, &gv2[(size_t) r * 2 * SDRT_WIDE_GV]);
             if (brc != 0 || combl == 0.0) ok = false;
             else if (r == 0) wp.w8mid_combine = combl;
             else if (combl != wp.w8mid_combine) ok = false;

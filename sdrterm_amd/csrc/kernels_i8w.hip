@@ -95,7 +95,7 @@ __device__ __forceinline__ int f32_tile_exponent(unsigned max_abs_bits) {
 }
 
 struct WideLds {        // byte offsets
-    int wmain, wloc, cF, cG, bp, mup, tpw, tailF, tailFc, psi, gv, pq, cpow, wiq, buf, buf_stride, total;
+    int wmain, wloc, cF, cG, bp, mup, tpw, tailF, tailFc, psi, gv, aopen, pq, cpow, wiq, buf, buf_stride, total;
     // per buffer (offsets in 16-byte units from its start): carF [SLOTS*8], carG [SLOTS*8], F0 [8 SEG], Gu [8 SEG], IQ: tile totals of
     // the offset [NT] and the weighted sum of the last 32 samples [1]
 };
@@ -131,12 +131,13 @@ __host__ __device__ inline WideLds wide_lds(int S, int nout, int nt, int iq, int
     const bool psf = wide_psf(nout, ntc, iq);
     l.psi = p; p += (psf ? nt + SDRT_TB : nt * SDRT_TB) * 16;      // column phasors of the row (psf: per tile, then per column in a tile)
     l.gv = p; p += psf ? 0 : 48 * 16;               // IQ, float32: rank-one vectors {g_re, g_im} per matrix row
+    l.aopen = p; p += iq != 0 && nsl == 2 ? 48 * 4 : 0;   // IQ, 16-bit records: what the lowest accumulators open at, matrix row order (3 tiles x 16)
     l.pq = p; p += psf ? 0 : 16 * 2 * 16;           // IQ: offset terms of the edge operators
     l.cpow = p; p += iq == 1 ? nt * SDRT_TB * 8 : 0;       // IQ from prefix tables: (1-lambda)^(column start)
     l.wiq = p; p += iq == 2 ? (SDRT_WIDE_LC / 32) * 1024 : 0;     // IQ fused: offset rows, one packed fragment per k-step (sdrt_build_i8_offset_rows)
     l.buf = p;
     const int seg = nt / ntc, slots = seg * (ntc + 1);          // carry slots: ntc + 1 per chunk of the item
-    l.buf_stride = (2 * slots * 8 + 16 * seg + (psf ? 0 : nt + 1)) * 16;
+    l.buf_stride = (2 * slots * 8 + 16 * seg + (iq == 2 ? nt + 1 : 0)) * 16;      // (IQ fused: the tiles' offset totals and the tail sum)
     p += (wide_shq(nout, ntc, iq, nsl) ? 4 : 3) * l.buf_stride;
     l.total = p;
     return l;
@@ -198,6 +199,9 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
     constexpr int NSTEP = KS * TPW;                  // k-steps per wave and item
     // NOUT == 4: the local tile has 8 rows; two digit planes share one matrix instruction (rows 0-7 / 8-15), see below
     constexpr bool PACK = NOUT == 4 && !RS;
+    // --correct-iq on 16-bit records: the accumulators of the lowest level open at a constant per row instead of zero, which makes
+    // an all-zero chunk at offset zero cancel to the last bit (operators.cpp: quantise_planes, "consistent")
+    constexpr bool AOPEN = IQ != 0 && NSL == 2;
     constexpr int PPF = RS ? 16 / NOUT : (PACK ? 2 : 1);         // digit planes per local-tile fragment
     constexpr int NHF = (S + PPF - 1) / PPF;                      // fragments used with the high (or only) slice
     constexpr int NLF = (PACK || RS) ? NHF + (NSL >= 2 ? (S - 1 + PPF - 1) / PPF : 0) : S;   // local-tile fragments per k-step (both plane pairings)
@@ -228,6 +232,7 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
     cd *cFL = (cd *) (smem + lo.cF), *cGL = (cd *) (smem + lo.cG), *bpL = (cd *) (smem + lo.bp), *mupL = (cd *) (smem + lo.mup), *tpwL = (cd *) (smem + lo.tpw);
     cd *tailFL = (cd *) (smem + lo.tailF), *tailFcL = (cd *) (smem + lo.tailFc), *psiL = (cd *) (smem + lo.psi);
     cd *gvL = (cd *) (smem + lo.gv), *pqL = (cd *) (smem + lo.pq);
+    const v4i *aopenL = (const v4i *) (smem + lo.aopen);          // [3 tiles][4 lane groups]: rows 4g .. 4g+3
     const v4i *wiqL = (const v4i *) (smem + lo.wiq);
     double *cpowL = (double *) (smem + lo.cpow);
     auto carF = [&](int b) { return (cd *) (smem + lo.buf + b * lo.buf_stride); };
@@ -341,9 +346,23 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
         // DUAL: 256 threads for 16 outputs x 32 samples: this thread's second pair, the tail output 8 + (tid >> 5)
         const cd *e_ab2 = e_ab + (DUAL ? 8 * 32 * 2 : 0);
         const cd e_A2 = DUAL ? e_ab2[0] : mk(0.0, 0.0), e_B2 = DUAL ? e_ab2[1] : mk(0.0, 0.0);
-        if constexpr (F32) { if (tid < 48) gvL[tid] = ((const cd *) a.gvec)[(size_t) row * 48 + tid]; }
+        if constexpr (F32) { if (tid < 48) gvL[tid] = ((const cd *) a.gvec)[(size_t) row * SDRT_WIDE_GV + tid]; }
         if constexpr (IQA) {
-            if (tid < 48) gvL[tid] = ((const cd *) a.gvec)[(size_t) row * 48 + tid];
+            if (tid < 48) gvL[tid] = ((const cd *) a.gvec)[(size_t) row * SDRT_WIDE_GV + tid];
+            if constexpr (AOPEN) {
+                // minus half the sum of every row's lowest digits (tables.h, sdrt_build_i8_weights_wide_pass), in the order the
+                // matrix results land in: aggregate rows as they are, local rows as the local tile above places them
+                if (tid >= 96 && tid < 144) {
+                    const int i = tid - 96, pr = i & 15;
+                    const int *src = (const int *) ((const cd *) a.gvec + (size_t) row * SDRT_WIDE_GV + 48);
+                    int from = i;
+                    if (i >= 32) {
+                        if constexpr (PACK) from = pr < 8 ? 32 + pr : -1;      // rows 8-15: the level above
+                        else { const int b = (pr >> 2) + 4 * ((pr >> 1) & 1); from = b < NOUT ? 32 + 2 * b + (pr & 1) : -1; }
+                    }
+                    ((int *) (smem + lo.aopen))[i] = from >= 0 ? src[from] : 0;
+                }
+            }
             if (tid >= 64 && tid < 96) pqL[tid - 64] = ((const cd *) a.edge_pq)[(size_t) row * 32 + (tid - 64)];
             if constexpr (IQT) for (int i = tid; i < NT * SDRT_TB; i += NTHR) cpowL[i] = a.iq_pow[i * cgs];
             if constexpr (IQF) for (int i = tid; i < KS * 64; i += NTHR) ((v4i *) (smem + lo.wiq))[i] = ((const v4i *) a.w8iq)[i];
@@ -1213,14 +1232,16 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
                                         // packed local tile: fragment d < 3 with the high (or only) slice starts accumulator d,
                                         // fragment 3 + a with the low slice adds to accumulator a
                                         if constexpr (d < 3) {
-                                            if constexpr (s == 0) acc[2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, NSL == 2 ? bhi : blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                            if constexpr (s == 0 && d == 0 && AOPEN) acc[2][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, aopenL[8 + g], 0, 0, 0);
+                                            else if constexpr (s == 0) acc[2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, NSL == 2 ? bhi : blo, (v4i) {0, 0, 0, 0}, 0, 0, 0);
                                             else acc[2][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, NSL == 2 ? bhi : blo, acc[2][d], 0, 0, 0);
                                         } else if constexpr (d < NLF) {
                                             acc[2][d - 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[2][d - 3], 0, 0, 0);
                                         }
                                     } else if constexpr (NSL == 2) {
                                         // digit d x high slice -> level d+1 (accumulator d); digit d x low slice -> level d (accumulator d-1)
-                                        if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, (v4i) {0, 0, 0, 0}, 0, 0, 0);
+                                        if constexpr (s == 0 && d == 0 && AOPEN) acc[rt][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, aopenL[4 * rt + g], 0, 0, 0);
+                                        else if constexpr (s == 0) acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, (v4i) {0, 0, 0, 0}, 0, 0, 0);
                                         else acc[rt][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, acc[rt][d], 0, 0, 0);
                                         if constexpr (d >= 1) acc[rt][d - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, acc[rt][d - 1], 0, 0, 0);
                                     } else {

@@ -492,8 +492,19 @@ namespace {
 
 // quantise rows x cols reals (row-major, leading dimension ld) to S balanced base-256 digits against one power-of-two
 // scale; emit(d, r, c, digit) receives every digit.  Returns the combine factor scale * 2^-(8S-1), or 0 on overflow.
+// consistent (round 4; the --correct-iq forms of the wide kernel, columns alternating re / im coefficients): rowsum[2 r + comp]
+// receives the integer sum of the QUANTISED weights of row r and component comp -- made a multiple of 16 by moving up to 8 weights
+// one unit each (so that 32896 x sum, the unsigned 16-bit records' constant, is still an exact double; the sums of the unmoved
+// weights are already off by ~5 units) -- and dhalf[r] HALF the sum of the row's lowest digits.  Why: those forms carry the
+// constant c the byte slices leave out in a rank-one term, value += (c - offset) g[row], and the 16-bit forms never compute the
+// product lowest digit x low slice (kernels_i8w.hip: LMIN).  For an all-zero chunk (low slices = -128 everywhere) the matrix cores
+// then deliver exactly -128 x (sum of the weights less their lowest digits); with g = the sum of the QUANTISED weights and the
+// accumulators of the level above opened at -dhalf (units of 256: -128 x the lowest digits' sum) the two cancel to the last bit --
+// the reference's exact zeros for a stream that starts silent (offset 0), instead of the FM angle of a 1e-10 residue.  For other
+// input the opening value is a constant per row of 2^-41 of full scale, below the products that are left out.
 template <class Emit>
-double quantise_planes(const double *W, int rows, int cols, int ld, int S, Emit emit) {
+double quantise_planes(const double *W, int rows, int cols, int ld, int S, Emit emit, bool consistent = false,
+                       long long *rowsum = nullptr, int *dhalf = nullptr) {
     double maxabs = 0.0;
     for (int r = 0; r < rows; ++r)
         for (int c = 0; c < cols; ++c) maxabs = std::fmax(maxabs, std::fabs(W[(size_t) r * ld + c]));
@@ -502,16 +513,51 @@ double quantise_planes(const double *W, int rows, int cols, int ld, int S, Emit 
     std::frexp(maxabs * 1.002, &e);
     const double scale = std::ldexp(1.0, e);
     const int B = 8 * S - 1;
-    for (int r = 0; r < rows; ++r)
+    std::vector<long long> I((size_t) cols);
+    auto low = [](long long v) { return ((v + 128) % 256 + 256) % 256 - 128; };      // balanced lowest digit in [-128, 127]
+    for (int r = 0; r < rows; ++r) {
+        for (int c = 0; c < cols; ++c) I[c] = std::llround(std::ldexp(W[(size_t) r * ld + c] / scale, B));
+        if (consistent) {
+            // every component's sum becomes a multiple of 16: up to 8 weights move one unit each, those that sit farthest from
+            // their unrounded values, towards them
+            for (int comp = 0; comp < 2; ++comp) {
+                long long sum = 0;
+                for (int c = comp; c < cols; c += 2) sum += I[c];
+                int adj = (int) (((sum % 16) + 16) % 16);        // sum = 16 k + adj
+                adj = adj <= 8 ? -adj : 16 - adj;
+                const int dir = adj > 0 ? 1 : -1;
+                for (; adj != 0; adj -= dir) {
+                    int best = -1;
+                    double gain = -2.0;
+                    for (int c = comp; c < cols; c += 2) {
+                        const double t = (std::ldexp(W[(size_t) r * ld + c] / scale, B) - (double) I[c]) * dir;   // > 0: the move reduces the error
+                        const long long nd = low(I[c]) + dir;
+                        if (nd < -128 || nd > 127 || std::fabs(t) > 0.5000001) continue;       // in range, and not moved already
+                        if (t > gain) { gain = t; best = c; }
+                    }
+                    if (best < 0) return 0.0;
+                    I[best] += dir;
+                }
+            }
+            long long d0 = 0;
+            for (int c = 0; c < cols; ++c) d0 += low(I[c]);
+            if (d0 & 1) return 0.0;                               // (the sum of the weights is even, and so is that of their lowest digits)
+            if (dhalf) dhalf[r] = (int) (-(d0 / 2));          // what the lowest accumulators open at
+            if (rowsum) {
+                rowsum[2 * r] = rowsum[2 * r + 1] = 0;
+                for (int c = 0; c < cols; ++c) rowsum[2 * r + (c & 1)] += I[c];
+            }
+        }
         for (int c = 0; c < cols; ++c) {
-            long long I = std::llround(std::ldexp(W[(size_t) r * ld + c] / scale, B));
+            long long v = I[c];
             for (int d = 0; d < S; ++d) {
-                const long long dig = ((I + 128) % 256 + 256) % 256 - 128;      // balanced digit in [-128, 127]
-                I = (I - dig) / 256;
+                const long long dig = low(v);
+                v = (v - dig) / 256;
                 emit(d, r, c, (signed char) dig);
             }
-            if (I != 0) return 0.0;
+            if (v != 0) return 0.0;
         }
+    }
     return std::ldexp(scale, -B);
 }
 
@@ -708,12 +754,20 @@ extern "C" int sdrt_build_i8_weights_wide_pass(const double *sos, int sections, 
             }
     if (gvec)                                  // lambda == 0: the rows stay, gvec = the rows' sums (float32: the slices' constant)
         for (int r = 0; r < 32; ++r) fold_iq(&Wf[(size_t) r * cols], LC, iq_lambda, gvec + 2 * r);
+    // --correct-iq: g = the sum of the QUANTISED weights, and half the sum of every row's lowest digits behind the vectors
+    // (quantise_planes: a stream that starts silent then cancels to exact zeros)
+    const bool consistent = gvec != nullptr && iq_lambda > 0.0;
+    std::vector<long long> rs((size_t) 32 * 2);
+    int *open = gvec ? (int *) (gvec + 2 * 48) : nullptr;          // [48] after the 48 vector pairs (SDRT_WIDE_GV)
+    if (open) memset(open, 0, 48 * sizeof(int));
     *main_combine = quantise_planes(Wf.data(), 32, cols, cols, S, [&](int d, int r, int c, signed char dig) {
         int ks, kg, j;
         kpos(c, ks, kg, j);
         main_out[(((((size_t) (r >> 4) * S + d) * KS + ks) * 64) + ((r & 15) + 16 * kg)) * 16 + j] = dig;
-    });
+    }, consistent, consistent ? rs.data() : nullptr, consistent ? open : nullptr);
     if (*main_combine == 0.0) return -1;
+    if (consistent)
+        for (int r = 0; r < 32; ++r) { gvec[2 * r] = *main_combine * (double) rs[2 * r]; gvec[2 * r + 1] = *main_combine * (double) rs[2 * r + 1]; }
     // local rows: output at sample b q of the column, the part that depends on this column's samples:
     //   d0' u[bq] + sum_i 2 Re( alpha_i sum_{t < bq} p_i^(bq-1-t) u[t] + (alpha_i/p_i) sum_{t >= bq} p_i^(t-bq) u[t] )
     C sum_a_over_p(0);
@@ -739,12 +793,15 @@ extern "C" int sdrt_build_i8_weights_wide_pass(const double *sos, int sections, 
         for (int r = 0; r < 16; ++r) gvec[2 * (32 + r)] = gvec[2 * (32 + r) + 1] = 0.0;
         for (int r = 0; r < NR; ++r) fold_iq(&Wl[(size_t) r * cols], LC, iq_lambda, gvec + 2 * (32 + r));
     }
+    std::vector<long long> rl((size_t) NR * 2);
     *loc_combine = quantise_planes(Wl.data(), NR, cols, cols, S, [&](int d, int r, int c, signed char dig) {
         int ks, kg, j;
         kpos(c, ks, kg, j);
         loc_out[(((((size_t) d * KS + ks) * 4 + kg) * NR) + r) * 16 + j] = dig;
-    });
+    }, consistent, consistent ? rl.data() : nullptr, consistent ? open + 32 : nullptr);
     if (*loc_combine == 0.0) return -1;
+    if (consistent)
+        for (int r = 0; r < NR; ++r) { gvec[2 * (32 + r)] = *loc_combine * (double) rl[2 * r]; gvec[2 * (32 + r) + 1] = *loc_combine * (double) rl[2 * r + 1]; }
     return 0;
 }
 
@@ -766,12 +823,16 @@ extern "C" int sdrt_build_i8_offset_rows(double lambda, int S, signed char *out,
         W[(size_t) 1 * cols + 2 * j + 1] = (double) w;      // row "im": coefficient of x_im
     }
     memset(out, 0, (size_t) KS * 64 * 16);
+    long long rs[4] = {0, 0, 0, 0};
     *combine = quantise_planes(W.data(), 2, cols, cols, S, [&](int d, int r, int c, signed char dig) {
         const int sample = c >> 1, comp = c & 1, ks = sample / 32, kg = (sample % 32) / 8, j = 2 * (sample % 8) + comp;
         out[(((size_t) ks * 64) + ((2 * d + r) + 16 * kg)) * 16 + j] = dig;
-    });
+    }, true, rs);
     if (*combine == 0.0) return -1;
-    consts[0] = (double) wsum;
+    // the sum of the QUANTISED weights: what the constant c of the slices adds; for an all-zero column the matrix cores deliver
+    // exactly -c x this (every product is computed here), and the offset stays 0.0
+    (void) wsum;
+    consts[0] = *combine * (double) rs[0];
     R p = pw[LC];
     for (int k = 0; k < 5; ++k) { consts[1 + k] = (double) p; p = p * p; }      // (1-lambda)^(LC 2^k), k = 0..4
     R p32 = 1;

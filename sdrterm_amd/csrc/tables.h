@@ -41,6 +41,7 @@ struct DecimTables {
 #define SDRT_WIDE_LC 256
 #define SDRT_WIDE_MAXOUT 8
 #define SDRT_WIDE_MAXTILES 16
+#define SDRT_WIDE_GV 60          // complex-sized entries per row of the IQ vectors: 48 pairs {g_re, g_im}, then 48 ints (accumulator openings)
 struct WideTables {
     int32_t q, nout, boff, nout_total;                       // outputs boff .. boff + nout - 1 of the nout_total = LC / q of a column
     double mu_pow[4][SDRT_NMODE][2];                         // (p_i^LC)^(1,2,4,8): column-to-column scan inside a tile
@@ -157,14 +158,17 @@ int sdrt_build_wide_tables_pass(const double *sos, int sections, int q, double d
 // (1-lambda)^(i-1-j) (j < i), g[i] = (1-lambda)^i.  The planes then hold W (I - T), and gvec[row] = {sum_t w_re[t] g[t],
 // sum_t w_im[t] g[t]} (rows 0..31 main, 32..32+NR-1 local; w_re / w_im = the row's coefficients of the real / imaginary
 // sample components) gives the rank-one rest: row value += (c - off).re * gvec[row][0] + (c - off).im * gvec[row][1], c =
-// the constant the int8 slices leave out.  gvec may be NULL when iq_lambda == 0.
+// the constant the int8 slices leave out.  gvec may be NULL when iq_lambda == 0.  With iq_lambda > 0 the vectors are the sums of the
+// QUANTISED weights, and 48 ints follow the 48 pairs: minus half the sum of every row's lowest digits (main rows 0-31, local rows
+// from 32), the value the 16-bit forms open their lowest accumulators at -- an all-zero chunk at offset 0 then cancels exactly
+// (operators.cpp: quantise_planes).
 int sdrt_build_i8_weights_wide(const double *sos, int sections, int q, double data_scale, const double *nco_samp, int S,
                                double iq_lambda, signed char *main_out, double *main_combine, signed char *loc_out,
-                               double *loc_combine, double *gvec /*[48][2]*/);
+                               double *loc_combine, double *gvec /*[SDRT_WIDE_GV][2]*/);
 // ... of one pass (see sdrt_build_wide_tables_pass): the local rows are outputs boff .. boff + nout_pass - 1 of the column
 int sdrt_build_i8_weights_wide_pass(const double *sos, int sections, int q, double data_scale, const double *nco_samp, int S,
                                     double iq_lambda, int nout_pass, int boff, signed char *main_out, double *main_combine,
-                                    signed char *loc_out, double *loc_combine, double *gvec /*[48][2]*/);
+                                    signed char *loc_out, double *loc_combine, double *gvec /*[SDRT_WIDE_GV][2]*/);
 
 // Offset rows of the wide-column kernel with IQ correction (iq_lambda > 0): per column the two sums  sum_j w_j x_re[j],
 // sum_j w_j x_im[j], w_j = lambda (1-lambda)^(LC-1-j) -- what the column adds to the carried offset.  All S digit planes of

@@ -118,11 +118,8 @@ CASES = [
     _c('f_q64_fm_zero_c', 'f', 64, 'fm', center=15700, n_chunks=3, amp=8000, seed=85, sig=dict(kind='zero', chunks=[1])),
     _c('h_q4_fm_zero_c', 'h', 4, 'fm', center=15700, omega_out=60000, n_chunks=3, amp=8000, seed=86, sig=dict(kind='zero', chunks=[1])),
     _c('h_q16_fm_zero_c', 'h', 16, 'fm', center=15700, omega_out=15000, n_chunks=3, amp=8000, seed=87, sig=dict(kind='zero', chunks=[1])),
-    # a stream that STARTS silent under --correct-iq (offset exactly zero): the reference writes zeros for that chunk.  The int8 forms
-    # with --correct-iq carry the slices' constant in the offset term and leave ~1e-10 of it behind (no ybias in those kernels), so their
-    # FM angle of that chunk is noise: the test compares that chunk through the decimated samples (silent_start), the rest as usual
-    _c('h_q64_fm_zero_iq_start', 'h', 64, 'fm', center=15700, correct_iq=True, n_chunks=3, amp=8000, seed=88, sig=dict(kind='zero', chunks=[0]),
-       silent_start=1),
+    # a stream that STARTS silent under --correct-iq (offset exactly zero): the reference writes zeros for that chunk
+    _c('h_q64_fm_zero_iq_start', 'h', 64, 'fm', center=15700, correct_iq=True, n_chunks=3, amp=8000, seed=88, sig=dict(kind='zero', chunks=[0])),
 ]
 
 BY_NAME = {c['name']: c for c in CASES}

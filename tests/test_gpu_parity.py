@@ -61,17 +61,9 @@ def test_golden_parity(case, golden, stage_a):
     gy0 = y.reshape(rows, nch, m)[:, 0, :]
     peak = float(np.abs(y0).max())
     yerr = np.abs(gy0 - y0).max() / (peak if peak > 0 else 1.0)
-    skip = 0
-    if case.get('silent_start') and eng.stage_a in ('i8w', 'i8t'):
-        # --correct-iq on the int8 forms, stream starts silent: the slices' constant leaves a residue (cases.py); bounded here
-        skip = int(case['silent_start'])
-        res = float(np.abs(y.reshape(rows, nch, m)[:, :skip]).max())
-        print(f'{name} [{eng.stage_a}]: silent start, decimated residue {res:.3e} (reference: 0)')
-        assert res <= 1e-6                      # of one LSB of the int16 records
-        yerr = 0.0                              # (y0 is that chunk: bounded just above)
-    elif peak == 0:
+    if peak == 0:
         assert float(np.abs(gy0).max()) == 0.0
-    err = np.abs(got[skip:] - exp[skip:]).max()
+    err = np.abs(got - exp).max()
     print(f'{name} [{eng.stage_a}]: decimated rel err {yerr:.3e}, output max abs err {err:.3e} (tol {ref_tol(case, exp):.1e})')
     assert yerr <= (1e-3 if case['code'] == 'f' else 1e-9)
     assert err <= ref_tol(case, exp)
@@ -569,6 +561,56 @@ def test_silent_chunks_anywhere_in_a_batch_come_out_as_exact_zeros(code, q, cent
         ref = eng.process(raw[2:6].tobytes()).reshape(rows, 4, n // q)
         assert np.array_equal(ref[:, :3], out[:, 2:5])
         eng.close()
+
+
+@pytest.mark.parametrize('code,q,center,rows,fused', [('h', 64, 15700, 1, None), ('h', 64, 15700, 1, '0'), ('H', 64, -203300, 1, None),
+                                                      ('B', 64, 15700, 1, None), ('b', 32, 15700, 1, '0'), ('h', 32, 0, 1, None),
+                                                      ('h', 128, 15700, 3, None), ('h', 256, 15700, 1, None), ('B', 128, 15700, 2, '0')])
+def test_a_stream_that_starts_silent_under_correct_iq_comes_out_as_exact_zeros(code, q, center, rows, fused, monkeypatch):
+    """--correct-iq (read_file.py:64-77): the offset starts at zero, so the silent head of a stream stays x - 0 = 0 and the reference
+    writes exact zeros until the first loud sample.  The int8 forms carry the constant their byte slices leave out in a rank-one
+    term; the weight planes of those forms are quantised so that this term cancels the matrix cores' share to the last bit
+    (operators.cpp: quantise_planes, "consistent").  Fused and prefix forms of the correction, one and several rows; the loud
+    chunks that follow must match oracle/chain.c as always."""
+    from sdrterm_amd.engine import Engine
+    from tests.golden import prng
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    if fused is None:
+        monkeypatch.delenv('SDRTERM_IQ_FUSED', raising=False)
+    else:
+        monkeypatch.setenv('SDRTERM_IQ_FUSED', fused)
+    fs, n, nch, head = 1024000, samples_per_chunk(code), 37, 19
+    item = {'b': 1, 'B': 1, 'h': 2, 'H': 2}[code]
+    freqs = [float(center + 50000 * r) for r in range(rows)]
+    omega = 5000 if q < 128 else (2500 if q < 256 else 1200)
+    raw = np.frombuffer(prng.raw_bytes(code, n * nch, seed=93, amp=100 if item == 1 else 8000), dtype=np.uint8).reshape(nch, -1).copy()
+    raw[:head] = 0
+    for mode in ('fm', 'am'):
+        eng = Engine(fs, q, mode, code, row_freqs=freqs, apply_shift=bool(center or rows > 1), omega_out=omega, correct_iq=True)
+        assert eng.stage_a == ('i8w' if q <= 64 else 'f64')       # (decimation 128 and up with --correct-iq: the fp64 kernel)
+        m = n // q
+        out = eng.process(raw.tobytes()).reshape(rows, nch, m)
+        worst = float(np.abs(out[:, :head - 1]).max())
+        print(f'{code} q={q} center={center} rows={rows} fused={fused} {mode} [{eng.stage_a}]: silent head max |out| = {worst:.3e}')
+        assert worst == 0.0
+        eng.close()
+        exp = _oracle_rows_iq(raw.tobytes(), code, n, q, mode, freqs, fs, omega, nch)
+        got = out.transpose(1, 0, 2)
+        # chunk head-1 ends where the loud samples begin (zero-phase filter: its tail already sees them); from there on the usual bound
+        err = float(np.abs(got[head - 1:] - exp[head - 1:]).max())
+        assert err <= tol_for(exp, mode), err
+
+
+def _oracle_rows_iq(raw, code, n, q, mode, freqs, fs, omega_out, nch):
+    """oracle.ref_chain (numpy restatement, --correct-iq carried across chunks) per row: (chunk, row, m)."""
+    from oracle import ref_chain
+    item = {'b': 1, 'B': 1, 'h': 2, 'H': 2}[code]
+    cb = n * 2 * item
+    res = []
+    for f in freqs:
+        ch = ref_chain.Chain(fs, q, mode, code, center=f, omega_out=omega_out, correct_iq=True)
+        res.append(np.stack([np.asarray(ch.process(raw[c * cb:(c + 1) * cb])).reshape(-1) for c in range(nch)]))
+    return np.stack(res, axis=1)
 
 
 @pytest.mark.parametrize('code,q,mode,rows', [('h', 16, 'fm', 3), ('h', 8, 'am', 2), ('H', 16, 'am', 1), ('B', 16, 'fm', 2), ('b', 8, 'fm', 1), ('h', 4, 'fm', 1)])

@@ -55,7 +55,7 @@ def run_pass(q, n, theta, seed, S, lam, off0, nout, boff):
     main = np.zeros(2 * S * KS * 64 * 16, np.int8)
     loc = np.zeros(S * KS * 4 * NR * 16, np.int8)
     cm, cl = C.c_double(), C.c_double()
-    gvec = np.zeros((48, 2))
+    gvec = np.zeros((60, 2))                 # SDRT_WIDE_GV: 48 vector pairs + 48 ints
     rc = lib.sdrt_build_i8_weights_wide_pass(sos.ctypes.data_as(C.c_void_p), 4, q, C.c_double(1.0),
                                              samp_ri.ctypes.data_as(C.c_void_p) if theta else None, S, C.c_double(lam), nout, boff,
                                              main.ctypes.data_as(C.c_void_p), C.byref(cm), loc.ctypes.data_as(C.c_void_p), C.byref(cl),
