@@ -145,13 +145,36 @@ __device__ __forceinline__ void wave_lds_fence() {
 #ifndef SDRT_P8_BLOCKS_AHEAD
 #define SDRT_P8_BLOCKS_AHEAD 16
 #endif
+// Eight lanes per item, pair products in: THREE waves per SIMD (round 4).  What held the kernel at two was 254 registers (every load
+// of an item in flight: 128 of them) and 17 KiB of exchange image per wave.  Both halve: the item's pair products arrive in two
+// halves, and the two bin series a lane finishes (k1 = l and 16 - l) go through the exchange image one after the other -- the image
+// is 8 rows of 9 slots instead of 17 (the same conflict-free residues: 9 = 17 - 8, items 72 = 8 mod 16 slots apart).
+#ifndef SDRT_P8_BLOCKS_AHEAD3
+#define SDRT_P8_BLOCKS_AHEAD3 2
+#endif
+#ifndef SDRT_P8_LEAN_SAMPLES
+#define SDRT_P8_LEAN_SAMPLES 0
+#endif
+#ifndef SDRT_P8_KEEPX
+#define SDRT_P8_KEEPX 1
+#endif
+#ifndef SDRT_P8_OCC
+#define SDRT_P8_OCC 2
+#endif
+#ifndef SDRT_P8_WAVES3
+#define SDRT_P8_WAVES3 1
+#endif
+__host__ __device__ constexpr bool p8_lean(int lpi, bool pairs) { return SDRT_P8_WAVES3 && (lpi == 8 || lpi == 16) && (pairs || SDRT_P8_LEAN_SAMPLES); }
+__host__ __device__ constexpr bool p8_halves(int lpi, bool pairs) { return p8_lean(lpi, pairs) && lpi == 8; }
 
 // LPI lanes per item: 8 (N = 256 pair angles, 512 outputs per chunk) or 16 (N = 512, 1024 outputs per chunk: a DPP row of
 // lanes is one item).  16-byte slots of an item's exchange image: 17 per n2 (8 x 17 = 136 = 8 mod 16, 16 x 17 = 272 = 0 mod 16:
 // what keeps the four lane groups of a ds_read_b128 on sixteen different slots in either form, tools/lds_banks.py).
 template <int LPI, int WPB, bool PAIRS>
-__global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_fft8_kernel(PostArgs a) {
-    constexpr int P = SDRT_P8_PPL, H = P * LPI, N = 2 * H, M = 2 * N, IPW = 64 / LPI, TAB = P * LPI, SO = 17 * LPI, NC = P / LPI;
+__global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : (p8_halves(LPI, PAIRS) && WPB == 4 ? SDRT_P8_OCC : 2)) void post_fft8_kernel(PostArgs a) {
+    constexpr bool HX = p8_halves(LPI, PAIRS), LEAN = p8_lean(LPI, PAIRS);
+    constexpr int ST = HX ? 9 : 17;                  // slots between the rows of an item's exchange image
+    constexpr int P = SDRT_P8_PPL, H = P * LPI, N = 2 * H, M = 2 * N, IPW = 64 / LPI, TAB = P * LPI, SO = ST * LPI, NC = P / LPI;
     static_assert(LPI == 4 || LPI == 8 || LPI == 16, "4, 8 or 16 lanes per item");
     extern __shared__ __align__(16) unsigned char smem[];
     cd *tabL = (cd *) smem;                                        // tw1 | tw2 | alpha | beta | lane rows
@@ -172,12 +195,26 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
         cd x[P];
         if constexpr (PAIRS) {
             const cd *y = (const cd *) a.y + it * (size_t) (a.pairs_wide ? M : N);      // d[2i] conj(d[2i+1]) from the chain kernel
+            if constexpr (LEAN) {
+                // half of the item's loads in flight, their angles, the other half (the third wave covers what that exposes)
+                static_for<0, 2>([&](auto hc) {
+                    constexpr int k0 = (P / 2) * decltype(hc)::value;
+                    cd pp[P / 2][2];
+#pragma unroll
+                    for (int k = 0; k < P / 2; ++k) { pp[k][0] = y[2 * (l + LPI * (k0 + k))]; pp[k][1] = y[2 * (l + LPI * (k0 + k)) + 1]; }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < P / 2; ++k) x[k0 + k] = mk(atan2_pi(pp[k][0].im, pp[k][0].re), atan2_pi(pp[k][1].im, pp[k][1].re));
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else {
             cd pp[P][2];                                           // every load of the item in flight before the first angle
 #pragma unroll
             for (int k = 0; k < P; ++k) { pp[k][0] = y[2 * (l + LPI * k)]; pp[k][1] = y[2 * (l + LPI * k) + 1]; }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < P; ++k) x[k] = mk(atan2_pi(pp[k][0].im, pp[k][0].re), atan2_pi(pp[k][1].im, pp[k][1].re));
+            }
         } else {
             const cd *y = (const cd *) a.y + it * (size_t) M;
             const cd *R = a.iq_R ? (const cd *) a.iq_R + (it / a.n_chunks) * (size_t) M : nullptr;
@@ -206,14 +243,33 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
         // stay in L2 / the Infinity Cache, where the item's own place in the output buffer is new memory every time)
         cd *stash = a.stash ? (cd *) a.stash + ((size_t) blockIdx.x * WPB + wave) * (size_t) (IPW * H) + (size_t) o * H + l
                             : (cd *) (a.out + it * (size_t) M) + l;
+        // KEEPX (round 4, with the halved loads / exchange image / parked results above): the angles stay in 64 registers through
+        // the transforms after all -- the stash was 0.27 GB each way per 2^32 samples through the memory counters (rocprofv3:
+        // WRITE_SIZE 0.79 GB against 0.54 GB of outputs), a third of this kernel's traffic, and the kernel is bound by that traffic
+        constexpr bool KEEPX = LEAN && SDRT_P8_KEEPX;
+        if constexpr (!KEEPX) {
 #pragma unroll
-        for (int k = 0; k < P; ++k) stash[LPI * k] = x[k];
+            for (int k = 0; k < P; ++k) stash[LPI * k] = x[k];
+        }
         // ---- forward: 16 points in the lane, twiddle, exchange, LPI points ---------------------------------------------------
         cd Z[NC][LPI];
         {
             cd X1[P];
             reg_fft<P, false>(x, X1);
             static_for<1, P>([&](auto kc) { constexpr int k1 = decltype(kc)::value; X1[k1] = cmul(X1[k1], tw1L[k1 * LPI + l]); });
+            if constexpr (HX) {
+                // bins 0-7 (series k1 = l), then bins 8-15 (series 16 - l, lane 0: 8) through the same 8 x 9 slots
+                static_for<0, 2>([&](auto hc) {
+                    constexpr int hh = decltype(hc)::value;
+                    if constexpr (hh == 1) wave_lds_fence();       // the first half's reads are done
+                    static_for<0, P / 2>([&](auto kc) { constexpr int k1 = decltype(kc)::value; X[ST * l + k1] = X1[8 * hh + k1]; });
+                    wave_lds_fence();
+                    cd V[LPI];
+#pragma unroll
+                    for (int j = 0; j < LPI; ++j) V[j] = X[ST * j + (cs[hh] & 7)];
+                    reg_fft<LPI, false>(V, Z[hh]);
+                });
+            } else {
             static_for<0, P>([&](auto kc) { constexpr int k1 = decltype(kc)::value; X[17 * l + k1] = X1[k1]; });
             wave_lds_fence();
             cd V[NC][LPI];
@@ -222,6 +278,7 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
 #pragma unroll
                 for (int ci = 0; ci < NC; ++ci) V[ci][j] = X[17 * j + cs[ci]];
             static_for<0, NC>([&](auto cc) { reg_fft<LPI, false>(V[decltype(cc)::value], Z[decltype(cc)::value]); });
+            }
         }
         // ---- packed spectrum of the angles -> packed spectrum of the half-sample shifted sequence ----------------------------
         // Y[k] = alpha_k Z[k] + beta_k conj(Z[H - k]).  8 lanes: bin k = c + 16 k2 pairs with H - k = (16 - c) + 16 (7 - k2), the
@@ -265,23 +322,57 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
 #pragma unroll
                 for (int ci = 0; ci < NC; ++ci) U[ci][n2] = cmul(U[ci][n2], tw2L[(ci * LPI + n2) * LPI + l]);
             });
+            cd Rr[P];
+            if constexpr (HX) {
+                static_for<0, 2>([&](auto hc) {
+                    constexpr int hh = decltype(hc)::value;
+                    wave_lds_fence();                              // the reads before (forward step, first half) are done
+#pragma unroll
+                    for (int n2 = 0; n2 < LPI; ++n2) X[ST * n2 + (cs[hh] & 7)] = U[hh][n2];
+                    wave_lds_fence();
+#pragma unroll
+                    for (int c = 0; c < P / 2; ++c) Rr[8 * hh + c] = X[ST * l + c];
+                });
+            } else {
             wave_lds_fence();                                      // the forward step's reads are done
 #pragma unroll
             for (int n2 = 0; n2 < LPI; ++n2)
 #pragma unroll
                 for (int ci = 0; ci < NC; ++ci) X[17 * n2 + cs[ci]] = U[ci][n2];
             wave_lds_fence();
-            cd Rr[P];
 #pragma unroll
             for (int c = 0; c < P; ++c) Rr[c] = X[17 * l + c];
+            }
             wave_lds_fence();                                      // ... before the next group's writes
+            if constexpr (LEAN) {
+                // the last butterflies by hand: the upper half of the results (blocks 8-15 of the lowpass) waits in the wave's
+                // exchange image, which nothing else uses until the next group (64 lanes x 8 slots of its 576) -- in registers
+                // they were what the allocator spilled, and a scratch reload in the lowpass waits for every store before it
+                cd ev[P / 2], od[P / 2], E[P / 2], O[P / 2];
+#pragma unroll
+                for (int k = 0; k < P / 2; ++k) { ev[k] = Rr[2 * k]; od[k] = Rr[2 * k + 1]; }
+                reg_fft<P / 2, true>(ev, E);
+                reg_fft<P / 2, true>(od, O);
+                cd *park = tabL + 4 * TAB + 8 * LPI + (size_t) wave * (IPW * SO) + lane;
+                static_for<0, P / 2>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const cd t = tw_mul<P, k, true>(O[k]);
+                    zz[k] = cadd(E[k], t);
+                    park[64 * k] = csub8(E[k], t);
+                });
+            } else
             reg_fft<P, true>(Rr, zz);                              // zz[n1] = b[2n] + i b[2n+1], n = l + LPI n1
         }
         // ---- output samples 4n .. 4n+3 = a[2n], b[2n], a[2n+1], b[2n+1]; lowpass; store ------------------------------------------
         double *out = a.out + it * (size_t) M + 4 * l;
         __builtin_amdgcn_sched_barrier(0);                         // (not before the last transform has let go of its registers)
+        // (three waves per SIMD: four of the stashed angle pairs in flight at a time, the others fetched as the blocks go by)
+        constexpr int SD = LEAN ? 4 : P, BA = LEAN ? SDRT_P8_BLOCKS_AHEAD3 : SDRT_P8_BLOCKS_AHEAD;
+        cd xs[SD];
+        if constexpr (!KEEPX) {
 #pragma unroll
-        for (int k = 0; k < P; ++k) x[k] = stash[LPI * k];
+            for (int k = 0; k < SD; ++k) xs[k] = stash[LPI * k];
+        }
         __builtin_amdgcn_sched_barrier(0);
         // the constants every lane shares are fetched here, not before the loop: some forty doubles that would otherwise sit in
         // scalar registers through the transforms (and be spilled to vector lanes there)
@@ -296,9 +387,9 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
         const double pbr = pu->pr_blk;
         // ... and the lane's own: scan multipliers inside the quad (zero where the quad permutation hands a lane its own or an
         // earlier lane's value), from the quad before, from the block's start (tables.h: the lane rows of the transform tables)
-        const cd mA1 = lpL[0 * LPI + l], mA2 = lpL[1 * LPI + l], nA = lpL[2 * LPI + l], mB = lpL[3 * LPI + l], mE = lpL[4 * LPI + l];
-        const cd nBE = lpL[5 * LPI + l], plc = lpL[6 * LPI + l], plq = lpL[7 * LPI + l];
-        const double nA1 = nA.re, nA2 = nA.im, nB = nBE.re, nE = nBE.im, plr = plq.re, q1 = plq.im;
+        const cd mA1_ = lpL[0 * LPI + l], mA2_ = lpL[1 * LPI + l], nA = lpL[2 * LPI + l], mB_ = lpL[3 * LPI + l], mE_ = lpL[4 * LPI + l];
+        const cd nBE = lpL[5 * LPI + l], plc_ = lpL[6 * LPI + l], plq = lpL[7 * LPI + l];
+        const double nA1_ = nA.re, nA2_ = nA.im, nB_ = nBE.re, nE_ = nBE.im, plr_ = plq.re, q1_ = plq.im;
         // 16 lanes: the scan runs over the item's whole row of lanes, multipliers p^4, p^8, p^16, p^32
         const cd s1 = mk(pu->pc4[0], pu->pc4[1]), s2 = mk(pu->pc8[0], pu->pc8[1]), s4 = mk(pu->pc_q[3][0], pu->pc_q[3][1]), s8 = mk(pu->pc32[0], pu->pc32[1]);
         const double t1 = pu->pr4, t2 = pu->pr8, t4 = pu->pr_q[3], t8 = pu->pr32;
@@ -306,7 +397,30 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
         double Cr = 0.0;
         static_for<0, P>([&](auto nc) {
             constexpr int n1 = decltype(nc)::value;
-            const double x0 = x[n1].re, x1 = zz[n1].re, x2 = x[n1].im, x3 = zz[n1].im;
+            cd xv;
+            if constexpr (KEEPX) xv = x[n1];
+            else {
+                xv = xs[n1 % SD];
+                if constexpr (n1 + SD < P) xs[n1 % SD] = stash[LPI * (n1 + SD)];
+            }
+            // three waves per SIMD: the lane's own multipliers come from the tables in every block instead of sitting in 32
+            // registers through all of them (the offset is opaque so that the reads are not merged back into one set)
+            cd mA1 = mA1_, mA2 = mA2_, mB = mB_, mE = mE_, plc = plc_;
+            double nA1 = nA1_, nA2 = nA2_, nB = nB_, nE = nE_, plr = plr_, q1 = q1_;
+            if constexpr (LEAN) {
+                int zo = 0;
+                asm volatile("" : "+v"(zo));
+                const cd *lp = lpL + zo + l;
+                mA1 = lp[0 * LPI]; mA2 = lp[1 * LPI]; mB = lp[3 * LPI]; mE = lp[4 * LPI]; plc = lp[6 * LPI];
+                const cd nA_ = lp[2 * LPI], nBE_ = lp[5 * LPI], plq_ = lp[7 * LPI];
+                nA1 = nA_.re; nA2 = nA_.im; nB = nBE_.re; nE = nBE_.im; plr = plq_.re; q1 = plq_.im;
+            }
+            cd zv = zz[n1 % (LEAN ? P / 2 : P)];
+            if constexpr (LEAN && n1 >= P / 2) {
+                const cd *park = tabL + 4 * TAB + 8 * LPI + (size_t) wave * (IPW * SO) + lane;
+                zv = park[64 * (n1 - P / 2)];
+            }
+            const double x0 = xv.re, x1 = zv.re, x2 = xv.im, x3 = zv.im;
             // the lane's run of four samples from a zero state: outputs and end state
             const double y00 = h0 * x0, y01 = fma(h0, x1, h1 * x0), y02 = fma(h0, x2, fma(h1, x1, h2 * x0));
             const double y03 = fma(h0, x3, fma(h1, x2, fma(h2, x1, h3 * x0)));
@@ -368,20 +482,20 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : 2) void post_
             *(double2 *) (out + 4 * LPI * n1) = make_double2(y0, y1);
             *(double2 *) (out + 4 * LPI * n1 + 2) = make_double2(y2, y3);
             // a few blocks at a time: enough independent work for the pipeline, few enough intermediate values for the registers
-            if constexpr (n1 % SDRT_P8_BLOCKS_AHEAD == SDRT_P8_BLOCKS_AHEAD - 1) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (n1 % BA == BA - 1) __builtin_amdgcn_sched_barrier(0);
         });
     }
 }
 
 bool post_fft8_supported(const PostArgs &a);
 
-size_t post_fft8_lds_bytes(int lpi, int wpb) {
-    return ((size_t) 4 * SDRT_P8_PPL * lpi + 8 * lpi + (size_t) wpb * (64 / lpi) * 17 * lpi) * 16;
+size_t post_fft8_lds_bytes(int lpi, int wpb, bool pairs) {
+    return ((size_t) 4 * SDRT_P8_PPL * lpi + 8 * lpi + (size_t) wpb * (64 / lpi) * (p8_halves(lpi, pairs) ? 9 : 17) * lpi) * 16;
 }
 
 template <int LPI, int WPB, bool PAIRS>
 static hipError_t launch_post_fft8_p(const PostArgs &a, hipStream_t s) {
-    const size_t lds = post_fft8_lds_bytes(LPI, WPB);
+    const size_t lds = post_fft8_lds_bytes(LPI, WPB, PAIRS);
     static thread_local int done_dev = -1;                      // once per device and instantiation
     int dev = 0;
     (void) hipGetDevice(&dev);
