@@ -373,8 +373,12 @@ hipError_t launch_chain_seq(const DecimArgs &a, int q, int dt, bool nco, bool iq
 }
 
 // output lowpass of an item's m samples in place (dsp_processor.py:32-36,149), 256 threads: a modal scan over the workgroup
+// (PAD: the samples sit in LDS, one pad element per 64 -- a thread's run of m/256 consecutive samples then starts two banks after
+// its neighbour's instead of on the same one)
+template <bool PAD = false>
 __device__ __forceinline__ void workgroup_lowpass(const PostArgs &a, double *out, cd (&ptot)[SDRT_OUT_MAXMODES][4]) {
     const int m = a.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto at = [&](int i) -> double & { return out[PAD ? i + (i >> 6) : i]; };
     // ---- output lowpass: y[t] = D x[t] + sum_k Re(r_k s_k(t)), s_k(t+1) = p_k s_k(t) + x[t], s_k(0) = 0 --------------------
     const OutTables *__restrict__ ot = a.otab;
     const int nm = ot->nmodes;
@@ -384,7 +388,7 @@ __device__ __forceinline__ void workgroup_lowpass(const PostArgs &a, double *out
             double st[2 * SDRT_MAX_OUT_SECTIONS];
             for (int s = 0; s < 2 * SDRT_MAX_OUT_SECTIONS; ++s) st[s] = 0.0;
             for (int i = 0; i < m; ++i) {
-                double xc = out[i];
+                double xc = at(i);
                 for (int s = 0; s < a.out_sections; ++s) {
                     const double *c = a.out_sos + 6 * s;
                     const double xn = fma(c[0], xc, st[2 * s]);
@@ -392,7 +396,7 @@ __device__ __forceinline__ void workgroup_lowpass(const PostArgs &a, double *out
                     st[2 * s + 1] = fma(c[2], xc, -c[5] * xn);
                     xc = xn;
                 }
-                out[i] = xc;
+                at(i) = xc;
             }
         }
         return;
@@ -405,7 +409,7 @@ __device__ __forceinline__ void workgroup_lowpass(const PostArgs &a, double *out
         rk[k] = k < nm ? mk(ot->r[k][0], ot->r[k][1]) : mk(0.0, 0.0);
         cd s = mk(0.0, 0.0);
         if (k < nm)
-            for (int e = 0; e < E; ++e) s = cfma(pk[k], s, mk(out[t0 + e], 0.0));
+            for (int e = 0; e < E; ++e) s = cfma(pk[k], s, mk(at(t0 + e), 0.0));
         const cd PE = cpow_u(pk[k], (unsigned) E);
         const cd sc = wave_scan_geometric(s, PE, lane);
         if (lane == 63) ptot[k][wave] = sc;
@@ -419,7 +423,7 @@ __device__ __forceinline__ void workgroup_lowpass(const PostArgs &a, double *out
     }
     const double Dd = ot->D;
     for (int e = 0; e < E; ++e) {
-        const double x = out[t0 + e];
+        const double x = at(t0 + e);
         double yv = Dd * x;
 #pragma unroll
         for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
@@ -428,7 +432,7 @@ __device__ __forceinline__ void workgroup_lowpass(const PostArgs &a, double *out
                 sst[k] = cfma(pk[k], sst[k], mk(x, 0.0));
             }
         }
-        out[t0 + e] = yv;
+        at(t0 + e) = yv;
     }
 }
 
@@ -561,13 +565,17 @@ __device__ __forceinline__ void fft_workgroup(cd (&x)[B][4], cd *X, const cd *__
     } else {
         radix4_pass_wg<B, SL, INV>(x, tw, tid, stX);
         __syncthreads();
-        // n = 2: y[q] = a + b, y[q + N/2] = a - b, q < N/2
+        // n = 2: y[q] = a + b, y[q + N/2] = a - b, q < N/2.  Everybody holds its points before the first result is stored:
+        // store_last may write over the image
+        cd u[N / 512], v[N / 512];
+#pragma unroll
+        for (int c = 0; c < N / 512; ++c) { u[c] = X[xq(tid + 256 * c)]; v[c] = X[xq(tid + 256 * c + N / 2)]; }
+        __syncthreads();
 #pragma unroll
         for (int c = 0; c < N / 512; ++c) {
             const int q = tid + 256 * c;
-            const cd u = X[xq(q)], v = X[xq(q + N / 2)];
-            store_last(q, cadd(u, v));
-            store_last(q + N / 2, csub_(u, v));
+            store_last(q, cadd(u[c], v[c]));
+            store_last(q + N / 2, csub_(u[c], v[c]));
         }
     }
 }
@@ -633,7 +641,7 @@ __global__ __launch_bounds__(256) void post_bigfftp_kernel(PostArgs a) {
     const size_t item = post_item(a, blockIdx.x);
     const cd *y = (const cd *) a.y + item * (size_t) ((PAIRS && !a.pairs_wide) ? N : M);
     double *out = a.out + item * (size_t) M;
-    cd x[B][4];
+    cd x[B][4], ev[B][4];
     auto angle_of = [&](int j) {
         if constexpr (PAIRS) {
             const cd z = y[j];                                  // d[2j] conj(d[2j+1]) from the chain kernel
@@ -650,9 +658,8 @@ __global__ __launch_bounds__(256) void post_bigfftp_kernel(PostArgs a) {
         for (int k = 0; k < 4; ++k) {
             const int n = tid + 256 * b + k * (H / 4);
             const double a0 = angle_of(2 * n), a1 = angle_of(2 * n + 1);
-            out[4 * n] = a0;
-            out[4 * n + 2] = a1;
             x[b][k] = mk(a0, a1);
+            ev[b][k] = x[b][k];                                 // (64 registers through the transforms: no round trip through memory)
         }
     fft_workgroup<B, false>(x, X, tw, tid, [&](int o, cd v) { X[xq(o)] = v; });
     __syncthreads();
@@ -668,9 +675,24 @@ __global__ __launch_bounds__(256) void post_bigfftp_kernel(PostArgs a) {
                          fma(c.x, Z.im, fma(c.y, Z.re, fma(c.w, Zm.re, -(c.z * Zm.im)))));
         }
     __syncthreads();
-    fft_workgroup<B, true>(x, X, tw, tid, [&](int o, cd v) { out[4 * o + 1] = v.re; out[4 * o + 3] = v.im; });
+    // The item's M output samples for the lowpass live in LDS, over the transform image (whose last reads are done when the last
+    // pass stores: fft_workgroup).  Round 4: they went through the output buffer before (8-byte stores 32 bytes apart, thread runs
+    // read back twice and written once, 512 bytes apart between lanes): 1.67 GB per 2^26 samples against 0.81 GB algorithmic.
+    double *zb = (double *) smem;
+    auto zp = [](int i) { return i + (i >> 6); };
+    fft_workgroup<B, true>(x, X, tw, tid, [&](int o, cd v) { zb[zp(4 * o + 1)] = v.re; zb[zp(4 * o + 3)] = v.im; });
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int n = tid + 256 * b + k * (H / 4);
+            zb[zp(4 * n)] = ev[b][k].re;
+            zb[zp(4 * n + 2)] = ev[b][k].im;
+        }
     __syncthreads();
-    workgroup_lowpass(a, out, ptot);
+    workgroup_lowpass<true>(a, zb, ptot);
+    __syncthreads();
+    for (int i = tid; i < M; i += 256) out[i] = zb[zp(i)];
 }
 
 bool post_bigfft_supported(const PostArgs &a) {
@@ -696,7 +718,9 @@ static hipError_t launch_post_bigfft_b(const PostArgs &a, hipStream_t s) {
 
 template <int B>
 static hipError_t launch_post_bigfftp_b(const PostArgs &a, hipStream_t s) {
-    const size_t lds = (size_t) (1024 * B + 64 * B) * 16;
+    // the transform image [H + H/16] complex, then (over it) the M = 4 H output samples, one pad element per 64
+    const size_t img = (size_t) (1024 * B + 64 * B) * 16, seq = (size_t) (4096 * B + 64 * B) * 8;
+    const size_t lds = img > seq ? img : seq;
     static thread_local int done_dev = -1;
     int dev = 0;
     (void) hipGetDevice(&dev);
