@@ -698,7 +698,14 @@ __global__ __launch_bounds__(256) void post_bigfftp_kernel(PostArgs a) {
 bool post_bigfft_supported(const PostArgs &a) {
     // (2048 / 4096 outputs per chunk stay with the one-wave kernel of kernels_post.hip: a workgroup per item measured 0.289 against
     // 0.251 ms per 2^29 8-bit samples at decimation 32 there, profiles/r03_experiments.txt)
-    return a.mode == SDRT_FM && a.fft_tw && a.fft_shift && !a.iq_R && !a.pairs && (a.m == 8192 || a.m == 16384);
+    if (!(a.mode == SDRT_FM && a.fft_tw && a.fft_shift && !a.iq_R)) return false;
+    // round 4: with the samples in LDS for the lowpass the packed workgroup form also takes 4096 outputs per chunk (decimation 8 of
+    // 16-bit records: 0.55 -> 0.345 ms per 2^28 samples against the one-wave kernel; SDRTERM_POST_WG4096=0 keeps that one)
+    if (a.m == 4096 && a.fftp_tw && a.fftp_ab && a.fft_ok) {
+        static const int on = [] { const char *e = getenv("SDRTERM_POST_WG4096"); return e ? atoi(e) : 1; }();
+        return on != 0;
+    }
+    return !a.pairs && (a.m == 8192 || a.m == 16384);
 }
 
 template <int B, bool PAIRS>
@@ -716,7 +723,7 @@ static hipError_t launch_post_bigfft_b(const PostArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int B>
+template <int B, bool PAIRS = false>
 static hipError_t launch_post_bigfftp_b(const PostArgs &a, hipStream_t s) {
     // the transform image [H + H/16] complex, then (over it) the M = 4 H output samples, one pad element per 64
     const size_t img = (size_t) (1024 * B + 64 * B) * 16, seq = (size_t) (4096 * B + 64 * B) * 8;
@@ -725,17 +732,18 @@ static hipError_t launch_post_bigfftp_b(const PostArgs &a, hipStream_t s) {
     int dev = 0;
     (void) hipGetDevice(&dev);
     if (done_dev != dev) {
-        hipError_t e = hipFuncSetAttribute((const void *) post_bigfftp_kernel<B, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        hipError_t e = hipFuncSetAttribute((const void *) post_bigfftp_kernel<B, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
         done_dev = dev;
     }
-    hipLaunchKernelGGL((post_bigfftp_kernel<B, false>), dim3((unsigned) a.items), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((post_bigfftp_kernel<B, PAIRS>), dim3((unsigned) a.items), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_post_bigfft(const PostArgs &a, hipStream_t s) {
     if (a.fftp_tw && a.fftp_ab) {                    // the packed form where its tables exist
         switch (a.m) {
+            case 4096: return a.pairs ? launch_post_bigfftp_b<1, true>(a, s) : launch_post_bigfftp_b<1, false>(a, s);
             case 8192: return launch_post_bigfftp_b<2>(a, s);
             case 16384: return launch_post_bigfftp_b<4>(a, s);
         }
