@@ -163,6 +163,6 @@ bool chain_seq_supported(int q, int n);
 hipError_t launch_chain_seq(const DecimArgs &a, int q, int dt, bool nco, bool iq, size_t n_chunks, hipStream_t s);
 bool post_big_supported(int m, int mode);
 hipError_t launch_post_big(const PostArgs &a, hipStream_t s);
-bool post_bigfft_supported(const PostArgs &a);        // FM at 8192 / 16384 outputs per chunk with the FFT tables: a workgroup transform
+bool post_bigfft_supported(const PostArgs &a);        // FM at 4096 .. 16384 outputs per chunk with the packed FFT tables: a workgroup transform
 hipError_t launch_post_bigfft(const PostArgs &a, hipStream_t s);
 hipError_t launch_swap_selftest(const double *x, const double *y, double *out, hipStream_t s);

@@ -375,9 +375,9 @@ hipError_t launch_chain_seq(const DecimArgs &a, int q, int dt, bool nco, bool iq
 // output lowpass of an item's m samples in place (dsp_processor.py:32-36,149), 256 threads: a modal scan over the workgroup
 // (PAD: the samples sit in LDS, one pad element per 64 -- a thread's run of m/256 consecutive samples then starts two banks after
 // its neighbour's instead of on the same one)
-template <bool PAD = false>
+template <bool PAD = false, int THR = 256>
 __device__ __forceinline__ void workgroup_lowpass(const PostArgs &a, double *out, cd (&ptot)[SDRT_OUT_MAXMODES][4]) {
-    const int m = a.m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = a.m, tid = threadIdx.x % THR, lane = tid & 63, wave = tid >> 6;
     auto at = [&](int i) -> double & { return out[PAD ? i + (i >> 6) : i]; };
     // ---- output lowpass: y[t] = D x[t] + sum_k Re(r_k s_k(t)), s_k(t+1) = p_k s_k(t) + x[t], s_k(0) = 0 --------------------
     const OutTables *__restrict__ ot = a.otab;
@@ -401,7 +401,7 @@ __device__ __forceinline__ void workgroup_lowpass(const PostArgs &a, double *out
         }
         return;
     }
-    const int E = m / 256, t0 = tid * E;
+    const int E = m / THR, t0 = tid * E;
     cd pk[SDRT_OUT_MAXMODES], rk[SDRT_OUT_MAXMODES], sst[SDRT_OUT_MAXMODES];
 #pragma unroll
     for (int k = 0; k < SDRT_OUT_MAXMODES; ++k) {
