@@ -101,6 +101,7 @@ struct PostArgs {
                                 // batch; items = (rows of this mode) * n_chunks.  NULL: every row, item w is item w
     int pairs;                  // FM: y holds [items][m/2] products y[2i] conj(y[2i+1]) (DecimArgs.pair_out)
     int pairs_wide;             //   ... each item in the place its m samples would take (DecimArgs.pair_wide: per-row modes)
+    int am_in_lds;              // post_big_kernel, AM: the item's samples fit the LDS for the lowpass (set by launch_post_big)
     // eight / sixteen lanes per item (kernels_post8.hip; FM, m = 512 / 1024, lowpass = one complex pole pair + one real pole), or NULL
     const double *fft8_tab;     // [4][16 LPI][2] + [8][LPI][2]: sdrt_build_post8_tables
     const Post8Tables *p8tab;

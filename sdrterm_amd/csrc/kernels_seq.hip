@@ -485,6 +485,19 @@ __global__ __launch_bounds__(256) void post_big_kernel(PostArgs a) {
 #pragma unroll
             for (int r = 0; r < R; ++r) out[2 * (j0 + r) + 1] = acc[r];
         }
+    } else if (a.am_in_lds) {
+        // AM (demodulation.py:41-48), round 4: the item's samples sit in LDS for the lowpass (one pad element per 64) instead of going
+        // through the output buffer as 512-byte-strided thread runs; one coalesced store of the result
+        double *zb = (double *) smem;
+        for (int k = tid; k < m; k += 256) {
+            const cd v = y[k];
+            zb[k + (k >> 6)] = v.re * v.re + v.im * v.im;
+        }
+        __syncthreads();
+        workgroup_lowpass<true>(a, zb, ptot);
+        __syncthreads();
+        for (int k = tid; k < m; k += 256) out[k] = zb[k + (k >> 6)];
+        return;
     } else {
         for (int k = tid; k < m; k += 256) {
             const cd v = y[k];
@@ -762,8 +775,11 @@ bool post_big_supported(int m, int mode) {
     return (N & (N - 1)) == 0 && N >= 4096 && (size_t) (N + 2048) * sizeof(double) <= 160 * 1024;
 }
 
-hipError_t launch_post_big(const PostArgs &a, hipStream_t s) {
-    const size_t lds = a.mode == SDRT_FM ? (size_t) (a.m / 2 + 2048) * sizeof(double) : 0;
+hipError_t launch_post_big(const PostArgs &a0, hipStream_t s) {
+    PostArgs a = a0;
+    const size_t seq = (size_t) (a.m + a.m / 64) * sizeof(double);
+    a.am_in_lds = a.mode != SDRT_FM && seq <= 144 * 1024;
+    const size_t lds = a.mode == SDRT_FM ? (size_t) (a.m / 2 + 2048) * sizeof(double) : (a.am_in_lds ? seq : 0);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *) post_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
