@@ -1226,7 +1226,9 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     }
     // FM on the wide-column kernel, likewise without a debug buffer: the pair products instead of the samples (half the bytes
     // between the two stages); not with the offset share still to come
-    const bool pairs = !ydec_dev && c->use_i8w && c->more_passes.empty() && !c->stamps_dev && !later && !c->mixed && post_takes_pairs(post_args(c, ybuf, n_chunks, out_dev, false, true));
+    // (several passes over the chunk: a pass finishes eight consecutive outputs of every column, whole pairs -- SDRTERM_PASS_PAIRS=0: samples)
+    static const bool pass_pairs = [] { const char *e = getenv("SDRTERM_PASS_PAIRS"); return !e || atoi(e) != 0; }();
+    const bool pairs = !ydec_dev && c->use_i8w && (c->more_passes.empty() || pass_pairs) && !c->stamps_dev && !later && !c->mixed && post_takes_pairs(post_args(c, ybuf, n_chunks, out_dev, false, true));
     // per-row modes: the FM rows' items as pair products, every item in the place its samples would take (eight- and sixteen-tile
     // chunks; the two-chunks-per-item forms keep samples)
     bool row_pairs = false;

@@ -718,7 +718,7 @@ bool post_bigfft_supported(const PostArgs &a) {
         static const int on = [] { const char *e = getenv("SDRTERM_POST_WG4096"); return e ? atoi(e) : 1; }();
         return on != 0;
     }
-    return !a.pairs && (a.m == 8192 || a.m == 16384);
+    return (!a.pairs || (a.fftp_tw && a.fftp_ab)) && (a.m == 8192 || a.m == 16384);      // (pair products: the packed form only)
 }
 
 template <int B, bool PAIRS>
@@ -757,8 +757,8 @@ hipError_t launch_post_bigfft(const PostArgs &a, hipStream_t s) {
     if (a.fftp_tw && a.fftp_ab) {                    // the packed form where its tables exist
         switch (a.m) {
             case 4096: return a.pairs ? launch_post_bigfftp_b<1, true>(a, s) : launch_post_bigfftp_b<1, false>(a, s);
-            case 8192: return launch_post_bigfftp_b<2>(a, s);
-            case 16384: return launch_post_bigfftp_b<4>(a, s);
+            case 8192: return a.pairs ? launch_post_bigfftp_b<2, true>(a, s) : launch_post_bigfftp_b<2, false>(a, s);
+            case 16384: return a.pairs ? launch_post_bigfftp_b<4, true>(a, s) : launch_post_bigfftp_b<4, false>(a, s);
         }
     }
     switch (a.m) {

@@ -220,7 +220,7 @@ def test_reader_options_against_the_c_oracle(code, q, mode, opt, monkeypatch):
         assert abs(eng.iq_offset - off) <= 1e-9 * max(abs(off), 1e-30)
 
 
-@pytest.mark.parametrize('code,q,rows', [('h', 64, 1), ('h', 32, 3), ('B', 64, 1), ('f', 64, 2)])
+@pytest.mark.parametrize('code,q,rows', [('h', 64, 1), ('h', 32, 3), ('B', 64, 1), ('f', 64, 2), ('h', 16, 2), ('h', 8, 1), ('B', 16, 1), ('h', 4, 1)])
 def test_pair_products_between_the_stages_equal_the_sample_path(code, q, rows, monkeypatch):
     """FM without a debug buffer: the wide-column kernel hands the demodulation stage the products y[2i] conj(y[2i+1])
     (demodulation.py:25-32) instead of the decimated samples.  Same outputs as the path that writes the samples (taken when
@@ -232,7 +232,8 @@ def test_pair_products_between_the_stages_equal_the_sample_path(code, q, rows, m
     n = samples_per_chunk(code)
     freqs = [15700.0, -203300.0, 100100.0][:rows]
     raw = prng.raw_bytes(code, n * nch, seed=77, amp=100 if code == 'B' else 3000)
-    eng = Engine(fs, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=5000)
+    # (decimation 4 .. 16: several passes of the wide kernel over the chunk, each finishing whole pairs)
+    eng = Engine(fs, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=5000 if q >= 32 else 8000 * (32 // q))
     assert eng.stage_a == 'i8w'
     a = eng.process(raw)
     b, _y = eng.process_debug(raw)
@@ -636,9 +637,12 @@ def test_small_decimations_in_passes_of_the_wide_kernel(code, q, mode, rows, mon
     tol = tol_for(exp, mode)
     print(f'{code} q={q} {mode} x {rows}: {256 // q // 8} passes, max abs err {err:.3e} (tol {tol:.1e})')
     assert err <= tol
-    # the same chunks in another batching: the same bits
+    # the same chunks in another batching: the same bits (process() hands FM over as pair products, process_debug() as samples:
+    # the two differ in the last place, test_pair_products_between_the_stages_equal_the_sample_path)
+    whole = eng.process(raw).reshape(rows, nch, m)
+    assert np.abs(whole - out.reshape(rows, nch, m)).max() <= 1e-12 * max(1.0, np.abs(whole).max())
     part = eng.process(raw[2 * eng.chunk_bytes:5 * eng.chunk_bytes]).reshape(rows, 3, m)
-    assert np.array_equal(part, out.reshape(rows, nch, m)[:, 2:5])
+    assert np.array_equal(part, whole[:, 2:5])
     monkeypatch.setenv('SDRTERM_STAGE_A', 'f64')
     from sdrterm_amd._native import SdrtError
     try:
