@@ -22,6 +22,9 @@
 #include <cstdlib>
 #include "kernels_common.hpp"
 
+#ifndef SDRT_PF8
+#define SDRT_PF8 1               // eight outputs per column, no IQ correction: k-steps of raw samples in flight
+#endif
 #ifndef SDRT_DUAL_PF
 #define SDRT_DUAL_PF 3           // DUAL form: k-steps of raw samples in flight per tile
 #endif
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(DUAL ? 256 : 512, DUAL ? 1 : 2) void chain_i8w_kern
     constexpr int NHF = (S + PPF - 1) / PPF;                      // fragments used with the high (or only) slice
     constexpr int NLF = (PACK || RS) ? NHF + (NSL >= 2 ? (S - 1 + PPF - 1) / PPF : 0) : S;   // local-tile fragments per k-step (both plane pairings)
     constexpr int NSLOT = (RS || F32) ? 1 : 4;                             // raw-sample register ring (RS: reloaded in place once sliced)
-    constexpr int PF = (NOUT == 8 || RS || F32) ? 1 : (DUAL ? SDRT_DUAL_PF : 2);            // k-steps of raw samples in flight (registers are scarcer with 8 outputs per column)
+    constexpr int PF = (NOUT == 8 && IQ == 0 && !RS && !F32) ? SDRT_PF8 : ((NOUT == 8 || RS || F32) ? 1 : (DUAL ? SDRT_DUAL_PF : 2));            // k-steps of raw samples in flight (registers are scarcer with 8 outputs per column)
     static_assert(NOUT == 4 || NOUT == 8, "4 or 8 outputs per column");
     static_assert(NTC == 4 || NTC == 8 || NTC == 16, "4, 8 or 16 tiles per chunk");
     typedef typename Enc<DT>::raw raw_t;
