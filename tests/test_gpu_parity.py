@@ -459,7 +459,8 @@ def test_float32_rows_sliced_once_per_chunk_give_the_same_bits(big_endian, nch, 
 
 
 @pytest.mark.parametrize('code,rows,iq,fused,q', [('B', 1, False, None, 64), ('b', 2, False, None, 64), ('B', 1, True, '1', 64), ('b', 1, True, '0', 64),
-                                                  ('B', 2, True, None, 64), ('h', 1, False, None, 64), ('B', 2, False, None, 32), ('b', 2, True, None, 32)])
+                                                  ('B', 2, True, None, 64), ('h', 1, False, None, 64), ('B', 2, False, None, 32), ('b', 2, True, None, 32),
+                                                  ('h', 1, True, '1', 64), ('h', 2, True, None, 64), ('h', 1, True, '0', 32), ('H', 1, True, '1', 64)])
 def test_sixteen_tiles_per_chunk_on_the_wide_kernel(code, rows, iq, fused, q, monkeypatch):
     """Chunks of sixteen tiles (8-bit records; 16-bit records in 65536-sample chunks): two tiles per wave, the column phase of a
     tile running in the pass after its matrix phase (kernels_i8w.hip, SHQ), with and without --correct-iq in both of its forms,
@@ -564,10 +565,12 @@ def test_silent_chunks_anywhere_in_a_batch_come_out_as_exact_zeros(code, q, cent
         eng.close()
 
 
-@pytest.mark.parametrize('code,q,center,rows,fused', [('h', 64, 15700, 1, None), ('h', 64, 15700, 1, '0'), ('H', 64, -203300, 1, None),
-                                                      ('B', 64, 15700, 1, None), ('b', 32, 15700, 1, '0'), ('h', 32, 0, 1, None),
-                                                      ('h', 128, 15700, 3, None), ('h', 256, 15700, 1, None), ('B', 128, 15700, 2, '0')])
-def test_a_stream_that_starts_silent_under_correct_iq_comes_out_as_exact_zeros(code, q, center, rows, fused, monkeypatch):
+@pytest.mark.parametrize('code,q,center,rows,fused,n', [('h', 64, 15700, 1, None, 0), ('h', 64, 15700, 1, '0', 0), ('H', 64, -203300, 1, None, 0),
+                                                        ('B', 64, 15700, 1, None, 0), ('b', 32, 15700, 1, '0', 0), ('h', 32, 0, 1, None, 0),
+                                                        ('h', 128, 15700, 3, None, 0), ('h', 256, 15700, 1, None, 0), ('B', 128, 15700, 2, '0', 0),
+                                                        ('h', 32, 15700, 3, None, 0), ('H', 32, 15700, 1, '0', 0),
+                                                        ('h', 64, 15700, 1, None, 65536), ('h', 32, 15700, 2, None, 65536), ('H', 64, 15700, 1, '0', 65536)])
+def test_a_stream_that_starts_silent_under_correct_iq_comes_out_as_exact_zeros(code, q, center, rows, fused, n, monkeypatch):
     """--correct-iq (read_file.py:64-77): the offset starts at zero, so the silent head of a stream stays x - 0 = 0 and the reference
     writes exact zeros until the first loud sample.  The int8 forms carry the constant their byte slices leave out in a rank-one
     term; the weight planes of those forms are quantised so that this term cancels the matrix cores' share to the last bit
@@ -580,14 +583,15 @@ def test_a_stream_that_starts_silent_under_correct_iq_comes_out_as_exact_zeros(c
         monkeypatch.delenv('SDRTERM_IQ_FUSED', raising=False)
     else:
         monkeypatch.setenv('SDRTERM_IQ_FUSED', fused)
-    fs, n, nch, head = 1024000, samples_per_chunk(code), 37, 19
+    # (n = 65536: chunks of sixteen tiles, two per wave -- the forms shortest of LDS)
+    fs, n, nch, head = 1024000, n or samples_per_chunk(code), 37 if not n else 11, 19 if not n else 5
     item = {'b': 1, 'B': 1, 'h': 2, 'H': 2}[code]
     freqs = [float(center + 50000 * r) for r in range(rows)]
     omega = 5000 if q < 128 else (2500 if q < 256 else 1200)
     raw = np.frombuffer(prng.raw_bytes(code, n * nch, seed=93, amp=100 if item == 1 else 8000), dtype=np.uint8).reshape(nch, -1).copy()
     raw[:head] = 0
     for mode in ('fm', 'am'):
-        eng = Engine(fs, q, mode, code, row_freqs=freqs, apply_shift=bool(center or rows > 1), omega_out=omega, correct_iq=True)
+        eng = Engine(fs, q, mode, code, n_samples=n, row_freqs=freqs, apply_shift=bool(center or rows > 1), omega_out=omega, correct_iq=True)
         assert eng.stage_a == ('i8w' if q <= 64 else 'f64')       # (decimation 128 and up with --correct-iq: the fp64 kernel)
         m = n // q
         out = eng.process(raw.tobytes()).reshape(rows, nch, m)
@@ -603,15 +607,11 @@ def test_a_stream_that_starts_silent_under_correct_iq_comes_out_as_exact_zeros(c
 
 
 def _oracle_rows_iq(raw, code, n, q, mode, freqs, fs, omega_out, nch):
-    """oracle.ref_chain (numpy restatement, --correct-iq carried across chunks) per row: (chunk, row, m)."""
-    from oracle import ref_chain
-    item = {'b': 1, 'B': 1, 'h': 2, 'H': 2}[code]
-    cb = n * 2 * item
-    res = []
-    for f in freqs:
-        ch = ref_chain.Chain(fs, q, mode, code, center=f, omega_out=omega_out, correct_iq=True)
-        res.append(np.stack([np.asarray(ch.process(raw[c * cb:(c + 1) * cb])).reshape(-1) for c in range(nch)]))
-    return np.stack(res, axis=1)
+    """oracle/chain.c with --correct-iq carried across the chunks (read_file.py:64-77, inductance 50 / fs): (chunk, row, m)."""
+    from oracle import c_chain, ref_chain
+    exp, _off = c_chain.process_stream(raw, code, n, q, mode, c_chain.shift_table(freqs, fs, n), ref_chain.cheby_sos(q),
+                                       ref_chain.ellip_sos(fs // q, omega_out), iq_inductance=50 / fs, threads=4)
+    return exp
 
 
 @pytest.mark.parametrize('code,q,mode,rows', [('h', 16, 'fm', 3), ('h', 8, 'am', 2), ('H', 16, 'am', 1), ('B', 16, 'fm', 2), ('b', 8, 'fm', 1), ('h', 4, 'fm', 1)])
