@@ -614,6 +614,38 @@ def _oracle_rows_iq(raw, code, n, q, mode, freqs, fs, omega_out, nch):
     return exp
 
 
+@pytest.mark.parametrize('code', list('bBhHiIfd'))
+def test_every_instantiation_of_the_per_sample_kernel(code, monkeypatch):
+    """chain_seq_kernel (decimation 2 and 4) exists once per encoding x decimation x frequency shift x --correct-iq: 64 instantiations
+    of a kernel that uses 450 - 490 registers.  Round 4 rebuilt its passes as compile-time blocks of 16 samples, and on the way two of
+    the 64 came back with ONE thread's anticausal aggregate overwritten (float32 at decimation 4, int8 at decimation 2: the outputs of
+    run 254 wrong, everything else to the last bit) depending on where an unrelated block of the source stood -- nothing the golden
+    cases, which exercise five of the 64, would have seen.  Hence every instantiation against oracle/chain.c, three chunks each, the
+    run length at its minimum (32 samples) for the 4- and 8-byte encodings and at 64 for the others."""
+    from sdrterm_amd.engine import Engine
+    from oracle import c_chain, ref_chain
+    from tests.golden import prng
+    monkeypatch.setenv('SDRTERM_STAGE_A', 'f64')            # (decimation 4 of the 8- and 16-bit encodings otherwise goes to the wide kernel)
+    fs, nch = 1024000, 3
+    n = {'b': 16384, 'B': 16384, 'h': 16384, 'H': 16384}.get(code, 8192)
+    raw = prng.raw_bytes(code, n * nch, seed=5, amp=100 if code in 'bB' else 3000)
+    worst = 0.0
+    for q in (2, 4):
+        for iq in (False, True):
+            for center in (0.0, 15700.0):
+                eng = Engine(fs, q, 'fm', code, n_samples=n, row_freqs=[center], apply_shift=bool(center), omega_out=60000, correct_iq=iq)
+                assert eng.stage_a == 'seq'
+                out = eng.process(raw)
+                eng.close()
+                shift = c_chain.shift_table([center], fs, n) if center else None
+                exp, _ = c_chain.process_stream(raw, code, n, q, 'fm', shift, ref_chain.cheby_sos(q), ref_chain.ellip_sos(fs // q, 60000),
+                                                iq_inductance=50 / fs if iq else None, threads=4)
+                err = float(np.abs(out.reshape(1, nch, n // q).transpose(1, 0, 2) - exp).max())
+                print(f'{code} n={n} q={q} iq={iq} center={center}: max abs err {err:.3e}')
+                worst = max(worst, err)
+    assert worst <= 1e-9
+
+
 @pytest.mark.parametrize('code,q,mode,rows', [('h', 16, 'fm', 3), ('h', 8, 'am', 2), ('H', 16, 'am', 1), ('B', 16, 'fm', 2), ('b', 8, 'fm', 1), ('h', 4, 'fm', 1)])
 def test_small_decimations_in_passes_of_the_wide_kernel(code, q, mode, rows, monkeypatch):
     """Decimation 4 / 8 / 16 on the wide-column int8 kernel: a 256-sample column has 64 / 32 / 16 outputs and the kernel finishes eight
