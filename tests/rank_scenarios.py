@@ -201,6 +201,12 @@ def halt_flag_with_live_helpers():
         flag.value = 1
         for h in helpers:
             h.join(40)
+            # (rank 0's own thread joins its helpers as well: whichever thread reaps the child stores the exit code, the other one
+            # may look a moment too early)
+            for _ in range(100):
+                if h.exitcode is not None:
+                    break
+                time.sleep(0.05)
             codes.append(h.exitcode)
     ths = [threading.Thread(target=fn, daemon=True) for fn in (feeder, clients, halter)]
     for t in ths:
