@@ -417,8 +417,8 @@ hipError_t launch_chain_seq(const DecimArgs &a, int q, int dt, bool nco, bool iq
 // output lowpass of an item's m samples in place (dsp_processor.py:32-36,149), 256 threads: a modal scan over the workgroup
 // (PAD: the samples sit in LDS, one pad element per 64 -- a thread's run of m/256 consecutive samples then starts two banks after
 // its neighbour's instead of on the same one)
-template <bool PAD = false, int THR = 256>
-__device__ __forceinline__ void workgroup_lowpass(const PostArgs &a, double *out, cd (&ptot)[SDRT_OUT_MAXMODES][4]) {
+template <bool PAD = false, int THR = 256, int NW = 4>
+__device__ __forceinline__ void workgroup_lowpass(const PostArgs &a, double *out, cd (&ptot)[SDRT_OUT_MAXMODES][NW]) {
     const int m = a.m, tid = threadIdx.x % THR, lane = tid & 63, wave = tid >> 6;
     auto at = [&](int i) -> double & { return out[PAD ? i + (i >> 6) : i]; };
     // ---- output lowpass: y[t] = D x[t] + sum_k Re(r_k s_k(t)), s_k(t+1) = p_k s_k(t) + x[t], s_k(0) = 0 --------------------
@@ -634,6 +634,67 @@ __device__ __forceinline__ void fft_workgroup(cd (&x)[B][4], cd *X, const cd *__
         }
     }
 }
+// The same transform for THR threads per item and N = 4 THR B points = 4^K or 2 x 4^K: K radix-4 passes, then a radix-2 pass where a
+// factor 2 is left -- pass for pass what fft_workgroup does with 256 threads (the butterflies are the same, only their owners differ).
+template <int THR, int B, int S_, bool INV, class Store>
+__device__ __forceinline__ void radix4_pass_grp(cd (&x)[B][4], const cd *__restrict__ tw, const int tid, Store store) {
+    constexpr int N = 4 * THR * B, n = N / S_;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const int t = tid + THR * b, p = t / S_, q = t % S_;
+        const cd a0 = x[b][0], a1 = x[b][1], a2 = x[b][2], a3 = x[b][3];
+        const cd t0 = cadd(a0, a2), t1 = csub_(a0, a2), t2 = cadd(a1, a3), t3 = csub_(a1, a3);
+        const cd jt3 = INV ? mk(-t3.im, t3.re) : mk(t3.im, -t3.re);
+        cd y0 = cadd(t0, t2), y1 = cadd(t1, jt3), y2 = csub_(t0, t2), y3 = csub_(t1, jt3);
+        if constexpr (n > 4) {
+            y1 = cmul_tw_<INV>(y1, tw[p * S_]);
+            y2 = cmul_tw_<INV>(y2, tw[2 * p * S_]);
+            y3 = cmul_tw_<INV>(y3, tw[3 * p * S_]);
+        }
+        const int o = q + S_ * 4 * p;
+        store(o, y0);
+        store(o + S_, y1);
+        store(o + 2 * S_, y2);
+        store(o + 3 * S_, y3);
+    }
+}
+__host__ __device__ constexpr int ilog2_(int v) { return v <= 1 ? 0 : 1 + ilog2_(v / 2); }
+__host__ __device__ constexpr int ipow4_(int e) { return e <= 0 ? 1 : 4 * ipow4_(e - 1); }
+template <int THR, int B, bool INV, class Store>
+__device__ __forceinline__ void fft_group(cd (&x)[B][4], cd *X, const cd *__restrict__ tw, const int tid, Store store_last) {
+    constexpr int N = 4 * THR * B, LG = ilog2_(N), K = LG / 2;
+    constexpr bool R2 = (LG & 1) != 0;
+    auto stX = [&](int o, cd v) { X[xq(o)] = v; };
+    static_for<0, K>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, S_ = ipow4_(i);
+        if constexpr (i + 1 < K || R2) {
+            radix4_pass_grp<THR, B, S_, INV>(x, tw, tid, stX);
+            __syncthreads();                         // the pass's stores are there
+            if constexpr (i + 1 < K) {
+#pragma unroll
+                for (int b = 0; b < B; ++b)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[b][k] = X[xq(tid + THR * b + k * (N / 4))];
+                __syncthreads();                     // everybody holds its points: the image may be overwritten
+            }
+        } else {
+            radix4_pass_grp<THR, B, S_, INV>(x, tw, tid, store_last);
+        }
+    });
+    if constexpr (R2) {
+        // everybody holds its points before the first result is stored: store_last may write over the image
+        constexpr int C = N / (2 * THR);
+        cd u[C], v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { u[c] = X[xq(tid + THR * c)]; v[c] = X[xq(tid + THR * c + N / 2)]; }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            store_last(tid + THR * c, cadd(u[c], v[c]));
+            store_last(tid + THR * c + N / 2, csub_(u[c], v[c]));
+        }
+    }
+}
 }  // namespace
 
 template <int B, bool PAIRS>
@@ -684,11 +745,13 @@ __global__ __launch_bounds__(256) void post_bigfft_kernel(PostArgs a) {
 
 // ... and with the pair angles packed two to a complex number (round 4, as post_fftp_kernel in kernels_post.hip): ONE transform of
 // H = N/2 = 1024 B points each way, half the passes' work and half the LDS image (two to four workgroups per CU instead of one or two).
-template <int B, bool PAIRS>
-__global__ __launch_bounds__(256) void post_bigfftp_kernel(PostArgs a) {
-    constexpr int H = 1024 * B, N = 2 * H, M = 2 * N;
+// (THR threads per item: 256, or 512 at 16384 outputs per chunk -- the samples take 133 KB of LDS there, one workgroup per CU: with 256
+// threads that was one wave per SIMD)
+template <int THR, int B, bool PAIRS>
+__global__ __launch_bounds__(THR) void post_bigfftp_kernel(PostArgs a) {
+    constexpr int H = 4 * THR * B, N = 2 * H, M = 2 * N;
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ cd ptot[SDRT_OUT_MAXMODES][4];
+    __shared__ cd ptot[SDRT_OUT_MAXMODES][THR / 64];
     cd *X = (cd *) smem;                                        // [H + H/16]
     const cd *__restrict__ tw = (const cd *) a.fftp_tw;         // [H] exp(-2 pi i k/H), from L2
     const double4 *__restrict__ ab = (const double4 *) a.fftp_ab;      // [H] alpha, beta (sdrt_build_fft_resample_packed)
@@ -711,19 +774,19 @@ __global__ __launch_bounds__(256) void post_bigfftp_kernel(PostArgs a) {
     for (int b = 0; b < B; ++b)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int n = tid + 256 * b + k * (H / 4);
+            const int n = tid + THR * b + k * (H / 4);
             const double a0 = angle_of(2 * n), a1 = angle_of(2 * n + 1);
             x[b][k] = mk(a0, a1);
             ev[b][k] = x[b][k];                                 // (64 registers through the transforms: no round trip through memory)
         }
-    fft_workgroup<B, false>(x, X, tw, tid, [&](int o, cd v) { X[xq(o)] = v; });
+    fft_group<THR, B, false>(x, X, tw, tid, [&](int o, cd v) { X[xq(o)] = v; });
     __syncthreads();
     // packed spectrum of the half-sample shifted sequence, bin by bin: alpha Z[f] + beta conj(Z[H - f])
 #pragma unroll
     for (int b = 0; b < B; ++b)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int f = tid + 256 * b + k * (H / 4);
+            const int f = tid + THR * b + k * (H / 4);
             const cd Z = X[xq(f)], Zm = X[xq((H - f) & (H - 1))];
             const double4 c = ab[f];
             x[b][k] = mk(fma(c.x, Z.re, fma(-c.y, Z.im, fma(c.z, Zm.re, c.w * Zm.im))),
@@ -735,19 +798,19 @@ __global__ __launch_bounds__(256) void post_bigfftp_kernel(PostArgs a) {
     // read back twice and written once, 512 bytes apart between lanes): 1.67 GB per 2^26 samples against 0.81 GB algorithmic.
     double *zb = (double *) smem;
     auto zp = [](int i) { return i + (i >> 6); };
-    fft_workgroup<B, true>(x, X, tw, tid, [&](int o, cd v) { zb[zp(4 * o + 1)] = v.re; zb[zp(4 * o + 3)] = v.im; });
+    fft_group<THR, B, true>(x, X, tw, tid, [&](int o, cd v) { zb[zp(4 * o + 1)] = v.re; zb[zp(4 * o + 3)] = v.im; });
 #pragma unroll
     for (int b = 0; b < B; ++b)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int n = tid + 256 * b + k * (H / 4);
+            const int n = tid + THR * b + k * (H / 4);
             zb[zp(4 * n)] = ev[b][k].re;
             zb[zp(4 * n + 2)] = ev[b][k].im;
         }
     __syncthreads();
-    workgroup_lowpass<true>(a, zb, ptot);
+    workgroup_lowpass<true, THR>(a, zb, ptot);
     __syncthreads();
-    for (int i = tid; i < M; i += 256) out[i] = zb[zp(i)];
+    for (int i = tid; i < M; i += THR) out[i] = zb[zp(i)];
 }
 
 bool post_bigfft_supported(const PostArgs &a) {
@@ -778,20 +841,21 @@ static hipError_t launch_post_bigfft_b(const PostArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int B, bool PAIRS = false>
+template <int B, bool PAIRS = false, int THR = 256>
 static hipError_t launch_post_bigfftp_b(const PostArgs &a, hipStream_t s) {
-    // the transform image [H + H/16] complex, then (over it) the M = 4 H output samples, one pad element per 64
+    // the transform image [H + H/16] complex, then (over it) the M = 4 H output samples, one pad element per 64 (B: in units of 1024 points)
     const size_t img = (size_t) (1024 * B + 64 * B) * 16, seq = (size_t) (4096 * B + 64 * B) * 8;
+    constexpr int BT = B * 256 / THR;                     // points per thread / 4
     const size_t lds = img > seq ? img : seq;
     static thread_local int done_dev = -1;
     int dev = 0;
     (void) hipGetDevice(&dev);
     if (done_dev != dev) {
-        hipError_t e = hipFuncSetAttribute((const void *) post_bigfftp_kernel<B, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        hipError_t e = hipFuncSetAttribute((const void *) post_bigfftp_kernel<THR, BT, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
         done_dev = dev;
     }
-    hipLaunchKernelGGL((post_bigfftp_kernel<B, PAIRS>), dim3((unsigned) a.items), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((post_bigfftp_kernel<THR, BT, PAIRS>), dim3((unsigned) a.items), dim3(THR), lds, s, a);
     return hipGetLastError();
 }
 
@@ -800,7 +864,11 @@ hipError_t launch_post_bigfft(const PostArgs &a, hipStream_t s) {
         switch (a.m) {
             case 4096: return a.pairs ? launch_post_bigfftp_b<1, true>(a, s) : launch_post_bigfftp_b<1, false>(a, s);
             case 8192: return a.pairs ? launch_post_bigfftp_b<2, true>(a, s) : launch_post_bigfftp_b<2, false>(a, s);
-            case 16384: return a.pairs ? launch_post_bigfftp_b<4, true>(a, s) : launch_post_bigfftp_b<4, false>(a, s);
+            case 16384: {
+                static const int thr = [] { const char *e = getenv("SDRTERM_POST_THR"); return e ? atoi(e) : 512; }();
+                if (thr == 256) return a.pairs ? launch_post_bigfftp_b<4, true>(a, s) : launch_post_bigfftp_b<4, false>(a, s);
+                return a.pairs ? launch_post_bigfftp_b<4, true, 512>(a, s) : launch_post_bigfftp_b<4, false, 512>(a, s);
+            }
         }
     }
     switch (a.m) {
