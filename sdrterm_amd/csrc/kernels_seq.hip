@@ -385,13 +385,29 @@ static hipError_t launch_seq_q(const DecimArgs &a, bool nco, bool iq, dim3 grid,
     }
     return hipGetLastError();
 }
-template <int DT>
-static hipError_t launch_seq_dt(const DecimArgs &a, int q, bool nco, bool iq, dim3 grid, hipStream_t s) {
-    if (q == 2) return launch_seq_q<DT, 1>(a, nco, iq, grid, s);
-    if (q == 4) return launch_seq_q<DT, 2>(a, nco, iq, grid, s);
-    return hipErrorInvalidValue;                           // (sdrt_create sends decimation 8 and up to the block kernels)
+// The 64 instantiations take minutes to compile: decimation 4 lives in a translation unit of its own (kernels_seq_b.hip includes this
+// file with SDRT_SEQ_PART_B and compiles nothing but them).
+template <int QS>
+static hipError_t launch_seq_every(const DecimArgs &a, int dt, bool nco, bool iq, dim3 grid, hipStream_t s) {
+    switch (dt) {
+        case SDRT_S8: return launch_seq_q<SDRT_S8, QS>(a, nco, iq, grid, s);
+        case SDRT_U8: return launch_seq_q<SDRT_U8, QS>(a, nco, iq, grid, s);
+        case SDRT_S16: return launch_seq_q<SDRT_S16, QS>(a, nco, iq, grid, s);
+        case SDRT_U16: return launch_seq_q<SDRT_U16, QS>(a, nco, iq, grid, s);
+        case SDRT_S32: return launch_seq_q<SDRT_S32, QS>(a, nco, iq, grid, s);
+        case SDRT_U32: return launch_seq_q<SDRT_U32, QS>(a, nco, iq, grid, s);
+        case SDRT_F32: return launch_seq_q<SDRT_F32, QS>(a, nco, iq, grid, s);
+        case SDRT_F64: return launch_seq_q<SDRT_F64, QS>(a, nco, iq, grid, s);
+    }
+    return hipErrorInvalidValue;
 }
+hipError_t launch_chain_seq_q4(const DecimArgs &a, int dt, bool nco, bool iq, dim3 grid, hipStream_t s);
 
+#ifdef SDRT_SEQ_PART_B
+hipError_t launch_chain_seq_q4(const DecimArgs &a, int dt, bool nco, bool iq, dim3 grid, hipStream_t s) {
+    return launch_seq_every<2>(a, dt, nco, iq, grid, s);
+}
+#else
 bool chain_seq_supported(int q, int n) {
     // every thread's run: whole load groups, whole IQ groups (16 samples), at least the 28-sample edge windows, whole outputs
     const int T = n / 256;
@@ -401,17 +417,9 @@ bool chain_seq_supported(int q, int n) {
 hipError_t launch_chain_seq(const DecimArgs &a, int q, int dt, bool nco, bool iq, size_t n_chunks, hipStream_t s) {
     const size_t groups = (n_chunks + 7) / 8;
     const dim3 grid((unsigned) (groups * 8 * (size_t) a.rows));
-    switch (dt) {
-        case SDRT_S8: return launch_seq_dt<SDRT_S8>(a, q, nco, iq, grid, s);
-        case SDRT_U8: return launch_seq_dt<SDRT_U8>(a, q, nco, iq, grid, s);
-        case SDRT_S16: return launch_seq_dt<SDRT_S16>(a, q, nco, iq, grid, s);
-        case SDRT_U16: return launch_seq_dt<SDRT_U16>(a, q, nco, iq, grid, s);
-        case SDRT_S32: return launch_seq_dt<SDRT_S32>(a, q, nco, iq, grid, s);
-        case SDRT_U32: return launch_seq_dt<SDRT_U32>(a, q, nco, iq, grid, s);
-        case SDRT_F32: return launch_seq_dt<SDRT_F32>(a, q, nco, iq, grid, s);
-        case SDRT_F64: return launch_seq_dt<SDRT_F64>(a, q, nco, iq, grid, s);
-    }
-    return hipErrorInvalidValue;
+    if (q == 2) return launch_seq_every<1>(a, dt, nco, iq, grid, s);
+    if (q == 4) return launch_chain_seq_q4(a, dt, nco, iq, grid, s);
+    return hipErrorInvalidValue;                           // (sdrt_create sends decimation 8 and up to the block kernels)
 }
 
 // output lowpass of an item's m samples in place (dsp_processor.py:32-36,149), 256 threads: a modal scan over the workgroup
@@ -897,3 +905,4 @@ hipError_t launch_post_big(const PostArgs &a0, hipStream_t s) {
     hipLaunchKernelGGL(post_big_kernel, dim3((unsigned) a.items), dim3(256), lds, s, a);
     return hipGetLastError();
 }
+#endif  // SDRT_SEQ_PART_B
