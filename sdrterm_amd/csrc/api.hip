@@ -851,7 +851,7 @@ int ensure_iqbufs(sdrt_ctx *c, size_t n_chunks) {
     if (!(c->use_i8w && c->iq_fused))
         HIP_TRY(hipMalloc(&c->d_iq_group, n_chunks * (size_t) (c->cfg.n_samples / c->iq_gs) * 2 * sizeof(double)));
     HIP_TRY(hipMalloc(&c->d_iq_agg, n_chunks * 2 * sizeof(double)));
-    HIP_TRY(hipMalloc(&c->d_iq_chunk, (n_chunks + 1) * 2 * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_iq_chunk, ((n_chunks + 1) * 2 + SDRT_IQ_SCAN_PARTS * 4) * sizeof(double)));      // (+ the scan's scratch)
     c->iq_cap_chunks = n_chunks;
     return SDRT_OK;
 }
@@ -931,6 +931,7 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
         ia.chunk_agg = c->d_iq_agg;
         ia.chunk_off = c->d_iq_chunk;
         ia.state = c->d_iq_state;
+        ia.scan_part = c->d_iq_chunk + (c->iq_cap_chunks + 1) * 2;
         ia.n_chunks = n_chunks;
         ia.n = c->cfg.n_samples;
         ia.gs = gs;

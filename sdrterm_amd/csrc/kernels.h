@@ -71,7 +71,9 @@ struct IqArgs {
     const double *pow_tab;      // [n/GS + 1] (1-lambda)^(GS k)  (same table the chain kernel uses)
     double norm_bias, lambda, pow_g /* (1-lambda)^GS */, pow_n /* (1-lambda)^n */;
     const double *col_w;        // [259] column form (iq_cols_kernel): lambda (1-lambda)^(255-t), t < 256; (1-lambda)^-32; ^256; ^224 (or NULL)
+    double *scan_part;          // [SDRT_IQ_SCAN_PARTS][4] scratch of the several-workgroup chunk scan (or NULL: one workgroup)
 };
+#define SDRT_IQ_SCAN_PARTS 512
 hipError_t launch_iq_local(const IqArgs &a, hipStream_t s);
 hipError_t launch_iq_scan(const IqArgs &a, hipStream_t s);
 // y[row][chunk][k] -= off[chunk] * R[row][k]: the share of the offset at the chunk's start (wide-column kernel, api.hip)

@@ -521,7 +521,112 @@ hipError_t launch_iq_local(const IqArgs &a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+// The same scan over several workgroups, for batches of many chunks (round 4: one workgroup took 0.23 ms for the 131072 chunks of a
+// bench step -- one CU walking 4 MB).  Three launches: every workgroup of 256 threads reduces its IQ_SCAN_SPAN chunks to one map
+// o -> P o + S; one workgroup chains the maps from the carried state; every workgroup walks its chunks again from its starting offset.
+constexpr int IQ_SCAN_PER = 8, IQ_SCAN_SPAN = 256 * IQ_SCAN_PER;
+namespace {
+// this thread's chunks [c0, c1) as a map, and the inclusive composition over the workgroup (P, S of the threads up to and including it)
+__device__ __forceinline__ void iq_block_maps(const IqArgs &a, size_t c0, size_t c1, double &P, cd &S, double &Pth, cd &Sth, cd *tot, double *pw) {
+    const cd *agg = (const cd *) a.chunk_agg;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cd v[IQ_SCAN_PER];
+#pragma unroll
+    for (int u = 0; u < IQ_SCAN_PER; ++u) v[u] = c0 + u < c1 ? agg[c0 + u] : mk(0.0, 0.0);
+    cd s = mk(0.0, 0.0);
+    double p = 1.0;
+#pragma unroll
+    for (int u = 0; u < IQ_SCAN_PER; ++u)
+        if (c0 + u < c1) { s = mk(fma(a.pow_n, s.re, v[u].re), fma(a.pow_n, s.im, v[u].im)); p *= a.pow_n; }
+    Pth = p; Sth = s;
+    P = p; S = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double Pu = __shfl_up(P, d);
+        const cd Su = mk(__shfl_up(S.re, d), __shfl_up(S.im, d));
+        if (lane >= d) { S = mk(fma(P, Su.re, S.re), fma(P, Su.im, S.im)); P *= Pu; }
+    }
+    if (lane == 63) { tot[wave] = S; pw[wave] = P; }
+    __syncthreads();
+    // the waves before this one
+    double Pb = 1.0;
+    cd Sb = mk(0.0, 0.0);
+    for (int w = 0; w < wave; ++w) { Sb = mk(fma(pw[w], Sb.re, tot[w].re), fma(pw[w], Sb.im, tot[w].im)); Pb *= pw[w]; }
+    S = mk(fma(P, Sb.re, S.re), fma(P, Sb.im, S.im));
+    P *= Pb;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void iq_scan_reduce_kernel(IqArgs a) {
+    __shared__ cd tot[4];
+    __shared__ double pw[4];
+    const size_t base = (size_t) blockIdx.x * IQ_SCAN_SPAN, c0 = base + (size_t) threadIdx.x * IQ_SCAN_PER;
+    const size_t c0c = c0 < a.n_chunks ? c0 : a.n_chunks;
+    double P, Pth;
+    cd S, Sth;
+    iq_block_maps(a, c0c, a.n_chunks, P, S, Pth, Sth, tot, pw);
+    if (threadIdx.x == 255) { a.scan_part[4 * blockIdx.x] = P; a.scan_part[4 * blockIdx.x + 1] = S.re; a.scan_part[4 * blockIdx.x + 2] = S.im; }
+}
+
+// one workgroup: the workgroups' maps chained from the carried state (parts <= SDRT_IQ_SCAN_PARTS, two per thread at most)
+__global__ __launch_bounds__(256) void iq_scan_top_kernel(IqArgs a, int parts) {
+    __shared__ double P_[SDRT_IQ_SCAN_PARTS];
+    __shared__ cd S_[SDRT_IQ_SCAN_PARTS];
+    for (int b = threadIdx.x; b < parts; b += 256) { P_[b] = a.scan_part[4 * b]; S_[b] = mk(a.scan_part[4 * b + 1], a.scan_part[4 * b + 2]); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cd o = mk(a.state[0], a.state[1]);
+        for (int b = 0; b < parts; ++b) {
+            const cd S = S_[b];
+            S_[b] = o;                                     // the workgroup's starting offset takes the place of its sum
+            o = mk(fma(P_[b], o.re, S.re), fma(P_[b], o.im, S.im));
+        }
+        ((cd *) a.chunk_off)[a.n_chunks] = o;
+        a.state[0] = o.re;
+        a.state[1] = o.im;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < parts; b += 256) { a.scan_part[4 * b + 1] = S_[b].re; a.scan_part[4 * b + 2] = S_[b].im; }
+}
+
+__global__ __launch_bounds__(256) void iq_scan_apply_kernel(IqArgs a) {
+    __shared__ cd tot[4];
+    __shared__ double pw[4];
+    const size_t base = (size_t) blockIdx.x * IQ_SCAN_SPAN, c0 = base + (size_t) threadIdx.x * IQ_SCAN_PER;
+    const size_t c0c = c0 < a.n_chunks ? c0 : a.n_chunks;
+    double P, Pth;
+    cd S, Sth;
+    iq_block_maps(a, c0c, a.n_chunks, P, S, Pth, Sth, tot, pw);
+    // exclusive: the threads before this one
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double Pe = __shfl_up(P, 1);
+    cd Se = mk(__shfl_up(S.re, 1), __shfl_up(S.im, 1));
+    if (lane == 0) {
+        Pe = 1.0; Se = mk(0.0, 0.0);
+        for (int w = 0; w < wave; ++w) { Se = mk(fma(pw[w], Se.re, tot[w].re), fma(pw[w], Se.im, tot[w].im)); Pe *= pw[w]; }
+    }
+    const cd b0 = mk(a.scan_part[4 * blockIdx.x + 1], a.scan_part[4 * blockIdx.x + 2]);
+    cd o = mk(fma(Pe, b0.re, Se.re), fma(Pe, b0.im, Se.im));            // offset at the start of this thread's first chunk
+    const cd *agg = (const cd *) a.chunk_agg;
+    cd *offc = (cd *) a.chunk_off;
+#pragma unroll
+    for (int u = 0; u < IQ_SCAN_PER; ++u)
+        if (c0c + u < a.n_chunks && c0 + u < base + IQ_SCAN_SPAN) {
+            const cd v = agg[c0c + u];
+            offc[c0c + u] = o;
+            o = mk(fma(a.pow_n, o.re, v.re), fma(a.pow_n, o.im, v.im));
+        }
+}
+
 hipError_t launch_iq_scan(const IqArgs &a, hipStream_t s) {
+    const size_t parts = (a.n_chunks + IQ_SCAN_SPAN - 1) / IQ_SCAN_SPAN;
+    static const int multi = [] { const char *e = getenv("SDRTERM_IQ_SCAN_MULTI"); return e ? atoi(e) : 1; }();
+    if (multi && a.scan_part && parts >= 4 && parts <= SDRT_IQ_SCAN_PARTS) {
+        hipLaunchKernelGGL(iq_scan_reduce_kernel, dim3((unsigned) parts), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(iq_scan_top_kernel, dim3(1), dim3(256), 0, s, a, (int) parts);
+        hipLaunchKernelGGL(iq_scan_apply_kernel, dim3((unsigned) parts), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(iq_scan_kernel, dim3(1), dim3(IQ_SCAN_THREADS), 0, s, a);
     return hipGetLastError();
 }

@@ -614,6 +614,33 @@ def _oracle_rows_iq(raw, code, n, q, mode, freqs, fs, omega_out, nch):
     return exp
 
 
+@pytest.mark.parametrize('fused', ['1', '0'])
+def test_correct_iq_over_a_batch_of_many_chunks(fused, monkeypatch):
+    """--correct-iq carries one offset through the whole stream (read_file.py:64-77).  Inside a batch the chunks' starting offsets are a
+    scan over the chunk aggregates; from 6145 chunks per call on it runs over several workgroups (kernels.hip: iq_scan_reduce / top /
+    apply; one workgroup took 0.23 ms for the 131072 chunks of a bench step).  6200 + 301 chunks in two calls against oracle/chain.c,
+    the carried offset included; both forms of the correction."""
+    from sdrterm_amd.engine import Engine
+    from oracle import c_chain, ref_chain
+    from tests.golden import prng
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    monkeypatch.setenv('SDRTERM_IQ_FUSED', fused)
+    fs, q, code, n, nch, first = 1024000, 64, 'h', 32768, 6501, 6200
+    one = np.frombuffer(prng.raw_bytes(code, n * 13, seed=19, amp=3000, dc=(700, -450)), dtype=np.uint8)
+    raw = np.tile(one, nch // 13 + 1)[:nch * n * 4].tobytes()
+    eng = Engine(fs, q, 'fm', code, n_samples=n, row_freqs=[15700.0], apply_shift=True, omega_out=5000, correct_iq=True)
+    assert eng.stage_a == 'i8w'
+    a = eng.process(raw[:first * n * 4])
+    b = eng.process(raw[first * n * 4:])
+    got = np.concatenate([a.reshape(1, first, n // q), b.reshape(1, nch - first, n // q)], axis=1).transpose(1, 0, 2)
+    exp, off = c_chain.process_stream(raw, code, n, q, 'fm', c_chain.shift_table([15700.0], fs, n), ref_chain.cheby_sos(q),
+                                      ref_chain.ellip_sos(fs // q, 5000), iq_inductance=50 / fs, threads=4)
+    err = float(np.abs(got - exp).max())
+    print(f'fused={fused}: {nch} chunks in two calls, max abs err {err:.3e}, carried offset {eng.iq_offset} vs {off}')
+    assert err <= 1e-6
+    assert abs(eng.iq_offset - off) <= 1e-9 * abs(off)
+
+
 @pytest.mark.parametrize('code', list('bBhHiIfd'))
 def test_every_instantiation_of_the_per_sample_kernel(code, monkeypatch):
     """chain_seq_kernel (decimation 2 and 4) exists once per encoding x decimation x frequency shift x --correct-iq: 64 instantiations
