@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SDRT_ABI_VERSION 6
+#define SDRT_ABI_VERSION 7
 
 /* Input encodings: src/misc/file_util.py:44-56 (DataType b,B,h,H,i,I,f,d). */
 enum sdrt_dtype {
@@ -45,6 +45,19 @@ enum sdrt_status {
     SDRT_ENOMEM = 3,
     SDRT_ENODEVICE = 4    /* no usable GPU: the library never falls back to the CPU */
 };
+
+/*
+ * Which arithmetic the decimator's block products ("stage A") run in -- the reference has one arithmetic,
+ * float64 (scipy.signal.decimate on complex128, dsp_processor.py:147); this build's default for 8/16-bit integer and float32
+ * records is exact integer slicing on the int8 matrix cores against a 40-bit image of the operator, which meets 1e-6 while the
+ * in-band signal is above about -100 dB of the chunk's peak ("Conditioning").
+ *   SDRT_STAGE_AUTO  the int8 forms where they apply, and every chunk whose decimated samples come out below 2^-33 of its
+ *                    input peak (where the 40-bit image could show) is done again in float64 before the demodulation stage
+ *   SDRT_STAGE_I8    the int8 forms where they apply, no second look
+ *   SDRT_STAGE_F64   float64 throughout (the fp64 matrix cores), whatever the encoding
+ * (Environment SDRTERM_STAGE_A=auto|i8|f64|i8t overrides the field: diagnostics.)
+ */
+enum sdrt_stage_a { SDRT_STAGE_AUTO = 0, SDRT_STAGE_I8 = 1, SDRT_STAGE_F64 = 2 };
 
 typedef struct sdrt_ctx sdrt_ctx;
 
@@ -76,6 +89,22 @@ typedef struct sdrt_config {
                                  (io_args.py:118).  Else [n_rows] of SDRT_FM / SDRT_AM: a build extension for --simo with FM
                                  and AM channels in one pass over the input (BASELINE configs[2]); row r then equals row r of a
                                  context created with mode = row_modes[r] and otherwise the same settings. */
+    /* ---- ABI 7 ---- */
+    int32_t stage_a;          /* enum sdrt_stage_a */
+    int32_t faithful_f32;     /* float32 records only (ignored for the other encodings, which the reference computes in float64
+                                 anyway): reproduce the reference's single-precision chain bit for bit.  `re + 1j*im` is complex64
+                                 there (read_file.py:100-101), the x / y buffers take that dtype (dsp_processor.py:171-177) and
+                                 scipy.signal.decimate runs its zero-phase IIR in complex64 (dsp_processor.py:147): the outputs carry
+                                 ~3e-4 of single-precision noise that only the same operations in the same order reproduce.
+                                 0: float32 records are filtered in float64 / exactly (more accurate than the reference, and several
+                                 times faster); 1: one (chunk, row) sequence per GPU lane runs scipy's recurrence as scipy runs it.
+                                 Needs f32_sos / f32_zi (and shift_table when apply_shift); not with correct_iq (the reference's
+                                 gufunc takes complex128 and leaves a complex64 buffer uncorrected, read_file.py:66-77). */
+    const float *f32_sos;     /* [dec_sections][6]: real parts of np.asarray(cheby1(8, 0.05, 0.8/q, output='sos'), complex64), the
+                                 cast scipy.signal.decimate makes (sos = np.asarray(sos, dtype=result_type)) */
+    const float *f32_zi;      /* [dec_sections][2]: real parts of scipy.signal.sosfilt_zi of that table (sosfiltfilt) */
+    const double *shift_table;/* [n_rows][n_samples][2]: the reference's shift table itself, exp(-2j pi (f/fs) arange(n)) as numpy
+                                 evaluates it (dsp_processor.py:185-187, vfo_processor.py:71-74); NULL when apply_shift == 0 */
 } sdrt_config;
 
 /* Library / device discovery. */
@@ -271,8 +300,8 @@ int sdrt_selftest_mfma_i8(int *mismatches);
 
 /* Which stage-A kernel the context uses: 0 = fp64 matrix cores; 2 = int8 matrix cores with exact integer slicing, one
  * block per column (16x16x64); 3 = the same arithmetic in the wide-column persistent kernel (default for 8/16-bit integer
- * encodings at decimation 32 / 64); 4 = the per-sample modal form in fp64 (decimation 2 and 4).  All meet the same tolerance.  Environment SDRTERM_STAGE_A=f64 or =i8t forces 0 or 2
- * (diagnostics). */
+ * encodings at decimation 32 / 64); 4 = the per-sample modal form in fp64 (decimation 2 and 4); 5 = the reference's complex64
+ * recurrence for float32 records (sdrt_config.faithful_f32).  0 - 4 meet the same tolerance; sdrt_config.stage_a chooses among them. */
 int sdrt_stage_a_kind(const sdrt_ctx *ctx);
 
 #ifdef __cplusplus

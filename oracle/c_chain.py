@@ -33,6 +33,7 @@ def lib():
         _lib.orc_decimate.restype = C.c_int
         _lib.orc_fm.restype = C.c_int
         _lib.orc_max_threads.restype = C.c_int
+        _lib.orc_process_stream_f32c.restype = C.c_int
     return _lib
 
 
@@ -120,3 +121,38 @@ def process_stream(raw: bytes, code: str, n: int, q: int, mode: str, shift, dec_
                     raise ValueError(f'orc_savgol rc={rc}')
                 out[c, r] = row
     return out, complex(offv[0])
+
+
+def faithful_f32_tables(q: int):
+    """The tables scipy.signal.decimate works with when its input is complex64 (dsp_processor.py:147 on float32 records):
+    the sos cast to the data's dtype and sosfilt_zi of THAT table -- the same scipy calls the reference's call makes."""
+    from scipy import signal
+    sos = np.asarray(signal.cheby1(8, 0.05, 0.8 / q, output='sos'), dtype=np.complex64)
+    zi = signal.sosfilt_zi(sos)
+    assert not sos.imag.any() and not zi.imag.any()
+    return np.ascontiguousarray(sos.real, dtype=np.float32), np.ascontiguousarray(zi.real, dtype=np.float32)
+
+
+def process_stream_f32c(raw: bytes, n: int, q: int, mode: str, shift, out_sos, *, big_endian=False, threads=1):
+    """float32 records in the reference's own arithmetic (complex64 through the decimator, chain.c: orc_process_stream_f32c).
+    ``shift`` must be the table numpy builds (ref_chain.shift_table), not c_chain.shift_table's.  Returns
+    (out[chunks, rows, m] float64, ydec[chunks, rows, m] complex64)."""
+    import sys
+    buf = np.frombuffer(raw, dtype=np.uint8)
+    n_chunks = buf.size // (8 * n)
+    rows = 1 if shift is None else shift.shape[0]
+    m = n // q
+    sos32, zi32 = faithful_f32_tables(q)
+    out_sos = np.ascontiguousarray(out_sos, dtype=np.float64)
+    if shift is not None:
+        shift = np.ascontiguousarray(shift, dtype=np.complex128)
+    out = np.empty((n_chunks, rows, m))
+    ydec = np.empty((n_chunks, rows, m), dtype=np.complex64)
+    swap = int(bool(big_endian) != (sys.byteorder == 'big'))
+    rc = lib().orc_process_stream_f32c(
+        _p(buf), C.c_int(swap), C.c_size_t(n), C.c_size_t(n_chunks), C.c_int(q), C.c_int(MODES[mode]),
+        _p(shift) if shift is not None else None, C.c_int(rows), _p(sos32), _p(zi32), C.c_int(4),
+        _p(out_sos), C.c_int(out_sos.shape[0]), _p(out), _p(ydec), C.c_int(threads))
+    if rc:
+        raise ValueError(f'orc_process_stream_f32c rc={rc}')
+    return out, ydec

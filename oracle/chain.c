@@ -381,6 +381,129 @@ int orc_process_stream(const void *raw, int code, int swap, size_t n, size_t n_c
     return rc_all;
 }
 
+/*
+ * ---- float32 records as the reference computes them: complex64 through the decimator ---------------------------------------
+ * read_file.py:100-101 makes `re + 1j*im` complex64 for float32 records; dsp_processor.py:171-177 gives x and y that dtype;
+ * shiftFreq's complex128 product is stored into x as complex64 (demodulation.py:71-79); scipy.signal.decimate keeps the dtype:
+ * sos = np.asarray(sos, dtype=complex64), sosfiltfilt = odd extension by 27, zi = sosfilt_zi(sos) * x[0], _sosfilt forwards,
+ * zi * y[-1], _sosfilt over the reversed sequence, [27:-27][::q] (scipy/signal/_signaltools.py, _sosfilt.pyx: _sosfilt_float
+ * with DTYPE = float complex).  Every operation below is the IEEE single-precision operation scipy's compiled loop performs,
+ * in its order; the coefficients' imaginary parts are zero, so a complex product is the two real products.  Bit-identical to
+ * scipy 1.15.3 on x86-64 (tests/test_oracle_golden.py pins it to the reference's complex64 `y0` vectors with array_equal).
+ * Everything after the decimator is float64 in the reference too (the numba kernels take complex128).
+ */
+typedef struct { float re, im; } c32;
+
+/* complex64(complex128(z) * shift): numpy's complex multiply loop on AVX2 / AVX-512 hosts is re = fma(ar, br, -(ai bi)),
+ * im = fma(ar, bi, ai br) (numpy/_core/src/umath/loops_arithm_fp.dispatch.c.src); the store into x rounds to single */
+static c32 shift_c64(float re, float im, const cplx *sh) {
+    c32 v;
+    if (sh) {
+        const double ar = re, ai = im, br = creal(*sh), bi = cimag(*sh);
+        const double pi = ai * bi, pr = ai * br;
+        v.re = (float) fma(ar, br, -pi);
+        v.im = (float) fma(ar, bi, pr);
+    } else {
+        v.re = re;
+        v.im = im;
+    }
+    return v;
+}
+
+static float load_f32(const unsigned char *p, int swap) {
+    uint32_t u;
+    memcpy(&u, p, 4);
+    if (swap) u = __builtin_bswap32(u);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+/* work: n + 54 elements.  y: n / q elements. */
+int orc_decimate_c64(const float *sos /* [nsec][6] */, const float *zi /* [nsec][2] */, int nsec, const c32 *x, size_t n, int q,
+                     c32 *y, c32 *work) {
+    enum { E = 27 };
+    if (nsec != 4 || n <= E) return -1;
+    const size_t N = n + 2 * E;
+    for (size_t e = 0; e < E; ++e) {
+        work[e].re = 2.0f * x[0].re - x[E - e].re;
+        work[e].im = 2.0f * x[0].im - x[E - e].im;
+        work[E + n + e].re = 2.0f * x[n - 1].re - x[n - 2 - e].re;
+        work[E + n + e].im = 2.0f * x[n - 1].im - x[n - 2 - e].im;
+    }
+    memcpy(work + E, x, n * sizeof(c32));
+    float z[4][2][2];
+    for (int pass = 0; pass < 2; ++pass) {
+        const c32 x0 = pass == 0 ? work[0] : work[N - 1];
+        for (int s = 0; s < nsec; ++s)
+            for (int k = 0; k < 2; ++k) { z[s][k][0] = zi[2 * s + k] * x0.re; z[s][k][1] = zi[2 * s + k] * x0.im; }
+        for (size_t t = 0; t < N; ++t) {
+            const size_t idx = pass == 0 ? t : N - 1 - t;
+            float xr = work[idx].re, xi = work[idx].im;
+            for (int s = 0; s < nsec; ++s) {
+                const float *c = sos + 6 * s;
+                const float nr = c[0] * xr + z[s][0][0], ni = c[0] * xi + z[s][0][1];
+                z[s][0][0] = (c[1] * xr - c[4] * nr) + z[s][1][0];
+                z[s][0][1] = (c[1] * xi - c[4] * ni) + z[s][1][1];
+                z[s][1][0] = c[2] * xr - c[5] * nr;
+                z[s][1][1] = c[2] * xi - c[5] * ni;
+                xr = nr;
+                xi = ni;
+            }
+            work[idx].re = xr;
+            work[idx].im = xi;
+        }
+    }
+    for (size_t k = 0; k < n / (size_t) q; ++k) y[k] = work[E + k * (size_t) q];
+    return 0;
+}
+
+/* float32 records, the whole chain per chunk and row as the reference runs it.  out: [chunk][row][m]; ydec (optional):
+ * [chunk][row][m] complex64, the value of `y` after dsp_processor.py:147. */
+int orc_process_stream_f32c(const void *raw, int swap, size_t n, size_t n_chunks, int q, int mode, const cplx *shift, int rows,
+                            const float *sos32, const float *zi32, int dec_nsec, const double *out_sos, int out_nsec,
+                            double *out, c32 *ydec, int nthreads) {
+    const size_t m = n / (size_t) q;
+    int rc_all = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel
+#endif
+    {
+        c32 *x = (c32 *) malloc((2 * n + 54 + m) * sizeof(c32));
+        cplx *yc = (cplx *) malloc((m + 2) * sizeof(cplx));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (long c = 0; c < (long) n_chunks; ++c) {
+            int rc = (x && yc) ? 0 : -2;
+            const unsigned char *cr = (const unsigned char *) raw + (size_t) c * n * 8;
+            for (int r = 0; r < rows && rc == 0; ++r) {
+                c32 *work = x + n, *y = work + n + 54;
+                for (size_t i = 0; i < n; ++i)
+                    x[i] = shift_c64(load_f32(cr + 8 * i, swap), load_f32(cr + 8 * i + 4, swap), shift ? shift + (size_t) r * n + i : NULL);
+                rc = orc_decimate_c64(sos32, zi32, dec_nsec, x, n, q, y, work);
+                if (rc) break;
+                if (ydec) memcpy(ydec + ((size_t) c * rows + r) * m, y, m * sizeof(c32));
+                for (size_t k = 0; k < m; ++k) yc[k] = (double) y[k].re + (double) y[k].im * I;
+                double *o = out + ((size_t) c * rows + r) * m;
+                if (mode == ORC_FM) rc = orc_fm(yc, m, o); else orc_am(yc, m, o);
+                double st[32] = {0};
+                orc_sosfilt_r(out_sos, out_nsec, o, m, st);
+            }
+            if (rc) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+                rc_all = rc;
+            }
+        }
+        free(x);
+        free(yc);
+    }
+    return rc_all;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

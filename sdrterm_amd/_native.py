@@ -16,9 +16,10 @@ LIB_PATH = os.environ.get('SDRTERM_HIP_LIB') or os.path.join(_HERE, 'libsdrterm_
 DTYPES = {'b': 0, 'B': 1, 'h': 2, 'H': 3, 'i': 4, 'I': 5, 'f': 6, 'd': 7}
 ITEM_SIZE = {'b': 1, 'B': 1, 'h': 2, 'H': 2, 'i': 4, 'I': 4, 'f': 4, 'd': 8}
 MODES = {'fm': 0, 'am': 1, 're': 2, 'im': 3}
+STAGE_A = {'auto': 0, 'i8': 1, 'f64': 2}      # enum sdrt_stage_a
 OK, EINVAL, EHIP, ENOMEM, ENODEVICE = 0, 1, 2, 3, 4
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 EXPORTS = (
     'sdrt_abi_version', 'sdrt_config_size', 'sdrt_device_count', 'sdrt_last_error', 'sdrt_create', 'sdrt_destroy',
     'sdrt_out_per_chunk', 'sdrt_rows', 'sdrt_process_device', 'sdrt_process_host',
@@ -56,6 +57,8 @@ class Config(C.Structure):
         ('norm_inv_range', C.c_double), ('correct_iq', C.c_int32), ('reserved0', C.c_int32),
         ('iq_inductance', C.c_double), ('dec_sos', C.POINTER(C.c_double)), ('dec_sections', C.c_int32),
         ('out_sections', C.c_int32), ('out_sos', C.POINTER(C.c_double)), ('row_modes', C.POINTER(C.c_int32)),
+        ('stage_a', C.c_int32), ('faithful_f32', C.c_int32), ('f32_sos', C.POINTER(C.c_float)),
+        ('f32_zi', C.POINTER(C.c_float)), ('shift_table', C.POINTER(C.c_double)),
     ]
 
 

@@ -102,6 +102,11 @@ struct sdrt_ctx {
     bool use_i8t = false;             //   ... one block per column (16x16x64), no IQ correction
     bool use_i8w = false;             //   ... wide columns, persistent workgroups (default where supported)
     bool use_seq = false;             // decimation < 8: per-sample modal form (chain_seq_kernel)
+    bool f32c = false;                // float32 records in the reference's complex64 arithmetic (sdrt_config.faithful_f32, kernels_f32c.hip)
+    F32cArgs f32c_args;               //   coefficient tables
+    double *d_shift_tab = nullptr;    //   [rows][n][2] the host's shift table
+    float *d_f32c_work = nullptr;     //   the extended sequences of a batch (grow-only)
+    size_t f32c_cap = 0;
     int iq_gs = 0;                    // samples per group of the IQ prefix tables
     WideTables *d_wtab = nullptr;
     double *d_edge_ab = nullptr, *d_edge_pq = nullptr, *d_gvec = nullptr;
@@ -515,7 +520,17 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     // that divides them (dsp_processor.py:147,173) is a power of two
     if (q & (q - 1)) return fail(SDRT_EINVAL, "this build supports decimation factors that are powers of two (got %d)", q);
     if (n <= SDRT_EDGE) return fail(SDRT_EINVAL, "n_samples must exceed the filter pad length %d", SDRT_EDGE);
-    const bool seq = q < 8;                                   // per-sample form; block forms from 8 up
+    // float32 records as the reference computes them (complex64 throughout the decimator): a path of its own
+    const bool f32c = cfg->faithful_f32 != 0 && cfg->dtype == SDRT_F32;
+    if (f32c) {
+        if (cfg->dec_sections != 4 || !cfg->f32_sos || !cfg->f32_zi)
+            return fail(SDRT_EINVAL, "faithful_f32 needs the four-section decimator of scipy.signal.decimate as f32_sos / f32_zi");
+        if (cfg->apply_shift && !cfg->shift_table) return fail(SDRT_EINVAL, "faithful_f32 with apply_shift needs shift_table");
+        if (cfg->correct_iq) return fail(SDRT_EINVAL, "faithful_f32 does not take correct_iq (the reference's complex128 gufunc leaves a complex64 buffer as it was)");
+        if (cfg->stage_a == SDRT_STAGE_F64) return fail(SDRT_EINVAL, "faithful_f32 and stage_a = f64 contradict each other");
+    }
+    if (cfg->stage_a < SDRT_STAGE_AUTO || cfg->stage_a > SDRT_STAGE_F64) return fail(SDRT_EINVAL, "unknown stage_a %d", cfg->stage_a);
+    const bool seq = q < 8 && !f32c;                          // per-sample form; block forms from 8 up
     const int L = q < SDRT_MAXL ? q : SDRT_MAXL;
     if (seq && !chain_seq_supported(q, n))
         return fail(SDRT_EINVAL, "decimation %d needs chunks of a multiple of %d samples (got %d)", q, 256 * (q > 16 ? q : 16), n);
@@ -548,6 +563,9 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     c->cfg.dec_sos = nullptr;
     c->cfg.out_sos = nullptr;
     c->cfg.row_modes = nullptr;
+    c->cfg.f32_sos = nullptr;
+    c->cfg.f32_zi = nullptr;
+    c->cfg.shift_table = nullptr;
     c->cfg.mode = uniform_mode;
     c->mixed = mixed;
     c->L = L;
@@ -567,7 +585,8 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     // the fp64 block kernel keeps a chunk's block states in LDS: too many blocks (8-bit records at decimation 8: 8192 of them) do
     // not fit.  The wide int8 kernel takes such a chunk where it applies (in passes, section 3c of DESIGN.md) -- without the
     // normalisation bias, whose response comes from the fp64 kernel; settled after the stage-A form has been chosen
-    const size_t lds = seq ? 0 : chain_lds_bytes(n, L, m);
+    c->f32c = f32c;
+    const size_t lds = seq || f32c ? 0 : chain_lds_bytes(n, L, m);
     const bool f64_fits = lds <= 160 * 1024;
     if (!f64_fits && !(chain_i8w_supported(q, cfg->dtype, n, cfg->correct_iq != 0) && c->norm_bias == 0.0)) {
         delete c;
@@ -689,7 +708,14 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
             }
         }
     }
-    if (rc == SDRT_OK) {
+    if (rc == SDRT_OK && f32c) {
+        F32cArgs &fa = c->f32c_args;
+        memset(&fa, 0, sizeof(fa));
+        memcpy(fa.sos, cfg->f32_sos, sizeof(fa.sos));
+        memcpy(fa.zi, cfg->f32_zi, sizeof(fa.zi));
+        if (c->nco) rc = upload(&c->d_shift_tab, cfg->shift_table, (size_t) c->rows * n * 2 * sizeof(double));
+    }
+    if (rc == SDRT_OK && !f32c) {
         const char *force = getenv("SDRTERM_STAGE_A");      // diagnostics: "f64" forces the fp64 matrix-core kernel,
         const bool want_i8 = !(force && strcmp(force, "f64") == 0);
         const bool want_t = force && strcmp(force, "i8t") == 0;       // "i8t" the one-block-per-column 16x16x64 kernel
@@ -781,6 +807,8 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_iq_agg);
     (void) hipFree(c->d_iq_chunk);
     (void) hipFree(c->d_iq_range);
+    (void) hipFree(c->d_shift_tab);
+    (void) hipFree(c->d_f32c_work);
     for (auto &sl : c->hs) {
         (void) hipFree(sl.d_raw);
         (void) hipFree(sl.d_out);
@@ -866,6 +894,17 @@ int ensure_iqrange(sdrt_ctx *c, size_t n_chunks) {
     return SDRT_OK;
 }
 
+// float32 in the reference's arithmetic: the odd-extended complex64 sequences of a batch, 64 to a group
+int ensure_f32c(sdrt_ctx *c, size_t n_chunks) {
+    if (!c->f32c || n_chunks <= c->f32c_cap) return SDRT_OK;
+    (void) hipFree(c->d_f32c_work);
+    c->d_f32c_work = nullptr;
+    c->f32c_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_f32c_work, f32c_work_bytes(c->cfg.n_samples, c->rows, n_chunks)));
+    c->f32c_cap = n_chunks;
+    return SDRT_OK;
+}
+
 // float32, several rows: the pre-sliced copy of a batch
 int ensure_prebufs(sdrt_ctx *c, size_t n_chunks) {
     if (!c->f32_pre || n_chunks <= c->pre_cap) return SDRT_OK;
@@ -895,6 +934,24 @@ int ensure_pairbufs(sdrt_ctx *c) {
 // pair_out: the wide-column kernel writes the products y[2i] conj(y[2i+1]) instead of the samples (FM, PostArgs.pairs)
 int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybuf, hipStream_t s, int n_cus, bool fix_later = false, bool pair_out = false,
                   bool row_pairs = false) {
+    if (c->f32c) {
+        int rcf = ensure_f32c(c, n_chunks);
+        if (rcf != SDRT_OK) return rcf;
+        F32cArgs fa = c->f32c_args;
+        fa.raw = raw_dev;
+        fa.shift = c->nco ? c->d_shift_tab : nullptr;
+        fa.work = c->d_f32c_work;
+        fa.ydec = ybuf;
+        fa.n_chunks = n_chunks;
+        fa.n = c->cfg.n_samples;
+        fa.m = c->m;
+        fa.q = c->cfg.decimation;
+        fa.rows = c->rows;
+        fa.swap = c->cfg.swap_endianness;
+        Timed t(c, s, 0);
+        HIP_TRY(launch_f32c(fa, s));
+        return SDRT_OK;
+    }
     DecimArgs da;
     memset(&da, 0, sizeof(da));
     da.raw = raw_dev;
@@ -1253,6 +1310,7 @@ int sdrt_reserve(sdrt_ctx *c, size_t max_chunks) {
     if (rc == SDRT_OK && c->iq) rc = ensure_iqrange(c, max_chunks);
     if (rc == SDRT_OK) rc = ensure_pairbufs(c);
     if (rc == SDRT_OK) rc = ensure_prebufs(c, max_chunks);
+    if (rc == SDRT_OK) rc = ensure_f32c(c, max_chunks);
     if (rc == SDRT_OK) {
         PostArgs pa = post_args(c, nullptr, max_chunks, nullptr, false, true);
         if (c->mixed) {                                       // per-row modes: the FM rows' launch is the one that keeps a stash
@@ -1772,7 +1830,7 @@ int sdrt_debug_stamps(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double 
     return SDRT_OK;
 }
 
-int sdrt_stage_a_kind(const sdrt_ctx *c) { return c ? (c->use_seq ? 4 : c->use_i8w ? 3 : (c->use_i8t ? 2 : (c->use_i8 ? 1 : 0))) : -1; }
+int sdrt_stage_a_kind(const sdrt_ctx *c) { return c ? (c->f32c ? 5 : c->use_seq ? 4 : c->use_i8w ? 3 : (c->use_i8t ? 2 : (c->use_i8 ? 1 : 0))) : -1; }
 
 int sdrt_selftest_mfma_i8(int *mismatches) {
     int bad = 0;

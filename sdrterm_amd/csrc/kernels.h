@@ -168,4 +168,17 @@ bool post_big_supported(int m, int mode);
 hipError_t launch_post_big(const PostArgs &a, hipStream_t s);
 bool post_bigfft_supported(const PostArgs &a);        // FM at 4096 .. 16384 outputs per chunk with the packed FFT tables: a workgroup transform
 hipError_t launch_post_bigfft(const PostArgs &a, hipStream_t s);
+// float32 records in the reference's own complex64 arithmetic (kernels_f32c.hip; sdrt_config.faithful_f32)
+struct F32cArgs {
+    const void *raw;            // [n_chunks][n][2] float32 records
+    const double *shift;        // [rows][n][2] the shift table exactly as the reference builds it with numpy (or NULL: no shift)
+    float *work;                // [groups of 64 items][n + 54][64][2] complex64: odd-extended shifted samples, filtered in place
+    double *ydec;               // [row][chunk][m][2]
+    size_t n_chunks;            // chunks in the batch = row stride of ydec
+    int n, m, q, rows, swap;
+    float sos[4][6];            // the decimator's sections as scipy casts them to the data's dtype (real parts; the imaginary are 0)
+    float zi[4][2];             // scipy.signal.sosfilt_zi of that table
+};
+size_t f32c_work_bytes(int n, int rows, size_t n_chunks);
+hipError_t launch_f32c(const F32cArgs &a, hipStream_t s);
 hipError_t launch_swap_selftest(const double *x, const double *y, double *out, hipStream_t s);

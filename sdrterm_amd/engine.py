@@ -38,6 +38,25 @@ def output_sos(fs_dec: int, omega_out, degree: int = 3) -> np.ndarray:
         ellip(degree, 1, 30, omega_out, btype='lowpass', analog=False, output='sos', fs=fs_dec), dtype=np.float64)
 
 
+def faithful_f32_tables(q: int):
+    """What scipy.signal.decimate builds for complex64 input (the reference's float32 records, dsp_processor.py:147,171-177):
+    ``sos = np.asarray(cheby1(8, 0.05, 0.8/q, output='sos'), dtype=x.dtype)`` and, inside sosfiltfilt, ``sosfilt_zi(sos)`` --
+    the same scipy calls on the same dtype, so the kernel starts from the reference's own single-precision tables."""
+    from scipy.signal import sosfilt_zi
+    sos = np.asarray(cheby1(8, 0.05, 0.8 / q, output='sos'), dtype=np.complex64)
+    zi = sosfilt_zi(sos)
+    if sos.imag.any() or zi.imag.any():
+        raise ValueError('decimator tables with non-zero imaginary parts are not supported')
+    return np.ascontiguousarray(sos.real, dtype=np.float32), np.ascontiguousarray(zi.real, dtype=np.float32)
+
+
+def reference_shift_table(freqs, fs, n: int) -> np.ndarray:
+    """The reference's shift table, evaluated as the reference evaluates it: ``exp(-2j*pi*(f/fs) * arange(n))`` per row
+    (dsp_processor.py:185-187, vfo_processor.py:48,71-74).  Only the faithful float32 mode reads it: there the rounding of every
+    shifted sample to complex64 must agree with the reference's, so the table has to be numpy's, not a better one."""
+    return np.ascontiguousarray(np.stack([np.exp((-2j * np.pi * (f / fs)) * np.arange(n)) for f in freqs]), dtype=np.complex128)
+
+
 def savgol_operator(window: int, polyorder: int = 3):
     """The linear operator of ``scipy.signal.savgol_filter(z, window, polyorder)`` (mode='interp'), which is what
     --smooth-output applies (src/dsp/dsp_processor.py:159-160), read off scipy's own result on unit impulses:
@@ -71,8 +90,10 @@ class Engine:
 
     def __init__(self, fs, decimation, mode, code='h', n_samples=None, row_freqs=None, apply_shift=None,
                  out_sos=None, omega_out=12500, normalize=False, correct_iq=False, impedance=50,
-                 big_endian=False, device=0, smooth=0, row_modes=None, reserve_chunks=0):
-        """``row_modes``: None (every row demodulates as ``mode``, as the reference does, io_args.py:118) or one of 'fm' / 'am' per
+                 big_endian=False, device=0, smooth=0, row_modes=None, reserve_chunks=0, stage_a='auto', faithful_f32=False):
+        """``stage_a``: 'auto' / 'i8' / 'f64' (include/sdrterm_hip.h: enum sdrt_stage_a).  ``faithful_f32``: float32 records in
+        the reference's own complex64 arithmetic (sdrt_config.faithful_f32); no effect on the other encodings.
+        ``row_modes``: None (every row demodulates as ``mode``, as the reference does, io_args.py:118) or one of 'fm' / 'am' per
         row -- FM and AM channels of a --simo run in one pass over the input (BASELINE configs[2])."""
         if mode not in nat.MODES:
             raise ValueError(f'unsupported demodulation mode {mode!r}')
@@ -125,10 +146,22 @@ class Engine:
             self.row_modes = list(row_modes)
             self._row_modes = np.ascontiguousarray([nat.MODES[md] for md in row_modes], dtype=np.int32)
             cfg.row_modes = self._row_modes.ctypes.data_as(C.POINTER(C.c_int32))
+        if stage_a not in nat.STAGE_A:
+            raise ValueError(f"stage_a: one of {sorted(nat.STAGE_A)} (got {stage_a!r})")
+        cfg.stage_a = nat.STAGE_A[stage_a]
+        self.faithful_f32 = bool(faithful_f32) and code == 'f'
+        if self.faithful_f32:
+            self._f32_sos, self._f32_zi = faithful_f32_tables(self.q)
+            cfg.faithful_f32 = 1
+            cfg.f32_sos = self._f32_sos.ctypes.data_as(C.POINTER(C.c_float))
+            cfg.f32_zi = self._f32_zi.ctypes.data_as(C.POINTER(C.c_float))
+            if apply_shift:
+                self._shift_table = reference_shift_table(freqs, fs, self.n)
+                cfg.shift_table = self._shift_table.ctypes.data_as(C.POINTER(C.c_double))
         self._ctx = C.c_void_p()
         nat.check(nat.lib().sdrt_create(C.byref(cfg), C.byref(self._ctx)))
         self.m = nat.lib().sdrt_out_per_chunk(self._ctx)
-        self.stage_a = {0: 'f64', 2: 'i8t', 3: 'i8w', 4: 'seq'}[nat.lib().sdrt_stage_a_kind(self._ctx)]   # which stage-A kernel runs
+        self.stage_a = {0: 'f64', 2: 'i8t', 3: 'i8w', 4: 'seq', 5: 'f32c'}[nat.lib().sdrt_stage_a_kind(self._ctx)]   # which stage-A kernel runs
         self.chunk_bytes = self.n * 2 * nat.ITEM_SIZE[code]
         if reserve_chunks:
             # device scratch for batches up to this size now, none inside the processing calls (include/sdrterm_hip.h: sdrt_reserve)

@@ -123,3 +123,41 @@ def test_plot_tap_restatements_match_the_reference_plots(code, normalize, golden
     assert tuple(z[f'tap/{code}/image_shape']) == full.shape == (1024, n // 128 + 1)
     ei, mi = 10.0 ** (img.astype(np.float64) / 10), 10.0 ** (full[:, cols] / 10)
     assert np.abs(mi - ei).max() <= tol * ei.max()
+
+
+F32_CASES = [c for c in CASES if c['code'] == 'f']
+
+
+@pytest.mark.parametrize('case', F32_CASES, ids=[c['name'] for c in F32_CASES])
+def test_c_oracle_in_the_references_float32_arithmetic(case, golden):
+    """float32 records: the reference runs its decimator in complex64 (read_file.py:100-101, dsp_processor.py:147,171-177).
+    chain.c: orc_process_stream_f32c performs scipy's single-precision operations in scipy's order: its decimated samples are
+    the reference's complex64 `y0` BIT FOR BIT, its outputs the reference's at the north-star tolerance (no float32 allowance)."""
+    z, _ = golden
+    name = case['name']
+    raw = case_raw(case)
+    n = samples_per_chunk('f')
+    rows = ref_chain.vfo_rows(case['center'], case.get('vfos'))
+    shift = ref_chain.shift_table(rows, case['fs'], n) if (case.get('vfos') or case['center']) else None
+    out, ydec = c_chain.process_stream_f32c(raw, n, case['q'], case['mode'], shift, z[f'{name}/ellip_sos'], threads=2)
+    y0 = np.ascontiguousarray(z[f'{name}/y0'])
+    assert y0.dtype == np.complex64
+    np.testing.assert_array_equal(np.ascontiguousarray(ydec[0]).view(np.uint32), y0.view(np.uint32))
+    exp = z[f'{name}/z']
+    assert out.shape == exp.shape
+    err = np.abs(out - exp).max()
+    assert err <= tol_for(exp, case['mode']), err
+    if shift is not None:           # the table itself: numpy's, as the reference builds it
+        np.testing.assert_array_equal(shift[:, ::1021], z[f'{name}/shift_sub'])
+
+
+def test_numpy_oracle_float32_is_bit_exact_too(golden):
+    """ref_chain.process_chunk(faithful_dtype=True) calls scipy as the reference does: same bits as the reference's y0."""
+    z, _ = golden
+    for case in F32_CASES:
+        raw = case_raw(case)
+        n = samples_per_chunk('f')
+        ch = _chain(case)
+        _, y = ref_chain.process_chunk(ch.read(raw[:n * 8]), case['q'], case['mode'], ch.shift, ch.out_sos, True)
+        y0 = np.ascontiguousarray(z[f"{case['name']}/y0"])
+        np.testing.assert_array_equal(np.ascontiguousarray(y.astype(np.complex64)).view(np.uint32), y0.view(np.uint32))
