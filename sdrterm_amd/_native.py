@@ -66,11 +66,12 @@ _lib = None
 
 
 def _share_hip_runtime_with_torch() -> None:
-    """One HIP runtime per process.  A PyTorch-ROCm wheel bundles its own libamdhip64 and insists on it when it is imported;
-    if this library had pulled in the system one first, torch would then find "no ROCm-capable device".  So when torch
-    is installed (not necessarily imported), its runtime is loaded first and this library binds to it through the common
-    SONAME; without torch the system runtime is used.  (Plumbing only: nothing of torch runs.)"""
-    if 'torch' in sys.modules or os.environ.get('SDRTERM_SYSTEM_HIP'):
+    """One HIP runtime per process.  By default this library binds to the SYSTEM runtime (libamdhip64 as the dynamic linker
+    finds it): the product does not depend on any other package's copy.  A PyTorch-ROCm wheel bundles its own libamdhip64 and
+    insists on it; a process that wants BOTH this library and torch on the GPU must let torch's runtime come first, so that
+    both bind to one copy -- that is either ``import torch`` before this module is used (then the runtime is already loaded
+    and this function does nothing), or SDRTERM_TORCH_HIP=1, which pre-loads torch's bundled runtime without importing torch."""
+    if 'torch' in sys.modules or os.environ.get('SDRTERM_TORCH_HIP') != '1':
         return
     try:
         import importlib.util

@@ -39,6 +39,33 @@ int fail(int code, const char *fmt, ...) {
 
 }  // namespace
 
+// Diagnostic switches (kernel-variant A/B measurements, the tests that force a form): ONE environment variable,
+// SDRTERM_DIAG="key=value,key=value", read where a context is created / a kernel is chosen.  Configuration proper goes through
+// sdrt_config (stage_a, faithful_f32, ...); nothing a caller needs is only reachable from here.
+const char *sdrt_diag(const char *key) {
+    static thread_local char val[64];
+    const char *e = getenv("SDRTERM_DIAG");
+    if (!e || !key) return nullptr;
+    const size_t kl = strlen(key);
+    for (const char *p = e; *p;) {
+        const char *end = strchr(p, ',');
+        const size_t len = end ? (size_t) (end - p) : strlen(p);
+        if (len > kl && strncmp(p, key, kl) == 0 && p[kl] == '=') {
+            const size_t vl = len - kl - 1 < sizeof(val) - 1 ? len - kl - 1 : sizeof(val) - 1;
+            memcpy(val, p + kl + 1, vl);
+            val[vl] = 0;
+            return val;
+        }
+        if (!end) break;
+        p = end + 1;
+    }
+    return nullptr;
+}
+int sdrt_diag_int(const char *key, int dflt) {
+    const char *v = sdrt_diag(key);
+    return v ? atoi(v) : dflt;
+}
+
 // used by the other translation units of the library (comm.hip)
 int sdrt_set_error(int code, const char *fmt, ...) {
     va_list ap;
@@ -102,6 +129,7 @@ struct sdrt_ctx {
     bool use_i8t = false;             //   ... one block per column (16x16x64), no IQ correction
     bool use_i8w = false;             //   ... wide columns, persistent workgroups (default where supported)
     bool use_seq = false;             // decimation < 8: per-sample modal form (chain_seq_kernel)
+    int stage = SDRT_STAGE_AUTO;      // enum sdrt_stage_a in effect (sdrt_config.stage_a unless SDRTERM_STAGE_A overrides it)
     bool f32c = false;                // float32 records in the reference's complex64 arithmetic (sdrt_config.faithful_f32, kernels_f32c.hip)
     F32cArgs f32c_args;               //   coefficient tables
     double *d_shift_tab = nullptr;    //   [rows][n][2] the host's shift table
@@ -123,8 +151,8 @@ struct sdrt_ctx {
     int *d_rows_of[2] = {nullptr, nullptr};      // [SDRT_FM], [SDRT_AM]
     int *d_row_pair = nullptr;                   // per-row modes: [rows] 1 = FM row (its items can leave the chain kernel as pair products)
     int n_rows_of[2] = {0, 0};
-    int sched = 0;                    // diagnostic builds only (SDRTERM_SCHED, kernels_i8w.hip: SDRT_SCHED_EXP)
-    int dual = 0;                     // wide kernel: one wave per SIMD on two tiles at once (SDRTERM_WIDE_DUAL)
+    int sched = 0;                    // diagnostic builds only (SDRTERM_DIAG=sched, kernels_i8w.hip: SDRT_SCHED_EXP)
+    int dual = 0;                     // wide kernel: one wave per SIMD on two tiles at once (SDRTERM_DIAG=wide_dual)
     signed char *d_w8 = nullptr, *d_w8mid = nullptr;
     DecimTables *d_tab8 = nullptr;    // tables for columns of SDRT_I8T_G blocks
     double *d_nco_tile8 = nullptr, *d_nco_phase8 = nullptr;
@@ -244,7 +272,7 @@ int setup_wide(sdrt_ctx *c, const sdrt_config *cfg, ScaleFn &) {
     WideTables wtab;
     if (sdrt_build_wide_tables_pass(cfg->dec_sos, cfg->dec_sections, q, c->norm_scale, nout_pass, 0, &wtab, &msg) != 0)
         return fail(SDRT_EINVAL, "wide-column tables: %s", msg ? msg : "failed");
-    const char *rsenv = getenv("SDRTERM_WIDE_RS");               // diagnostics: "0" keeps the general form
+    const char *rsenv = sdrt_diag("wide_rs");               // diagnostics: "0" keeps the general form
     c->wide_rs = passes == 1 && !c->nco && !c->iq && chain_i8w_rs_supported(cfg->dtype, n) && !(rsenv && strcmp(rsenv, "0") == 0);
     const size_t per_row = c->wide_rs ? (size_t) S * (LC / 64) * 64 * 16 : (size_t) 2 * S * KS * 64 * 16;
     const size_t per_row_loc = c->wide_rs ? (size_t) S * (LC / 64) * 4 * (NR / 2) * 16 : (size_t) S * KS * 4 * NR * 16;
@@ -677,15 +705,15 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         sdrt_build_resample_odd(m / 2, h.data());
         rc = upload(&c->d_resample, h.data(), h.size() * sizeof(double));
         const int N = m / 2;
-        const char *pf = getenv("SDRTERM_RESAMPLE");             // diagnostics: "direct" forces the circulant product
-        if (rc == SDRT_OK && (N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096 || N == 8192) && !(pf && strcmp(pf, "direct") == 0)) {
+        const bool resample_direct = [] { const char *v = sdrt_diag("resample"); return v && strcmp(v, "direct") == 0; }();     // diagnostics: the circulant product
+        if (rc == SDRT_OK && (N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096 || N == 8192) && !resample_direct) {
             std::vector<double> tw((size_t) N * 2), sh((size_t) N * 2);
             sdrt_build_fft_resample(N, tw.data(), sh.data());
             rc = upload(&c->d_fft_tw, tw.data(), tw.size() * sizeof(double));
             if (rc == SDRT_OK) rc = upload(&c->d_fft_shift, sh.data(), sh.size() * sizeof(double));
             c->fft_ok = rc == SDRT_OK;
-            const char *pp = getenv("SDRTERM_POST_PACKED");      // diagnostics: "0" keeps the full-size complex transforms
-            if (rc == SDRT_OK && (N == 1024 || N == 2048 || N == 4096 || N == 8192) && !(pp && strcmp(pp, "0") == 0)) {
+            // (diagnostics: post_packed=0 keeps the full-size complex transforms)
+            if (rc == SDRT_OK && (N == 1024 || N == 2048 || N == 4096 || N == 8192) && sdrt_diag_int("post_packed", 1) != 0) {
                 // 2048 / 4096 outputs per chunk (decimation 16 / 8 of 16-bit records): the real angles packed two to a complex number
                 std::vector<double> twp((size_t) N), ab((size_t) N * 2);
                 sdrt_build_fft_resample_packed(N, twp.data(), ab.data());
@@ -694,10 +722,10 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
             }
         }
         // FM with 512 outputs per chunk (decimation 64 of 16-bit records, 32 of float32 records) and the usual output lowpass
-        // (one complex pole pair + one real pole): eight lanes per item (diagnostics: SDRTERM_POST=wave keeps one wave per item)
-        const char *pk = getenv("SDRTERM_POST");
-        const bool fft_wanted = !(pf && strcmp(pf, "direct") == 0);      // (256 outputs per chunk: this kernel only, the one-wave FFT form starts at 512)
-        if (rc == SDRT_OK && fft_wanted && (m == 256 || m == 512 || m == 1024) && !(pk && strcmp(pk, "wave") == 0)) {
+        // (one complex pole pair + one real pole): eight lanes per item (diagnostics: SDRTERM_DIAG=post=wave keeps one wave per item)
+        const bool post_wave = [] { const char *v = sdrt_diag("post"); return v && strcmp(v, "wave") == 0; }();
+        const bool fft_wanted = !resample_direct;      // (256 outputs per chunk: this kernel only, the one-wave FFT form starts at 512)
+        if (rc == SDRT_OK && fft_wanted && (m == 256 || m == 512 || m == 1024) && !post_wave) {
             const int lpi = m / 64;                            // 4, 8 or 16 lanes per item
             Post8Tables p8;
             std::vector<double> ft((size_t) (4 * SDRT_P8_PPL * lpi + 8 * lpi) * 2);
@@ -716,21 +744,28 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         if (c->nco) rc = upload(&c->d_shift_tab, cfg->shift_table, (size_t) c->rows * n * 2 * sizeof(double));
     }
     if (rc == SDRT_OK && !f32c) {
-        const char *force = getenv("SDRTERM_STAGE_A");      // diagnostics: "f64" forces the fp64 matrix-core kernel,
-        const bool want_i8 = !(force && strcmp(force, "f64") == 0);
-        const bool want_t = force && strcmp(force, "i8t") == 0;       // "i8t" the one-block-per-column 16x16x64 kernel
+        // sdrt_config.stage_a; the environment variable overrides it (diagnostics: auto / i8 / f64, and i8t = the
+        // one-block-per-column 16x16x64 kernel where it applies)
+        int stage = cfg->stage_a;
+        const char *force = getenv("SDRTERM_STAGE_A");
+        if (force && strcmp(force, "f64") == 0) stage = SDRT_STAGE_F64;
+        else if (force && (strcmp(force, "i8") == 0 || strcmp(force, "i8t") == 0)) stage = SDRT_STAGE_I8;
+        else if (force && strcmp(force, "auto") == 0) stage = SDRT_STAGE_AUTO;
+        c->stage = stage;
+        const bool want_i8 = stage != SDRT_STAGE_F64;
+        const bool want_t = force && strcmp(force, "i8t") == 0;
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->n_cus = cus;
-        if (const char *e = getenv("SDRTERM_SCHED")) c->sched = atoi(e);
-        if (const char *e = getenv("SDRTERM_WIDE_DUAL")) c->dual = atoi(e);
-        if (const char *e = getenv("SDRTERM_WIDE_CUS")) { const int v = atoi(e); if (v >= 8 && v <= c->n_cus) c->n_cus = v / 8 * 8; }   // diagnostics: fewer persistent workgroups
+        if (const char *e = sdrt_diag("sched")) c->sched = atoi(e);
+        if (const char *e = sdrt_diag("wide_dual")) c->dual = atoi(e);
+        if (const char *e = sdrt_diag("wide_cus")) { const int v = atoi(e); if (v >= 8 && v <= c->n_cus) c->n_cus = v / 8 * 8; }   // diagnostics: fewer persistent workgroups
         // int8 matrix-core forms in order of preference; a form that cannot represent this configuration (unequal
         // power-of-two scales between rows, a digit overflow) releases what it uploaded and the next one is tried; the
         // fp64 matrix-core kernel takes whatever is left
         // one row: the offsets come out of the wide kernel's own matrix rows (no second pass over the input); several rows share
-        // one prefix pass instead of each recomputing them (diagnostics: SDRTERM_IQ_FUSED=0 / 1 forces either)
+        // one prefix pass instead of each recomputing them (diagnostics: SDRTERM_DIAG=iq_fused=0 / 1 forces either)
         c->iq_fused = c->iq && c->rows == 1;
-        if (const char *e = getenv("SDRTERM_IQ_FUSED")) c->iq_fused = c->iq && atoi(e) != 0;
+        if (const char *e = sdrt_diag("iq_fused")) c->iq_fused = c->iq && atoi(e) != 0;
         if (seq && !(want_i8 && !c->iq && c->norm_bias == 0.0 && chain_i8w_supported(q, cfg->dtype, n, c->iq))) {
             // nothing to set up: the per-sample form reads DecimTables only
         } else if (want_i8 && !want_t && chain_i8w_supported(q, cfg->dtype, n, c->iq) && chain_i8w_lds_bytes(q, n, c->iq ? (c->iq_fused ? 2 : 1) : 0, cfg->dtype) <= 160 * 1024)
@@ -738,11 +773,11 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         if (rc == SDRT_OK && !seq && !c->use_i8w && want_i8 && !c->iq && want_i8_fallback_t(L, cfg->dtype, n, m))
             rc = setup_i8t(c, cfg, scale_tables);
         c->use_i8 = c->use_i8w || c->use_i8t;
-        if (seq && c->use_i8w) c->use_seq = false;               // decimation 4 (and, SDRTERM_WIDE_SMALLQ=1, 2) as 8 (16) passes of the wide kernel
+        if (seq && c->use_i8w) c->use_seq = false;               // decimation 4 (and, SDRTERM_DIAG=wide_smallq=1, 2) as 8 (16) passes of the wide kernel
         // float32 on the wide kernel with several rows: every row of a chunk would slice the same records again (the larger part
-        // of that form's vector work); from four rows up one pass slices them once (diagnostics: SDRTERM_F32_PRE=0 / 1)
+        // of that form's vector work); from four rows up one pass slices them once (diagnostics: SDRTERM_DIAG=f32_pre=0 / 1)
         c->f32_pre = c->use_i8w && cfg->dtype == SDRT_F32 && c->rows >= 4;
-        if (const char *e = getenv("SDRTERM_F32_PRE")) c->f32_pre = c->use_i8w && cfg->dtype == SDRT_F32 && atoi(e) != 0;
+        if (const char *e = sdrt_diag("f32_pre")) c->f32_pre = c->use_i8w && cfg->dtype == SDRT_F32 && atoi(e) != 0;
     }
     if (rc == SDRT_OK && !f64_fits && !c->use_i8w)
         rc = fail(SDRT_EINVAL, "chunk needs %zu bytes of LDS (> 160 KiB) on the fp64 kernel and the int8 form does not apply: n_samples/decimation combination unsupported", lds);
@@ -1002,7 +1037,7 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
         ia.pow_tab = c->d_iq_pow;
         ia.pow_g = c->iq_pow_e;
         ia.pow_n = c->iq_pow_n;
-        const char *colenv = getenv("SDRTERM_IQ_COLS");            // diagnostics: "0" keeps the per-group prefix kernel
+        const char *colenv = sdrt_diag("iq_cols");            // diagnostics: "0" keeps the per-group prefix kernel
         ia.col_w = c->use_i8w && !(colenv && strcmp(colenv, "0") == 0) ? c->d_iq_colw : nullptr;
         if (!(c->use_i8w && c->iq_fused)) {
             // prefix pass over the input, then the chunks chained: the kernels below take offsets from these tables
@@ -1121,7 +1156,10 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
 // chunk do not depend on the batch around it (tests: the batch-size and determinism cases, zero chunks scattered over a batch).
 int calibrate_zero_response(sdrt_ctx *c) {
     // (--correct-iq: the offset term carries the constant and those forms take no ybias)
-    if (!c->use_i8 || c->iq || c->x_offset == 0.0 || !c->d_ybias) return SDRT_OK;
+    // Signed 8-bit records have no slice offset, but with --normalize-input their ybias holds the bias response in the whole
+    // chunk's layout: several passes still need their own slices of it (b, normalised, decimation 8 / 16 read pass 0's
+    // slice with the wrong stride and zeros in the further passes)
+    if (!c->use_i8 || c->iq || !c->d_ybias || (c->x_offset == 0.0 && c->more_passes.empty())) return SDRT_OK;
     const size_t cb = (size_t) c->cfg.n_samples * 2 * kItemSize[c->cfg.dtype];
     const size_t cnt = (size_t) c->rows * c->m * 2;
     void *d_zero = nullptr;
@@ -1196,7 +1234,7 @@ PostArgs post_args(sdrt_ctx *c, const double *ybuf, size_t n_chunks, double *out
 
 // the angle stash of the eight / sixteen-lanes-per-item demodulation stage for a batch of this size
 int ensure_stash(sdrt_ctx *c, PostArgs &pa) {
-    const char *e = getenv("SDRTERM_POST_STASH");              // diagnostics: "out" keeps the angles in the output buffer
+    const char *e = sdrt_diag("post_stash");              // diagnostics: "out" keeps the angles in the output buffer
     if (e && strcmp(e, "out") == 0) return SDRT_OK;
     const size_t need = post_fft8_stash_bytes(pa);
     if (need > c->stash_cap) {
@@ -1284,8 +1322,8 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     }
     // FM on the wide-column kernel, likewise without a debug buffer: the pair products instead of the samples (half the bytes
     // between the two stages); not with the offset share still to come
-    // (several passes over the chunk: a pass finishes eight consecutive outputs of every column, whole pairs -- SDRTERM_PASS_PAIRS=0: samples)
-    static const bool pass_pairs = [] { const char *e = getenv("SDRTERM_PASS_PAIRS"); return !e || atoi(e) != 0; }();
+    // (several passes over the chunk: a pass finishes eight consecutive outputs of every column, whole pairs -- SDRTERM_DIAG=pass_pairs=0: samples)
+    const bool pass_pairs = sdrt_diag_int("pass_pairs", 1) != 0;
     const bool pairs = !ydec_dev && c->use_i8w && (c->more_passes.empty() || pass_pairs) && !c->stamps_dev && !later && !c->mixed && post_takes_pairs(post_args(c, ybuf, n_chunks, out_dev, false, true));
     // per-row modes: the FM rows' items as pair products, every item in the place its samples would take (eight- and sixteen-tile
     // chunks; the two-chunks-per-item forms keep samples)

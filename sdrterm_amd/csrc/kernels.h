@@ -8,6 +8,10 @@
 
 #define SDRT_MAX_OUT_SECTIONS 4
 
+// diagnostic switches: the value of `key` in SDRTERM_DIAG="key=value,key=value" or nullptr (api.hip); valid until the next call
+const char *sdrt_diag(const char *key);
+int sdrt_diag_int(const char *key, int dflt);
+
 struct DecimArgs {
     const void *raw;            // [n_chunks][n][2] records of the input encoding
     const DecimTables *tab;     // device copy
@@ -52,7 +56,7 @@ struct DecimArgs {
     double *iq_chunk_agg;       //   IQ out: [chunk][2] offset at the chunk's end when it starts from zero
     const void *raw_orig;       //   float32, pre-sliced input (f32_exp != NULL): the records themselves, for the edge operators
     const int *f32_exp;         //   float32, pre-sliced input: [chunk][4] tile exponents; raw then holds the slices (launch_f32_preslice)
-    int sched;                  //   diagnostic builds only (-DSDRT_SCHED_EXP): wave priority assignment, SDRTERM_SCHED
+    int sched;                  //   diagnostic builds only (-DSDRT_SCHED_EXP): wave priority assignment, SDRTERM_DIAG=sched
     int dual;                   //   chain_i8w_kernel: one wave per SIMD on two tiles at once (DUAL form)
     int out_mul, out_off;       //   eight outputs per column: output b of column c goes to index c * out_mul + out_off + b (one pass: 8, 0)
     int m_local;                //   ... and the pass's ybias holds m_local entries per row (one pass: m)

@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void iq_scan_apply_kernel(IqArgs a) {
 
 hipError_t launch_iq_scan(const IqArgs &a, hipStream_t s) {
     const size_t parts = (a.n_chunks + IQ_SCAN_SPAN - 1) / IQ_SCAN_SPAN;
-    static const int multi = [] { const char *e = getenv("SDRTERM_IQ_SCAN_MULTI"); return e ? atoi(e) : 1; }();
+    const int multi = sdrt_diag_int("iq_scan_multi", 1);
     if (multi && a.scan_part && parts >= 4 && parts <= SDRT_IQ_SCAN_PARTS) {
         hipLaunchKernelGGL(iq_scan_reduce_kernel, dim3((unsigned) parts), dim3(256), 0, s, a);
         hipLaunchKernelGGL(iq_scan_top_kernel, dim3(1), dim3(256), 0, s, a, (int) parts);

@@ -1541,8 +1541,8 @@ bool chain_i8w_supported(int q, int dt, int n, bool iq) {
     // decimation 8 and 16 (round 4): 32 / 16 outputs per column, eight per pass -- 4 / 2 passes over the chunk (api.hip: WidePass);
     // plain integer forms (no IQ correction, no normalisation bias at decimation 4) at 8 or 16 tiles per chunk
     // ... and decimation 4 as 8 passes (measured against the per-sample kernel: chain 1.245 -> 0.765 ms per 2^26 samples); decimation 2
-    // would be 16 passes and ties with it (0.78 / 0.80 ms per 2^25): it stays there unless SDRTERM_WIDE_SMALLQ=1 (diagnostics)
-    const char *sq = getenv("SDRTERM_WIDE_SMALLQ");
+    // would be 16 passes and ties with it (0.78 / 0.80 ms per 2^25): it stays there unless SDRTERM_DIAG=wide_smallq=1 (diagnostics)
+    const char *sq = sdrt_diag("wide_smallq");
     if (q == 4 && sq && atoi(sq) == 0) return false;
     if (q == 4 || q == 8 || q == 16 || (q == 2 && sq && atoi(sq) != 0)) return !iq && (nt == 8 || nt == 16) && (dt == SDRT_S8 || dt == SDRT_U8 || dt == SDRT_S16 || dt == SDRT_U16);
     if (!(q == 32 || q == 64)) return false;

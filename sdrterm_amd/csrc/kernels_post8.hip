@@ -528,9 +528,9 @@ size_t post_fft8_stash_bytes(const PostArgs &a) {
 bool post_fft8_supported(const PostArgs &a) {
     // with the IQ offset share still to subtract every angle takes four samples and four table entries: at 512 outputs per chunk the
     // one-wave-per-item kernel holds those loads better (0.54 against 0.63 ms per 2^32 samples), at 1024 this one does (0.085
-    // against 0.099 ms per 2^29 8-bit samples; profiles/r03_experiments.txt).  SDRTERM_POST8_IQ=0 / 2: never / at both sizes
+    // against 0.099 ms per 2^29 8-bit samples; profiles/r03_experiments.txt).  SDRTERM_DIAG=post8_iq=0 / 2: never / at both sizes
     if (a.iq_R) {
-        static const int with_share = [] { const char *e = getenv("SDRTERM_POST8_IQ"); return e ? atoi(e) : 1; }();
+        const int with_share = sdrt_diag_int("post8_iq", 1);
         if (!(with_share == 2 || (with_share == 1 && a.m == 1024))) return false;
     }
     return a.mode == SDRT_FM && a.fft8_tab && a.p8tab && ((a.m == 256 && a.p8_lpi == 4) || (a.m == 512 && a.p8_lpi == 8) || (a.m == 1024 && a.p8_lpi == 16));

@@ -826,9 +826,9 @@ bool post_bigfft_supported(const PostArgs &a) {
     // 0.251 ms per 2^29 8-bit samples at decimation 32 there, profiles/r03_experiments.txt)
     if (!(a.mode == SDRT_FM && a.fft_tw && a.fft_shift && !a.iq_R)) return false;
     // round 4: with the samples in LDS for the lowpass the packed workgroup form also takes 4096 outputs per chunk (decimation 8 of
-    // 16-bit records: 0.55 -> 0.345 ms per 2^28 samples against the one-wave kernel; SDRTERM_POST_WG4096=0 keeps that one)
+    // 16-bit records: 0.55 -> 0.345 ms per 2^28 samples against the one-wave kernel; SDRTERM_DIAG=post_wg4096=0 keeps that one)
     if (a.m == 4096 && a.fftp_tw && a.fftp_ab && a.fft_ok) {
-        static const int on = [] { const char *e = getenv("SDRTERM_POST_WG4096"); return e ? atoi(e) : 1; }();
+        const int on = sdrt_diag_int("post_wg4096", 1);
         return on != 0;
     }
     return (!a.pairs || (a.fftp_tw && a.fftp_ab)) && (a.m == 8192 || a.m == 16384);      // (pair products: the packed form only)
@@ -873,7 +873,7 @@ hipError_t launch_post_bigfft(const PostArgs &a, hipStream_t s) {
             case 4096: return a.pairs ? launch_post_bigfftp_b<1, true>(a, s) : launch_post_bigfftp_b<1, false>(a, s);
             case 8192: return a.pairs ? launch_post_bigfftp_b<2, true>(a, s) : launch_post_bigfftp_b<2, false>(a, s);
             case 16384: {
-                static const int thr = [] { const char *e = getenv("SDRTERM_POST_THR"); return e ? atoi(e) : 512; }();
+                const int thr = sdrt_diag_int("post_thr", 512);
                 if (thr == 256) return a.pairs ? launch_post_bigfftp_b<4, true>(a, s) : launch_post_bigfftp_b<4, false>(a, s);
                 return a.pairs ? launch_post_bigfftp_b<4, true, 512>(a, s) : launch_post_bigfftp_b<4, false, 512>(a, s);
             }

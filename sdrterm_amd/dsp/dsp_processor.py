@@ -66,6 +66,16 @@ class DspProcessor(DataProcessor):
         self._engineReader = {}
         self._device = int(kwargs.get('device') or 0)
         self._workingReIm = bool(kwargs.get('workingReIm') or os.environ.get('SDRTERM_WORKING_REIM') == '1')
+        # which arithmetic the decimator's block products run in (include/sdrterm_hip.h: enum sdrt_stage_a): 'auto' / 'i8' / 'f64'
+        self._stageA = str(kwargs.get('stageA') or 'auto')
+        if self._stageA not in ('auto', 'i8', 'f64'):
+            raise ValueError(f"stageA must be 'auto', 'i8' or 'f64', not {self._stageA!r}")
+        # float32 input exactly as the reference computes it -- complex64 through scipy.signal.decimate (read_file.py:100-101,
+        # dsp_processor.py:147,171-177): sdrt_config.faithful_f32.  Off: float32 input is filtered in float64 / exactly, which is
+        # closer to the true result than the reference's own output and several times faster, but not identical to it
+        self._faithfulF32 = bool(kwargs.get('faithfulF32') or os.environ.get('SDRTERM_FAITHFUL_F32') == '1')
+        self._pinned = None           # page-locked input ring of _submitBatch (created in the process that runs processData)
+        self._pinnedNext = 0
 
     # ---- rates ----------------------------------------------------------------------------------------
     @property
@@ -181,7 +191,8 @@ class DspProcessor(DataProcessor):
         sos = np.asarray(self._outputFilters, dtype=np.float64).reshape(-1, 6) if len(self._outputFilters) else None
         self._engine = Engine(self._fs, self._decimationFactor, mode, code, n_samples=n, row_freqs=self._rowFreqs(),
                               apply_shift=self._applyShift(), out_sos=sos, device=self._device, smooth=window,
-                              row_modes=self._rowModes(), reserve_chunks=self.MAX_BATCH, **reader)
+                              row_modes=self._rowModes(), reserve_chunks=self.MAX_BATCH, stage_a=self._stageA,
+                              faithful_f32=self._faithfulF32, **reader)
         self._engineReader = reader
         return self._engine
 
@@ -226,11 +237,31 @@ class DspProcessor(DataProcessor):
         """Starts the batch on the GPU (copy-in, kernels and copy-out are asynchronous: Engine.submit) and returns a handle for
         ``_collectBatch``: the next batch's copy-in then overlaps this one's kernels."""
         eng = self._getEngine(chunks[0].size, self._encodingOf(chunks[0]), **self._readerSteps(chunks[0]))
-        if self._readerSteps(chunks[0]):
-            raw = b''.join(c.data for c in chunks)
-        else:
-            raw = np.ascontiguousarray(np.stack(chunks) if len(chunks) > 1 else chunks[0])
+        raw = self._stage(eng, chunks)
         return eng, eng.submit(raw, len(chunks)), len(chunks)
+
+    PINNED_RING = 4     # > the batches the library keeps in flight (include/sdrterm_hip.h: sdrt_submit_host, three slots)
+
+    def _stage(self, eng, chunks) -> np.ndarray:
+        """The batch's bytes, chunk after chunk, in one of PINNED_RING page-locked buffers (sdrt_host_alloc): the copy to the GPU
+        then runs asynchronously at the full PCIe rate straight from where the chunks were put, instead of through a pageable
+        ``b''.join`` that the runtime has to stage once more (pinned double buffering on the input
+        side).  A buffer is reused PINNED_RING submits later, when the library has long completed the batch that read it (a
+        fourth submit first finishes the oldest of its three slots)."""
+        from .. import _native as nat
+        cb = eng.chunk_bytes
+        if self._pinned is None or self._pinned[0].size < self.MAX_BATCH * cb:
+            self._pinned = [nat.pinned_array(self.MAX_BATCH * cb) for _ in range(self.PINNED_RING)]
+            self._pinnedNext = 0
+        buf = self._pinned[self._pinnedNext]
+        self._pinnedNext = (self._pinnedNext + 1) % self.PINNED_RING
+        raw_items = bool(self._readerSteps(chunks[0]))
+        for k, c in enumerate(chunks):
+            src = np.frombuffer(c.data, dtype=np.uint8) if raw_items else np.ascontiguousarray(c).view(np.uint8).reshape(-1)
+            if src.size != cb:
+                raise ValueError(f'chunk {k} of the batch has {src.size} bytes, the batch was opened with {cb}-byte chunks')
+            buf[k * cb:(k + 1) * cb] = src
+        return buf[:len(chunks) * cb]
 
     def _collectBatch(self, pending) -> np.ndarray:
         eng, handle, n = pending
@@ -342,4 +373,5 @@ class DspProcessor(DataProcessor):
     def __getstate__(self):
         state = dict(self.__dict__)
         state['_engine'] = None       # ctypes / HIP handles never cross the spawn boundary
+        state['_pinned'] = None       # ... nor does page-locked memory
         return state

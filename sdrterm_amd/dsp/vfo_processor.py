@@ -64,7 +64,7 @@ class VfoProcessor(DspProcessor):
         self._gpus = max(1, int(kwargs.get('gpus') or os.environ.get('SDRTERM_GPUS') or 1))
         self._rank, self._world, self._uid = 0, 1, None
         self._deviceBase = self._device
-        self._transportKind = kwargs.get('transport') or 'rccl'       # 'torch': an initialised torch.distributed group (tests)
+        self._transportKind = kwargs.get('transport') or 'rccl'       # or a picklable factory of a transport object (the CPU tests)
         # build extension (the reference's demodulation is processor-wide, io_args.py:118): one of 'fm' / 'am' per row, in the
         # row order above (csv entries, then the center), as a list or a csv string -- FM and AM channels from one pass
         modes = kwargs.get('rowModes')
@@ -126,8 +126,8 @@ class VfoProcessor(DspProcessor):
     # ---- several GPUs: block exchange ------------------------------------------------------------------------------
     def _openChannel(self, chunk_bytes: int):
         from .. import parallel
-        if self._transportKind == 'torch':
-            t = parallel.TorchTransport()
+        if callable(self._transportKind):
+            t = self._transportKind()        # tests: a transport on a gloo group (tests/torch_transport.py)
         else:
             t = parallel.RcclTransport(self._rank, self._world, self._device, self._uid, alive=self._jobAlive)
         self._channel = parallel.BlockChannel(t, chunk_bytes)

@@ -9,8 +9,9 @@
 
     ``RcclTransport``   device buffers, RCCL broadcast over xGMI through the C ABI (``sdrt_comm_*``, include/sdrterm_hip.h);
                         the 128-byte unique id travels over a TCP socket at MASTER_ADDR:MASTER_PORT
-    ``TorchTransport``  a ``torch.distributed`` process group the caller initialised ("nccl" is RCCL on ROCm; "gloo" on
-                        CPU is what the tests use); torch is imported lazily, the single-GPU product path never needs it
+  or any object with the same five methods (``bcast_bytes``, ``bcast_block``, ``block_consumed``, ``allgather_bytes``, ``close``
+  and ``rank`` / ``world`` / ``on_device``): the CPU tests pass one built on a gloo group (tests/torch_transport.py).  Nothing in
+  this package imports torch.
 
 ``SimoShard`` is what ``VfoProcessor`` uses: which rows this rank serves, which TCP port, and the channel.
 ``chain_iq_offsets`` is the one exchange a chunk-sharded stream needs when ``--correct-iq`` is on (the carried offset).
@@ -72,44 +73,6 @@ def env_rank_world() -> Tuple[int, int, int]:
 
 
 # ---- transports ------------------------------------------------------------------------------------------------------
-class TorchTransport:
-    """Broadcast through an initialised ``torch.distributed`` group.  Blocks are host (gloo) or device (nccl) uint8 tensors."""
-
-    def __init__(self, group=None, device=None):
-        import torch
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError('torch.distributed is not initialised')
-        self._torch, self._dist, self._group = torch, dist, group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self.device = device if device is not None else torch.device('cpu')
-        self.on_device = self.device.type != 'cpu'
-
-    def bcast_bytes(self, data: Optional[bytes], nbytes: int, root: int = 0) -> bytes:
-        t = self._torch.empty(nbytes, dtype=self._torch.uint8, device=self.device)
-        if self.rank == root:
-            t.copy_(self._torch.frombuffer(bytearray(data), dtype=self._torch.uint8))
-        self._dist.broadcast(t, src=root, group=self._group)
-        return t.cpu().numpy().tobytes()
-
-    def bcast_block(self, data: Optional[bytes], nbytes: int, root: int = 0, slot: int = 0):
-        """('host', bytes): the block as every rank's engine takes it from host memory."""
-        return 'host', self.bcast_bytes(data, nbytes, root)
-
-    def block_consumed(self, slot: int, stream: int = 0) -> None:
-        pass
-
-    def allgather_bytes(self, data: bytes) -> List[bytes]:
-        """Every rank's ``data`` (same length everywhere), in rank order."""
-        mine = self._torch.frombuffer(bytearray(data), dtype=self._torch.uint8).to(self.device)
-        parts = [self._torch.empty_like(mine) for _ in range(self.world)]
-        self._dist.all_gather(parts, mine, group=self._group)
-        return [p.cpu().numpy().tobytes() for p in parts]
-
-    def close(self):
-        pass
-
-
 class RcclTransport:
     """RCCL broadcast between device buffers through the C ABI; no torch.  ``uid``: the 128-byte id (rank 0 creates it with
     ``RcclTransport.unique_id()`` and the launcher passes it on), or None to exchange it over TCP at MASTER_ADDR:MASTER_PORT."""
@@ -464,14 +427,3 @@ class SimoShard:
 
     def port(self, base_port: int) -> int:
         return base_port
-
-
-def max_over_ranks(value: float, device=None) -> float:
-    """Wall time of the slowest rank (bench.py contract)."""
-    import torch
-    import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())

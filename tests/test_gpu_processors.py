@@ -8,9 +8,11 @@ import time
 import numpy as np
 import pytest
 
-from tests.util import BY_NAME, case_raw, ref_tol, samples_per_chunk
+from tests.util import BY_NAME, case_raw, samples_per_chunk, tol_for
 
 pytestmark = pytest.mark.gpu
+
+from tests.util import set_diag as _diag  # noqa: E402
 
 
 class _Flag:
@@ -64,7 +66,7 @@ def test_dsp_processor_process_data_matches_reference(golden):
         got = np.fromfile(path, dtype='=f8')
     exp = z['h_q64_fm_c/z']
     assert got.size == exp.size
-    assert np.abs(got.reshape(exp.shape) - exp).max() <= ref_tol(case, exp)
+    assert np.abs(got.reshape(exp.shape) - exp).max() <= tol_for(exp, case['mode'])
 
 
 def test_dsp_processor_smooth_output_matches_reference(golden):
@@ -82,7 +84,7 @@ def test_dsp_processor_smooth_output_matches_reference(golden):
         got = np.fromfile(path, dtype='=f8')
     exp = z['h_q64_fm_c_smooth11/z']
     assert got.size == exp.size
-    assert np.abs(got.reshape(exp.shape) - exp).max() <= ref_tol(case, exp)
+    assert np.abs(got.reshape(exp.shape) - exp).max() <= tol_for(exp, case['mode'])
     chunks = _reader_chunks(case)
     n = chunks[0].size
     x = np.empty((1, n), complex)
@@ -91,7 +93,7 @@ def test_dsp_processor_smooth_output_matches_reference(golden):
     x[0, :] = chunks[0]
     p._processChunk(x, y, out)
     from scipy.signal import savgol_filter
-    assert np.abs(savgol_filter(out, case['smooth'], 3) - exp[0]).max() <= ref_tol(case, exp)
+    assert np.abs(savgol_filter(out, case['smooth'], 3) - exp[0]).max() <= tol_for(exp, case['mode'])
     assert np.abs(out - exp[0]).max() > 1e-4          # i.e. _processChunk did not smooth
 
 
@@ -111,7 +113,7 @@ def test_process_chunk_signature_matches_reference(golden):
     p._processChunk(x, y, out)
     y0 = z['h_q64_am_norm_c/y0']
     assert np.abs(y - y0).max() <= 1e-9 * np.abs(y0).max()
-    assert np.abs(out - z['h_q64_am_norm_c/z'][0]).max() <= ref_tol(case, z['h_q64_am_norm_c/z'][0])
+    assert np.abs(out - z['h_q64_am_norm_c/z'][0]).max() <= tol_for(z['h_q64_am_norm_c/z'][0], case['mode'])
 
 
 def _client(host, port, nbytes, sink, idx):
@@ -163,7 +165,7 @@ def test_vfo_processor_simo_fanout_matches_reference(golden):
     for k in range(rows):
         got = np.frombuffer(sink[k], dtype='>f8')
         assert got.size == nch * m
-        assert np.abs(got.reshape(nch, m) - exp[:, k, :]).max() <= ref_tol(case, exp)
+        assert np.abs(got.reshape(nch, m) - exp[:, k, :]).max() <= tol_for(exp, case['mode'])
 
 
 def test_standalone_discriminators_known_answers(golden):
@@ -271,14 +273,15 @@ def test_raw_reader_feeds_the_gpu_processor(golden, name):
         buf = Q([])
         readFile(bitsPerSample=sample, fs=case['fs'], buffers=[buf], processes=[P()], isDead=_Flag(), inFile=src,
                  correctIq=bool(case.get('correct_iq')), normalize=bool(case.get('normalize')))
+        # (float32 records: the reference's complex64 arithmetic is a mode of the processor, faithfulF32)
         p = DspProcessor(case['fs'], center=case['center'], omegaOut=case['omega_out'], dec=case['q'],
-                         fileInfo={'bitsPerSample': str(sample)})
+                         fileInfo={'bitsPerSample': str(sample)}, faithfulF32=True)
         {'fm': p.selectOutputFm, 'am': p.selectOutputAm}[case['mode']]()
         p.processData(_Flag(), buf, dst)
         got = np.fromfile(dst, dtype='=f8')
     exp = z[f'{name}/z']
     assert got.size == exp.size
-    assert np.abs(got.reshape(exp.shape) - exp).max() <= ref_tol(case, exp)
+    assert np.abs(got.reshape(exp.shape) - exp).max() <= tol_for(exp, case['mode'])
 
 
 @pytest.mark.parametrize('code', ['h', 'B'])
@@ -570,7 +573,7 @@ def test_iq_offset_of_a_chunk_range_and_a_stream_processed_in_two_parts(code, fu
     from sdrterm_amd.parallel import fold_iq_pairs
     from oracle import ref_chain
     from tests.golden import prng
-    monkeypatch.setenv('SDRTERM_IQ_FUSED', fused)
+    _diag(monkeypatch, iq_fused=fused)
     fs, q, nch, split = 1024000, 64, 7, 3
     kw = dict(row_freqs=[15700.0], apply_shift=True, omega_out=5000, correct_iq=True)
     whole = Engine(fs, q, 'fm', code, **kw)

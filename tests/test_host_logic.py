@@ -6,6 +6,7 @@ import math
 import os
 import pickle
 import re
+from tests.torch_transport import TorchTransport, max_over_ranks  # noqa: F401
 
 import numpy as np
 import pytest
@@ -116,7 +117,7 @@ def test_shared_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(lib, n), f'{n} declared in the header but not exported'
     assert set(_native.EXPORTS) <= names
-    assert _native.lib().sdrt_abi_version() == _native.ABI_VERSION == 6
+    assert _native.lib().sdrt_abi_version() == _native.ABI_VERSION == 7
     assert ctypes.sizeof(_native.Config) == _native.lib().sdrt_config_size()
 
 
@@ -151,7 +152,7 @@ def _gloo_worker(rank, world, port, q):
     mine, (lo, hi) = parallel.shard_rows(rows, world, rank)
     c0, c1 = parallel.shard_chunks(37, world, rank)
     # only rank 0 holds the IQ block; the channel hands every rank the same (chunks, eof, bytes)
-    ch = parallel.BlockChannel(parallel.TorchTransport(), chunk_bytes=2048)
+    ch = parallel.BlockChannel(TorchTransport(), chunk_bytes=2048)
     src = torch.arange(4096, dtype=torch.int16).numpy().tobytes() if rank == 0 else None
     blk = ch.exchange(src, 4, False)
     end = ch.exchange(b'' if rank == 0 else None, 0, True)
@@ -159,7 +160,7 @@ def _gloo_worker(rank, world, port, q):
     block = torch.frombuffer(bytearray(blk.host), dtype=torch.int16)
     gathered = [None] * world
     dist.all_gather_object(gathered, {'rows': (lo, hi), 'chunks': (c0, c1), 'sum': int(block.sum())})
-    slow = parallel.max_over_ranks(1.0 + rank)
+    slow = max_over_ranks(1.0 + rank)
     if rank == 0:
         q.put((gathered, slow))
     dist.destroy_process_group()
@@ -203,7 +204,7 @@ def _gloo_iq_worker(rank, world, port, q):
     z = (rng.normal(size=n * chunks) + 1j * rng.normal(size=n * chunks)) * 100 + (37 - 12j)
     c0, c1 = parallel.shard_chunks(chunks, world, rank)
     a, b = _iq_pair(z[c0 * n:c1 * n], fs)
-    start, end = parallel.chain_iq_offsets(parallel.TorchTransport(), a, b, off0=3 + 4j)
+    start, end = parallel.chain_iq_offsets(TorchTransport(), a, b, off0=3 + 4j)
     q.put((rank, (c0, c1), start, end))
     dist.destroy_process_group()
 

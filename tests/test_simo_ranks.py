@@ -9,6 +9,7 @@ import queue
 import socket
 import threading
 import time
+from tests.torch_transport import TorchTransport, max_over_ranks  # noqa: F401
 
 import numpy as np
 import pytest
@@ -77,7 +78,7 @@ def _rank_worker(rank, world, master_port, base_port, q, feed='all at once', fla
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(master_port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    p = StubVfo(FS, vfoHost=f'127.0.0.1:{base_port}', vfos=VFOS, center=1000, dec=Q, omegaOut=5000, transport='torch')
+    p = StubVfo(FS, vfoHost=f'127.0.0.1:{base_port}', vfos=VFOS, center=1000, dec=Q, omegaOut=5000, transport=TorchTransport)
     p.selectOutputFm()
     p._enterRank(rank, world)
     seen = []                                   # (chunks, end of stream, more queued) of every block this rank took
@@ -254,7 +255,7 @@ def _handed_rank(port, bounds):
 def test_rank_zero_releases_the_others_when_halted_before_any_data():
     """The halt flag set before the first block: rank 0 must still hand the others an end-of-stream block (they wait in a
     collective), here with world == 1 semantics checked on the bookkeeping only."""
-    p = StubVfo(FS, vfoHost='127.0.0.1', vfos=VFOS, dec=Q, omegaOut=5000, transport='torch')
+    p = StubVfo(FS, vfoHost='127.0.0.1', vfos=VFOS, dec=Q, omegaOut=5000, transport=TorchTransport)
     p._enterRank(0, 1)
     p._releaseRanks()                      # world 1: nothing to do, must not raise
     assert not getattr(p, '_eofSent', False)

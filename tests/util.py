@@ -40,14 +40,16 @@ def case_raw(case: dict) -> bytes:
     return prng.case_bytes(case, n)
 
 
-# float32 input: the reference itself runs the decimator in complex64 (see oracle/ref_chain.process_chunk),
-# so its outputs carry ~2e-4 relative single-precision noise that no fp64 implementation can (or should)
-# reproduce.  fp64 implementations are compared with the real-reference vectors at this loose bound and
-# with the fp64 oracle at ABS_TOL.
-F32_REF_RTOL = 5e-3
-
-
-def ref_tol(case: dict, expected: np.ndarray) -> float:
-    if case['code'] == 'f':
-        return F32_REF_RTOL * max(1.0, float(np.abs(expected).max()))
-    return tol_for(expected, case['mode'])
+def set_diag(monkeypatch, **switches) -> None:
+    """Set / clear keys of the library's one diagnostic variable, SDRTERM_DIAG="key=value,key=value" (csrc/api.hip: sdrt_diag);
+    a value of None removes the key."""
+    cur = dict(kv.split('=', 1) for kv in os.environ.get('SDRTERM_DIAG', '').split(',') if '=' in kv)
+    for k, v in switches.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = str(v)
+    if cur:
+        monkeypatch.setenv('SDRTERM_DIAG', ','.join(f'{k}={v}' for k, v in cur.items()))
+    else:
+        monkeypatch.delenv('SDRTERM_DIAG', raising=False)

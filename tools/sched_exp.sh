@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.." || exit 1
 out=${1:-gpurun_out/sched_exp.jsonl}
 : > "$out"
 for k in ${SCHEDS:-0 1 2 3 4 5 6 0}; do
-    SDRTERM_HIP_LIB=$PWD/sdrterm_amd/libsdrterm_hip_exp.so SDRTERM_SCHED=$k python bench.py --steps 20 --warmup 3 --settle-seconds 1.5 --long-seconds 0 --no-cpu-baseline \
+    SDRTERM_HIP_LIB=$PWD/sdrterm_amd/libsdrterm_hip_exp.so SDRTERM_DIAG=sched=$k python bench.py --steps 20 --warmup 3 --settle-seconds 1.5 --long-seconds 0 --no-cpu-baseline \
         | python -c "import sys, json; d = json.loads(sys.stdin.readline()); d['sched'] = $k; print(json.dumps(d))" >> "$out" || exit 1
     python - "$out" <<'PY'
 import json, sys

@@ -45,7 +45,7 @@ def main():
     show('recombination + queue', 2, 3)
     show('barrier wait', 3, 4)
     show('iteration', 0, 4)
-    if os.environ.get('SDRTERM_WIDE_DUAL'):
+    if 'wide_dual=1' in os.environ.get('SDRTERM_DIAG', ''):
         for a_, b_, nm in ((1, 5, 'top -> k-step 0'), (5, 6, 'k-steps 0-1'), (6, 7, 'k-steps 2-3'), (7, 8, 'k-steps 4-5'), (8, 2, 'k-steps 6-7')):
             show('DUAL ' + nm, a_, b_)
     k = (s[:, :, 2] - s[:, :, 1])
