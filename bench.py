@@ -116,7 +116,7 @@ def synth_iq_host(n_samples, seed, code='h', fs=FS, start=0):
     return out
 
 
-def cpu_baseline(raw_bytes, q, freqs, budget_s=10.0, code='h', N=N, FS=FS, correct_iq=False):
+def cpu_baseline(raw_bytes, q, freqs, budget_s=10.0, code='h', N=N, FS=FS, correct_iq=False, faithful=False):
     """The plain-C oracle (oracle/chain.c) timed on this host's cores on a bounded sample of the same workload: all cores
     (OpenMP over chunks) and one core."""
     from oracle import c_chain, ref_chain
@@ -130,7 +130,11 @@ def cpu_baseline(raw_bytes, q, freqs, budget_s=10.0, code='h', N=N, FS=FS, corre
         want = max(threads, min(avail, (avail // threads) * threads))
         if threads == 1:
             want = min(avail, 8)
-        run = lambda: c_chain.process_stream(raw_bytes[:want * chunk_b], code, N, q, 'fm', shift, dec, outs, threads=threads, iq_inductance=L)
+        if faithful:
+            nshift = ref_chain.shift_table(freqs, FS, N)
+            run = lambda: c_chain.process_stream_f32c(raw_bytes[:want * chunk_b], N, q, 'fm', nshift, outs, threads=threads)
+        else:
+            run = lambda: c_chain.process_stream(raw_bytes[:want * chunk_b], code, N, q, 'fm', shift, dec, outs, threads=threads, iq_inductance=L)
         run()                                                   # warm (thread pool, page faults)
         t0 = time.perf_counter()
         run()
@@ -148,7 +152,8 @@ def cpu_baseline(raw_bytes, q, freqs, budget_s=10.0, code='h', N=N, FS=FS, corre
     return {'value': round(v_all, 3), 'unit': 'MSamples/s', 'cores': threads, 'kind': 'port',
             'sample': f'{reps} pass(es) over {want} chunks x {N} samples of the same stream ({len(freqs)} row(s), dec={q}'
                       f'{", --correct-iq" if correct_iq else ""}), '
-                      f'oracle/chain.c (fp64 C port of the reference chain), {threads} OpenMP threads, {dt:.1f} s',
+                      + ("oracle/chain.c (C port of the reference's complex64 chain for float32 records)" if faithful else 'oracle/chain.c (fp64 C port of the reference chain)')
+                      + f', {threads} OpenMP threads, {dt:.1f} s',
             'single_core': {'value': round(v_one, 3), 'unit': 'MSamples/s', 'cores': 1,
                             'sample': f'{reps1} pass(es) over {want1} chunks, 1 thread, {dt1:.1f} s'}}
 
@@ -250,7 +255,7 @@ class Gpu:
         return uniq
 
 
-def parity_check(gpu, eng, raw_buf, out_buf, n_chunks, code, q, fs, freqs, row_modes, correct_iq, chunk_samples, raw_offset=0):
+def parity_check(gpu, eng, raw_buf, out_buf, n_chunks, code, q, fs, freqs, row_modes, correct_iq, chunk_samples, raw_offset=0, faithful=False):
     """Outputs of sampled chunks of the buffer that was just timed against oracle/chain.c on the same raw bytes (outside the timed
     region).  --correct-iq: the timed steps carry the offset from step to step, so the check is an extra pass from a zero offset
     over the first eight chunks of the same buffer instead."""
@@ -281,7 +286,13 @@ def parity_check(gpu, eng, raw_buf, out_buf, n_chunks, code, q, fs, freqs, row_m
     dec, outs = ref_chain.cheby_sos(q), ref_chain.ellip_sos(int(fs) // q, OMEGA_OUT)
     L = 50.0 / fs if correct_iq else None
     modes = sorted(set(row_modes)) if row_modes else ['fm']
-    exp = {md: c_chain.process_stream(raw.tobytes(), code, chunk_samples, q, md, shift, dec, outs, threads=4, iq_inductance=L)[0] for md in modes}
+    if faithful:
+        # the reference's complex64 chain (oracle/chain.c: orc_process_stream_f32c, pinned bit for bit to the reference's vectors),
+        # with the shift table numpy builds, as the reference does
+        nshift = ref_chain.shift_table(freqs, fs, chunk_samples)
+        exp = {md: c_chain.process_stream_f32c(raw.tobytes(), chunk_samples, q, md, nshift, outs, threads=4)[0] for md in modes}
+    else:
+        exp = {md: c_chain.process_stream(raw.tobytes(), code, chunk_samples, q, md, shift, dec, outs, threads=4, iq_inductance=L)[0] for md in modes}
     fm_err, am_rel = 0.0, 0.0
     for r in range(rows):
         md = row_modes[r] if row_modes else 'fm'
@@ -292,7 +303,9 @@ def parity_check(gpu, eng, raw_buf, out_buf, n_chunks, code, q, fs, freqs, row_m
         else:
             am_rel = max(am_rel, d / max(1.0, float(np.abs(e).max())))
     ok = bool(np.isfinite(got).all()) and fm_err <= 1e-6 and am_rel <= 1e-6
-    res = {'max_abs_err': fm_err, 'tol': 1e-6, 'ok': ok, 'chunks': idx, 'rows': rows, 'checker': 'oracle/chain.c (fp64 CPU restatement of the reference chain)',
+    res = {'max_abs_err': fm_err, 'tol': 1e-6, 'ok': ok, 'chunks': idx, 'rows': rows,
+           'checker': "oracle/chain.c, the reference's complex64 chain for float32 records (bit-pinned to the reference's vectors)" if faithful
+                      else 'oracle/chain.c (fp64 CPU restatement of the reference chain)',
            'what': how}
     if row_modes and 'am' in row_modes:
         res['am_max_err_rel_to_peak'] = am_rel
@@ -318,6 +331,9 @@ def main():
                          'by N; bcast: ncclBroadcast from rank 0; allgather: every rank holds 1/N)')
     ap.add_argument('--no-same-arithmetic', action='store_true', help="skip the fp64 kernel's side figure")
     ap.add_argument('--force-comm', action='store_true', help='diagnostic: the RCCL communicator with a single rank too (barrier / maximum / block exchange path on one GPU)')
+    ap.add_argument('--faithful', action='store_true', help="float32 workloads (fm64f, f32x256) in the reference's own complex64 arithmetic (sdrt_config.faithful_f32); "
+                                                           'parity is then checked against the complex64 restatement in oracle/chain.c, bit-pinned to the reference')
+    ap.add_argument('--no-comm-selftest', action='store_true', help='skip the pre-flight of the block feeds (N > 1)')
     ap.add_argument('--dry-run', action='store_true', help='with --gpus N > 1 and no launcher: print the ranks that would be started')
     args = ap.parse_args()
 
@@ -342,8 +358,21 @@ def main():
         comm = parallel.RcclTransport(rank, world, local_dev)        # the id travels over TCP at MASTER_ADDR:MASTER_PORT+17
     q, rows_total, default_chunks, scaling, code, FS, wl_iq, wl_modes = WORKLOADS[args.workload]
     correct_iq = bool(args.correct_iq or wl_iq)
+    faithful = bool(args.faithful)
+    if faithful and code != 'f':
+        raise SystemExit('--faithful is for the float32 workloads (fm64f, f32x256): the other encodings are float64 in the reference too')
     N = 131072 // (2 * ITEM[code])            # complex samples per 131072-byte chunk
     n_chunks = args.chunks or default_chunks
+    if rows_total > 1 and world > 1 and not args.chunks:
+        # rows are sharded: a rank's share of a step shrinks with N, and at the one-GPU block size a step at N = 8 would be ~0.15 ms
+        # against two collectives' launch latency -- the run would measure RCCL latency, not the design.  The block grows with the
+        # ranks instead, so that a rank's step keeps the one-GPU duration (>= 1 ms) and the exchange is what a long stream costs per
+        # sample: per-GPU work fixed -> "weak" on the line; value is samples per second either way
+        n_chunks *= world
+        scaling = 'weak'
+    if faithful and not args.chunks:
+        # one (chunk, row) sequence per lane: the faithful kernel wants >= 64 x 4 SIMDs x 256 CUs x a few sequences in flight
+        n_chunks = {'fm64f': 131072, 'f32x256': 1024}[args.workload]
     n_samples = n_chunks * N
     sb = 2 * ITEM[code]
     block_bytes = n_samples * sb
@@ -351,6 +380,23 @@ def main():
     feed = args.feed
     if feed == 'auto':
         feed = 'scatter' if block_bytes % max(world, 1) == 0 else 'bcast'
+    # pre-flight of the feeds: one small block by every route, checked on every rank, before anything is timed (the default feed
+    # has never met RCCL with N > 1 on this builder's boxes: the run must not bet the whole curve on it)
+    comm_report = None
+    if comm is not None and not args.no_comm_selftest:
+        try:
+            comm_report = comm.selftest()
+        except Exception as e:                       # an RCCL error: say which, leave non-zero (a fresh process per run)
+            raise SystemExit(f'comm selftest failed on rank {rank}: {type(e).__name__}: {e}')
+        if not single:
+            needed = {'scatter': 'scatter_ok', 'bcast': 'bcast_ok', 'allgather': 'allgather_ok'}[feed]
+            if not comm_report[needed]:
+                if args.feed == 'auto' and comm_report['bcast_ok']:
+                    comm_report['feed_fallback'] = f'{feed} delivered wrong bytes in the pre-flight: ncclBroadcast instead'
+                    feed = 'bcast'
+                else:
+                    raise SystemExit(f'comm selftest: feed {feed!r} delivered wrong bytes ({json.dumps(comm_report)})')
+        comm_report['feed'] = feed if not single else 'none (chunk-sharded: no data-path collective)'
     src = None
     if single:
         freqs_all = [float(CENTER)]
@@ -392,7 +438,7 @@ def main():
             bufs = [gpu.malloc(block_bytes) for _ in range(2)]
     modes = list(wl_modes[lo:hi]) if wl_modes else None
     eng = Engine(FS, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_dev, correct_iq=correct_iq,
-                 row_modes=modes, reserve_chunks=n_chunks)         # no allocation inside the timed calls
+                 row_modes=modes, reserve_chunks=n_chunks, faithful_f32=faithful)         # no allocation inside the timed calls
     rows = len(freqs)
     out = gpu.malloc(rows * n_chunks * eng.m * 8)
     # everything is submitted to one non-blocking stream of this process (not the legacy default stream, which orders itself against
@@ -476,8 +522,15 @@ def main():
     step_ms = sorted(gpu.elapsed_ms(evs[i], evs[i + 1]) for i in range(args.steps))
     last_buf = bufs[(state['k'] - 1) % len(bufs)]
     parity = None
-    if not args.no_parity and rank == 0:
-        parity = parity_check(gpu, eng, last_buf, out, n_chunks, code, q, FS, freqs, modes, correct_iq, N)
+    if not args.no_parity:
+        # every rank checks ITS rows / chunks; rank 0 prints its own record with the other ranks' verdicts folded in
+        parity = parity_check(gpu, eng, last_buf, out, n_chunks, code, q, FS, freqs, modes, correct_iq, N, faithful=faithful)
+        if comm is not None:
+            votes = comm.allgather_bytes(struct.pack('<dd', 1.0 if parity['ok'] else 0.0, float(parity['max_abs_err'])))
+            votes = [struct.unpack('<dd', v) for v in votes]
+            parity['ranks_ok'] = [bool(v[0]) for v in votes]
+            parity['max_abs_err_over_ranks'] = max(v[1] for v in votes)
+            parity['ok'] = all(parity['ranks_ok'])
 
     # ---- steady state: a longer run, no per-kernel events ---------------------------------------------------------------
     steady = None
@@ -494,7 +547,7 @@ def main():
         dt_long = max(over_ranks(time.perf_counter() - t1))
         steady = {'steps': n_long, 'seconds': round(dt_long, 3), 'ms_per_step': round(dt_long / n_long * 1e3, 4)}
 
-    KERNEL_OF = {'i8w': 'chain_i8w_kernel', 'i8t': 'chain_i8t_kernel', 'f64': 'chain_kernel', 'seq': 'chain_seq_kernel'}
+    KERNEL_OF = {'i8w': 'chain_i8w_kernel', 'i8t': 'chain_i8t_kernel', 'f64': 'chain_kernel', 'seq': 'chain_seq_kernel', 'f32c': 'f32c_seq_kernel'}
     if rank == 0:
         per_gpu = 1 if scaling == 'strong' else world
         total_samples = float(n_samples) * args.steps * per_gpu
@@ -541,7 +594,17 @@ def main():
                'from_profile': from_profile}
         i8 = {'int8_pops': round(i8_ops / (k_avg_ms * 1e-3) / 1e15, 3) if (i8_ops and k_avg_ms) else None,
               'int8_frac': round(i8_ops / (k_avg_ms * 1e-3) / 1e15 / I8_PEAK_POPS, 4) if (i8_ops and k_avg_ms) else None}
-        if rows == 1 or not i8['int8_pops']:
+        if eng.stage_a == 'f32c':
+            # the reference's recurrence, one sequence per lane: 2 passes x 4 sections x 9 packed single-precision operations (no
+            # fused multiply-adds: every rounding is the reference's) per row-sample; the vector units' packed fp32 rate is its
+            # other roof (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
+            ops = 2 * 4 * 9 * 2 * float(rows) * n_samples
+            peak = 256 * 4 * 16 * 2 * 2.4e9 / 1e12
+            roof = dict(hbm, f32_valu={'achieved': round(ops / (k_avg_ms * 1e-3) / 1e12, 2) if k_avg_ms else None, 'peak': round(peak, 1),
+                                        'unit': 'Top/s (packed fp32 multiply / add, unfused)',
+                                        'frac': round(ops / (k_avg_ms * 1e-3) / 1e12 / peak, 4) if k_avg_ms else None},
+                        kernel_traffic_model='8 B complex64 per row-sample: written by the preparation pass, read and written by the forward pass, read by the backward pass (+ 16 B of shift table per row-sample)')
+        elif rows == 1 or not i8['int8_pops']:
             roof = dict(hbm, **i8)
         else:
             # many rows per input sample: the int8 matrix work, not the input stream, is what bounds the kernel
@@ -560,7 +623,8 @@ def main():
             'scaling': scaling, 'vs_baseline': None,
             # what the arithmetic is: int8 x int8 -> int32 matrix products of 5 base-256 weight digits x 2 byte slices (exact),
             # recombined and finished in fp64; 'f64' when the fp64 matrix-core kernel runs
-            'dtype': ('f32->4 x i8 block fixed point, i8x5-split+f64' if code == 'f' else 'i8x5-split+f64') if eng.stage_a in ('i8w', 'i8t') else 'f64', 'data': 'synthetic',
+            'dtype': ('f32->4 x i8 block fixed point, i8x5-split+f64' if code == 'f' else 'i8x5-split+f64') if eng.stage_a in ('i8w', 'i8t')
+                     else ("c64 (the reference's own arithmetic for float32 records) + f64" if eng.stage_a == 'f32c' else 'f64'), 'data': 'synthetic',
             'config': {'workload': (f'configs[1]{"" if code == "h" and q == 64 else (f" as {ENC_NAME[code]} records" if code != "h" else f" at decimation {q}")}: {FS // 1_000_000} MS/s synthetic {ENC_NAME[code]} IQ (FM tone + noise), FM demod, dec={q}, single VFO, '
                                     f'center={CENTER} Hz{", --correct-iq" if correct_iq else ""}, {n_chunks} chunks x {N} samples per GPU per step, inputs resident in HBM')
                        if single else
@@ -568,6 +632,10 @@ def main():
                         f'{", --correct-iq" if correct_iq else ""}, {n_chunks} chunks x {N} samples per step, ' + (feed_txt if world > 1 else 'inputs resident in HBM')),
                        'chunks_per_step_per_gpu': n_chunks, 'samples_per_chunk': N, 'rows_per_gpu': rows,
                        'parallelism': f'chunk-sharded x{world}' if single else f'rows-sharded x{world} + {feed}',
+                       'faithful_f32': faithful,
+                       #  one GPU, many rows: the resident blocks are processed where they lie; N > 1 stages every block
+                       # into one of two block buffers (a device copy on rank 0 + the exchange) -- the N = 1 point carries no staging
+                       'staging': None if single else ('none: resident blocks processed in place' if comm is None else f'device copy on rank 0 + {feed} per step'),
                        'settle_steps': settle_steps + args.warmup,
                        'distinct_samples_per_buffer': min(n_samples * (1 if single else 2), max(UNIQUE_SAMPLES // N, 1) * N)},
             'step_ms': {'median': round(step_ms[len(step_ms) // 2], 4), 'min': round(step_ms[0], 4), 'max': round(step_ms[-1], 4),
@@ -579,15 +647,13 @@ def main():
                            'iq_prefix_kernels': round(q_avg_ms, 4) if q_avg_ms else None},
             'stage_a': eng.stage_a,
             'parity': parity,
+            'comm': comm_report,
         }
         # the same workload in the reference's own arithmetic: stage A on the fp64 matrix cores (SDRTERM_STAGE_A=f64), same
         # buffers, same process, a few steps
-        if not args.no_same_arithmetic and eng.stage_a != 'f64':
-            os.environ['SDRTERM_STAGE_A'] = 'f64'
-            try:
-                e64 = Engine(FS, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_dev, correct_iq=correct_iq, row_modes=modes)
-            finally:
-                del os.environ['SDRTERM_STAGE_A']
+        if not args.no_same_arithmetic and eng.stage_a not in ('f64', 'f32c'):
+            e64 = Engine(FS, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=OMEGA_OUT, device=local_dev, correct_iq=correct_iq, row_modes=modes,
+                         stage_a='f64')
             n64 = 4 if single else 2
             e64.process_device(bufs[0].ptr, n_chunks, out.ptr, S)
             gpu.sync()
@@ -602,10 +668,10 @@ def main():
             e64.close()
         if not args.no_cpu_baseline and world == 1:
             import numpy as np
-            take = min(n_chunks, 2048) * N * sb
+            take = min(n_chunks, 2048 if single else 128) * N * sb
             sample = np.empty(take, dtype=np.uint8)
             bufs[0].download_at(0, sample)
-            line['cpu_baseline'] = cpu_baseline(sample.tobytes(), q, freqs_all, code=code, N=N, FS=FS, correct_iq=correct_iq)
+            line['cpu_baseline'] = cpu_baseline(sample.tobytes(), q, freqs_all, code=code, N=N, FS=FS, correct_iq=correct_iq, faithful=faithful)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)

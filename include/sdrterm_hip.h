@@ -255,8 +255,8 @@ int sdrt_comm_init(const void *id128, int world, int rank, int device, sdrt_comm
 int sdrt_comm_bcast(sdrt_comm *comm, void *dev_buf, size_t bytes, int root, void *stream);
 int sdrt_comm_allgather(sdrt_comm *comm, const void *send_dev, void *recv_dev, size_t bytes_per_rank, void *stream);
 /* sdrt_comm_bcast's result built for point-to-point links: the root sends every rank its 1/world of the block, the ranks then
- * all-gather the shards in place -- every link carries one shard instead of every hop the whole block.  bytes % world != 0 or a
- * single rank: plain sdrt_comm_bcast. */
+ * all-gather the shards in place -- every link carries one shard instead of every hop the whole block.  bytes % world != 0, a
+ * single rank, less than 1 MiB, or a librccl without ncclSend / ncclRecv / ncclGroup*: plain sdrt_comm_bcast. */
 int sdrt_comm_bcast_scatter(sdrt_comm *comm, void *dev_buf, size_t bytes, int root, void *stream);
 int sdrt_comm_world(const sdrt_comm *comm);
 int sdrt_comm_rank(const sdrt_comm *comm);

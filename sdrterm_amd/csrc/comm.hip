@@ -124,12 +124,15 @@ int sdrt_comm_bcast(sdrt_comm *c, void *dev_buf, size_t bytes, int root, void *s
 // the root's links at once, each carrying one shard), then the ranks all-gather the shards in place (every link of every rank
 // carries one shard).  A ring broadcast moves the whole block over every hop instead.  Needs bytes % world == 0 (a chunked block
 // always divides by the GPU counts of a node); otherwise, and with a single rank, this is sdrt_comm_bcast.
+#define SDRT_SCATTER_MIN_BYTES ((size_t) 1 << 20)
 int sdrt_comm_bcast_scatter(sdrt_comm *c, void *dev_buf, size_t bytes, int root, void *stream) {
     if (!c || (!dev_buf && bytes) || root < 0 || root >= c->world) return sdrt_set_error(SDRT_EINVAL, "bad argument");
     if (bytes == 0) return SDRT_OK;
-    if (c->world == 1 || bytes % (size_t) c->world) return sdrt_comm_bcast(c, dev_buf, bytes, root, stream);
-    if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
-        return sdrt_set_error(SDRT_EINVAL, "this librccl has no ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+    // small payloads (headers, a few chunks): two collectives' latency buys nothing over one; and a librccl without the
+    // point-to-point entry points still has ncclBroadcast
+    if (c->world == 1 || bytes % (size_t) c->world || bytes < SDRT_SCATTER_MIN_BYTES || !g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart ||
+        !g_rccl.GroupEnd)
+        return sdrt_comm_bcast(c, dev_buf, bytes, root, stream);
     const size_t shard = bytes / (size_t) c->world;
     char *buf = (char *) dev_buf;
     ncclResult_t e = g_rccl.GroupStart();

@@ -51,6 +51,8 @@ class RowFanOut:
         self._lock = threading.Lock()
         self._full = threading.Event()   # set once every row has a client
         self._stop = threading.Event()
+        self.failed = None               # why the fan-out can no longer be completed (a client socket could not reach its rank)
+        self._hello = {}                 # hand-off connections that have not said which rank they are yet: socket -> deadline
         self._listener = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         self._listener.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         self._listener.bind((host, port))
@@ -81,43 +83,73 @@ class RowFanOut:
         if self._accepted >= self._total and not self._waiting:
             self._full.set()
 
-    def _hand_on(self, rank: int, conn) -> None:
+    def _fail(self, why: str) -> None:
+        """A row's client cannot reach the rank that computes it: the job as a whole cannot start (the reference starts once
+        EVERY row has its client, vfo_processor.py:77).  wait_for_clients returns False and the processor goes down -- instead
+        of rank 0 entering the first collective while a helper still waits for a socket that will never come."""
+        if self.failed is None:
+            self.failed = why
+            eprint(f'--simo fan-out failed: {why}')
+        self._stop.set()
+
+    def _hand_on(self, rank: int, conn) -> bool:
+        """The client socket to the process of ``rank``; False (and the fan-out marked failed) when that cannot be done."""
         peer = self._peers.get(rank)
         if peer is None:
             self._waiting.setdefault(rank, []).append(conn)       # that rank has not knocked yet: in order, as soon as it does
+            return True
+        try:
+            socket.send_fds(peer, [b'c'], [conn.fileno()])
+        except OSError as e:
+            self._fail(f'hand-off of a client socket to rank {rank} failed: {e}')
+            return False
+        finally:
+            conn.close()                                          # the owning process holds the connection now (or nobody will)
+        return True
+
+    def _take_hello(self, conn) -> None:
+        """A hand-off connection has become readable: its four bytes say which rank it is.  (Read here, off the accept path: a
+        local process that connects and stays silent only ever costs its own slot, never the other accepts.)"""
+        self._hello.pop(conn, None)
+        try:
+            conn.setblocking(False)
+            hello = conn.recv(4)
+            conn.setblocking(True)
+            rank = struct.unpack('<i', hello)[0] if len(hello) == 4 else -1
+        except OSError:
+            rank = -1
+        if not _same_user(conn) or not (0 < rank < len(self._bounds)) or rank in self._peers:
+            conn.close()
             return
-        socket.send_fds(peer, [b'c'], [conn.fileno()])
-        conn.close()                                              # the owning process holds the connection now
+        with self._lock:
+            self._peers[rank] = conn
+            for held in self._waiting.pop(rank, []):
+                if not self._hand_on(rank, held):
+                    break
+            self._check_full()
 
     def _accept_loop(self) -> None:
         socks = [self._listener] + ([self._unix] if self._unix is not None else [])
         while not self._stop.is_set():
+            now = time.monotonic()
+            for c in [c for c, t in self._hello.items() if t < now]:       # silent for five seconds: not one of ours
+                self._hello.pop(c)
+                c.close()
             try:
-                ready, _, _ = select.select(socks, [], [], 0.2)
+                ready, _, _ = select.select(socks + list(self._hello), [], [], 0.2)
             except (OSError, ValueError):
                 break
             for s in ready:
+                if s in self._hello:
+                    self._take_hello(s)
+                    continue
                 try:
                     conn, peer = s.accept()
                 except OSError:
                     return
                 if s is self._unix:
-                    # a rank of this job announces itself with its number
-                    try:
-                        conn.settimeout(5)
-                        hello = conn.recv(4)
-                        rank = struct.unpack('<i', hello)[0] if len(hello) == 4 else -1
-                        conn.settimeout(None)
-                    except OSError:
-                        rank = -1
-                    if not _same_user(conn) or not (0 < rank < len(self._bounds)) or rank in self._peers:
-                        conn.close()
-                        continue
-                    with self._lock:
-                        self._peers[rank] = conn
-                        for held in self._waiting.pop(rank, []):
-                            self._hand_on(rank, held)
-                        self._check_full()
+                    # a rank of this job; it announces itself with its number (read when it arrives: _take_hello)
+                    self._hello[conn] = time.monotonic() + 5.0
                     continue
                 eprint(f'Connection request from {peer}')
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
@@ -131,19 +163,17 @@ class RowFanOut:
                     self._accepted += 1
                     if owner == 0:
                         self._sinks.append(conn)
-                    else:
-                        try:
-                            self._hand_on(owner, conn)
-                        except OSError as e:
-                            eprint(f'hand-off of row {k} to rank {owner} failed: {e}')
-                            conn.close()
+                    elif not self._hand_on(owner, conn):
+                        return                                    # the row has no client and never will: the job is marked failed
                     self._check_full()
 
     def wait_for_clients(self, is_dead=None, poll: float = 0.25) -> bool:
         """Blocks until every row has a client (or ``is_dead()`` turns true).  Returns True when complete."""
         while not self._full.wait(poll):
-            if self._stop.is_set() or (is_dead is not None and is_dead()):
+            if self.failed or self._stop.is_set() or (is_dead is not None and is_dead()):
                 return False
+        if self.failed:
+            return False
         eprint('Connection(s) established')
         return True
 
@@ -180,9 +210,10 @@ class RowFanOut:
                 for s in held:
                     s.close()
             self._waiting.clear()
-            for s in self._peers.values():
+            for s in list(self._peers.values()) + list(self._hello):
                 s.close()
             self._peers.clear()
+            self._hello.clear()
 
 
 class HandedRowFanOut(RowFanOut):
@@ -197,7 +228,8 @@ class HandedRowFanOut(RowFanOut):
         self._full = threading.Event()
         self._stop = threading.Event()
         self._listener = self._unix = None
-        self._peers, self._waiting = {}, {}
+        self._peers, self._waiting, self._hello = {}, {}, {}
+        self.failed = None
         self._conn = None
         self.address = (host, port)
         self._thread = threading.Thread(target=self._receive_loop, name='simo-handoff', daemon=True)
@@ -213,6 +245,14 @@ class HandedRowFanOut(RowFanOut):
             c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
             try:
                 c.connect(handoff_name(self._port))
+                if not _same_user(c):
+                    # the name is derivable from the port: whoever bound it must be this user's rank 0, or the descriptors it
+                    # sends are not this job's clients
+                    c.close()
+                    self.failed = f'the hand-off socket of port {self._port} belongs to another user'
+                    eprint(f'rank {self._rank}: {self.failed}')
+                    self._stop.set()
+                    return
                 conn = c
                 break
             except OSError:

@@ -287,6 +287,44 @@ class RcclTransport:
             recv.free()
         return [allb[r * nb:(r + 1) * nb] for r in range(self.world)]
 
+    def selftest(self, nbytes: int = 8 << 20) -> dict:
+        """Pre-flight of the block feeds, before anything depends on them: a block of ``nbytes`` patterned bytes goes from rank 0
+        to every rank once with ncclBroadcast and once as 1/N shards + all-gather (sdrt_comm_bcast_scatter), and once as an
+        all-gather of every rank's own shard; every rank checks what arrived against the pattern (which it can compute itself) and
+        the verdicts are gathered.  Returns {'world', 'ranks_seen', 'bcast_ok', 'scatter_ok', 'allgather_ok', 'selftest_ok',
+        'bytes'}: ``selftest_ok`` only when every rank saw every feed deliver the right bytes.  Collective: every rank calls it.
+        (The scatter form has only ever met RCCL on real hardware with a world of one: DESIGN section 5.)"""
+        nat = self._nat
+        unit = 16 * self.world                                   # divides by the ranks, shards 16-byte aligned
+        nbytes = (max(int(nbytes), 1 << 20) + unit - 1) // unit * unit       # (the scatter form starts at 1 MiB: comm.hip)
+        pattern = ((np.arange(nbytes, dtype=np.uint64) * np.uint64(2654435761) >> np.uint64(7)) & np.uint64(0xff)).astype(np.uint8)
+        buf, out = nat.DeviceBuffer(nbytes), nat.DeviceBuffer(nbytes)
+        got = np.empty(nbytes, dtype=np.uint8)
+        res = {}
+        try:
+            for name, scatter in (('bcast_ok', False), ('scatter_ok', True)):
+                buf.upload(pattern if self.rank == 0 else np.zeros(nbytes, dtype=np.uint8))
+                self.bcast_device(buf.ptr, nbytes, 0, self._s_comm, scatter=scatter)
+                self._finish(name)
+                res[name] = bool(np.array_equal(buf.download(got), pattern))
+            shard = nbytes // self.world
+            mine = np.zeros(nbytes, dtype=np.uint8)
+            mine[:shard] = pattern[self.rank * shard:(self.rank + 1) * shard]
+            buf.upload(mine)
+            self.allgather_device(buf.ptr, out.ptr, shard, self._s_comm)
+            self._finish('allgather_ok')
+            res['allgather_ok'] = bool(np.array_equal(out.download(got), pattern))
+        finally:
+            buf.free()
+            out.free()
+        mine_ok = bytes([int(res['bcast_ok']), int(res['scatter_ok']), int(res['allgather_ok'])])
+        votes = self.allgather_bytes(mine_ok + bytes(13))
+        for k, name in enumerate(('bcast_ok', 'scatter_ok', 'allgather_ok')):
+            res[name] = all(v[k] == 1 for v in votes)
+        res.update(world=self.world, ranks_seen=len(votes), bytes=int(nbytes),
+                   selftest_ok=bool(res['bcast_ok'] and res['scatter_ok'] and res['allgather_ok'] and len(votes) == self.world))
+        return res
+
     def bcast_block(self, data: Optional[bytes], nbytes: int, root: int = 0, slot: int = 0):
         """('dev', pointer): the block stays in device memory on every rank (one upload on the root, RCCL broadcast,
         sdrt_process_device on the spot).  Asynchronous: upload and broadcast are queued on the communication stream behind

@@ -220,7 +220,54 @@ def halt_flag_with_live_helpers():
     assert codes == [0], f'helper exit codes {codes}: it did not leave on the end-of-stream block'
 
 
+def chunk_sharded_stream_with_correct_iq():
+    """SURVEY 8e, "by chunk", with --correct-iq: ONE stream of chunks split into contiguous ranges over the ranks.  The carried
+    offset (read_file.py:53,64-77) is the only thing a chunk hands to the next; every rank asks what its range does to it
+    (sdrt_iq_range_device), the 24-byte pairs are all-gathered through the communicator, every rank folds the ranges before it into
+    its starting offset and processes its range.  Every rank's outputs against oracle/chain.c run over the WHOLE stream; the
+    verdicts are gathered and rank 0 reports.  Started once per rank (RANK / WORLD_SIZE in the environment); without them this
+    process starts the ranks."""
+    import os
+    import struct
+    import subprocess
+    if 'WORLD_SIZE' not in os.environ:
+        import bench
+        world = len(os.environ['SDRTERM_DEVICE_MAP'].split(','))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        procs = [subprocess.Popen([sys.executable, '-m', 'tests.rank_scenarios', 'iqshard'], env=env) for env in bench.rank_environments(world, port)]
+        codes = [p.wait(timeout=500) for p in procs]
+        assert codes == [0] * world, f'rank exit codes {codes}'
+        return
+    from oracle import c_chain, ref_chain
+    from sdrterm_amd import parallel
+    from sdrterm_amd.engine import Engine
+    from tests.golden import prng
+    rank, local, world = parallel.env_rank_world()
+    dev = parallel.device_for(local)
+    fs, q, n, nch = 1024000, 64, 32768, 7 * world + 3                  # uneven ranges
+    raw = prng.raw_bytes('h', n * nch, seed=58, amp=3000, dc=(700, -450))
+    lo, hi = parallel.shard_chunks(nch, world, rank)
+    t = parallel.RcclTransport(rank, world, dev)
+    eng = Engine(fs, q, 'fm', 'h', row_freqs=[15700], omega_out=5000, correct_iq=True, device=dev)
+    mine = raw[lo * n * 4:hi * n * 4]
+    a, b = eng.iq_range(mine)
+    start, end = parallel.chain_iq_offsets(t, a, b, off0=0j)
+    eng.iq_offset = start
+    out = eng.process(mine).reshape(hi - lo, n // q)
+    exp, off_end = c_chain.process_stream(raw, 'h', n, q, 'fm', c_chain.shift_table([15700], fs, n), ref_chain.cheby_sos(q),
+                                          ref_chain.ellip_sos(fs // q, 5000), iq_inductance=50 / fs, threads=2)
+    err = float(np.abs(out - exp[lo:hi, 0, :]).max())
+    ok = err <= 1e-6 and abs(end - off_end) <= 1e-9 * max(1.0, abs(off_end))
+    votes = [struct.unpack('<dd', v) for v in t.allgather_bytes(struct.pack('<dd', 1.0 if ok else 0.0, err))]
+    t.close()
+    print(f'rank {rank}: chunks [{lo}, {hi}), start offset {start:.6g}, max abs err {err:.3e}', flush=True)
+    assert all(v[0] == 1.0 for v in votes), f'per-rank (ok, err): {votes}'
+
+
 if __name__ == '__main__':
-    {'rows': simo_rows_over_rank_processes, 'rows4': lambda: simo_rows_over_rank_processes(4), 'kill': a_helper_rank_that_dies,
+    {'iqshard': chunk_sharded_stream_with_correct_iq, 'rows': simo_rows_over_rank_processes, 'rows4': lambda: simo_rows_over_rank_processes(4), 'kill': a_helper_rank_that_dies,
      'halt': halt_flag_with_live_helpers}[sys.argv[1]]()
     print('scenario ok')

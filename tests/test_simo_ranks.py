@@ -376,3 +376,40 @@ def test_communicator_id_exchange_keeps_two_jobs_apart(monkeypatch):
     for t in [ta, tb] + others:
         t.join(60)
     assert got == {('A', 0): ids['A'], ('A', 1): ids['A'], ('B', 0): ids['B'], ('B', 1): ids['B']}
+
+
+def test_a_failed_hand_off_fails_the_fan_out_instead_of_hanging_it():
+    """a helper that has died takes its rows' clients with it.  Rank 0 must not count such a row as served (it would
+    enter the first collective while the owner never gets its socket) nor lose its acceptor thread to the OSError: the fan-out is
+    marked failed and wait_for_clients returns False.  A local process that connects to the hand-off socket and says nothing
+    must not hold up the TCP accepts either."""
+    import struct
+    from sdrterm_amd.dsp import fanout
+    fo = fanout.RowFanOut('127.0.0.1', 0, 1, bounds=[(0, 1), (1, 2)])
+    fo.start()
+    port = fo.address[1]
+    try:
+        silent = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        silent.connect(fanout.handoff_name(port))                 # never says which rank it is
+        t0 = time.monotonic()
+        c0 = socket.create_connection(('127.0.0.1', port))        # row 0: rank 0's own
+        deadline = time.monotonic() + 2
+        while not fo.clients and time.monotonic() < deadline:
+            time.sleep(0.01)
+        assert fo.clients and time.monotonic() - t0 < 2.0         # (the old blocking recv held every accept for five seconds)
+        helper = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        helper.connect(fanout.handoff_name(port))
+        helper.sendall(struct.pack('<i', 1))
+        deadline = time.monotonic() + 2
+        while 1 not in fo._peers and time.monotonic() < deadline:
+            time.sleep(0.01)
+        assert 1 in fo._peers
+        helper.close()                                            # the helper dies
+        time.sleep(0.05)
+        c1 = socket.create_connection(('127.0.0.1', port))        # row 1: cannot reach its rank any more
+        assert fo.wait_for_clients(lambda: False, poll=0.05) is False
+        assert fo.failed and 'rank 1' in fo.failed
+        for s in (silent, c0, c1):
+            s.close()
+    finally:
+        fo.close()
