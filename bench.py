@@ -158,10 +158,10 @@ def cpu_baseline(raw_bytes, q, freqs, budget_s=10.0, code='h', N=N, FS=FS, corre
                             'sample': f'{reps1} pass(es) over {want1} chunks, 1 thread, {dt1:.1f} s'}}
 
 
-def committed_record(workload, correct_iq):
+def committed_record(workload, correct_iq, faithful=False):
     """The newest committed counter record of this workload (tools/pmc.sh -> profiles/): (file name, record) or (None, None)."""
-    tag = workload + ('_iq' if correct_iq and not WORKLOADS[workload][6] else '')
-    names = [f'r04_pmc_record_{tag}.json'] + (['r03_pmc_record.json'] if tag == 'fm64' else [])
+    tag = workload + ('_iq' if correct_iq and not WORKLOADS[workload][6] else '') + ('_faithful' if faithful else '')
+    names = [f'r05_pmc_record_{tag}.json', f'r04_pmc_record_{tag}.json'] + (['r03_pmc_record.json'] if tag == 'fm64' else [])
     for name in names:
         try:
             return name, json.load(open(os.path.join(ROOT, 'profiles', name)))
@@ -570,7 +570,7 @@ def main():
         # hardware counters cannot be read from inside this run: the committed record of rocprofv3 passes over this very workload
         # (tools/pmc.sh) is quoted under "from_profile", with the file it comes from and the commit it was taken at; traffic is per
         # launch and scales with the chunks of a launch, so a run with another --chunks quotes it scaled (and says so)
-        pmc_file, pmc = committed_record(args.workload, correct_iq)
+        pmc_file, pmc = committed_record(args.workload, correct_iq, faithful)
         pmc_ok = bool(pmc) and pmc.get('kernel', '') in KERNEL_OF[eng.stage_a] and pmc.get('chunks_per_step_per_gpu')
         from_profile = None
         if pmc_ok:

@@ -303,6 +303,9 @@ int sdrt_selftest_mfma_i8(int *mismatches);
  * encodings at decimation 32 / 64); 4 = the per-sample modal form in fp64 (decimation 2 and 4); 5 = the reference's complex64
  * recurrence for float32 records (sdrt_config.faithful_f32).  0 - 4 meet the same tolerance; sdrt_config.stage_a chooses among them. */
 int sdrt_stage_a_kind(const sdrt_ctx *ctx);
+/* stage_a = SDRT_STAGE_AUTO: how many (chunk, row) items this context has done a second time in float64 so far (their in-band
+ * content lay near the int8 forms' operator image; DESIGN.md section 1, "Conditioning").  Synchronises the device. */
+int sdrt_refined_items(sdrt_ctx *ctx, unsigned long long *total);
 
 #ifdef __cplusplus
 }

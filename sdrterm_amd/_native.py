@@ -33,7 +33,7 @@ EXPORTS = (
     'sdrt_comm_destroy', 'sdrt_submit_host', 'sdrt_wait', 'sdrt_spectrum_host', 'sdrt_stft_host', 'sdrt_iq_range_device',
     'sdrt_event_create', 'sdrt_event_destroy', 'sdrt_event_record', 'sdrt_stream_wait_event', 'sdrt_event_query',
     'sdrt_event_synchronize', 'sdrt_reserve', 'sdrt_taps_release', 'sdrt_mem_info', 'sdrt_alloc_count',
-    'sdrt_event_create_timed', 'sdrt_event_elapsed_ms', 'sdrt_memcpy_d2d_async',
+    'sdrt_event_create_timed', 'sdrt_event_elapsed_ms', 'sdrt_memcpy_d2d_async', 'sdrt_refined_items',
 )
 
 
@@ -139,6 +139,7 @@ def lib():
     l.sdrt_selftest_mfma.argtypes = [C.POINTER(C.c_double)]
     l.sdrt_selftest_mfma_i8.argtypes = [C.POINTER(C.c_int)]
     l.sdrt_stage_a_kind.argtypes = [C.c_void_p]
+    l.sdrt_refined_items.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     l.sdrt_set_smoothing.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     l.sdrt_demodulate_host.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     l.sdrt_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]

@@ -61,6 +61,11 @@ struct DecimArgs {
     int out_mul, out_off;       //   eight outputs per column: output b of column c goes to index c * out_mul + out_off + b (one pass: 8, 0)
     int m_local;                //   ... and the pass's ybias holds m_local entries per row (one pass: m)
     int rs;                     //   real-stream form (no shift, no IQ correction): w8 / w8mid hold sdrt_build_i8_weights_wide_rs planes
+    // second look of stage_a = auto (chain_kernel only): the (row, chunk) items listed by the demodulation stage are done again in
+    // float64, each result written over the item's first try
+    const int *fix_list;        //   [*fix_count] item = row * n_chunks + chunk (NULL: every item of the grid, the normal launch)
+    const unsigned *fix_count;
+    int fix_pairs;              //   the items' place in ydec holds [m/2] products y[2i] conj(y[2i+1]) (as pair_out of the wide kernel)
 };
 
 struct IqArgs {
@@ -114,6 +119,15 @@ struct PostArgs {
     int p8_lpi;                 // lanes per item the tables were built for: 8 (m = 512) or 16 (m = 1024)
     double *stash;              // scratch of post_fft8_stash_bytes() bytes: the pair angles of the items in flight (or NULL: they wait in `out`)
     size_t stash_bytes;
+    // stage_a = auto (post_fft8_kernel on pair products): an item of whose pair products half lie under cond_thr (in some lane's
+    // evenly spread share; not exactly zero: silence is exact on every path) has its in-band content near the 40-bit operator image
+    // of the int8 forms -- it is appended to cond_list for a second, float64 pass.  fix_list / fix_count: this launch IS that second pass: work item w stands
+    // for item fix_list[w], w < *fix_count.
+    int *cond_list;             // [items] (or NULL: no second look)
+    unsigned *cond_count;       // [2]: items listed by this launch; [1] running total (diagnostics: sdrt_refined_items)
+    double cond_thr;
+    const int *fix_list;
+    const unsigned *fix_count;
 };
 bool post_fft8_supported(const PostArgs &a);
 size_t post_fft8_stash_bytes(const PostArgs &a);

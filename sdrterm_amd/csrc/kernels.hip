@@ -1,7 +1,9 @@
 // chain_kernel (f64 stage A on v_mfma_f64_16x16x4) + IQ prefix kernels + stand-alone discriminators + launchers.
 #include "kernels_common.hpp"
 
-template <int L, int DT, bool NCO, bool IQ>
+// FIX: the second look of stage_a = auto -- the workgroups walk over the listed items (DecimArgs.fix_list).  A form of its own:
+// wrapping the body in that loop costs the normal launch its register allocation (36 -> 264 bytes of scratch at L = 64).
+template <int L, int DT, bool NCO, bool IQ, bool FIX = false>
 __global__ __launch_bounds__(256, 4) void chain_kernel(DecimArgs a) {
     constexpr int KS = L / 4;                       // k-steps == samples per lane per tile
     constexpr int ITEM = Enc<DT>::size;
@@ -16,10 +18,23 @@ __global__ __launch_bounds__(256, 4) void chain_kernel(DecimArgs a) {
     // (chunk, row) from the block id: all rows of a chunk get ids that share an XCD (ids are dealt round-robin
     // over 8 XCDs), so the chunk is pulled through one L2 only.  Placement changes speed only, never results.
     const unsigned bid = blockIdx.x;
-    const unsigned xcd = bid & 7u, slot = bid >> 3;
-    const long chunk = (long) (slot / (unsigned) a.rows) * 8 + xcd;
-    const int row = (int) (slot % (unsigned) a.rows);
-    if (chunk >= (long) a.n_chunks) return;
+    // (second look of stage_a = auto: the workgroups walk over the listed items instead; one body, so the loop wraps it)
+    const unsigned fix_n = FIX ? *a.fix_count : 0u;
+    for (unsigned fw = bid;; fw += gridDim.x) {
+    long chunk;
+    int row;
+    if constexpr (FIX) {
+        if (fw >= fix_n) return;
+        const int item = a.fix_list[fw];
+        row = item / (int) a.n_chunks;
+        chunk = item - (long) row * (long) a.n_chunks;
+        if (fw != bid) __syncthreads();              // the previous item's LDS is done with
+    } else {
+        const unsigned xcd = bid & 7u, slot = bid >> 3;
+        chunk = (long) (slot / (unsigned) a.rows) * 8 + xcd;
+        row = (int) (slot % (unsigned) a.rows);
+        if (chunk >= (long) a.n_chunks) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, nb = lane & 15;
     const bool swap = a.swap != 0;
@@ -177,6 +192,8 @@ __global__ __launch_bounds__(256, 4) void chain_kernel(DecimArgs a) {
         return mk(xr, xi);
     };
     chain_tail(a, L, row, chunk, smem, stp, edge, (const cd *) nullptr);
+    if constexpr (!FIX) return;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -701,8 +718,25 @@ static hipError_t launch_chain_k(const DecimArgs &a, dim3 grid, size_t lds, hipS
     return hipGetLastError();
 }
 
+template <int L, int DT, bool NCO>
+static hipError_t launch_chain_fix(const DecimArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *) chain_kernel<L, DT, NCO, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((chain_kernel<L, DT, NCO, false, true>), grid, dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int L, int DT>
 static hipError_t launch_chain_ldt(const DecimArgs &a, bool nco, bool iq, dim3 grid, size_t lds, hipStream_t s) {
+    if (a.fix_list) {
+        // (only where stage_a = auto looks twice: 8/16-bit integer records at the decimations of the wide kernel, no IQ correction)
+        if constexpr ((L == 32 || L == 64) && (DT == SDRT_S8 || DT == SDRT_U8 || DT == SDRT_S16 || DT == SDRT_U16))
+            return nco ? launch_chain_fix<L, DT, true>(a, grid, lds, s) : launch_chain_fix<L, DT, false>(a, grid, lds, s);
+        else
+            return hipErrorInvalidValue;
+    }
     if (nco) return iq ? launch_chain_k<L, DT, true, true>(a, grid, lds, s) : launch_chain_k<L, DT, true, false>(a, grid, lds, s);
     return iq ? launch_chain_k<L, DT, false, true>(a, grid, lds, s) : launch_chain_k<L, DT, false, false>(a, grid, lds, s);
 }
@@ -724,8 +758,10 @@ static hipError_t launch_chain_l(const DecimArgs &a, int dt, bool nco, bool iq, 
 
 hipError_t launch_chain(const DecimArgs &a, int L, int dt, bool nco, bool iq, size_t n_chunks, hipStream_t s) {
     // ids are (slot << 3 | xcd): round the chunk count up to a multiple of 8, surplus blocks exit at once
+    // (a.fix_list: a fixed number of workgroups walks over the listed items -- usually none: the launch costs a few microseconds)
     const size_t groups = (n_chunks + 7) / 8;
-    const dim3 grid((unsigned) (groups * 8 * (size_t) a.rows));
+    const size_t all = groups * 8 * (size_t) a.rows;
+    const dim3 grid((unsigned) (a.fix_list ? (all < 1024 ? all : 1024) : all));
     const size_t lds = chain_lds_bytes(a.n, L, a.m);
     switch (L) {
         case 8: return launch_chain_l<8>(a, dt, nco, iq, grid, lds, s);

@@ -296,7 +296,7 @@ __device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, cons
     SDRT_STAMP(4);
     // ---- phase 3: add the carried parts at the output blocks -> decimated samples y, stored for the post kernel ---------
     const int stride = tab->out_stride;
-    double *yd = a.ydec + ((size_t) row * a.n_chunks + chunk) * (size_t) m * 2;
+    double *yd = a.ydec + ((size_t) row * a.n_chunks + chunk) * (size_t) (a.fix_pairs ? m / 2 : m) * 2;
     for (int k = tid; k < m; k += 256) {
         const int kb = k * stride, tile = kb / TBG, nbk = kb % TBG;
         cd v = o_lds[kb];
@@ -310,6 +310,12 @@ __device__ __forceinline__ void chain_tail(const DecimArgs &a, const int L, cons
         }
         if (ybias) { v.re += ybias[k].re; v.im += ybias[k].im; }
         else { v.re += 0.0; v.im += 0.0; }           // -0.0 -> +0.0: angle(-0) would be pi where the reference's exact zeros give 0
+        if (a.fix_pairs) {
+            // the second look of stage_a = auto: the item's place holds pair products (as the wide kernel leaves them); output
+            // k + 1 sits in the next lane (m is even and a multiple of the wave here)
+            const cd w = mk(__shfl_down(v.re, 1), __shfl_down(v.im, 1));
+            if (!(k & 1)) *(double2 *) (yd + (size_t) k) = make_double2(v.re * w.re + v.im * w.im, v.im * w.re - v.re * w.im);
+        } else
         *(double2 *) (yd + 2 * (size_t) k) = make_double2(v.re, v.im);
     }
     SDRT_STAMP(5);

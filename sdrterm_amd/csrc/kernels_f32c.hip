@@ -70,9 +70,13 @@ __device__ __forceinline__ f2 extended(const uint32_t *chunk_raw, const double *
 // tile's samples (coalesced reads of the records and of the shift table); the tile leaves transposed, 512 bytes per time step
 __global__ __launch_bounds__(256) void f32c_prep_kernel(const F32cArgs a) {
     __shared__ f2 tile[64][65];
-    const int N = a.n + 2 * kEdge, tiles = (N + 63) / 64;
-    const size_t g = blockIdx.x / tiles;
-    const int t0 = (int) (blockIdx.x % tiles) * 64;
+    // the group index runs fastest: the workgroups in flight at any time work on the same 64 time steps, so the shift table's
+    // columns for those steps (rows x 64 x 16 bytes: 256 KiB at 256 rows) are read from memory once and from L2 by every other
+    // group -- the table would otherwise cost 16 bytes per row-sample, as much as everything else the pass moves
+    const int N = a.n + 2 * kEdge;
+    const size_t groups = (a.n_chunks * (size_t) a.rows + 63) / 64;
+    const size_t g = blockIdx.x % groups;
+    const int t0 = (int) (blockIdx.x / groups) * 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t items = a.n_chunks * (size_t) a.rows;
     for (int j = wv; j < 64; j += 4) {

@@ -187,10 +187,20 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : (p8_halves(LP
     const int cs[4] = {l, LPI <= 8 ? (l ? 16 - l : 8) : 0, 4 + l, 12 - l};
     const bool l0 = l == 0;
 
-    const size_t ngroups = (a.items + IPW - 1) / IPW;
+    // (a.fix_list: the second look of stage_a = auto -- the listed items only, their number read from the device)
+    const size_t n_items = a.fix_list ? (size_t) *a.fix_count : a.items;
+    if (a.fix_list && blockIdx.x == 0 && tid == 0 && n_items) atomicAdd(&a.cond_count[1], (unsigned) n_items);      // running total (sdrt_refined_items)
+    if (n_items == 0) return;
+    const size_t ngroups = (n_items + IPW - 1) / IPW;
     for (size_t grp = (size_t) blockIdx.x * WPB + wave; grp < ngroups; grp += (size_t) gridDim.x * WPB) {
         // (lane groups beyond the last item redo it: the same values to the same places, no branch anywhere in the loop)
-        const size_t item = grp * IPW + o, it = post_item(a, item < a.items ? item : a.items - 1);
+        const size_t item = grp * IPW + o, item_c = item < n_items ? item : n_items - 1;
+        const size_t it = a.fix_list ? (size_t) a.fix_list[item_c] : post_item(a, item_c);
+        // stage_a = auto: which lanes have found half of a batch of their pair products under the threshold / a non-zero one at
+        // all (wave masks in scalar registers: nothing of this stays in vector registers through the transforms).  A lane's
+        // products are spread evenly over the chunk (n = l + LPI k), so "half of them small" is a statement about the chunk's in-band
+        // level that a few large samples -- the filter's edge transients under a strong out-of-band signal -- do not undo
+        unsigned long long m_weak = 0, m_any = 0;
         // ---- pair angles: x[k] = a[2n] + i a[2n+1], n = l + LPI k (demodulation.py:25-32) -------------------------------
         cd x[P];
         if constexpr (PAIRS) {
@@ -203,6 +213,20 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : (p8_halves(LP
 #pragma unroll
                     for (int k = 0; k < P / 2; ++k) { pp[k][0] = y[2 * (l + LPI * (k0 + k))]; pp[k][1] = y[2 * (l + LPI * (k0 + k)) + 1]; }
                     __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (LPI != 4) {              // (four lanes per item: float32 records, which stage_a = auto does not look at twice)
+                        double big = 0.0;
+                        int weak = 0;
+#pragma unroll
+                        for (int k = 0; k < P / 2; ++k)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const double mag = fmax(fabs(pp[k][u].re), fabs(pp[k][u].im));
+                                weak += mag < a.cond_thr ? 1 : 0;
+                                big = fmax(big, mag);
+                            }
+                        m_weak |= __ballot(weak >= P / 2);
+                        m_any |= __ballot(big > 0.0);
+                    }
 #pragma unroll
                     for (int k = 0; k < P / 2; ++k) x[k0 + k] = mk(atan2_pi(pp[k][0].im, pp[k][0].re), atan2_pi(pp[k][1].im, pp[k][1].re));
                     __builtin_amdgcn_sched_barrier(0);
@@ -212,9 +236,24 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : (p8_halves(LP
 #pragma unroll
             for (int k = 0; k < P; ++k) { pp[k][0] = y[2 * (l + LPI * k)]; pp[k][1] = y[2 * (l + LPI * k) + 1]; }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LPI != 4) {
+                double big = 0.0;
+                int weak = 0;
+#pragma unroll
+                for (int k = 0; k < P; ++k)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const double mag = fmax(fabs(pp[k][u].re), fabs(pp[k][u].im));
+                        weak += mag < a.cond_thr ? 1 : 0;
+                        big = fmax(big, mag);
+                    }
+                m_weak |= __ballot(weak >= P);
+                m_any |= __ballot(big > 0.0);
+            }
 #pragma unroll
             for (int k = 0; k < P; ++k) x[k] = mk(atan2_pi(pp[k][0].im, pp[k][0].re), atan2_pi(pp[k][1].im, pp[k][1].re));
             }
+
         } else {
             const cd *y = (const cd *) a.y + it * (size_t) M;
             const cd *R = a.iq_R ? (const cd *) a.iq_R + (it / a.n_chunks) * (size_t) M : nullptr;
@@ -484,6 +523,18 @@ __global__ __launch_bounds__(64 * WPB, LPI == 16 && WPB == 8 ? 1 : (p8_halves(LP
             // a few blocks at a time: enough independent work for the pipeline, few enough intermediate values for the registers
             if constexpr (n1 % BA == BA - 1) __builtin_amdgcn_sched_barrier(0);
         });
+        if constexpr (PAIRS && LPI != 4) {
+            if (a.cond_list) {
+                // (at the end of the item, where nothing else is alive) some lane of the item's LPI has found half of a batch of its
+                // pair products under the threshold, and not all were zero (silence is exact on every path): the in-band content of
+                // this (chunk, row) is near the operator image of the int8 forms -- listed for the float64 pass
+                const unsigned long long grp_mask = ((LPI == 64 ? 0ull : (1ull << LPI)) - 1ull) << (o * LPI);
+                if (l0 && grp * IPW + o < n_items && (m_weak & grp_mask) != 0 && (m_any & grp_mask) != 0) {
+                    const unsigned slot = atomicAdd(a.cond_count, 1u);
+                    a.cond_list[slot] = (int) (a.fix_list ? (size_t) a.fix_list[grp * IPW + o] : post_item(a, grp * IPW + o));
+                }
+            }
+        }
     }
 }
 

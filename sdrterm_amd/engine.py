@@ -267,6 +267,13 @@ class Engine:
         finally:
             d_raw.free()
 
+    @property
+    def refined_items(self) -> int:
+        """stage_a='auto': (chunk, row) items done a second time in float64 so far (include/sdrterm_hip.h: sdrt_refined_items)."""
+        n = C.c_ulonglong(0)
+        nat.check(nat.lib().sdrt_refined_items(self._ctx, C.byref(n)))
+        return int(n.value)
+
     def profile(self, enable: bool = True):
         nat.check(nat.lib().sdrt_profile_enable(self._ctx, int(enable)))
 

@@ -12,6 +12,7 @@ cd /tmp
 ARGS="--steps 3 --warmup 1 --settle-seconds 0.5 --long-seconds 0 --no-cpu-baseline --no-same-arithmetic --no-parity ${BENCH_ARGS:-}"
 WL=$(echo " ${BENCH_ARGS:-}" | sed -n 's/.*--workload[ =]\([a-z0-9]*\).*/\1/p'); WL=${WL:-fm64}
 case " ${BENCH_ARGS:-} " in *" --correct-iq "*) case $WL in simo8) ;; *) WL=${WL}_iq ;; esac ;; esac
+case " ${BENCH_ARGS:-} " in *" --faithful "*) WL=${WL}_faithful ;; esac
 export BENCH_WORKLOAD=$WL
 pass() {
     name=$1; shift
