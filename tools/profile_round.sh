@@ -30,5 +30,15 @@ for w in fm64f fm64b fm16 fm2 simo8 simo64 f32x256; do
     python3 "$ROOT/bench.py" --workload $w --steps 300 > "$OUT/${w}_n1.json" 2> "$OUT/${w}.err" || echo "$w failed"
 done
 python3 "$ROOT/bench.py" --correct-iq --steps 300 > "$OUT/fm64_correct_iq.json" 2> "$OUT/fm64_correct_iq.err" || echo "fm64 --correct-iq failed"
+# float32 records in the reference's own complex64 arithmetic (sdrt_config.faithful_f32)
+python3 "$ROOT/bench.py" --workload fm64f --faithful --steps 20 --warmup 2 > "$OUT/fm64f_faithful_n1.json" 2> "$OUT/fm64f_faithful.err" || echo "fm64f --faithful failed"
+python3 "$ROOT/bench.py" --workload f32x256 --faithful --steps 20 --warmup 2 > "$OUT/f32x256_faithful_n1.json" 2> "$OUT/f32x256_faithful.err" || echo "f32x256 --faithful failed"
+# the second look of stage_a = auto costs the headline nothing: the same run without it
+SDRTERM_DIAG=refine=0 python3 "$ROOT/bench.py" --steps 300 --no-cpu-baseline --no-same-arithmetic > "$OUT/fm64_without_second_look.json" 2> /dev/null || echo "refine=0 failed"
+# counter records of the other workloads (tools/pmc.sh), each stamped with the commit
+for a in "--workload fm2" "--workload fm16" "--workload fm64b" "--workload simo8" "--workload simo64" "--workload f32x256" "--workload f32x256 --faithful" "--workload fm64f --faithful"; do
+    BENCH_ARGS="$a" bash "$ROOT/tools/pmc.sh" > /dev/null 2>&1
+done
+cp "$ROOT"/gpurun_out/pmc/summary_*.txt "$ROOT"/gpurun_out/pmc/pmc_record_*.json "$OUT"/ 2>/dev/null
 python3 "$ROOT/tools/bench_extra.py" > "$OUT/secondary_workloads.jsonl" 2> "$OUT/secondary.err"
 echo "workloads done"
