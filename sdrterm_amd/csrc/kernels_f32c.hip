@@ -98,6 +98,52 @@ __global__ __launch_bounds__(256) void f32c_prep_kernel(const F32cArgs a) {
         if (t0 + tt < N) w[(size_t) (t0 + tt) * 64 + lane] = tile[tt][lane];
 }
 
+// The same when the rows are a multiple of 64 (the many-row --simo layouts): a group is 64 consecutive rows of ONE chunk, so a
+// workgroup keeps its (row group, time tile) share of the shift table in registers -- sixteen entries per thread -- and walks over
+// kCPB chunks with it: the table is read once per kCPB chunks instead of once per chunk (it was half of this pass's traffic, from L2),
+// and a chunk's records once per wave instead of once per row.
+constexpr int kCPB = 16;
+__global__ __launch_bounds__(256) void f32c_prep_rows_kernel(const F32cArgs a) {
+    __shared__ f2 tile[64][65];
+    const int N = a.n + 2 * kEdge, tiles = (N + 63) / 64, RQ = a.rows / 64;
+    const int rq = (int) (blockIdx.x % RQ);
+    const size_t rest = blockIdx.x / RQ;
+    const int t0 = (int) (rest % tiles) * 64;
+    const size_t c0 = (rest / tiles) * kCPB, c1 = c0 + kCPB < a.n_chunks ? c0 + kCPB : a.n_chunks;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int e = t0 + lane, k = e - kEdge;
+    const bool middle = k >= 0 && k < a.n;              // a sample of the chunk itself (the extension takes two: the general way)
+    double tr[16], ti[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const double *sr = a.shift + ((size_t) (rq * 64 + wv + 4 * i) * a.n + (middle ? k : 0)) * 2;
+        tr[i] = sr[0];
+        ti[i] = sr[1];
+    }
+    for (size_t c = c0; c < c1; ++c) {
+        const uint32_t *cr = (const uint32_t *) a.raw + c * (size_t) a.n * 2;
+        double ar = 0.0, ai = 0.0;
+        if (middle) { ar = (double) f32_record(cr + 2 * (size_t) k, a.swap); ai = (double) f32_record(cr + 2 * (size_t) k + 1, a.swap); }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            f2 v = {0.0f, 0.0f};
+            if (middle) {
+                const double pi = ai * ti[i], pr = ai * tr[i];
+                v.x = (float) fma(ar, tr[i], -pi);
+                v.y = (float) fma(ar, ti[i], pr);
+            } else if (e < N) {
+                v = extended(cr, a.shift + (size_t) (rq * 64 + wv + 4 * i) * a.n * 2, e, a.n, a.swap);
+            }
+            tile[lane][wv + 4 * i] = v;
+        }
+        __syncthreads();
+        f2 *w = (f2 *) a.work + (c * RQ + rq) * (size_t) N * 64;
+        for (int tt = wv; tt < 64; tt += 4)
+            if (t0 + tt < N) w[(size_t) (t0 + tt) * 64 + lane] = tile[tt][lane];
+        __syncthreads();
+    }
+}
+
 struct Sos {
     float b0[kNS], b1[kNS], b2[kNS], a1[kNS], a2[kNS];
 };
@@ -193,6 +239,10 @@ hipError_t launch_f32c(const F32cArgs &a, hipStream_t s) {
     if (!groups) return hipSuccess;
     const size_t tiles = (size_t) (a.n + 2 * kEdge + 63) / 64;
     if (groups * tiles > 0x7fffffffull) return hipErrorInvalidValue;
+    if (a.shift && a.rows % 64 == 0) {
+        const size_t blocks = (size_t) (a.rows / 64) * tiles * ((a.n_chunks + kCPB - 1) / kCPB);
+        hipLaunchKernelGGL(f32c_prep_rows_kernel, dim3((unsigned) blocks), dim3(256), 0, s, a);
+    } else
     hipLaunchKernelGGL(f32c_prep_kernel, dim3((unsigned) (groups * tiles)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(f32c_seq_kernel, dim3((unsigned) groups), dim3(64), 0, s, a);
     return hipGetLastError();

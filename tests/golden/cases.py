@@ -140,6 +140,10 @@ CASES = [
     _c('h_q64_fm_blk100', 'h', 64, 'fm', center=15625, seed=95, sig=dict(kind='blocker', a1=32000, f1=215625, f2=16625, db=-100)),
     _c('h_q64_fm_blk110', 'h', 64, 'fm', center=15625, seed=96, sig=dict(kind='blocker', a1=32000, f1=215625, f2=16625, db=-110)),
     _c('h_q64_fm_blk120', 'h', 64, 'fm', center=15625, seed=97, sig=dict(kind='blocker', a1=32000, f1=215625, f2=16625, db=-120)),
+    # the same class at 1024 outputs per chunk (the sixteen-lanes-per-item demodulation stage) and with two rows of which only one
+    # is weak (the other sits ON the strong tone): the second look of stage_a = auto is per (chunk, row)
+    _c('h_q32_fm_blk120', 'h', 32, 'fm', center=15625, seed=98, sig=dict(kind='blocker', a1=32000, f1=215625, f2=16625, db=-120)),
+    _c('h_q64_fm_blk120_vfo2', 'h', 64, 'fm', center=15625, vfos='200000', seed=99, sig=dict(kind='blocker', a1=32000, f1=215625, f2=16625, db=-120)),
 ]
 
 BY_NAME = {c['name']: c for c in CASES}

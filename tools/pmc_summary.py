@@ -17,12 +17,12 @@ for pas in sorted(os.listdir(out)):
             k = r.get('Kernel_Name', '')
             if 'chain' not in k and 'post' not in k and 'iq_' not in k and 'preslice' not in k and 'f32c' not in k:
                 continue
-            acc[k.split('(')[0][:64]][r['Counter_Name']].append(float(r['Counter_Value']))
+            acc[k.replace('(anonymous namespace)::', '').split('(')[0][:64]][r['Counter_Name']].append(float(r['Counter_Value']))
     for f in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r.get('Kernel_Name', '')
             if 'chain' in k or 'post' in k or 'iq_' in k or 'preslice' in k or 'f32c' in k:
-                dur[k.split('(')[0][:64]].append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) * 1e-6)
+                dur[k.replace('(anonymous namespace)::', '').split('(')[0][:64]].append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) * 1e-6)
 
 def big(vals):
     """the workload's launches (sdrt_create also runs small one-chunk launches)"""
