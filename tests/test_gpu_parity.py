@@ -55,7 +55,7 @@ def stage_a(request, monkeypatch):
 #    Under stage_a = auto that (chunk, row) is recognised and done again in float64: within the tolerance.
 STATED_LIMITS = {
     ('h_q64_fm_zero_iq_dc_c', 'auto'): 5e-5, ('h_q64_fm_zero_iq_dc_c', 'i8'): 5e-5, ('h_q64_fm_zero_iq_dc_c', 'f64'): 5e-5,
-    ('h_q64_fm_blk120', 'i8'): 5e-6,
+    ('h_q64_fm_blk120', 'i8'): 5e-6, ('h_q32_fm_blk120', 'i8'): 1e-5, ('h_q64_fm_blk120_vfo2', 'i8'): 5e-6,
 }
 
 
