@@ -547,7 +547,7 @@ def main():
         dt_long = max(over_ranks(time.perf_counter() - t1))
         steady = {'steps': n_long, 'seconds': round(dt_long, 3), 'ms_per_step': round(dt_long / n_long * 1e3, 4)}
 
-    KERNEL_OF = {'i8w': 'chain_i8w_kernel', 'i8t': 'chain_i8t_kernel', 'f64': 'chain_kernel', 'seq': 'chain_seq_kernel', 'f32c': 'f32c_seq_kernel'}
+    KERNEL_OF = {'i8w': 'chain_i8w_kernel', 'i8t': 'chain_i8t_kernel', 'f64': 'chain_kernel', 'seq': 'chain_seq_kernel', 'f32c': 'f32c_seq_kernel', 'sq': 'chain_sq_kernel'}
     if rank == 0:
         per_gpu = 1 if scaling == 'strong' else world
         total_samples = float(n_samples) * args.steps * per_gpu
@@ -566,6 +566,9 @@ def main():
         # (decimation below 32: 256 / q / 8 passes of the eight-outputs-per-column form)
         mfma_table = {'h': {64: 184, 32: 216, 16: 2 * 216, 8: 4 * 216, 4: 8 * 216}, 'f': {64: 288, 32: 336}, 'B': {64: 104, 32: 120, 16: 2 * 120, 8: 4 * 120}}
         mfma_per_tile = (mfma_table[code].get(q, 0) + (16 if fused_iq else 0) or None) if eng.stage_a == 'i8w' else ({'h': 160, 'f': 224}.get(code) if eng.stage_a == 'i8t' else None)
+        if eng.stage_a == 'sq':
+            # one pass: two aggregate row tiles + 2 x (256 / q) / 16 local row tiles, 72 matrix instructions each per 4096-sample tile
+            mfma_per_tile = 72 * (2 + 32 // q)
         i8_ops = mfma_per_tile * 32768.0 * rows * n_samples / 4096 if mfma_per_tile else None
         # hardware counters cannot be read from inside this run: the committed record of rocprofv3 passes over this very workload
         # (tools/pmc.sh) is quoted under "from_profile", with the file it comes from and the commit it was taken at; traffic is per
@@ -623,7 +626,7 @@ def main():
             'scaling': scaling, 'vs_baseline': None,
             # what the arithmetic is: int8 x int8 -> int32 matrix products of 5 base-256 weight digits x 2 byte slices (exact),
             # recombined and finished in fp64; 'f64' when the fp64 matrix-core kernel runs
-            'dtype': ('f32->4 x i8 block fixed point, i8x5-split+f64' if code == 'f' else 'i8x5-split+f64') if eng.stage_a in ('i8w', 'i8t')
+            'dtype': ('f32->4 x i8 block fixed point, i8x5-split+f64' if code == 'f' else 'i8x5-split+f64') if eng.stage_a in ('i8w', 'i8t', 'sq')
                      else ("c64 (the reference's own arithmetic for float32 records) + f64" if eng.stage_a == 'f32c' else 'f64'), 'data': 'synthetic',
             'config': {'workload': (f'configs[1]{"" if code == "h" and q == 64 else (f" as {ENC_NAME[code]} records" if code != "h" else f" at decimation {q}")}: {FS // 1_000_000} MS/s synthetic {ENC_NAME[code]} IQ (FM tone + noise), FM demod, dec={q}, single VFO, '
                                     f'center={CENTER} Hz{", --correct-iq" if correct_iq else ""}, {n_chunks} chunks x {N} samples per GPU per step, inputs resident in HBM')

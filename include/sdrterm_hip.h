@@ -301,7 +301,8 @@ int sdrt_selftest_mfma_i8(int *mismatches);
 /* Which stage-A kernel the context uses: 0 = fp64 matrix cores; 2 = int8 matrix cores with exact integer slicing, one
  * block per column (16x16x64); 3 = the same arithmetic in the wide-column persistent kernel (default for 8/16-bit integer
  * encodings at decimation 32 / 64); 4 = the per-sample modal form in fp64 (decimation 2 and 4); 5 = the reference's complex64
- * recurrence for float32 records (sdrt_config.faithful_f32).  0 - 4 meet the same tolerance; sdrt_config.stage_a chooses among them. */
+ * recurrence for float32 records (sdrt_config.faithful_f32); 6 = decimation 2 .. 16 of 16-bit records in one pass on the int8 matrix
+ * cores.  0 - 4 and 6 meet the same tolerance; sdrt_config.stage_a chooses among them. */
 int sdrt_stage_a_kind(const sdrt_ctx *ctx);
 /* stage_a = SDRT_STAGE_AUTO: how many (chunk, row) items this context has done a second time in float64 so far (their in-band
  * content lay near the int8 forms' operator image; DESIGN.md section 1, "Conditioning").  Synchronises the device. */

@@ -136,6 +136,11 @@ struct sdrt_ctx {
     unsigned *d_cond_count = nullptr; //   [2] listed by the launch in flight; running total
     size_t refine_cap = 0;
     int stage = SDRT_STAGE_AUTO;      // enum sdrt_stage_a in effect (sdrt_config.stage_a unless SDRTERM_STAGE_A overrides it)
+    bool use_sq = false;              // decimation 2 .. 16 of 16-bit records in one pass on the int8 matrix cores (kernels_sq.hip)
+    SqTables *d_sqtab = nullptr;
+    double *d_sq_share = nullptr;
+    signed char *d_sq_agg = nullptr, *d_sq_master = nullptr;
+    double sq_comb_agg = 0.0, sq_comb_loc = 0.0;
     bool f32c = false;                // float32 records in the reference's complex64 arithmetic (sdrt_config.faithful_f32, kernels_f32c.hip)
     F32cArgs f32c_args;               //   coefficient tables
     double *d_shift_tab = nullptr;    //   [rows][n][2] the host's shift table
@@ -494,6 +499,73 @@ int setup_pass_ybias(sdrt_ctx *c) {
     return SDRT_OK;
 }
 
+int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybuf, hipStream_t s, int n_cus, bool fix_later = false, bool pair_out = false,
+                  bool row_pairs = false);
+
+// Decimation 2 .. 16 of 16-bit records in one pass (kernels_sq.hip): the context's tables, every row's planes (NCO folded in), and
+// ybias = - (the kernel's own response to an all-zero chunk) + normalisation bias x (its response to a unit chunk - that): the
+// constant the byte slices leave out and the bias of --normalize-input come back exactly as the kernel itself sees constants, so a
+// silent chunk cancels to the bit (section 1 of DESIGN.md).  `tab`: the context's DecimTables with the data scale applied.
+int setup_sq(sdrt_ctx *c, const sdrt_config *cfg, const DecimTables &tab) {
+    const int q = cfg->decimation, n = cfg->n_samples, S = SDRT_I8_DIGITS, LC = SDRT_SQ_LC, m = c->m;
+    const int nout = LC / q, ncp = 2 * q >= 16 ? 1 : 16 / (2 * q);
+    SqTables st;
+    std::vector<double> share((size_t) nout * 8 * 2);
+    if (sdrt_build_sq_tables(&tab, q, &st, share.data()) != 0) return SDRT_OK;       // (not this form: the others take over)
+    const size_t per_agg = (size_t) 2 * S * (LC / 32) * 64 * 16, per_master = (size_t) 2 * S * ncp * SDRT_SQ_MASTER;
+    std::vector<signed char> agg(per_agg * c->rows), master(per_master * c->rows);
+    std::vector<double> samp((size_t) c->rows * LC * 2), col((size_t) c->rows * (n / LC) * 2);
+    for (int r = 0; r < c->rows; ++r) {
+        double ca = 0.0, cl = 0.0;
+        double *sp = &samp[(size_t) r * LC * 2];
+        if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, LC, n / LC, sp, &col[(size_t) r * (n / LC) * 2]);
+        if (sdrt_build_sq_row(&tab, q, c->nco ? sp : nullptr, S, agg.data() + per_agg * r, &ca, master.data() + per_master * r, &cl) != 0) return SDRT_OK;
+        if (r == 0) { c->sq_comb_agg = ca; c->sq_comb_loc = cl; }
+        else if (ca != c->sq_comb_agg || cl != c->sq_comb_loc) return SDRT_OK;      // one power-of-two scale per context
+    }
+    int rc = upload(&c->d_sqtab, &st, sizeof(st));
+    if (rc == SDRT_OK) rc = upload(&c->d_sq_share, share.data(), share.size() * sizeof(double));
+    if (rc == SDRT_OK) rc = upload(&c->d_sq_agg, agg.data(), agg.size());
+    if (rc == SDRT_OK) rc = upload(&c->d_sq_master, master.data(), master.size());
+    if (rc == SDRT_OK && c->nco) {
+        rc = upload(&c->d_nco_tile8, samp.data(), samp.size() * sizeof(double));
+        if (rc == SDRT_OK) rc = upload(&c->d_nco_phase8, col.data(), col.size() * sizeof(double));
+    }
+    if (rc != SDRT_OK) return rc;
+    c->use_sq = true;
+    // ybias from the kernel's own responses
+    const size_t cnt = (size_t) c->rows * m * 2, cb = (size_t) n * 4;
+    if (hipMalloc(&c->d_ybias, cnt * sizeof(double)) != hipSuccess) return fail(SDRT_ENOMEM, "hipMalloc failed");
+    double *d_bias = c->d_ybias;
+    c->d_ybias = nullptr;                                            // (the calibration runs without it)
+    void *d_in = nullptr;
+    double *d_r = nullptr;
+    if (hipMalloc(&d_in, cb) != hipSuccess || hipMalloc(&d_r, cnt * sizeof(double)) != hipSuccess) rc = fail(SDRT_ENOMEM, "hipMalloc failed");
+    std::vector<double> r0(cnt), r1(cnt), bias(cnt);
+    std::vector<unsigned char> unit(cb, 0);
+    auto respond = [&](std::vector<double> &dst) {
+        if (rc == SDRT_OK && hipMemcpy(d_in, unit.data(), cb, hipMemcpyHostToDevice) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemcpy failed");
+        if (rc == SDRT_OK) rc = enqueue_chain(c, d_in, 1, d_r, nullptr, c->n_cus);
+        if (rc == SDRT_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(SDRT_EHIP, "calibration kernel failed");
+        if (rc == SDRT_OK && hipMemcpy(dst.data(), d_r, cnt * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemcpy failed");
+    };
+    respond(r0);                                                     // all-zero records
+    if (rc == SDRT_OK && c->norm_bias != 0.0) {
+        // records with re = 1, im = 0 (in the records' byte order)
+        const bool be = cfg->swap_endianness != 0;
+        for (int i = 0; i < n; ++i) unit[(size_t) i * 4 + (be ? 1 : 0)] = 1;
+        respond(r1);
+    }
+    if (rc == SDRT_OK) {
+        for (size_t i = 0; i < cnt; ++i) bias[i] = -r0[i] + (c->norm_bias != 0.0 ? c->norm_bias * (r1[i] - r0[i]) : 0.0);
+        if (hipMemcpy(d_bias, bias.data(), cnt * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemcpy failed");
+    }
+    c->d_ybias = d_bias;
+    (void) hipFree(d_in);
+    (void) hipFree(d_r);
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -622,7 +694,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
     c->f32c = f32c;
     const size_t lds = seq || f32c ? 0 : chain_lds_bytes(n, L, m);
     const bool f64_fits = lds <= 160 * 1024;
-    if (!f64_fits && !(chain_i8w_supported(q, cfg->dtype, n, cfg->correct_iq != 0) && c->norm_bias == 0.0)) {
+    if (!f64_fits && !(chain_i8w_supported(q, cfg->dtype, n, cfg->correct_iq != 0) && c->norm_bias == 0.0) && !(chain_sq_supported(q, cfg->dtype, n) && !cfg->correct_iq)) {
         delete c;
         return fail(SDRT_EINVAL, "chunk needs %zu bytes of LDS (> 160 KiB): n_samples/decimation combination unsupported", lds);
     }
@@ -772,7 +844,15 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         // one prefix pass instead of each recomputing them (diagnostics: SDRTERM_DIAG=iq_fused=0 / 1 forces either)
         c->iq_fused = c->iq && c->rows == 1;
         if (const char *e = sdrt_diag("iq_fused")) c->iq_fused = c->iq && atoi(e) != 0;
-        if (seq && !(want_i8 && !c->iq && c->norm_bias == 0.0 && chain_i8w_supported(q, cfg->dtype, n, c->iq))) {
+        // decimation 2 .. 16 of 16-bit records: ONE pass on the matrix cores (kernels_sq.hip; diagnostics: sq=0 keeps the passes of the
+        // wide kernel / the per-sample kernel)
+        if (want_i8 && !want_t && !c->iq && chain_sq_supported(q, cfg->dtype, n) && sdrt_diag_int("sq", 1) != 0) {
+            rc = setup_sq(c, cfg, tab);
+            if (c->use_sq) c->use_seq = false;
+        }
+        if (c->use_sq || rc != SDRT_OK) {
+            // (set up above)
+        } else if (seq && !(want_i8 && !c->iq && c->norm_bias == 0.0 && chain_i8w_supported(q, cfg->dtype, n, c->iq))) {
             // nothing to set up: the per-sample form reads DecimTables only
         } else if (want_i8 && !want_t && chain_i8w_supported(q, cfg->dtype, n, c->iq) && chain_i8w_lds_bytes(q, n, c->iq ? (c->iq_fused ? 2 : 1) : 0, cfg->dtype) <= 160 * 1024)
             rc = setup_wide(c, cfg, scale_tables);
@@ -785,7 +865,7 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         c->f32_pre = c->use_i8w && cfg->dtype == SDRT_F32 && c->rows >= 4;
         if (const char *e = sdrt_diag("f32_pre")) c->f32_pre = c->use_i8w && cfg->dtype == SDRT_F32 && atoi(e) != 0;
     }
-    if (rc == SDRT_OK && !f64_fits && !c->use_i8w)
+    if (rc == SDRT_OK && !f64_fits && !c->use_i8w && !c->use_sq)
         rc = fail(SDRT_EINVAL, "chunk needs %zu bytes of LDS (> 160 KiB) on the fp64 kernel and the int8 form does not apply: n_samples/decimation combination unsupported", lds);
     if (rc == SDRT_OK && c->use_i8w && c->stage == SDRT_STAGE_AUTO && !c->iq && !mixed && f64_fits && c->more_passes.empty() && any_fm
         && (cfg->dtype == SDRT_S8 || cfg->dtype == SDRT_U8 || cfg->dtype == SDRT_S16 || cfg->dtype == SDRT_U16)) {
@@ -857,6 +937,10 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_iq_agg);
     (void) hipFree(c->d_iq_chunk);
     (void) hipFree(c->d_iq_range);
+    (void) hipFree(c->d_sqtab);
+    (void) hipFree(c->d_sq_share);
+    (void) hipFree(c->d_sq_agg);
+    (void) hipFree(c->d_sq_master);
     (void) hipFree(c->d_cond_list);
     (void) hipFree(c->d_cond_count);
     (void) hipFree(c->d_shift_tab);
@@ -999,8 +1083,32 @@ int ensure_pairbufs(sdrt_ctx *c) {
 // fix_later: the share of the IQ offset at each chunk's start (wide-column kernel, fused form) is subtracted by the post
 // kernel while it loads the decimated samples (enqueue_post), not by a pass of its own
 // pair_out: the wide-column kernel writes the products y[2i] conj(y[2i+1]) instead of the samples (FM, PostArgs.pairs)
-int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybuf, hipStream_t s, int n_cus, bool fix_later = false, bool pair_out = false,
-                  bool row_pairs = false) {
+int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybuf, hipStream_t s, int n_cus, bool fix_later, bool pair_out,
+                  bool row_pairs) {
+    if (c->use_sq) {
+        SqArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.raw = raw_dev;
+        sa.ydec = ybuf;
+        sa.n_chunks = n_chunks;
+        sa.n = c->cfg.n_samples;
+        sa.m = c->m;
+        sa.rows = c->rows;
+        sa.swap = c->cfg.swap_endianness;
+        sa.pair_out = pair_out ? 1 : 0;
+        sa.tab = c->d_sqtab;
+        sa.share = c->d_sq_share;
+        sa.agg = c->d_sq_agg;
+        sa.master = c->d_sq_master;
+        sa.nco_samp = c->nco ? c->d_nco_tile8 : nullptr;
+        sa.nco_col = c->nco ? c->d_nco_phase8 : nullptr;
+        sa.ybias = c->d_ybias;
+        sa.comb_agg = c->sq_comb_agg;
+        sa.comb_loc = c->sq_comb_loc;
+        Timed t(c, s, 0);
+        HIP_TRY(launch_chain_sq(sa, c->cfg.decimation, c->cfg.dtype, n_cus, s));
+        return SDRT_OK;
+    }
     if (c->f32c) {
         int rcf = ensure_f32c(c, n_chunks);
         if (rcf != SDRT_OK) return rcf;
@@ -1396,7 +1504,7 @@ int sdrt_process_device_debug(sdrt_ctx *c, const void *raw_dev, size_t n_chunks,
     // between the two stages); not with the offset share still to come
     // (several passes over the chunk: a pass finishes eight consecutive outputs of every column, whole pairs -- SDRTERM_DIAG=pass_pairs=0: samples)
     const bool pass_pairs = sdrt_diag_int("pass_pairs", 1) != 0;
-    const bool pairs = !ydec_dev && c->use_i8w && (c->more_passes.empty() || pass_pairs) && !c->stamps_dev && !later && !c->mixed && post_takes_pairs(post_args(c, ybuf, n_chunks, out_dev, false, true));
+    const bool pairs = !ydec_dev && (c->use_i8w || c->use_sq) && (c->more_passes.empty() || pass_pairs) && !c->stamps_dev && !later && !c->mixed && post_takes_pairs(post_args(c, ybuf, n_chunks, out_dev, false, true));
     // per-row modes: the FM rows' items as pair products, every item in the place its samples would take (eight- and sixteen-tile
     // chunks; the two-chunks-per-item forms keep samples)
     bool row_pairs = false;
@@ -1953,7 +2061,7 @@ int sdrt_refined_items(sdrt_ctx *c, unsigned long long *total) {
     return SDRT_OK;
 }
 
-int sdrt_stage_a_kind(const sdrt_ctx *c) { return c ? (c->f32c ? 5 : c->use_seq ? 4 : c->use_i8w ? 3 : (c->use_i8t ? 2 : (c->use_i8 ? 1 : 0))) : -1; }
+int sdrt_stage_a_kind(const sdrt_ctx *c) { return c ? (c->use_sq ? 6 : c->f32c ? 5 : c->use_seq ? 4 : c->use_i8w ? 3 : (c->use_i8t ? 2 : (c->use_i8 ? 1 : 0))) : -1; }
 
 int sdrt_selftest_mfma_i8(int *mismatches) {
     int bad = 0;

@@ -186,6 +186,23 @@ bool post_big_supported(int m, int mode);
 hipError_t launch_post_big(const PostArgs &a, hipStream_t s);
 bool post_bigfft_supported(const PostArgs &a);        // FM at 4096 .. 16384 outputs per chunk with the packed FFT tables: a workgroup transform
 hipError_t launch_post_bigfft(const PostArgs &a, hipStream_t s);
+// decimation 2 .. 16 of 16-bit records in one pass on the int8 matrix cores (kernels_sq.hip)
+struct SqArgs {
+    const void *raw;            // [n_chunks][n][2] 16-bit records
+    double *ydec;               // [row][chunk][m][2] decimated samples, or with pair_out [row][chunk][m/2][2] products y[2i] conj(y[2i+1])
+    size_t n_chunks;
+    int n, m, rows, swap, pair_out;
+    const SqTables *tab;        // device copy
+    const double *share;        // [256 / q][8][2]   (sdrt_build_sq_tables)
+    const signed char *agg;     // [rows][2][S][8][64][16]      (sdrt_build_sq_row)
+    const signed char *master;  // [rows][2][S][ncp][1024]
+    const double *nco_samp;     // [rows][256][2] exp(i theta j) or NULL (no shift)
+    const double *nco_col;      // [rows][n / 256][2] exp(i theta 256 c)
+    const double *ybias;        // [rows][m][2] or NULL
+    double comb_agg, comb_loc;  // combine factors of the two plane sets (the same for every row)
+};
+bool chain_sq_supported(int q, int dt, int n);
+hipError_t launch_chain_sq(const SqArgs &a, int q, int dt, int n_cus, hipStream_t s);
 // float32 records in the reference's own complex64 arithmetic (kernels_f32c.hip; sdrt_config.faithful_f32)
 struct F32cArgs {
     const void *raw;            // [n_chunks][n][2] float32 records

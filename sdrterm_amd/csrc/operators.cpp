@@ -940,3 +940,116 @@ extern "C" void sdrt_build_wide_edge(const WideTables *wt, const double *nco_sam
         pq[o16 * 4 + 2] = (double) Q.re; pq[o16 * 4 + 3] = (double) Q.im;
     }
 }
+
+// ---- chain_sq_kernel (decimation 2 .. 16 in one pass, kernels_sq.hip) --------------------------------------------------------------
+namespace {
+typedef long double LD;
+struct CL { LD re, im; };
+inline CL cmulL(CL a, CL b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+// p^k, k = 0 .. kmax
+std::vector<CL> powersL(const double *p2, int kmax) {
+    std::vector<CL> r((size_t) kmax + 1);
+    const CL p = {(LD) p2[0], (LD) p2[1]};
+    r[0] = {1.0L, 0.0L};
+    for (int k = 1; k <= kmax; ++k) r[k] = cmulL(r[k - 1], p);
+    return r;
+}
+}  // namespace
+
+extern "C" int sdrt_build_sq_tables(const DecimTables *tab, int q, SqTables *out, double *share) {
+    const int LC = SDRT_SQ_LC;
+    if (!tab || !out || !share || q < 2 || q > 16 || (q & (q - 1))) return -1;
+    memset(out, 0, sizeof(*out));
+    out->q = q;
+    out->nout = LC / q;
+    out->ncp = 2 * q >= 16 ? 1 : 16 / (2 * q);
+    out->nrt = 2 * out->nout / 16;
+    for (int i = 0; i < SDRT_NMODE; ++i) {
+        const std::vector<CL> pw = powersL(tab->pole[i], LC);
+        out->mu[i][0] = (double) pw[LC].re;
+        out->mu[i][1] = (double) pw[LC].im;
+        for (int b = 0; b < out->nout; ++b) {
+            const int s = b * q;
+            share[((size_t) b * 8 + i) * 2 + 0] = (double) (2.0L * pw[s].re);
+            share[((size_t) b * 8 + i) * 2 + 1] = (double) (2.0L * pw[s].im);
+            share[((size_t) b * 8 + 4 + i) * 2 + 0] = (double) (2.0L * pw[LC - s].re);
+            share[((size_t) b * 8 + 4 + i) * 2 + 1] = (double) (2.0L * pw[LC - s].im);
+        }
+    }
+    memcpy(out->head, tab->head, sizeof(out->head));
+    memcpy(out->tailF, tab->tailF, sizeof(out->tailF));
+    memcpy(out->tailFc, tab->tailFc, sizeof(out->tailFc));
+    memcpy(out->tailU, tab->tailU, sizeof(out->tailU));
+    return 0;
+}
+
+extern "C" int sdrt_build_sq_row(const DecimTables *tab, int q, const double *nco_samp, int S, signed char *agg, double *agg_combine,
+                                 signed char *master, double *loc_combine) {
+    const int LC = SDRT_SQ_LC, KS = LC / 32;
+    if (!tab || !agg || !master || q < 2 || q > 16 || (q & (q - 1))) return -1;
+    const int ncp = 2 * q >= 16 ? 1 : 16 / (2 * q);
+    std::vector<CL> pw[SDRT_NMODE];
+    for (int i = 0; i < SDRT_NMODE; ++i) pw[i] = powersL(tab->pole[i], LC);
+    auto phasor = [&](int j) -> CL {                       // exp(i theta j), j in (-256, 256)
+        if (!nco_samp) return {1.0L, 0.0L};
+        const int a = j < 0 ? -j : j;
+        return {(LD) nco_samp[2 * a], j < 0 ? -(LD) nco_samp[2 * a + 1] : (LD) nco_samp[2 * a + 1]};
+    };
+    // column aggregates: row r = 4 mode + 2 stream + part of tile 0 (causal: ac p^(255 - j)) and tile 1 (anticausal: aa p^j); column
+    // 2 j + comp of the 512: what the row takes of component comp of sample j, the sample's phasor exp(i theta j) folded in
+    //   stream re = c xr - s xi,  stream im = s xr + c xi;  part re / im of (w x stream) = w.re / w.im x stream
+    {
+        const int cols = 2 * LC;
+        std::vector<double> W((size_t) 32 * cols);
+        for (int tile = 0; tile < 2; ++tile)
+            for (int i = 0; i < SDRT_NMODE; ++i) {
+                const CL a = tile == 0 ? CL{(LD) tab->ac[i][0], (LD) tab->ac[i][1]} : CL{(LD) tab->aa[i][0], (LD) tab->aa[i][1]};
+                for (int j = 0; j < LC; ++j) {
+                    const CL w = cmulL(a, pw[i][tile == 0 ? LC - 1 - j : j]);
+                    const CL ph = phasor(j);
+                    for (int st = 0; st < 2; ++st)
+                        for (int pt = 0; pt < 2; ++pt) {
+                            const LD wv = pt ? w.im : w.re;
+                            const LD k0 = st == 0 ? ph.re : ph.im, k1 = st == 0 ? -ph.im : ph.re;
+                            const int r = 16 * tile + 4 * i + 2 * st + pt;
+                            W[(size_t) r * cols + 2 * j] = (double) (wv * k0);
+                            W[(size_t) r * cols + 2 * j + 1] = (double) (wv * k1);
+                        }
+                }
+            }
+        *agg_combine = quantise_planes(W.data(), 32, cols, cols, S, [&](int d, int r, int c, signed char dig) {
+            // K position c = 2 j + comp, j = 32 ks + 8 kg + jj: byte 2 jj + comp of lane (kg, row)
+            const int j = c >> 1, comp = c & 1, ks = j >> 5, kg = (j >> 3) & 3, jj = j & 7;
+            agg[((((size_t) (r >> 4) * S + d) * KS + ks) * 64 + (16 * kg + (r & 15))) * 16 + 2 * jj + comp] = dig;
+        });
+        if (*agg_combine == 0.0) return -1;
+    }
+    // local master: m[dd] = h[dd] exp(i theta dd), dd = j - s in (-256, 256);  h[dd] = sum_i 2 Re(aa_i p_i^dd) (dd >= 0, + d0p at 0),
+    // sum_i 2 Re(ac_i p_i^(-dd - 1)) (dd < 0).  Part 0 (real part of the output): (m.re, -m.im) on (re, im); part 1: (m.im, m.re).
+    {
+        const int cols = SDRT_SQ_MASTER;
+        std::vector<double> W((size_t) 2 * cols, 0.0);
+        for (int dd = -(LC - 1); dd <= LC - 1; ++dd) {
+            LD h = dd == 0 ? (LD) tab->d0p : 0.0L;
+            for (int i = 0; i < SDRT_NMODE; ++i) {
+                const CL a = dd >= 0 ? CL{(LD) tab->aa[i][0], (LD) tab->aa[i][1]} : CL{(LD) tab->ac[i][0], (LD) tab->ac[i][1]};
+                h += 2.0L * cmulL(a, pw[i][dd >= 0 ? dd : -dd - 1]).re;
+            }
+            const CL ph = phasor(dd);
+            const int pos = 2 * (dd + 256);
+            W[(size_t) 0 * cols + pos] = (double) (h * ph.re);
+            W[(size_t) 0 * cols + pos + 1] = (double) (-h * ph.im);
+            W[(size_t) 1 * cols + pos] = (double) (h * ph.im);
+            W[(size_t) 1 * cols + pos + 1] = (double) (h * ph.re);
+        }
+        memset(master, 0, (size_t) 2 * S * ncp * SDRT_SQ_MASTER);
+        *loc_combine = quantise_planes(W.data(), 2, cols, cols, S, [&](int d, int r, int c, signed char dig) {
+            for (int cp = 0; cp < ncp; ++cp) {
+                const int y = c + 2 * cp * q;                      // copy cp: the sequence delayed by 2 cp q bytes
+                if (y < SDRT_SQ_MASTER) master[(((size_t) r * S + d) * ncp + cp) * SDRT_SQ_MASTER + y] = dig;
+            }
+        });
+        if (*loc_combine == 0.0) return -1;
+    }
+    return 0;
+}

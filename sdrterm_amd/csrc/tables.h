@@ -57,6 +57,22 @@ struct WideTables {
     double tailU[SDRT_NMODE][SDRT_EDGE + 1][2];
 };
 
+// One-pass form for decimation 2 .. 16 on the int8 matrix cores (chain_sq_kernel, kernels_sq.hip).  A column
+// is 256 samples with all of its nout = 256 / q outputs; the part of output b (at sample s = b q of the column) that depends on the
+// column's own samples is a convolution, row b = ONE master sequence h[j - s] e^(i theta (j - s)) shifted by s, so the local operator
+// is 2 x S x ncp x 1 KB of digit bytes instead of nout x 2 x 512 bytes per digit; the column states are the modal states of the
+// per-sample form of DecimTables (pole / ac / aa) at the column boundaries.
+#define SDRT_SQ_LC 256
+#define SDRT_SQ_MASTER 1024          // bytes per (part, digit, copy) of the master sequence: position 2 (d + 256) + component
+struct SqTables {
+    int32_t q, nout, ncp, nrt;                   // outputs per column; byte-alignment copies of the master (16 / (2 q), at least 1); row tiles of 16
+    double mu[SDRT_NMODE][2];                    // p_i^256: column to column
+    double head[SDRT_NMODE][SDRT_EDGE + 1][2];   // edge operators, as in DecimTables
+    double tailF[SDRT_NMODE][SDRT_NMODE][2];
+    double tailFc[SDRT_NMODE][SDRT_NMODE][2];
+    double tailU[SDRT_NMODE][SDRT_EDGE + 1][2];
+};
+
 // Output lowpass (scipy sosfilt, zero initial state per chunk) in parallel modal form for a 64-lane (one wave) scan:
 //   y[t] = D x[t] + sum_k Re(r_k s_k(t)),   s_k(t+1) = p_k s_k(t) + x[t],   s_k(0) = 0
 // r_k already carries the weight 2 for a complex pole that stands for its conjugate pair too.
@@ -197,6 +213,15 @@ void sdrt_build_wide_edge(const struct WideTables *wt, const double *nco_samp, c
 
 // Packed (real-input) form of the FM resampler's transform tables: see operators.cpp.  tw [N/2][2], ab [N/2][4].
 void sdrt_build_fft_resample_packed(int N, double *tw, double *ab);
+// chain_sq_kernel: `tab` is the context's DecimTables (data scale applied).  share: [256 / q][8][2] = 2 p_i^(b q) (i < 4), then
+// 2 p_i^(256 - b q): what the states at the column's start / end add to output b (inside 2 Re).
+int sdrt_build_sq_tables(const struct DecimTables *tab, int q, struct SqTables *out, double *share);
+// One row's digit planes: agg [2 tiles][S][8 k-steps][64 lanes][16] (A-operand order; tile 0 causal, 1 anticausal column aggregates,
+// row 4 mode + 2 stream + part, the within-column NCO phasor folded in) and master [2 parts][S][ncp][SDRT_SQ_MASTER] (part 0 / 1:
+// what the real / imaginary part of an output takes of (re, im) of the samples; copy c = the sequence delayed by 2 c q bytes).
+// nco_samp: [256][2] exp(i theta j) or NULL.  Returns 0, or -1 when a plane set does not fit S digits.
+int sdrt_build_sq_row(const struct DecimTables *tab, int q, const double *nco_samp, int S, signed char *agg, double *agg_combine,
+                      signed char *master, double *loc_combine);
 
 // IQ-correction geometric weights: pw[j] = (1-lambda)^j, j <= count.
 void sdrt_build_iq_pow(double lambda, int count, double *pw);

@@ -161,7 +161,7 @@ class Engine:
         self._ctx = C.c_void_p()
         nat.check(nat.lib().sdrt_create(C.byref(cfg), C.byref(self._ctx)))
         self.m = nat.lib().sdrt_out_per_chunk(self._ctx)
-        self.stage_a = {0: 'f64', 2: 'i8t', 3: 'i8w', 4: 'seq', 5: 'f32c'}[nat.lib().sdrt_stage_a_kind(self._ctx)]   # which stage-A kernel runs
+        self.stage_a = {0: 'f64', 2: 'i8t', 3: 'i8w', 4: 'seq', 5: 'f32c', 6: 'sq'}[nat.lib().sdrt_stage_a_kind(self._ctx)]   # which stage-A kernel runs
         self.chunk_bytes = self.n * 2 * nat.ITEM_SIZE[code]
         if reserve_chunks:
             # device scratch for batches up to this size now, none inside the processing calls (include/sdrterm_hip.h: sdrt_reserve)

@@ -78,7 +78,7 @@ def test_golden_parity(case, golden, stage_a):
         pass
     elif stage_a == 'f64':
         assert eng.stage_a in ('f64', 'seq')         # decimation < 8 always takes the per-sample fp64 form
-    elif stage_a in ('auto', 'i8') and eng.stage_a not in ('i8w', 'i8t'):
+    elif stage_a in ('auto', 'i8') and eng.stage_a not in ('i8w', 'i8t', 'sq'):
         pytest.skip(f'{stage_a}: the library uses {eng.stage_a} for this case (covered by another run)')
     elif stage_a not in ('auto', 'i8') and eng.stage_a != stage_a:
         pytest.skip(f'{stage_a}: the library uses {eng.stage_a} for this case (covered by another run)')
@@ -652,7 +652,7 @@ def test_silent_chunks_anywhere_in_a_batch_come_out_as_exact_zeros(code, q, cent
     raw[silent] = 0
     for mode in ('fm', 'am'):
         eng = Engine(fs, q, mode, code, row_freqs=freqs, apply_shift=bool(center or rows > 1), omega_out=5000 if q < 128 else 2500)
-        assert eng.stage_a in ('i8w', 'i8t')
+        assert eng.stage_a in ('i8w', 'i8t', 'sq')
         out = eng.process(raw.tobytes()).reshape(rows, nch, n // q)
         worst = float(np.abs(out[:, silent]).max())
         loud = float(np.abs(out[:, ~silent]).min(axis=2).max())
@@ -772,28 +772,40 @@ def test_every_instantiation_of_the_per_sample_kernel(code, monkeypatch):
     assert worst <= 1e-9
 
 
-@pytest.mark.parametrize('code,q,mode,rows', [('h', 16, 'fm', 3), ('h', 8, 'am', 2), ('H', 16, 'am', 1), ('B', 16, 'fm', 2), ('b', 8, 'fm', 1), ('h', 4, 'fm', 1)])
-def test_small_decimations_in_passes_of_the_wide_kernel(code, q, mode, rows, monkeypatch):
+@pytest.mark.parametrize('form', ['one-pass', 'passes'])
+@pytest.mark.parametrize('code,q,mode,rows', [('h', 16, 'fm', 3), ('h', 8, 'am', 2), ('H', 16, 'am', 1), ('B', 16, 'fm', 2), ('b', 8, 'fm', 1), ('h', 4, 'fm', 1),
+                                              ('h', 2, 'fm', 2), ('H', 2, 'am', 1), ('H', 4, 'fm', 3), ('h', 8, 'fm', 1)])
+def test_small_decimations_in_passes_of_the_wide_kernel(code, q, mode, rows, form, monkeypatch):
     """Decimation 4 / 8 / 16 on the wide-column int8 kernel: a 256-sample column has 64 / 32 / 16 outputs and the kernel finishes eight
     per pass (8 / 4 / 2 passes over the chunk, tables and local planes per pass: api.hip WidePass).  Against oracle/chain.c (the
     reference's chain, dsp_processor.py:140-149) on several rows, FM and AM, odd batch sizes; the bits of a chunk must not depend on
-    the batch it arrives in; and the fp64 kernel forced on the same input must agree to the usual 1e-9 of the decimated peak."""
+    the batch it arrives in; and the fp64 kernel forced on the same input must agree to the usual 1e-9 of the decimated peak.
+    Round 5, form 'one-pass': 16-bit records at decimation 2 .. 16 take chain_sq_kernel instead (kernels_sq.hip: all 256 / q outputs
+    of a column from ONE read of the input, the local operator as windows of one master sequence) -- the same checks; 'passes'
+    keeps the older forms under test (SDRTERM_DIAG=sq=0: they still serve 8-bit records and are what a context falls back to)."""
     from sdrterm_amd.engine import Engine
     from tests.golden import prng
     monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    if form == 'passes':
+        _diag(monkeypatch, sq=0)
+        if q == 2:
+            pytest.skip('decimation 2 without the one-pass kernel is the per-sample kernel (test_every_instantiation_of_the_per_sample_kernel)')
+    elif code in 'bB':
+        pytest.skip('8-bit records keep the passes of the wide kernel')
     fs, n, nch = 1024000, samples_per_chunk(code), 7
     freqs = [15700.0, -203300.0, 100100.0][:rows]
     omega = 60000 if q == 4 else (30000 if q == 8 else 15000)
     raw = prng.raw_bytes(code, n * nch, seed=400 + q, amp=100 if code in 'bB' else 8000)
+    omega = 100000 if q == 2 else omega
     eng = Engine(fs, q, mode, code, row_freqs=freqs, apply_shift=True, omega_out=omega)
-    assert eng.stage_a == 'i8w'
+    assert eng.stage_a == ('sq' if form == 'one-pass' else 'i8w')
     out, y = eng.process_debug(raw)
     m = n // q
     exp = _oracle_rows(raw, code, n, q, mode, freqs, fs, omega, range(nch), range(rows))
     got = out.reshape(rows, nch, m).transpose(1, 0, 2)
     err = float(np.abs(got - exp).max())
     tol = tol_for(exp, mode)
-    print(f'{code} q={q} {mode} x {rows}: {256 // q // 8} passes, max abs err {err:.3e} (tol {tol:.1e})')
+    print(f'{code} q={q} {mode} x {rows} [{eng.stage_a}]: max abs err {err:.3e} (tol {tol:.1e})')
     assert err <= tol
     # the same chunks in another batching: the same bits (process() hands FM over as pair products, process_debug() as samples:
     # the two differ in the last place, test_pair_products_between_the_stages_equal_the_sample_path)
