@@ -512,7 +512,7 @@ int setup_sq(sdrt_ctx *c, const sdrt_config *cfg, const DecimTables &tab) {
     SqTables st;
     std::vector<double> share((size_t) nout * 8 * 2);
     if (sdrt_build_sq_tables(&tab, q, &st, share.data()) != 0) return SDRT_OK;       // (not this form: the others take over)
-    const size_t per_agg = (size_t) 2 * S * (LC / 32) * 64 * 16, per_master = (size_t) 2 * S * ncp * SDRT_SQ_MASTER;
+    const size_t per_agg = (size_t) 2 * S * (LC / 32) * 64 * 16, per_master = (size_t) SDRT_SQ_MASTER_BYTES(q, S, ncp);
     std::vector<signed char> agg(per_agg * c->rows), master(per_master * c->rows);
     std::vector<double> samp((size_t) c->rows * LC * 2), col((size_t) c->rows * (n / LC) * 2);
     for (int r = 0; r < c->rows; ++r) {

@@ -1042,11 +1042,12 @@ extern "C" int sdrt_build_sq_row(const DecimTables *tab, int q, const double *nc
             W[(size_t) 1 * cols + pos] = (double) (h * ph.im);
             W[(size_t) 1 * cols + pos + 1] = (double) (h * ph.re);
         }
-        memset(master, 0, (size_t) 2 * S * ncp * SDRT_SQ_MASTER);
+        memset(master, 0, (size_t) SDRT_SQ_MASTER_BYTES(q, S, ncp));
+        const size_t CS = (size_t) SDRT_SQ_CS(q) * 16, PS = (size_t) SDRT_SQ_PS(q, S, ncp) * 16;
         *loc_combine = quantise_planes(W.data(), 2, cols, cols, S, [&](int d, int r, int c, signed char dig) {
             for (int cp = 0; cp < ncp; ++cp) {
                 const int y = c + 2 * cp * q;                      // copy cp: the sequence delayed by 2 cp q bytes
-                if (y < SDRT_SQ_MASTER) master[(((size_t) r * S + d) * ncp + cp) * SDRT_SQ_MASTER + y] = dig;
+                if (y < SDRT_SQ_MASTER) master[(size_t) r * PS + ((size_t) d * ncp + cp) * CS + y] = dig;
             }
         });
         if (*loc_combine == 0.0) return -1;

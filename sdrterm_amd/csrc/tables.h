@@ -64,6 +64,14 @@ struct WideTables {
 // per-sample form of DecimTables (pole / ac / aa) at the column boundaries.
 #define SDRT_SQ_LC 256
 #define SDRT_SQ_MASTER 1024          // bytes per (part, digit, copy) of the master sequence: position 2 (d + 256) + component
+// Where the copies sit in LDS, in 16-byte units: a lane reads one unit per matrix instruction, sixteen lanes (one row tile: 8 outputs x
+// 2 parts) per LDS cycle -- their units must fall on sixteen different bank groups (unit index mod 16).  A lane's unit is
+// part * PS + digit * ncp * CS + copy * CS + (k-step, lane group) - (s >> 3): the strides are padded so that copy and part move the
+// residue by what (s >> 3) leaves free (unpadded, decimation 2 read eight ways conflicted).
+#define SDRT_SQ_CS(q) (SDRT_SQ_MASTER / 16 + ((q) == 2 ? 2 : ((q) == 4 ? 4 : 0)))
+#define SDRT_SQ_PS_BASE(q, S, ncp) ((S) * (ncp) * SDRT_SQ_CS(q))
+#define SDRT_SQ_PS(q, S, ncp) (SDRT_SQ_PS_BASE(q, S, ncp) + ((((q) == 16 ? 1 : 8) - SDRT_SQ_PS_BASE(q, S, ncp) % 16 + 16) % 16))
+#define SDRT_SQ_MASTER_BYTES(q, S, ncp) (2 * SDRT_SQ_PS(q, S, ncp) * 16)
 struct SqTables {
     int32_t q, nout, ncp, nrt;                   // outputs per column; byte-alignment copies of the master (16 / (2 q), at least 1); row tiles of 16
     double mu[SDRT_NMODE][2];                    // p_i^256: column to column
@@ -217,7 +225,7 @@ void sdrt_build_fft_resample_packed(int N, double *tw, double *ab);
 // 2 p_i^(256 - b q): what the states at the column's start / end add to output b (inside 2 Re).
 int sdrt_build_sq_tables(const struct DecimTables *tab, int q, struct SqTables *out, double *share);
 // One row's digit planes: agg [2 tiles][S][8 k-steps][64 lanes][16] (A-operand order; tile 0 causal, 1 anticausal column aggregates,
-// row 4 mode + 2 stream + part, the within-column NCO phasor folded in) and master [2 parts][S][ncp][SDRT_SQ_MASTER] (part 0 / 1:
+// row 4 mode + 2 stream + part, the within-column NCO phasor folded in) and master (SDRT_SQ_MASTER_BYTES; unit layout above; part 0 / 1:
 // what the real / imaginary part of an output takes of (re, im) of the samples; copy c = the sequence delayed by 2 c q bytes).
 // nco_samp: [256][2] exp(i theta j) or NULL.  Returns 0, or -1 when a plane set does not fit S digits.
 int sdrt_build_sq_row(const struct DecimTables *tab, int q, const double *nco_samp, int S, signed char *agg, double *agg_combine,
