@@ -788,6 +788,8 @@ def test_small_decimations_in_passes_of_the_wide_kernel(code, q, mode, rows, for
     monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
     if form == 'passes':
         _diag(monkeypatch, sq=0)
+    elif q == 16:
+        _diag(monkeypatch, sq=16)          # (decimation 16 stays on the wide kernel's two passes by default: they are faster there)
         if q == 2:
             pytest.skip('decimation 2 without the one-pass kernel is the per-sample kernel (test_every_instantiation_of_the_per_sample_kernel)')
     elif code in 'bB':
