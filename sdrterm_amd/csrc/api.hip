@@ -140,6 +140,7 @@ struct sdrt_ctx {
     SqTables *d_sqtab = nullptr;
     double *d_sq_share = nullptr;
     signed char *d_sq_agg = nullptr, *d_sq_master = nullptr;
+    double *d_sq_samp = nullptr, *d_sq_col = nullptr;      // exp(i theta j), exp(i theta 256 c) per row (ones without a shift)
     double sq_comb_agg = 0.0, sq_comb_loc = 0.0;
     bool f32c = false;                // float32 records in the reference's complex64 arithmetic (sdrt_config.faithful_f32, kernels_f32c.hip)
     F32cArgs f32c_args;               //   coefficient tables
@@ -519,6 +520,10 @@ int setup_sq(sdrt_ctx *c, const sdrt_config *cfg, const DecimTables &tab) {
         double ca = 0.0, cl = 0.0;
         double *sp = &samp[(size_t) r * LC * 2];
         if (c->nco) sdrt_build_nco(cfg->row_freqs[r], cfg->fs, LC, n / LC, sp, &col[(size_t) r * (n / LC) * 2]);
+        else {                                                           // (no shift: the kernel reads the same tables, holding ones)
+            for (int i = 0; i < LC; ++i) { sp[2 * i] = 1.0; sp[2 * i + 1] = 0.0; }
+            for (int i = 0; i < n / LC; ++i) { col[((size_t) r * (n / LC) + i) * 2] = 1.0; col[((size_t) r * (n / LC) + i) * 2 + 1] = 0.0; }
+        }
         if (sdrt_build_sq_row(&tab, q, c->nco ? sp : nullptr, S, agg.data() + per_agg * r, &ca, master.data() + per_master * r, &cl) != 0) return SDRT_OK;
         if (r == 0) { c->sq_comb_agg = ca; c->sq_comb_loc = cl; }
         else if (ca != c->sq_comb_agg || cl != c->sq_comb_loc) return SDRT_OK;      // one power-of-two scale per context
@@ -527,17 +532,15 @@ int setup_sq(sdrt_ctx *c, const sdrt_config *cfg, const DecimTables &tab) {
     if (rc == SDRT_OK) rc = upload(&c->d_sq_share, share.data(), share.size() * sizeof(double));
     if (rc == SDRT_OK) rc = upload(&c->d_sq_agg, agg.data(), agg.size());
     if (rc == SDRT_OK) rc = upload(&c->d_sq_master, master.data(), master.size());
-    if (rc == SDRT_OK && c->nco) {
-        rc = upload(&c->d_nco_tile8, samp.data(), samp.size() * sizeof(double));
-        if (rc == SDRT_OK) rc = upload(&c->d_nco_phase8, col.data(), col.size() * sizeof(double));
-    }
+    if (rc == SDRT_OK) rc = upload(&c->d_sq_samp, samp.data(), samp.size() * sizeof(double));
+    if (rc == SDRT_OK) rc = upload(&c->d_sq_col, col.data(), col.size() * sizeof(double));
     if (rc != SDRT_OK) return rc;
     c->use_sq = true;
     // ybias from the kernel's own responses
     const size_t cnt = (size_t) c->rows * m * 2, cb = (size_t) n * 4;
     if (hipMalloc(&c->d_ybias, cnt * sizeof(double)) != hipSuccess) return fail(SDRT_ENOMEM, "hipMalloc failed");
     double *d_bias = c->d_ybias;
-    c->d_ybias = nullptr;                                            // (the calibration runs without it)
+    if (hipMemset(d_bias, 0, cnt * sizeof(double)) != hipSuccess) return fail(SDRT_EHIP, "hipMemset failed");    // (the calibration runs with zeros)
     void *d_in = nullptr;
     double *d_r = nullptr;
     if (hipMalloc(&d_in, cb) != hipSuccess || hipMalloc(&d_r, cnt * sizeof(double)) != hipSuccess) rc = fail(SDRT_ENOMEM, "hipMalloc failed");
@@ -560,7 +563,6 @@ int setup_sq(sdrt_ctx *c, const sdrt_config *cfg, const DecimTables &tab) {
         for (size_t i = 0; i < cnt; ++i) bias[i] = -r0[i] + (c->norm_bias != 0.0 ? c->norm_bias * (r1[i] - r0[i]) : 0.0);
         if (hipMemcpy(d_bias, bias.data(), cnt * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = fail(SDRT_EHIP, "hipMemcpy failed");
     }
-    c->d_ybias = d_bias;
     (void) hipFree(d_in);
     (void) hipFree(d_r);
     return rc;
@@ -941,6 +943,8 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_sq_share);
     (void) hipFree(c->d_sq_agg);
     (void) hipFree(c->d_sq_master);
+    (void) hipFree(c->d_sq_samp);
+    (void) hipFree(c->d_sq_col);
     (void) hipFree(c->d_cond_list);
     (void) hipFree(c->d_cond_count);
     (void) hipFree(c->d_shift_tab);
@@ -1100,11 +1104,21 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
         sa.share = c->d_sq_share;
         sa.agg = c->d_sq_agg;
         sa.master = c->d_sq_master;
-        sa.nco_samp = c->nco ? c->d_nco_tile8 : nullptr;
-        sa.nco_col = c->nco ? c->d_nco_phase8 : nullptr;
+        sa.nco_samp = c->d_sq_samp;
+        sa.nco_col = c->d_sq_col;
         sa.ybias = c->d_ybias;
         sa.comb_agg = c->sq_comb_agg;
         sa.comb_loc = c->sq_comb_loc;
+        sa.stamps = c->stamps_dev;
+        sa.stamp_wgs = c->stamp_wgs;
+        {
+            // workgroups of an XCD started apart in phase (kernels_sq.hip): worth one chunk's time at the start of the launch, so only
+            // for launches that give every workgroup several chunks
+            const char *e = sdrt_diag("sq_stagger");
+            const int per = e ? atoi(e) : 16;          // (8 .. 32 measure alike at every decimation, 64 is too far apart: r05_experiments.txt section 9)
+            const size_t wpr = std::max<size_t>(1, (size_t) n_cus / (size_t) c->rows);
+            sa.stagger = n_chunks >= 6 * wpr ? per : 0;
+        }
         Timed t(c, s, 0);
         HIP_TRY(launch_chain_sq(sa, c->cfg.decimation, c->cfg.dtype, n_cus, s));
         return SDRT_OK;

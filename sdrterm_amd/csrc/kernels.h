@@ -196,10 +196,13 @@ struct SqArgs {
     const double *share;        // [256 / q][8][2]   (sdrt_build_sq_tables)
     const signed char *agg;     // [rows][2][S][8][64][16]      (sdrt_build_sq_row)
     const signed char *master;  // [rows][2][S][ncp][1024]
-    const double *nco_samp;     // [rows][256][2] exp(i theta j) or NULL (no shift)
+    const double *nco_samp;     // [rows][256][2] exp(i theta j) (ones without a shift)
     const double *nco_col;      // [rows][n / 256][2] exp(i theta 256 c)
-    const double *ybias;        // [rows][m][2] or NULL
+    const double *ybias;        // [rows][m][2] (zeros while it is being calibrated)
     double comb_agg, comb_loc;  // combine factors of the two plane sets (the same for every row)
+    int stagger;                // > 0: workgroup b starts (b / 8) x stagger sleeps of 64 cycles late (its XCD's workgroups apart in phase)
+    unsigned long long *stamps; // optional diagnostic (-DSDRT_STAMPS builds, tools/stamps_sq.py): [wg < stamp_wgs][wave][16] s_memtime
+    int stamp_wgs;
 };
 bool chain_sq_supported(int q, int dt, int n);
 hipError_t launch_chain_sq(const SqArgs &a, int q, int dt, int n_cus, hipStream_t s);

@@ -17,21 +17,29 @@
 // recombination per value -- as kernels_i8w.hip; the constant the slices leave out and the normalisation
 // bias come back through ybias, calibrated with this kernel's own response to a zero / a unit chunk (api.hip: setup_sq).
 //
-// One persistent 256-thread workgroup per CU keeps a row's planes in LDS (80 KB aggregates + 10 .. 40 KB master) and walks over
-// chunks; ONE wave per SIMD with the whole register file (512 registers: the slices of its two tiles, 128 of them, stay in
-// registers from the aggregate phase to the local phase; with two waves per SIMD at 256 registers the allocator spilled addresses
-// and reloaded them between dependent LDS reads: profiles/r05_experiments.txt section 7); wave w <-> tiles w, w + 4 (16 columns each).
-//   per chunk:  E  edge operators (head / tail, 28 samples each)
-//               A1 aggregate tiles, scanned over the tile's 16 columns in the lanes of a DPP row -> LDS         | barrier
+// One persistent 256-thread workgroup per CU keeps a row's planes and tables in LDS (80 KB aggregates + 10 .. 40 KB master + the
+// states' shares and the phasors: 152 of 160 KB at decimation 2) and walks over chunks; ONE wave per SIMD with the whole register
+// file, wave w <-> tiles w, w + 4 (16 columns each): the byte slices of both tiles (128 registers) stay in registers from the
+// aggregate phase to the local phase, and every A fragment read from LDS feeds the matrix instructions of BOTH tiles.
+//   per chunk:  E  edge operators (head / tail, 28 samples each); their loads go out before A1's, their sums come while A1's fly
+//               A1 aggregate tiles, scanned over the tile's 16 columns in the lanes of a DPP row; lane (g, nb) keeps mode g of
+//                  column nb in registers, the tile totals go to LDS                                            | barrier
 //               P2 tile carries: eight chains in eight lanes of one wave, the tiles one after the other       | barrier
-//               A2 local tiles (nout / 8 of them), states' shares, ybias, store                               | barrier
+//               A2 per row tile (8 outputs x 2 parts of every column of both tiles) 72 + 72 matrix instructions; between their
+//                  quarters the vector work of the PREVIOUS row tile: recombination and rotation, what the lane's mode adds to
+//                  all eight outputs of its column (reduce-scattered over the four lane groups by permlane swaps: every lane ends
+//                  with the four modes' sum for its own two outputs), ybias, pair product, store                 | barrier
+// LDS reads of A fragments are issued a quarter (two k-steps, ten fragments) ahead of the matrix instructions that take them --
+// written one fragment before its use the compiler waited for every single read (lgkmcnt(0) forty times per row tile: 4700 cycles
+// per row tile and tile against 1152 of matrix work, profiles/r05_experiments.txt section 7).  What is left per row tile of both
+// tiles (5000 cycles) is the SUM of 2304 cycles of matrix instructions and ~300 fp64 vector instructions at the 7.5 cycles they
+// cost with one wave on the SIMD: on this chip the two do not overlap (r02_ubench_coexec.txt: 8 matrix + 22 fp64 FMAs take the sum
+// of their times in every arrangement), so neither alternating them instruction by instruction nor two waves per SIMD moved it
+// (section 8 of the experiments).
 #include "kernels_common.hpp"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
-
-#ifndef SDRT_SQ_WAVES
-#define SDRT_SQ_WAVES 8          // waves per workgroup: 8 (two per SIMD, a tile each) or 4 (one per SIMD with 512 registers, two tiles each)
-#endif
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -39,10 +47,10 @@ template <int DT> struct SqEnc;        // slices per component, what each slice 
 template <> struct SqEnc<SDRT_S16> { static constexpr unsigned xlo = 0x80808080u, xhi = 0u; static constexpr double off = 128.0; };
 template <> struct SqEnc<SDRT_U16> { static constexpr unsigned xlo = 0x80808080u, xhi = 0x80808080u; static constexpr double off = 32896.0; };
 
-constexpr int SQ_S = SDRT_I8_DIGITS, SQ_LC = SDRT_SQ_LC, SQ_KS = SQ_LC / 32, SQ_MAXCOL = 128, SQ_WV = SDRT_SQ_WAVES, SQ_TPW = 8 / SQ_WV, SQ_MAXT = SQ_WV * SQ_TPW;
+constexpr int SQ_S = SDRT_I8_DIGITS, SQ_LC = SDRT_SQ_LC, SQ_KS = SQ_LC / 32, SQ_MAXCOL = 128, SQ_WV = 4, SQ_TPW = 2, SQ_MAXT = SQ_WV * SQ_TPW;
 
 struct SqLds {          // byte offsets
-    int agg, master, fx, gx, tf, tg, cf, cg, f0, gu, psi, samp, cst, share, total;
+    int agg, master, tf, tg, cf, cg, f0, gu, psi, samp, cst, share, total;
 };
 __host__ __device__ inline SqLds sq_lds(int ncp, int nout) {
     const int q = SQ_LC / nout;
@@ -50,20 +58,31 @@ __host__ __device__ inline SqLds sq_lds(int ncp, int nout) {
     int p = 0;
     l.agg = p; p += 2 * SQ_S * SQ_KS * 64 * 16;
     l.master = p; p += SDRT_SQ_MASTER_BYTES(q, SQ_S, ncp);
-    l.fx = p; p += SQ_MAXCOL * 8 * 16;                // causal state at the start of column c when its TILE starts from zero, [c][mode][stream]
-    l.gx = p; p += SQ_MAXCOL * 8 * 16;                // anticausal state at the start of column c + 1 when the tile's right neighbour is zero
     l.tf = p; p += SQ_MAXT * 8 * 16;                  // the tiles' totals ...
     l.tg = p; p += SQ_MAXT * 8 * 16;
     l.cf = p; p += (SQ_MAXT + 1) * 8 * 16;              // ... and what enters each tile from the left / from the right
     l.cg = p; p += (SQ_MAXT + 1) * 8 * 16;
     l.f0 = p; p += 8 * 16;
     l.gu = p; p += 8 * 16;
-    l.psi = p; p += nout <= 64 ? SQ_MAXCOL * 16 : 0;  // exp(i theta 256 c)       (decimation 2: both phasor tables are read from memory,
-    l.samp = p; p += nout <= 64 ? SQ_LC * 16 : 0;     // exp(i theta j), j < 256    the LDS is full)
+    l.psi = p; p += SQ_MAXCOL * 16;                   // exp(i theta 256 c)
+    l.samp = p; p += SQ_LC * 16;                      // exp(i theta j), j < 256
     l.cst = p; p += 4 * 13 * 16;                      // per mode: mu^(1, 2, 4, 8, 16), tailF[mode][0..3], tailFc[mode][0..3]
-    l.share = p; p += nout <= 64 ? nout * 8 * 16 : 0; // the states' shares per output (decimation 2: 16 KB, read from memory instead)
+    l.share = p; p += nout * 8 * 16;                  // the states' shares per output
     l.total = p;
     return l;
+}
+
+// x' + y' after exchanging halves: lanes 0-31 get x(l) + x(l+32), lanes 32-63 get y(l-32) + y(l)
+__device__ __forceinline__ double sq_swap32_add(double x, double y) {
+    const v2u lo = __builtin_amdgcn_permlane32_swap((unsigned) __double2loint(x), (unsigned) __double2loint(y), false, false);
+    const v2u hi = __builtin_amdgcn_permlane32_swap((unsigned) __double2hiint(x), (unsigned) __double2hiint(y), false, false);
+    return __hiloint2double((int) hi[0], (int) lo[0]) + __hiloint2double((int) hi[1], (int) lo[1]);
+}
+// rows (16 lanes) 0 and 2 get x(row) + x(row+1), rows 1 and 3 get y(row-1) + y(row)
+__device__ __forceinline__ double sq_swap16_add(double x, double y) {
+    const v2u lo = __builtin_amdgcn_permlane16_swap((unsigned) __double2loint(x), (unsigned) __double2loint(y), false, false);
+    const v2u hi = __builtin_amdgcn_permlane16_swap((unsigned) __double2hiint(x), (unsigned) __double2hiint(y), false, false);
+    return __hiloint2double((int) hi[0], (int) lo[0]) + __hiloint2double((int) hi[1], (int) lo[1]);
 }
 
 // mu^k, k < 16, from the squarings mp[0..3] = mu^(1, 2, 4, 8)
@@ -75,34 +94,37 @@ __device__ __forceinline__ cd mu_pow(const cd *mp, int k) {
     return r;
 }
 
-template <int DT, int QS>
-__global__ __launch_bounds__(64 * SQ_WV, SQ_WV / 4) void chain_sq_kernel(const SqArgs a) {
+#ifndef SDRT_SQ_TOUCH
+#define SDRT_SQ_TOUCH 128          // bytes per touched word of the next chunk (64 and 32 read the same: section 8 of the experiments)
+#endif
+#define SQ_MFMA(A, B, C) __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, C, 0, 0, 0)
+
+template <int DT, int QS, bool PAIR>
+__global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a) {
     constexpr int q = 1 << QS, NOUT = SQ_LC / q, NRT = 2 * NOUT / 16, NCP = 2 * q >= 16 ? 1 : 16 / (2 * q), S = SQ_S, KS = SQ_KS;
-    constexpr bool SHL = NOUT <= 64;                  // the share table fits the LDS
+    constexpr int DSTR = NCP * SDRT_SQ_CS(q);          // master: 16-byte units from one digit's copies to the next digit's
+    // touches of the next chunk: one word per SDRT_SQ_TOUCH bytes of the wave's two tiles, spread over the row tiles
+    constexpr int TUNITS = 16 * SQ_LC * 4 / SDRT_SQ_TOUCH, NTOUCH = SQ_TPW * TUNITS / 64, TPS = (NTOUCH + NRT - 1) / NRT;
+    static_assert(NRT % 2 == 0 && KS == 8 && SQ_TPW == 2, "the local phase walks row tiles in pairs, k-steps in quarters, two tiles per wave");
     typedef typename Enc<DT>::raw raw_t;
     extern __shared__ __align__(16) unsigned char smem[];
     const SqLds lo = sq_lds(NCP, NOUT);
     const v4i *aggL = (const v4i *) (smem + lo.agg);
     const v4i *masterL = (const v4i *) (smem + lo.master);
-    cd *FxL = (cd *) (smem + lo.fx), *GxL = (cd *) (smem + lo.gx), *TFL = (cd *) (smem + lo.tf), *TGL = (cd *) (smem + lo.tg);
+    cd *TFL = (cd *) (smem + lo.tf), *TGL = (cd *) (smem + lo.tg);
     cd *CFL = (cd *) (smem + lo.cf), *CGL = (cd *) (smem + lo.cg), *F0L = (cd *) (smem + lo.f0), *GuL = (cd *) (smem + lo.gu);
     cd *psiL = (cd *) (smem + lo.psi), *sampL = (cd *) (smem + lo.samp), *cstL = (cd *) (smem + lo.cst), *shareL = (cd *) (smem + lo.share);
-    // exp(i theta 256 c) / exp(i theta j): from the LDS, or (decimation 2) from the row's tables in memory
-    const cd *psiG = (const cd *) a.nco_col + (size_t) blockIdx.x % (unsigned) a.rows * (size_t) (a.n / SQ_LC);
-    const cd *sampG = (const cd *) a.nco_samp + (size_t) blockIdx.x % (unsigned) a.rows * SQ_LC;
-    auto psi_at = [&](int c) -> cd { if constexpr (SHL) return psiL[c]; else return a.nco_samp ? psiG[c] : mk(1.0, 0.0); };
-    auto samp_at = [&](int j) -> cd { if constexpr (SHL) return sampL[j]; else return a.nco_samp ? sampG[j] : mk(1.0, 0.0); };
     const SqTables *__restrict__ tab = a.tab;
     const int n = a.n, m = a.m, NC = n / SQ_LC, ntiles = NC / 16;
     const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
-    const bool swap = a.swap != 0, nco = a.nco_samp != nullptr;
+    const bool swap = a.swap != 0;
     int lane = lane0, g = lane0 >> 4, nb = lane0 & 15;
     // which row, which chunks: workgroup b serves row b % rows, chunks (b / rows), + wpr, ...
     const int row = (int) (blockIdx.x % (unsigned) a.rows);
     const size_t wpr = gridDim.x / (unsigned) a.rows, first = blockIdx.x / (unsigned) a.rows;
     if (first >= wpr) return;
 
-    // ---- the row's planes, phasors and constants into LDS, once ---------------------------------------------------------------------
+    // ---- the row's planes, phasors (ones without a shift) and constants into LDS, once ----------------------------------------------
     {
         const v4i *src = (const v4i *) (a.agg + (size_t) row * (2 * S * KS * 64 * 16));
         v4i *dst = (v4i *) (smem + lo.agg);
@@ -110,11 +132,9 @@ __global__ __launch_bounds__(64 * SQ_WV, SQ_WV / 4) void chain_sq_kernel(const S
         const v4i *srm = (const v4i *) (a.master + (size_t) row * SDRT_SQ_MASTER_BYTES(q, S, NCP));
         v4i *dsm = (v4i *) (smem + lo.master);
         for (int i = tid; i < SDRT_SQ_MASTER_BYTES(q, S, NCP) / 16; i += 64 * SQ_WV) dsm[i] = srm[i];
-        if constexpr (SHL) {
-            for (int i = tid; i < NC; i += 64 * SQ_WV) psiL[i] = nco ? ((const cd *) a.nco_col)[(size_t) row * NC + i] : mk(1.0, 0.0);
-            for (int i = tid; i < SQ_LC; i += 64 * SQ_WV) sampL[i] = nco ? ((const cd *) a.nco_samp)[(size_t) row * SQ_LC + i] : mk(1.0, 0.0);
-        }
-        if constexpr (SHL) for (int i = tid; i < NOUT * 8; i += 64 * SQ_WV) shareL[i] = ((const cd *) a.share)[i];
+        for (int i = tid; i < NC; i += 64 * SQ_WV) psiL[i] = ((const cd *) a.nco_col)[(size_t) row * NC + i];
+        for (int i = tid; i < SQ_LC; i += 64 * SQ_WV) sampL[i] = ((const cd *) a.nco_samp)[(size_t) row * SQ_LC + i];
+        for (int i = tid; i < NOUT * 8; i += 64 * SQ_WV) shareL[i] = ((const cd *) a.share)[i];
         if (tid < 4) {
             cd *cs = cstL + tid * 13;
             cd v = mk(tab->mu[tid][0], tab->mu[tid][1]);
@@ -123,15 +143,18 @@ __global__ __launch_bounds__(64 * SQ_WV, SQ_WV / 4) void chain_sq_kernel(const S
         }
     }
     __syncthreads();
+    // Every workgroup does the same work in the same time: started together they all read their 128 KB of a chunk in the same few
+    // microseconds (32 MB at the memory's full rate, 10 - 17 thousand cycles of waiting per chunk, the next chunk's lines touched
+    // ahead or not: an XCD's L2 is exactly one round of its workgroups) and leave the memory idle for the rest of the chunk.  With
+    // a.stagger the workgroups of an XCD start a.stagger x (position in the XCD) sleeps of 64 cycles apart and stay apart
+    if (a.stagger > 0)
+        for (int i = (int) (blockIdx.x >> 3) * a.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(1);
     const double cagg = a.comb_agg * 256.0, cloc = a.comb_loc * 256.0;       // accumulator index a holds level a + 1
     const double off = SqEnc<DT>::off;
-    // this thread's edge coefficient (the same for every chunk)
+    // (this thread's edge coefficients, the phasors of its two edge samples and the powers that carry a tile's entry states to its
+    // columns are the same for every chunk -- and are fetched / formed again in every chunk: 32 registers held through the local phase
+    // are what that phase is short of)
     const int e_o = (tid >> 5) & 7, e_l = tid & 31;
-    cd e_head = mk(0.0, 0.0), e_tailc = mk(0.0, 0.0);
-    if (e_l <= SDRT_EDGE) {
-        e_head = mk(tab->head[e_o >> 1][e_l][0], tab->head[e_o >> 1][e_l][1]);
-        e_tailc = mk(tab->tailU[e_o >> 1][e_l][0], tab->tailU[e_o >> 1][e_l][1]);
-    }
     unsigned touched = 0;                                                     // (the next chunk's lines pulled towards the L2: see A2)
 
     for (size_t chunk = first; chunk < a.n_chunks; chunk += wpr) {
@@ -140,18 +163,56 @@ __global__ __launch_bounds__(64 * SQ_WV, SQ_WV / 4) void chain_sq_kernel(const S
         // out of this loop -- sixteen load addresses, the LDS addresses of every phase -- those values outlive the whole iteration, the
         // allocator spills them, and every reload waits for all memory traffic in flight, one load address at a time)
         asm volatile("" : "+v"(lane), "+v"(g), "+v"(nb));
-        // ---- E: edge operators.  F_0,i = sum_l head[i][l] u[l], the sample part of G_end,i = sum_l tailU[i][l] u[n - 28 + l], per
-        // real stream; u = (x - off) exp(i theta t): the same x - off the slices carry (ybias returns what is left out)
+#ifdef SDRT_STAMPS
+        // diagnostic build (tools/stamps_sq.py): phase stamps of the workgroup's third chunk
+        unsigned long long *stp = (a.stamps && chunk == first + 2 * wpr && (int) (blockIdx.x * SQ_WV + wave) < a.stamp_wgs * 4 && lane0 == 0)
+                                      ? a.stamps + ((size_t) blockIdx.x * SQ_WV + wave) * 16 : nullptr;
+#define SQ_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                         if (stp) stp[i] = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SQ_STAMP(i) do { } while (0)
+#endif
+        SQ_STAMP(0);
+        const bool have0 = wave < ntiles, have1 = wave + SQ_WV < ntiles;
+        // ---- E (loads): the chunk's first and last 28 records, this thread's two edge coefficients
+        raw_t e_raw[2][2] = {{0, 0}, {0, 0}};
+        cd e_head = mk(0.0, 0.0), e_tailc = mk(0.0, 0.0);
+        if (e_l <= SDRT_EDGE) {
+            e_head = mk(tab->head[e_o >> 1][e_l][0], tab->head[e_o >> 1][e_l][1]);
+            e_tailc = mk(tab->tailU[e_o >> 1][e_l][0], tab->tailU[e_o >> 1][e_l][1]);
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const long idx = tl ? (long) n - (SDRT_EDGE + 1) + e_l : e_l;
+                const raw_t *rp = (const raw_t *) chunk_raw + 2 * idx;
+                e_raw[tl][0] = rp[0];
+                e_raw[tl][1] = rp[1];
+            }
+        }
+        // ---- A1 (loads): the wave's two tiles, 16 columns each: every load in flight before anything waits for one
+        uint32_t cur[SQ_TPW][KS][8];
+#pragma unroll
+        for (int j = 0; j < SQ_TPW; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (wave + SQ_WV * j < ntiles) load_words<32>(chunk_raw + ((size_t) ((wave + SQ_WV * j) * 16 + nb) * SQ_LC + 32 * ks + 8 * g) * 4, cur[j][ks]);
+                else {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) cur[j][ks][w] = 0;
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- E (sums).  F_0,i = sum_l head[i][l] u[l], the sample part of G_end,i = sum_l tailU[i][l] u[n - 28 + l], per real
+        // stream; u = (x - off) exp(i theta t): the same x - off the slices carry (ybias returns what is left out)
         {
             const int st = e_o & 1;
             cd f = mk(0.0, 0.0), gq = mk(0.0, 0.0);
-            if (e_l <= SDRT_EDGE && tid < 256) {
+            if (e_l <= SDRT_EDGE) {
+                const int i1 = n - (SDRT_EDGE + 1) + e_l;
+                const cd e_ph0 = cmul(sampL[e_l], psiL[0]), e_ph1 = cmul(sampL[i1 & (SQ_LC - 1)], psiL[i1 / SQ_LC]);
 #pragma unroll
                 for (int tl = 0; tl < 2; ++tl) {
-                    const long idx = tl ? (long) n - (SDRT_EDGE + 1) + e_l : e_l;
-                    const raw_t *rp = (const raw_t *) chunk_raw + 2 * idx;
-                    const double xr = decode<DT>(rp[0], swap) - off, xi = decode<DT>(rp[1], swap) - off;
-                    const cd ph = cmul(samp_at((int) (idx & (SQ_LC - 1))), psi_at((int) (idx / SQ_LC)));
+                    const double xr = decode<DT>(e_raw[tl][0], swap) - off, xi = decode<DT>(e_raw[tl][1], swap) - off;
+                    const cd ph = tl ? e_ph1 : e_ph0;
                     const double us = st ? xr * ph.im + xi * ph.re : xr * ph.re - xi * ph.im;
                     if (tl) gq = mk(e_tailc.re * us, e_tailc.im * us); else f = mk(e_head.re * us, e_head.im * us);
                 }
@@ -163,85 +224,104 @@ __global__ __launch_bounds__(64 * SQ_WV, SQ_WV / 4) void chain_sq_kernel(const S
                 gq.re += __shfl_xor(gq.re, d);
                 gq.im += __shfl_xor(gq.im, d);
             }
-            if (e_l == 0 && tid < 256) { F0L[e_o] = f; GuL[e_o] = gq; }
+            if (e_l == 0) { F0L[e_o] = f; GuL[e_o] = gq; }
         }
-        // ---- A1: the wave's tile: its 16 columns' byte slices (kept for A2), their aggregates, the scans over the tile's columns ------------
+        SQ_STAMP(1);
+        // ---- A1: byte slices (kept for A2), the aggregates of both tiles from ONE read of every A fragment, the scans over a tile's columns
         v4i bhi[SQ_TPW][KS], blo[SQ_TPW][KS];
-        uint32_t cur[SQ_TPW][KS][8];
-#pragma unroll
-        for (int j = 0; j < SQ_TPW; ++j)
-            if (wave + SQ_WV * j < ntiles)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    load_words<32>(chunk_raw + ((size_t) ((wave + SQ_WV * j) * 16 + nb) * SQ_LC + 32 * ks + 8 * g) * 4, cur[j][ks]);
-        // (every load of both tiles in flight before anything waits for one: left to itself the compiler sinks each k-step's loads to
-        // its matrix instructions -- eight memory round trips one after the other)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < SQ_TPW; ++j) {
-        const int tile = wave + SQ_WV * j, col = tile * 16 + nb;
-        const bool have = tile < ntiles;
-        if (have) {
+        // lane (g, nb): mode g of column nb of tile j: the causal state at the column's start, the anticausal one at the start of the
+        // next column, per real stream -- first as if the tile's neighbours were zero (A1), then with the tile's carries (A2)
+        cd Fl[SQ_TPW][2], Gl[SQ_TPW][2];
+        {
             const unsigned sel_lo = swap ? 0x07050301u : 0x06040200u, sel_hi = swap ? 0x06040200u : 0x07050301u;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    blo[j][ks][w] = (int) (__builtin_amdgcn_perm(cur[j][ks][2 * w + 1], cur[j][ks][2 * w], sel_lo) ^ SqEnc<DT>::xlo);
-                    bhi[j][ks][w] = (int) (__builtin_amdgcn_perm(cur[j][ks][2 * w + 1], cur[j][ks][2 * w], sel_hi) ^ SqEnc<DT>::xhi);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            const cd ps = psi_at(col);
-            const cd *cstG = cstL + g * 13;                                   // mode g = this lane's aggregate rows
-            const cd m1 = cstG[0], m2 = cstG[1], m4 = cstG[2], m8 = cstG[3];
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                v4i acc[S];
-#pragma unroll
-                for (int d = 0; d < S; ++d) acc[d] = (v4i) {0, 0, 0, 0};
+            for (int j = 0; j < SQ_TPW; ++j)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int d = 0; d < S; ++d) {
-                        const v4i A = aggL[((rt * S + d) * KS + ks) * 64 + lane];
-                        acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi[j][ks], acc[d], 0, 0, 0);                  // digit d x high slice: level d + 1
-                        if (d >= 1) acc[d - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo[j][ks], acc[d - 1], 0, 0, 0);  // x low slice: level d
+                    for (int w = 0; w < 4; ++w) {
+                        blo[j][ks][w] = (int) (__builtin_amdgcn_perm(cur[j][ks][2 * w + 1], cur[j][ks][2 * w], sel_lo) ^ SqEnc<DT>::xlo);
+                        bhi[j][ks][w] = (int) (__builtin_amdgcn_perm(cur[j][ks][2 * w + 1], cur[j][ks][2 * w], sel_hi) ^ SqEnc<DT>::xhi);
                     }
-                double val[4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    double sum = (double) acc[S - 1][v];
-#pragma unroll
-                    for (int d = S - 2; d >= 0; --d) sum = fma(sum, 256.0, (double) acc[d][v]);
-                    val[v] = sum * cagg;
-                }
-                // lane (g, nb): mode g of column nb; (val0, val1) the state of the re stream, (val2, val3) of the im stream.  The column's
-                // common phasor rotates the complex DATA: re' = c re - s im, im' = s re + c im (stream by stream, both state components)
-                cd x0 = mk(fma(ps.re, val[0], -(ps.im * val[2])), fma(ps.re, val[1], -(ps.im * val[3])));
-                cd x1 = mk(fma(ps.im, val[0], ps.re * val[2]), fma(ps.im, val[1], ps.re * val[3]));
-                if (rt == 0) {
-                    // causal: inclusive scan over the tile's 16 columns (the lanes of a DPP row), F(c + 1) = mu F(c) + A_c from zero
-                    x0 = cfma(m1, dpp_row<0x111>(x0), x0); x1 = cfma(m1, dpp_row<0x111>(x1), x1);
-                    x0 = cfma(m2, dpp_row<0x112>(x0), x0); x1 = cfma(m2, dpp_row<0x112>(x1), x1);
-                    x0 = cfma(m4, dpp_row<0x114>(x0), x0); x1 = cfma(m4, dpp_row<0x114>(x1), x1);
-                    x0 = cfma(m8, dpp_row<0x118>(x0), x0); x1 = cfma(m8, dpp_row<0x118>(x1), x1);
-                    if (nb == 15) { TFL[tile * 8 + g * 2] = x0; TFL[tile * 8 + g * 2 + 1] = x1; }
-                    FxL[col * 8 + g * 2] = dpp_row<0x111>(x0);           // exclusive: the state at the column's own start
-                    FxL[col * 8 + g * 2 + 1] = dpp_row<0x111>(x1);
-                } else {
-                    // anticausal: G(c) = B_c + mu G(c + 1), from zero beyond the tile
-                    x0 = cfma(m1, dpp_row<0x101>(x0), x0); x1 = cfma(m1, dpp_row<0x101>(x1), x1);
-                    x0 = cfma(m2, dpp_row<0x102>(x0), x0); x1 = cfma(m2, dpp_row<0x102>(x1), x1);
-                    x0 = cfma(m4, dpp_row<0x104>(x0), x0); x1 = cfma(m4, dpp_row<0x104>(x1), x1);
-                    x0 = cfma(m8, dpp_row<0x108>(x0), x0); x1 = cfma(m8, dpp_row<0x108>(x1), x1);
-                    if (nb == 0) { TGL[tile * 8 + g * 2] = x0; TGL[tile * 8 + g * 2 + 1] = x1; }
-                    GxL[col * 8 + g * 2] = dpp_row<0x101>(x0);           // the state at the start of the NEXT column
-                    GxL[col * 8 + g * 2 + 1] = dpp_row<0x101>(x1);
-                }
-            }
         }
+        if (have0) {
+            v4i Aq[2][2 * S], acc[SQ_TPW][S];
+            auto load_agg = [&](auto stc) {
+                constexpr int st = decltype(stc)::value, rt = st >> 2, kq = st & 3;
+#pragma unroll
+                for (int ksl = 0; ksl < 2; ++ksl)
+#pragma unroll
+                    for (int d = 0; d < S; ++d) Aq[st & 1][ksl * S + d] = aggL[((rt * S + d) * KS + 2 * kq + ksl) * 64 + lane];
+            };
+            load_agg(std::integral_constant<int, 0>{});
+            static_for<0, 8>([&](auto stc) {
+                constexpr int st = decltype(stc)::value, rt = st >> 2, kq = st & 3;
+                if constexpr (kq == 0) {
+#pragma unroll
+                    for (int j = 0; j < SQ_TPW; ++j)
+#pragma unroll
+                        for (int d = 0; d < S; ++d) acc[j][d] = (v4i) {0, 0, 0, 0};
+                }
+                if constexpr (st + 1 < 8) load_agg(std::integral_constant<int, st + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ksl = 0; ksl < 2; ++ksl)
+#pragma unroll
+                    for (int d = 0; d < S; ++d)
+#pragma unroll
+                        for (int j = 0; j < SQ_TPW; ++j) {
+                            acc[j][d] = SQ_MFMA(Aq[st & 1][ksl * S + d], bhi[j][2 * kq + ksl], acc[j][d]);                     // digit d x high slice: level d + 1
+                            if (d >= 1) acc[j][d - 1] = SQ_MFMA(Aq[st & 1][ksl * S + d], blo[j][2 * kq + ksl], acc[j][d - 1]);    // x low slice: level d
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (kq == 3) {
+                    const cd *cstG = cstL + g * 13;                                   // mode g = this lane's aggregate rows
+                    const cd m1 = cstG[0], m2 = cstG[1], m4 = cstG[2], m8 = cstG[3];
+#pragma unroll
+                    for (int j = 0; j < SQ_TPW; ++j) {
+                        const int tile = wave + SQ_WV * j, col = tile * 16 + nb;
+                        if (tile >= ntiles) { if constexpr (rt == 0) Fl[j][0] = Fl[j][1] = mk(0.0, 0.0); else Gl[j][0] = Gl[j][1] = mk(0.0, 0.0); }
+                        else {
+                            const cd ps = psiL[col];
+                            double val[4];
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                double sum = (double) acc[j][S - 1][v];
+#pragma unroll
+                                for (int d = S - 2; d >= 0; --d) sum = fma(sum, 256.0, (double) acc[j][d][v]);
+                                val[v] = sum * cagg;
+                            }
+                            // lane (g, nb): mode g of column nb; (val0, val1) the state of the re stream, (val2, val3) of the im stream.  The column's
+                            // common phasor rotates the complex DATA: re' = c re - s im, im' = s re + c im (stream by stream, both state components)
+                            cd x0 = mk(fma(ps.re, val[0], -(ps.im * val[2])), fma(ps.re, val[1], -(ps.im * val[3])));
+                            cd x1 = mk(fma(ps.im, val[0], ps.re * val[2]), fma(ps.im, val[1], ps.re * val[3]));
+                            if constexpr (rt == 0) {
+                                // causal: inclusive scan over the tile's 16 columns (the lanes of a DPP row), F(c + 1) = mu F(c) + A_c from zero
+                                x0 = cfma(m1, dpp_row<0x111>(x0), x0); x1 = cfma(m1, dpp_row<0x111>(x1), x1);
+                                x0 = cfma(m2, dpp_row<0x112>(x0), x0); x1 = cfma(m2, dpp_row<0x112>(x1), x1);
+                                x0 = cfma(m4, dpp_row<0x114>(x0), x0); x1 = cfma(m4, dpp_row<0x114>(x1), x1);
+                                x0 = cfma(m8, dpp_row<0x118>(x0), x0); x1 = cfma(m8, dpp_row<0x118>(x1), x1);
+                                if (nb == 15) { TFL[tile * 8 + g * 2] = x0; TFL[tile * 8 + g * 2 + 1] = x1; }
+                                Fl[j][0] = dpp_row<0x111>(x0);           // exclusive: the state at the column's own start
+                                Fl[j][1] = dpp_row<0x111>(x1);
+                            } else {
+                                // anticausal: G(c) = B_c + mu G(c + 1), from zero beyond the tile
+                                x0 = cfma(m1, dpp_row<0x101>(x0), x0); x1 = cfma(m1, dpp_row<0x101>(x1), x1);
+                                x0 = cfma(m2, dpp_row<0x102>(x0), x0); x1 = cfma(m2, dpp_row<0x102>(x1), x1);
+                                x0 = cfma(m4, dpp_row<0x104>(x0), x0); x1 = cfma(m4, dpp_row<0x104>(x1), x1);
+                                x0 = cfma(m8, dpp_row<0x108>(x0), x0); x1 = cfma(m8, dpp_row<0x108>(x1), x1);
+                                if (nb == 0) { TGL[tile * 8 + g * 2] = x0; TGL[tile * 8 + g * 2 + 1] = x1; }
+                                Gl[j][0] = dpp_row<0x101>(x0);           // the state at the start of the NEXT column
+                                Gl[j][1] = dpp_row<0x101>(x1);
+                            }
+                        }
+                    }
+                }
+            });
         }
+        SQ_STAMP(2);
         __syncthreads();
+        SQ_STAMP(3);
         // ---- P2: what enters every tile from the left / right: eight chains (mode, stream) in eight lanes, the tiles one after the other
         if (wave == 0) {
             const int o = lane & 7, mode = o >> 1, st = o & 1;
@@ -265,116 +345,242 @@ __global__ __launch_bounds__(64 * SQ_WV, SQ_WV / 4) void chain_sq_kernel(const S
                 G = cfma(mu16, G, TGL[t * 8 + o]);
             }
         }
+        SQ_STAMP(4);
         __syncthreads();
-        // ---- A2: the local part of every output of the tile's columns, the states' shares, ybias, store --------------------------------------
+        SQ_STAMP(5);
+        // ---- A2: the local part of every output of both tiles' columns, the states' shares, ybias, store ------------------------------------
+        if (have0) {
+            // the columns' true states: the tile-local value + the tile's carry through nb / 15 - nb columns (mode g)
+            {
+                const cd pfc = mu_pow(cstL + g * 13, nb), pgc = mu_pow(cstL + g * 13, 15 - nb);
 #pragma unroll
-        for (int j = 0; j < SQ_TPW; ++j) {
-        const int tile = wave + SQ_WV * j, col = tile * 16 + nb;
-        if (tile < ntiles) {
-            // (while the matrix cores work: one word of every 128-byte line of this wave's tile of the NEXT chunk, so that the next
-            // iteration's loads find it in the L2 -- the workgroup is alone on its CU and nothing else covers that round trip)
-            if (chunk + wpr < a.n_chunks) {
-                const unsigned char *nx = chunk_raw + wpr * (size_t) n * 4 + (size_t) tile * 16 * SQ_LC * 4;
-                touched ^= *(const unsigned *) (nx + (size_t) lane * 128) ^ *(const unsigned *) (nx + (size_t) (lane + 64) * 128);
-            }
-            // this lane's outputs belong to column nb: the states at its start (causal) and at the start of the next one (anticausal),
-            // every (mode, stream): the tile-local value + the tile's carry through nb / 15 - nb columns
-            cd Fs[8], Gn[8];
+                for (int j = 0; j < SQ_TPW; ++j) {
+                    const int tcl = wave + SQ_WV * j < ntiles ? wave + SQ_WV * j : wave;
 #pragma unroll
-            for (int md = 0; md < 4; ++md) {
-                const cd pf = mu_pow(cstL + md * 13, nb), pg = mu_pow(cstL + md * 13, 15 - nb);
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    const int i = md * 2 + st;
-                    Fs[i] = cfma(pf, CFL[tile * 8 + i], FxL[col * 8 + i]);
-                    Gn[i] = cfma(pg, CGL[tile * 8 + i], GxL[col * 8 + i]);
+                    for (int st = 0; st < 2; ++st) {
+                        Fl[j][st] = cfma(pfc, CFL[tcl * 8 + g * 2 + st], Fl[j][st]);
+                        Gl[j][st] = cfma(pgc, CGL[tcl * 8 + g * 2 + st], Gl[j][st]);
+                    }
                 }
             }
-            const cd ps = psi_at(col);
             const int r = lane & 15, part = r & 1, bl = r >> 1;                 // A operand: row r of the row tile = output bl, part
+            // 16-byte units (tables.h: SDRT_SQ_CS / _PS): part PS + (d NCP + copy) CS + (64 ks + 16 g - 16 (s >> 3) + 512) / 16 for the
+            // output at sample s = (8 rt + bl) q of the column: row tile rt sits rt q units before row tile 0
+            const int s0 = bl << QS;
+            const int abase0 = part * SDRT_SQ_PS(q, S, NCP) + ((s0 & 7) >> QS) * SDRT_SQ_CS(q) + g - (s0 >> 3) + 32;
             const size_t item = (size_t) row * a.n_chunks + chunk;
-            double *yd = a.ydec + item * (size_t) (a.pair_out ? m / 2 : m) * 2;
-            const cd *yb = a.ybias ? (const cd *) a.ybias + (size_t) row * m : nullptr;
+            double *yd = a.ydec + item * (size_t) (PAIR ? m / 2 : m) * 2;
+            const cd *yb = (const cd *) a.ybias + (size_t) row * m;
+            // (one word of every SDRT_SQ_TOUCH bytes of this wave's tiles of the NEXT chunk, spread over the row tiles: the next
+            // iteration's loads find at least part of it on the way)
+            const bool more = chunk + wpr < a.n_chunks;
+            const unsigned char *nx = chunk_raw + (more ? wpr * (size_t) n * 4 : 0);
+            unsigned tv = 0;
+
+            v4i Aq[2][2 * S], accA[SQ_TPW][S], accB[SQ_TPW][S];
+            auto load_master = [&](auto kqc, const int rt) {
+                constexpr int kq = decltype(kqc)::value;
+                const int ab = abase0 - rt * q;
+#pragma unroll
+                for (int ksl = 0; ksl < 2; ++ksl)
+#pragma unroll
+                    for (int d = 0; d < S; ++d) Aq[kq & 1][ksl * S + d] = masterL[ab + d * DSTR + 4 * (2 * kq + ksl)];
+            };
+            // the vector unit's share of row tile rt, both tiles, in four pieces (one behind each quarter of the next row tile's matrix
+            // work; each piece's LDS reads go out ahead of that quarter, beside the A fragments of the next):
+            //   0  recombination of the int32 sums, the outputs' own phasors            -> y2[tile][h], outputs 8 rt + 2 g + h of column nb
+            //   1  what the lane's mode g adds to outputs 8 rt + {0, 1, 4, 5} of its column (both streams), halves of the wave exchanged
+            //   2  the same for {2, 3, 6, 7}; rows exchanged: every lane now holds the four modes' sum for its own two outputs
+            //   3  ybias, pair product, store
+            cd y2[SQ_TPW][2], smp[2], psj[SQ_TPW], pf[4], pg[4], ybv[SQ_TPW][2];
+            double r1[SQ_TPW][2][2];                        // [tile][k = 0, 1][re, im] after the exchange of halves
+            auto epi_recombine_loads = [&](const int rt) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) smp[h] = sampL[(rt * 8 + 2 * g + h) << QS];
+#pragma unroll
+                for (int j = 0; j < SQ_TPW; ++j) psj[j] = psiL[(wave + SQ_WV * j < ntiles ? wave + SQ_WV * j : wave) * 16 + nb];
+            };
+            auto epi_recombine = [&](const v4i (&pv)[SQ_TPW][S]) {
+#pragma unroll
+                for (int j = 0; j < SQ_TPW; ++j) {
+                    double val[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        double sum = (double) pv[j][S - 1][v];
+#pragma unroll
+                        for (int d = S - 2; d >= 0; --d) sum = fma(sum, 256.0, (double) pv[j][d][v]);
+                        val[v] = sum * cloc;
+                    }
+                    // result rows 4 g + v of column nb: outputs b0 (val0 + i val1) and b0 + 1 (val2 + i val3)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const cd rot = cmul(psj[j], smp[h]);                             // exp(i theta (256 c + s)): the output's own phasor
+                        y2[j][h] = mk(fma(rot.re, val[2 * h], -(rot.im * val[2 * h + 1])), fma(rot.re, val[2 * h + 1], rot.im * val[2 * h]));
+                    }
+                }
+            };
+            // share[b][i] = 2 p_i^(b q), share[b][4 + i] = 2 p_i^(256 - b q): what the states at the column's start / at the next column's
+            // start add to output b (inside 2 Re), per real stream
+            auto epi_modes_loads = [&](const int rt, auto kc) {
+                constexpr int k0 = decltype(kc)::value;           // 0: outputs {0, 1 | 4, 5} of the row tile, 2: {2, 3 | 6, 7}
+                const cd *sh = shareL + (size_t) (rt * 8) * 8 + g;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int b = k0 + (u & 1) + 4 * (u >> 1);
+                    pf[u] = sh[b * 8];
+                    pg[u] = sh[b * 8 + 4];
+                }
+            };
+            auto epi_modes = [&](auto kc) {
+                constexpr int k0 = decltype(kc)::value;
+#pragma unroll
+                for (int j = 0; j < SQ_TPW; ++j)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            // outputs k0 + k (wanted by the lower half of the wave) and k0 + k + 4 (by the upper half)
+                            const double lo_ = fma(pf[k].re, Fl[j][c].re, fma(-pf[k].im, Fl[j][c].im, fma(pg[k].re, Gl[j][c].re, -(pg[k].im * Gl[j][c].im))));
+                            const double hi_ = fma(pf[2 + k].re, Fl[j][c].re, fma(-pf[2 + k].im, Fl[j][c].im, fma(pg[2 + k].re, Gl[j][c].re, -(pg[2 + k].im * Gl[j][c].im))));
+                            const double sw = sq_swap32_add(lo_, hi_);
+                            if constexpr (k0 == 0) r1[j][k][c] = sw;
+                            else {
+                                // rows: even g takes outputs 0, 1 of its half, odd g 2, 3
+                                if (c == 0) y2[j][k].re += sq_swap16_add(r1[j][k][0], sw);
+                                else y2[j][k].im += sq_swap16_add(r1[j][k][1], sw);
+                            }
+                        }
+            };
+            // ybias of a row tile's outputs: asked for three quarters of a row tile before the store takes it, and BEFORE that row tile's
+            // touch of the next chunk -- a wait for a load also waits for every older load and store, and the touch goes to HBM
+            auto load_yb = [&](const int rt) {
+#pragma unroll
+                for (int j = 0; j < SQ_TPW; ++j) {
+                    const int tcl = wave + SQ_WV * j < ntiles ? wave + SQ_WV * j : wave;
+                    const cd *p = yb + (size_t) (tcl * 16 + nb) * NOUT + rt * 8 + 2 * g;
+                    ybv[j][0] = p[0];
+                    ybv[j][1] = p[1];
+                }
+            };
+            auto epi_store = [&](const int rt) {
+#pragma unroll
+                for (int j = 0; j < SQ_TPW; ++j) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        y2[j][h].re = (y2[j][h].re + ybv[j][h].re) + 0.0;           // -0.0 -> +0.0 (angle(-0) would be pi)
+                        y2[j][h].im = (y2[j][h].im + ybv[j][h].im) + 0.0;
+                    }
+                    if (wave + SQ_WV * j < ntiles) {
+                        const int col = (wave + SQ_WV * j) * 16 + nb, k0 = col * NOUT + rt * 8 + 2 * g;
+                        if constexpr (PAIR) {
+                            // FM without a debug buffer: the product the discriminator takes the angle of (demodulation.py:25-32)
+                            *(double2 *) (yd + (size_t) k0) = make_double2(y2[j][0].re * y2[j][1].re + y2[j][0].im * y2[j][1].im, y2[j][0].im * y2[j][1].re - y2[j][0].re * y2[j][1].im);
+                        } else {
+                            *(double2 *) (yd + 2 * (size_t) k0) = make_double2(y2[j][0].re, y2[j][0].im);
+                            *(double2 *) (yd + 2 * (size_t) k0 + 2) = make_double2(y2[j][1].re, y2[j][1].im);
+                        }
+                    }
+                }
+            };
+            // one row tile: 4 quarters of 36 matrix instructions into `ac`; behind each the piece of the previous row tile's vector work (`pv`)
+            auto step = [&](auto epc, auto lastc, v4i (&ac)[SQ_TPW][S], const v4i (&pv)[SQ_TPW][S], const int rt) {
+                constexpr bool EPI = decltype(epc)::value, LAST = decltype(lastc)::value;
+#pragma unroll
+                for (int j = 0; j < SQ_TPW; ++j)
+#pragma unroll
+                    for (int d = 0; d < S; ++d) ac[j][d] = (v4i) {0, 0, 0, 0};
+                static_for<0, 4>([&](auto kqc) {
+                    constexpr int kq = decltype(kqc)::value;
+                    if constexpr (kq < 3) load_master(std::integral_constant<int, kq + 1>{}, rt);
+                    else if constexpr (!LAST) load_master(std::integral_constant<int, 0>{}, rt + 1);
+                    if constexpr (EPI) {
+                        if constexpr (kq == 0) epi_recombine_loads(rt - 1);
+                        if constexpr (kq == 1) epi_modes_loads(rt - 1, std::integral_constant<int, 0>{});
+                        if constexpr (kq == 2) epi_modes_loads(rt - 1, std::integral_constant<int, 2>{});
+                    }
+                    if constexpr (kq == 0) {
+                        if constexpr (EPI) load_yb(rt - 1);
+                        touched ^= tv;
+                        tv = 0;
+#pragma unroll
+                        for (int t = 0; t < TPS; ++t) {
+                            const int ti = rt * TPS + t;                                  // touch ti covers units 64 ti .. 64 ti + 63 of the wave's TUNITS per tile
+                            const bool ok = ti < NTOUCH && (ti * 64 < TUNITS || have1);
+                            const int u = ok ? ti * 64 + lane : 0;
+                            tv ^= *(const unsigned *) (nx + (size_t) (wave * 16 * SQ_LC * 4) + (size_t) (u / TUNITS) * (SQ_WV * 16 * SQ_LC * 4) + (size_t) (u % TUNITS) * SDRT_SQ_TOUCH);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ksl = 0; ksl < 2; ++ksl)
+#pragma unroll
+                        for (int d = 0; d < S; ++d)
+#pragma unroll
+                            for (int j = 0; j < SQ_TPW; ++j) {
+                                ac[j][d] = SQ_MFMA(Aq[kq & 1][ksl * S + d], bhi[j][2 * kq + ksl], ac[j][d]);
+                                if (d >= 1) ac[j][d - 1] = SQ_MFMA(Aq[kq & 1][ksl * S + d], blo[j][2 * kq + ksl], ac[j][d - 1]);
+                            }
+                    if constexpr (EPI) {
+                        if constexpr (kq == 0) epi_recombine(pv);
+                        if constexpr (kq == 1) epi_modes(std::integral_constant<int, 0>{});
+                        if constexpr (kq == 2) epi_modes(std::integral_constant<int, 2>{});
+                        if constexpr (kq == 3) epi_store(rt - 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            };
+            constexpr std::true_type yes{};
+            constexpr std::false_type no{};
+            SQ_STAMP(6);
+            load_master(std::integral_constant<int, 0>{}, 0);
+            step(no, no, accA, accB, 0);
 #pragma unroll 1
-            for (int rt = 0; rt < NRT; ++rt) {
-                const int s = (rt * 8 + bl) << QS;                                // sample of the column the A row's output sits on
-                // 16-byte units (tables.h: SDRT_SQ_CS / _PS): part PS + (d NCP + copy) CS + (64 ks + 16 g - 16 (s >> 3) + 512) / 16
-                const int abase = part * SDRT_SQ_PS(q, S, NCP) + ((s & 7) >> QS) * SDRT_SQ_CS(q) + g - (s >> 3) + 32;
-                v4i acc[S];
-#pragma unroll
-                for (int d = 0; d < S; ++d) acc[d] = (v4i) {0, 0, 0, 0};
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int d = 0; d < S; ++d) {
-                        const v4i A = masterL[abase + d * NCP * SDRT_SQ_CS(q) + 4 * ks];
-                        acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi[j][ks], acc[d], 0, 0, 0);
-                        if (d >= 1) acc[d - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo[j][ks], acc[d - 1], 0, 0, 0);
-                    }
-                double val[4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    double sum = (double) acc[S - 1][v];
-#pragma unroll
-                    for (int d = S - 2; d >= 0; --d) sum = fma(sum, 256.0, (double) acc[d][v]);
-                    val[v] = sum * cloc;
-                }
-                // result rows 4 g + v of column nb: outputs b0 = 8 rt + 2 g (val0 + i val1) and b0 + 1 (val2 + i val3)
-                cd y2[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int b = rt * 8 + 2 * g + h, so = b << QS;
-                    const cd rot = cmul(ps, samp_at(so));                             // exp(i theta (256 c + s)): the output's own phasor
-                    cd y = mk(fma(rot.re, val[2 * h], -(rot.im * val[2 * h + 1])), fma(rot.re, val[2 * h + 1], rot.im * val[2 * h]));
-                    const cd *sh = (SHL ? (const cd *) shareL : (const cd *) a.share) + (size_t) b * 8;          // 2 p_i^s (i < 4), 2 p_i^(256 - s)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const cd pf = sh[i], pg = sh[4 + i];
-                        y.re = fma(pf.re, Fs[2 * i].re, fma(-pf.im, Fs[2 * i].im, fma(pg.re, Gn[2 * i].re, fma(-pg.im, Gn[2 * i].im, y.re))));
-                        y.im = fma(pf.re, Fs[2 * i + 1].re, fma(-pf.im, Fs[2 * i + 1].im, fma(pg.re, Gn[2 * i + 1].re, fma(-pg.im, Gn[2 * i + 1].im, y.im))));
-                    }
-                    const int k = col * NOUT + b;
-                    if (yb) { y.re += yb[k].re; y.im += yb[k].im; }
-                    else { y.re += 0.0; y.im += 0.0; }           // -0.0 -> +0.0 (angle(-0) would be pi)
-                    y2[h] = y;
-                }
-                const int k0 = col * NOUT + rt * 8 + 2 * g;
-                if (a.pair_out) {
-                    // FM without a debug buffer: the product the discriminator takes the angle of (demodulation.py:25-32)
-                    *(double2 *) (yd + (size_t) k0) = make_double2(y2[0].re * y2[1].re + y2[0].im * y2[1].im, y2[0].im * y2[1].re - y2[0].re * y2[1].im);
-                } else {
-                    *(double2 *) (yd + 2 * (size_t) k0) = make_double2(y2[0].re, y2[0].im);
-                    *(double2 *) (yd + 2 * (size_t) k0 + 2) = make_double2(y2[1].re, y2[1].im);
-                }
+            for (int rt = 1; rt < NRT - 1; rt += 2) {
+                step(yes, no, accB, accA, rt);
+                step(yes, no, accA, accB, rt + 1);
             }
+            step(yes, yes, accB, accA, NRT - 1);
+            SQ_STAMP(7);
+            load_yb(NRT - 1);
+            epi_recombine_loads(NRT - 1);
+            epi_recombine(accB);
+            epi_modes_loads(NRT - 1, std::integral_constant<int, 0>{});
+            epi_modes(std::integral_constant<int, 0>{});
+            epi_modes_loads(NRT - 1, std::integral_constant<int, 2>{});
+            epi_modes(std::integral_constant<int, 2>{});
+            epi_store(NRT - 1);
+            touched ^= tv;
         }
-        }
+        SQ_STAMP(10);
         __syncthreads();            // the state arrays are free for the next chunk
+        SQ_STAMP(11);
     }
     if (touched == 0x9e3779b9u && a.n < 0) a.ydec[0] = 0.0;            // (never: keeps the touches alive)
 }
 
 template <int DT>
 hipError_t launch_sq_q(const SqArgs &a, int q, dim3 grid, hipStream_t s) {
-    auto go = [&](auto qc) -> hipError_t {
+    auto go = [&](auto qc, auto pc) -> hipError_t {
         constexpr int QS = decltype(qc)::value, qq = 1 << QS, NCP = 2 * qq >= 16 ? 1 : 16 / (2 * qq);
+        constexpr bool PAIR = decltype(pc)::value;
         const size_t lds = (size_t) sq_lds(NCP, SQ_LC / qq).total;
         static thread_local int done_dev = -1;
         int dev = 0;
         (void) hipGetDevice(&dev);
         if (done_dev != dev) {
-            hipError_t e = hipFuncSetAttribute((const void *) chain_sq_kernel<DT, QS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            hipError_t e = hipFuncSetAttribute((const void *) chain_sq_kernel<DT, QS, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e != hipSuccess) return e;
             done_dev = dev;
         }
-        hipLaunchKernelGGL((chain_sq_kernel<DT, QS>), grid, dim3(64 * SQ_WV), lds, s, a);
+        hipLaunchKernelGGL((chain_sq_kernel<DT, QS, PAIR>), grid, dim3(64 * SQ_WV), lds, s, a);
         return hipGetLastError();
     };
+    auto pick = [&](auto qc) -> hipError_t { return a.pair_out ? go(qc, std::true_type{}) : go(qc, std::false_type{}); };
     switch (q) {
-        case 2: return go(std::integral_constant<int, 1>{});
-        case 4: return go(std::integral_constant<int, 2>{});
-        case 8: return go(std::integral_constant<int, 3>{});
-        case 16: return go(std::integral_constant<int, 4>{});
+        case 2: return pick(std::integral_constant<int, 1>{});
+        case 4: return pick(std::integral_constant<int, 2>{});
+        case 8: return pick(std::integral_constant<int, 3>{});
+        case 16: return pick(std::integral_constant<int, 4>{});
     }
     return hipErrorInvalidValue;
 }
@@ -383,10 +589,10 @@ hipError_t launch_sq_q(const SqArgs &a, int q, dim3 grid, hipStream_t s) {
 
 bool chain_sq_supported(int q, int dt, int n) {
     const int nc = n / SQ_LC;
-    // decimation 16 runs here too (the template covers it, SDRTERM_DIAG=sq=16 selects it) but two passes of the wide kernel are faster
-    // there: 389 against 238 GS/s (profiles/r05_experiments.txt section 7) -- a chunk costs this kernel ~30 us before its first local tile
+    // (SDRTERM_DIAG=sq=8 leaves decimation 16 to the two passes of the wide kernel, as before the A fragments were read ahead:
+    // 389 - 413 GS/s there against 457 here, profiles/r05_experiments.txt section 9)
     const char *e = sdrt_diag("sq");
-    const int maxq = e && atoi(e) == 16 ? 16 : 8;
+    const int maxq = e && atoi(e) == 8 ? 8 : 16;
     return (q == 2 || q == 4 || q == 8 || q == 16) && q <= maxq && (dt == SDRT_S16 || dt == SDRT_U16) && n % (16 * SQ_LC) == 0 && nc >= 16 && nc <= SQ_MAXCOL;
 }
 

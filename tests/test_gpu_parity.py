@@ -332,9 +332,9 @@ def test_pair_products_between_the_stages_equal_the_sample_path(code, q, rows, m
     freqs = [15700.0, -203300.0, 100100.0][:rows]
     raw = prng.raw_bytes(code, n * nch, seed=77, amp=100 if code == 'B' else 3000)
     # (decimation 4 .. 16: several passes of the wide kernel over the chunk, each finishing whole pairs; 16-bit records at decimation
-    # 4 and 8: the one-pass kernel, whose lanes hold both outputs of a pair)
+    # 4 .. 16: the one-pass kernel, whose lanes hold both outputs of a pair)
     eng = Engine(fs, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=5000 if q >= 32 else 8000 * (32 // q))
-    assert eng.stage_a == ('sq' if code in 'hH' and q <= 8 else 'i8w')
+    assert eng.stage_a == ('sq' if code in 'hH' and q <= 16 else 'i8w')
     a = eng.process(raw)
     b, _y = eng.process_debug(raw)
     err = np.abs(a - b).max()
@@ -793,8 +793,6 @@ def test_small_decimations_in_passes_of_the_wide_kernel(code, q, mode, rows, for
             pytest.skip('decimation 2 without the one-pass kernel is the per-sample kernel (test_every_instantiation_of_the_per_sample_kernel)')
     elif code in 'bB':
         pytest.skip('8-bit records keep the passes of the wide kernel')
-    elif q == 16:
-        _diag(monkeypatch, sq=16)          # (decimation 16 stays on the wide kernel's two passes by default: they are faster there)
     fs, n, nch = 1024000, samples_per_chunk(code), 7
     freqs = [15700.0, -203300.0, 100100.0][:rows]
     omega = 60000 if q == 4 else (30000 if q == 8 else 15000)
