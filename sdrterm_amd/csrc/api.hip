@@ -1118,6 +1118,9 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
             const int per = e ? atoi(e) : 16;          // (8 .. 32 measure alike at every decimation, 64 is too far apart: r05_experiments.txt section 9)
             const size_t wpr = std::max<size_t>(1, (size_t) n_cus / (size_t) c->rows);
             sa.stagger = n_chunks >= 6 * wpr ? per : 0;
+            // the touches of the next chunk double the input's HBM reads (an XCD's L2 does not keep a round of chunks: counters in
+            // r05_experiments.txt section 11) and buy 2 % at decimation 16, nothing at 2 .. 8
+            sa.touch = sdrt_diag_int("sq_touch", c->cfg.decimation >= 16 ? 1 : 0);
         }
         Timed t(c, s, 0);
         HIP_TRY(launch_chain_sq(sa, c->cfg.decimation, c->cfg.dtype, n_cus, s));

@@ -200,6 +200,7 @@ struct SqArgs {
     const double *nco_col;      // [rows][n / 256][2] exp(i theta 256 c)
     const double *ybias;        // [rows][m][2] (zeros while it is being calibrated)
     double comb_agg, comb_loc;  // combine factors of the two plane sets (the same for every row)
+    int touch;                  // != 0: the next chunk's lines are touched during the local phase
     int stagger;                // > 0: workgroup b starts (b / 8) x stagger sleeps of 64 cycles late (its XCD's workgroups apart in phase)
     unsigned long long *stamps; // optional diagnostic (-DSDRT_STAMPS builds, tools/stamps_sq.py): [wg < stamp_wgs][wave][16] s_memtime
     int stamp_wgs;

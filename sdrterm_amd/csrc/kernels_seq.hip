@@ -875,6 +875,7 @@ hipError_t launch_post_bigfft(const PostArgs &a, hipStream_t s) {
             case 16384: {
                 const int thr = sdrt_diag_int("post_thr", 512);
                 if (thr == 256) return a.pairs ? launch_post_bigfftp_b<4, true>(a, s) : launch_post_bigfftp_b<4, false>(a, s);
+                // (1024 threads -- four waves per SIMD at 122 registers -- measured 0.352 against 0.327 ms per 2^26 samples: r05_experiments.txt section 11)
                 return a.pairs ? launch_post_bigfftp_b<4, true, 512>(a, s) : launch_post_bigfftp_b<4, false, 512>(a, s);
             }
         }

@@ -156,6 +156,33 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
     // are what that phase is short of)
     const int e_o = (tid >> 5) & 7, e_l = tid & 31;
     unsigned touched = 0;                                                     // (the next chunk's lines pulled towards the L2: see A2)
+    // A chunk's records are asked for as soon as the registers for them are free: behind the last matrix instruction of the chunk
+    // before (the byte slices are dead there), so that they travel during its last row tile's vector work and this chunk's E.
+    // E: the chunk's first and last 28 records; A1: the wave's two tiles, 16 columns each (lane (g, nb): 32 bytes of column nb per k-step)
+    raw_t e_raw[2][2] = {{0, 0}, {0, 0}};
+    uint32_t cur[SQ_TPW][KS][8];
+    auto ask_for = [&](const unsigned char *chunk_raw) {
+        if (e_l <= SDRT_EDGE) {
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const long idx = tl ? (long) n - (SDRT_EDGE + 1) + e_l : e_l;
+                const raw_t *rp = (const raw_t *) chunk_raw + 2 * idx;
+                e_raw[tl][0] = rp[0];
+                e_raw[tl][1] = rp[1];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SQ_TPW; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (wave + SQ_WV * j < ntiles) load_words<32>(chunk_raw + ((size_t) ((wave + SQ_WV * j) * 16 + (lane0 & 15)) * SQ_LC + 32 * ks + 8 * (lane0 >> 4)) * 4, cur[j][ks]);
+                else {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) cur[j][ks][w] = 0;
+                }
+            }
+    };
+    ask_for((const unsigned char *) a.raw + first * (size_t) n * 4);
 
     for (size_t chunk = first; chunk < a.n_chunks; chunk += wpr) {
         const unsigned char *chunk_raw = (const unsigned char *) a.raw + chunk * (size_t) n * 4;
@@ -174,33 +201,12 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
 #endif
         SQ_STAMP(0);
         const bool have0 = wave < ntiles, have1 = wave + SQ_WV < ntiles;
-        // ---- E (loads): the chunk's first and last 28 records, this thread's two edge coefficients
-        raw_t e_raw[2][2] = {{0, 0}, {0, 0}};
+        // ---- E: this thread's two edge coefficients (its records: ask_for)
         cd e_head = mk(0.0, 0.0), e_tailc = mk(0.0, 0.0);
         if (e_l <= SDRT_EDGE) {
             e_head = mk(tab->head[e_o >> 1][e_l][0], tab->head[e_o >> 1][e_l][1]);
             e_tailc = mk(tab->tailU[e_o >> 1][e_l][0], tab->tailU[e_o >> 1][e_l][1]);
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl) {
-                const long idx = tl ? (long) n - (SDRT_EDGE + 1) + e_l : e_l;
-                const raw_t *rp = (const raw_t *) chunk_raw + 2 * idx;
-                e_raw[tl][0] = rp[0];
-                e_raw[tl][1] = rp[1];
-            }
         }
-        // ---- A1 (loads): the wave's two tiles, 16 columns each: every load in flight before anything waits for one
-        uint32_t cur[SQ_TPW][KS][8];
-#pragma unroll
-        for (int j = 0; j < SQ_TPW; ++j)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (wave + SQ_WV * j < ntiles) load_words<32>(chunk_raw + ((size_t) ((wave + SQ_WV * j) * 16 + nb) * SQ_LC + 32 * ks + 8 * g) * 4, cur[j][ks]);
-                else {
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) cur[j][ks][w] = 0;
-                }
-            }
-        __builtin_amdgcn_sched_barrier(0);
         // ---- E (sums).  F_0,i = sum_l head[i][l] u[l], the sample part of G_end,i = sum_l tailU[i][l] u[n - 28 + l], per real
         // stream; u = (x - off) exp(i theta t): the same x - off the slices carry (ybias returns what is left out)
         {
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
 #pragma unroll
                         for (int t = 0; t < TPS; ++t) {
                             const int ti = rt * TPS + t;                                  // touch ti covers units 64 ti .. 64 ti + 63 of the wave's TUNITS per tile
-                            const bool ok = ti < NTOUCH && (ti * 64 < TUNITS || have1);
+                            const bool ok = a.touch && ti < NTOUCH && (ti * 64 < TUNITS || have1);
                             const int u = ok ? ti * 64 + lane : 0;
                             tv ^= *(const unsigned *) (nx + (size_t) (wave * 16 * SQ_LC * 4) + (size_t) (u / TUNITS) * (SQ_WV * 16 * SQ_LC * 4) + (size_t) (u % TUNITS) * SDRT_SQ_TOUCH);
                         }
@@ -542,6 +548,9 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
             step(yes, yes, accB, accA, NRT - 1);
             SQ_STAMP(7);
             load_yb(NRT - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            ask_for(nx);                                   // (behind ybias: the last row tile's store waits for that, not for these; the last chunk asks for itself again)
+            __builtin_amdgcn_sched_barrier(0);
             epi_recombine_loads(NRT - 1);
             epi_recombine(accB);
             epi_modes_loads(NRT - 1, std::integral_constant<int, 0>{});
@@ -551,8 +560,10 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
             epi_store(NRT - 1);
             touched ^= tv;
         }
+        // (no barrier here: what the next chunk writes before its first barrier -- F0 / Gu in E, the tile totals in A1 -- was read by
+        // wave 0 before this chunk's second barrier; the carries it writes in P2 come after a barrier every wave reaches only behind
+        // its reads of them here)
         SQ_STAMP(10);
-        __syncthreads();            // the state arrays are free for the next chunk
         SQ_STAMP(11);
     }
     if (touched == 0x9e3779b9u && a.n < 0) a.ydec[0] = 0.0;            // (never: keeps the touches alive)
