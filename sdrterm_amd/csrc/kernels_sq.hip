@@ -249,6 +249,13 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
                         blo[j][ks][w] = (int) (__builtin_amdgcn_perm(cur[j][ks][2 * w + 1], cur[j][ks][2 * w], sel_lo) ^ SqEnc<DT>::xlo);
                         bhi[j][ks][w] = (int) (__builtin_amdgcn_perm(cur[j][ks][2 * w + 1], cur[j][ks][2 * w], sel_hi) ^ SqEnc<DT>::xhi);
                     }
+            // (each slice ONE value in four consecutive accumulation registers from here on: only matrix instructions read them.  Left
+            // to the allocator the slices sat there anyway, word by word, and were copied out in front of every matrix instruction
+            // that takes one: 150 of the 590 vector instructions of a row tile)
+#pragma unroll
+            for (int j = 0; j < SQ_TPW; ++j)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(bhi[j][ks]), "+a"(blo[j][ks]));
         }
         if (have0) {
             v4i Aq[2][2 * S], acc[SQ_TPW][S];

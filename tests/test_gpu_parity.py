@@ -706,6 +706,43 @@ def test_a_stream_that_starts_silent_under_correct_iq_comes_out_as_exact_zeros(c
         assert err <= tol_for(exp, mode), err
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,q,mode,rows', [(8192, 2, 'fm', 1), (4096, 16, 'am', 2), (8192, 4, 'fm', 3), (12288, 8, 'am', 1), (16384, 2, 'fm', 2), (20480, 16, 'am', 1),
+                                            (28672, 4, 'am', 2), (16384, 16, 'fm', 1)])
+def test_one_pass_kernel_on_other_chunk_sizes(n, q, mode, rows, monkeypatch):
+    """chain_sq_kernel gives each of its four waves the tiles w and w + 4 of a chunk (16 columns of 256 samples each): the reference's
+    16-bit chunk has eight (32768 samples, read_file.py:51), the C ABI takes any multiple of 4096 samples up to that (from 8192 at
+    decimation 2 and 4) -- one to seven
+    tiles: waves without a tile, waves with one, an odd count.  Against oracle/chain.c (dsp_processor.py:140-149), several rows, with
+    the chunk's bits independent of the batch it arrives in.  (FM where the chunk's output count is a power of two: the resampler.)"""
+    from sdrterm_amd.engine import Engine
+    from tests.golden import prng
+    monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
+    code, fs, nch = 'h', 1024000, 9
+    freqs = [15700.0, -203300.0, 100100.0][:rows]
+    omega = 100000 if q == 2 else (60000 if q == 4 else (30000 if q == 8 else 15000))
+    raw = prng.raw_bytes(code, n * nch, seed=900 + n // 4096 + q, amp=8000)
+    eng = Engine(fs, q, mode, code, n_samples=n, row_freqs=freqs, apply_shift=True, omega_out=omega)
+    assert eng.stage_a == 'sq'
+    out, y = eng.process_debug(raw)
+    m = n // q
+    exp = _oracle_rows(raw, code, n, q, mode, freqs, fs, omega, range(nch), range(rows))
+    got = out.reshape(rows, nch, m).transpose(1, 0, 2)
+    err = float(np.abs(got - exp).max())
+    tol = tol_for(exp, mode)
+    print(f'n={n} q={q} {mode} x {rows} [{eng.stage_a}]: max abs err {err:.3e} (tol {tol:.1e})')
+    assert err <= tol
+    whole = eng.process(raw).reshape(rows, nch, m)
+    part = eng.process(raw[3 * eng.chunk_bytes:8 * eng.chunk_bytes]).reshape(rows, 5, m)
+    assert np.array_equal(part, whole[:, 3:8])
+    # a silent chunk between loud ones comes out as exact zeros (demodulation.py:30-32: angle(0) = 0; AM: 0)
+    quiet = bytearray(raw)
+    quiet[4 * eng.chunk_bytes:5 * eng.chunk_bytes] = bytes(eng.chunk_bytes)
+    z = eng.process(bytes(quiet)).reshape(rows, nch, m)
+    assert float(np.abs(z[:, 4]).max()) == 0.0
+    assert np.array_equal(z[:, :4], whole[:, :4])
+
+
 def _oracle_rows_iq(raw, code, n, q, mode, freqs, fs, omega_out, nch):
     """oracle/chain.c with --correct-iq carried across the chunks (read_file.py:64-77, inductance 50 / fs): (chunk, row, m)."""
     from oracle import c_chain, ref_chain
