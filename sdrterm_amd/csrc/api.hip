@@ -1112,12 +1112,15 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
         sa.stamps = c->stamps_dev;
         sa.stamp_wgs = c->stamp_wgs;
         {
-            // workgroups of an XCD started apart in phase (kernels_sq.hip): worth one chunk's time at the start of the launch, so only
-            // for launches that give every workgroup several chunks
+            // workgroups of an XCD started apart in phase (kernels_sq.hip): the last one starts 31 steps late, so the step is sized to
+            // keep that under ~3 % of what a workgroup has to do in this launch (a chunk costs it ~110 / 60 / 45 / 35 thousand cycles
+            // at decimation 2 / 4 / 8 / 16), and 16 sleeps of 64 cycles at most (8 .. 32 measure alike: r05_experiments.txt section 9)
             const char *e = sdrt_diag("sq_stagger");
-            const int per = e ? atoi(e) : 16;          // (8 .. 32 measure alike at every decimation, 64 is too far apart: r05_experiments.txt section 9)
+            const int q = c->cfg.decimation;
             const size_t wpr = std::max<size_t>(1, (size_t) n_cus / (size_t) c->rows);
-            sa.stagger = n_chunks >= 6 * wpr ? per : 0;
+            const double per_chunk = q == 2 ? 110e3 : q == 4 ? 60e3 : q == 8 ? 45e3 : 35e3;
+            const double fit = 0.03 * per_chunk * (double) (n_chunks / wpr) / (31.0 * 64.0);
+            sa.stagger = e ? atoi(e) : (int) std::min(16.0, fit);
             // the touches of the next chunk double the input's HBM reads (an XCD's L2 does not keep a round of chunks: counters in
             // r05_experiments.txt section 11) and buy 2 % at decimation 16, nothing at 2 .. 8
             sa.touch = sdrt_diag_int("sq_touch", c->cfg.decimation >= 16 ? 1 : 0);

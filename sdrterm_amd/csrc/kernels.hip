@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void demod_kernel(const double *y, double *out
         const int N = m >> 1;
         for (int j = tid; j < N; j += 256) {
             const cd p = yr[2 * j], c = yr[2 * j + 1];
-            av[j] = atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);
+            av[j] = atan2_pi(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);
         }
         __syncthreads();
         for (int j = tid; j < N; j += 256) {

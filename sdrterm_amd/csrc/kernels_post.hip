@@ -147,12 +147,12 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
     if (fm && a.pairs) {
         for (int j = lane; j < N; j += 64) {
             const cd z = y[j];                                                      // d[2j] * conj(d[2j+1]) from the chain kernel
-            av[j] = atan2(z.im, z.re);
+            av[j] = atan2_pi(z.im, z.re);
         }
     } else if (fm) {
         for (int j = lane; j < N; j += 64) {
             const cd p = load_y(y, R, h, 2 * j), c = load_y(y, R, h, 2 * j + 1);
-            av[j] = atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);    // angle(d[i] * conj(d[i+1]))
+            av[j] = atan2_pi(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);    // angle(d[i] * conj(d[i+1]))
         }
     }
     if (fm) {
@@ -328,10 +328,10 @@ __global__ __launch_bounds__(64 * WPB) void post_fft_kernel(PostArgs a) {
                     double an;
                     if constexpr (PAIRS) {
                         const cd z = y[j];
-                        an = atan2(z.im, z.re);
+                        an = atan2_pi(z.im, z.re);
                     } else {
                         const cd p = load_y(y, R, h, 2 * j), c = load_y(y, R, h, 2 * j + 1);
-                        an = atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);
+                        an = atan2_pi(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);
                     }
                     x[b][k] = mk(an, 0.0);
                     ev[b][k] = an;                              // even output samples are the input
@@ -391,10 +391,10 @@ __global__ __launch_bounds__(64 * WPB) void post_fftp_kernel(PostArgs a) {
             // angle(d[i] * conj(d[i+1])) (demodulation.py:25-32); pairs: the product comes from the chain kernel
             if constexpr (PAIRS) {
                 const cd z = y[j];
-                return atan2(z.im, z.re);
+                return atan2_pi(z.im, z.re);
             } else {
                 const cd p = load_y(y, R, h, 2 * j), c = load_y(y, R, h, 2 * j + 1);
-                return atan2(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);
+                return atan2_pi(p.im * c.re - p.re * c.im, p.re * c.re + p.im * c.im);
             }
         };
         auto angles = [&]() {

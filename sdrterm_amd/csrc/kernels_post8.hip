@@ -79,41 +79,7 @@ __device__ __forceinline__ double swz_bcast_last8(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// atan2 for the pair angles (demodulation.py:30-32: angle()).  t = min(|x|,|y|) / max(|x|,|y|) in [0, 1] by one reciprocal, two
-// Newton steps and a residual correction; atan(t) = t q(t^2), q of degree 16 (tools/fit_atan.py: 4e-15 over [0, 1]); octant
-// and sign put back with selects.  Signed zeros as C99 / numpy: (+-0, +0) -> +-0, (+-0, -0) -> +-pi.  39 instructions against
-// the library's 70 (half of this kernel's arithmetic was atan2).
-__device__ __forceinline__ double atan2_pi(double y, double x) {
-    const double ax = fabs(x), ay = fabs(y);
-    const double mx = fmax(fmax(ax, ay), 2.2250738585072014e-308), mn = fmin(ax, ay);    // (0, 0): t = 0 / tiny = 0
-    double r = __builtin_amdgcn_rcp(mx);
-    r = fma(fma(-mx, r, 1.0), r, r);
-    r = fma(fma(-mx, r, 1.0), r, r);
-    double t = mn * r;
-    t = fma(fma(-mx, t, mn), r, t);
-    const double s = t * t;
-    double p = 7.03825190772905e-05;
-    p = fma(p, s, -0.0006752461871228126);
-    p = fma(p, s, 0.0030574650642366205);
-    p = fma(p, s, -0.008772278251586507);
-    p = fma(p, s, 0.01816674618350375);
-    p = fma(p, s, -0.02955359506524126);
-    p = fma(p, s, 0.0404892227192373);
-    p = fma(p, s, -0.049763055792462756);
-    p = fma(p, s, 0.057934563768719034);
-    p = fma(p, s, -0.06645912139302747);
-    p = fma(p, s, 0.07688758456599037);
-    p = fma(p, s, -0.09090481197187922);
-    p = fma(p, s, 0.11111076687817362);
-    p = fma(p, s, -0.1428571258641315);
-    p = fma(p, s, 0.19999999955253506);
-    p = fma(p, s, -0.3333333333285598);
-    p = fma(p, s, 0.9999999999999907);
-    double u = t * p;
-    u = ay > ax ? 1.5707963267948966 - u : u;
-    u = __double2hiint(x) < 0 ? 3.141592653589793 - u : u;
-    return copysign(u, y);
-}
+// (atan2_pi: kernels_common.hpp)
 
 // DPP quad permutation (control = the four source lanes of a quad, two bits each); sources never leave the quad
 template <int CTRL>

@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void post_big_kernel(PostArgs a) {
         for (int i = tid; i < N; i += 256) hr[i] = a.resample_odd[i == 0 ? 0 : N - i];
         for (int j = tid; j < N; j += 256) {
             const cd pa = y[2 * j], c = y[2 * j + 1];
-            out[2 * j] = atan2(pa.im * c.re - pa.re * c.im, pa.re * c.re + pa.im * c.im);    // angle(d[i] * conj(d[i+1]))
+            out[2 * j] = atan2_pi(pa.im * c.re - pa.re * c.im, pa.re * c.re + pa.im * c.im);    // angle(d[i] * conj(d[i+1]))
         }
         __syncthreads();
         // z_odd[j] = sum_k a[k] hr[(k - j) mod N]: thread owns R consecutive outputs per turn; a sliding register window
@@ -727,10 +727,10 @@ __global__ __launch_bounds__(256) void post_bigfft_kernel(PostArgs a) {
             double an;
             if constexpr (PAIRS) {
                 const cd z = y[j];                              // d[2j] conj(d[2j+1]) from the chain kernel
-                an = atan2(z.im, z.re);
+                an = atan2_pi(z.im, z.re);
             } else {
                 const cd pa = y[2 * j], c = y[2 * j + 1];
-                an = atan2(pa.im * c.re - pa.re * c.im, pa.re * c.re + pa.im * c.im);
+                an = atan2_pi(pa.im * c.re - pa.re * c.im, pa.re * c.re + pa.im * c.im);
             }
             out[2 * j] = an;
             x[b][k] = mk(an, 0.0);
@@ -771,10 +771,10 @@ __global__ __launch_bounds__(THR) void post_bigfftp_kernel(PostArgs a) {
     auto angle_of = [&](int j) {
         if constexpr (PAIRS) {
             const cd z = y[j];                                  // d[2j] conj(d[2j+1]) from the chain kernel
-            return atan2(z.im, z.re);
+            return atan2_pi(z.im, z.re);
         } else {
             const cd pa = y[2 * j], c = y[2 * j + 1];
-            return atan2(pa.im * c.re - pa.re * c.im, pa.re * c.re + pa.im * c.im);
+            return atan2_pi(pa.im * c.re - pa.re * c.im, pa.re * c.re + pa.im * c.im);
         }
     };
     // pair angles (demodulation.py:25-32): the even output samples, and -- two to a point -- the input of the transform
