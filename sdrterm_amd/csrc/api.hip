@@ -537,7 +537,8 @@ int setup_sq(sdrt_ctx *c, const sdrt_config *cfg, const DecimTables &tab) {
     if (rc != SDRT_OK) return rc;
     c->use_sq = true;
     // ybias from the kernel's own responses
-    const size_t cnt = (size_t) c->rows * m * 2, cb = (size_t) n * 4;
+    const int bpc = (cfg->dtype == SDRT_S8 || cfg->dtype == SDRT_U8) ? 1 : 2;          // bytes per component
+    const size_t cnt = (size_t) c->rows * m * 2, cb = (size_t) n * 2 * bpc;
     if (hipMalloc(&c->d_ybias, cnt * sizeof(double)) != hipSuccess) return fail(SDRT_ENOMEM, "hipMalloc failed");
     double *d_bias = c->d_ybias;
     if (hipMemset(d_bias, 0, cnt * sizeof(double)) != hipSuccess) return fail(SDRT_EHIP, "hipMemset failed");    // (the calibration runs with zeros)
@@ -556,7 +557,7 @@ int setup_sq(sdrt_ctx *c, const sdrt_config *cfg, const DecimTables &tab) {
     if (rc == SDRT_OK && c->norm_bias != 0.0) {
         // records with re = 1, im = 0 (in the records' byte order)
         const bool be = cfg->swap_endianness != 0;
-        for (int i = 0; i < n; ++i) unit[(size_t) i * 4 + (be ? 1 : 0)] = 1;
+        for (int i = 0; i < n; ++i) unit[(size_t) i * 2 * bpc + (bpc == 2 && be ? 1 : 0)] = 1;
         respond(r1);
     }
     if (rc == SDRT_OK) {
@@ -786,14 +787,14 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         rc = upload(&c->d_resample, h.data(), h.size() * sizeof(double));
         const int N = m / 2;
         const bool resample_direct = [] { const char *v = sdrt_diag("resample"); return v && strcmp(v, "direct") == 0; }();     // diagnostics: the circulant product
-        if (rc == SDRT_OK && (N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096 || N == 8192) && !resample_direct) {
+        if (rc == SDRT_OK && (N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096 || N == 8192 || N == 16384) && !resample_direct) {
             std::vector<double> tw((size_t) N * 2), sh((size_t) N * 2);
             sdrt_build_fft_resample(N, tw.data(), sh.data());
             rc = upload(&c->d_fft_tw, tw.data(), tw.size() * sizeof(double));
             if (rc == SDRT_OK) rc = upload(&c->d_fft_shift, sh.data(), sh.size() * sizeof(double));
             c->fft_ok = rc == SDRT_OK;
             // (diagnostics: post_packed=0 keeps the full-size complex transforms)
-            if (rc == SDRT_OK && (N == 1024 || N == 2048 || N == 4096 || N == 8192) && sdrt_diag_int("post_packed", 1) != 0) {
+            if (rc == SDRT_OK && (N == 1024 || N == 2048 || N == 4096 || N == 8192 || N == 16384) && sdrt_diag_int("post_packed", 1) != 0) {
                 // 2048 / 4096 outputs per chunk (decimation 16 / 8 of 16-bit records): the real angles packed two to a complex number
                 std::vector<double> twp((size_t) N), ab((size_t) N * 2);
                 sdrt_build_fft_resample_packed(N, twp.data(), ab.data());

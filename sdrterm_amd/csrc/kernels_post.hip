@@ -632,7 +632,7 @@ bool post_takes_pairs(const PostArgs &a) {
     if (a.mode != SDRT_FM) return false;
     if (post_fft8_supported(a)) return true;
     if (a.fft_tw && a.fft_shift && a.fft_ok && (a.m == 512 || a.m == 1024 || a.m == 2048 || a.m == 4096)) return true;
-    if ((a.m == 8192 || a.m == 16384) && a.fft_tw && a.fft_shift && a.fftp_tw && a.fftp_ab && !a.iq_R) return true;    // post_bigfftp_kernel
+    if ((a.m == 8192 || a.m == 16384 || a.m == 32768) && a.fft_tw && a.fft_shift && a.fftp_tw && a.fftp_ab && !a.iq_R) return true;    // post_bigfftp_kernel
     if (a.m >= 8192 && post_big_supported(a.m, a.mode)) return false;
     return post_waves_per_block(a.m, a.mode) != 0;
 }

@@ -758,6 +758,9 @@ __global__ __launch_bounds__(256) void post_bigfft_kernel(PostArgs a) {
 template <int THR, int B, bool PAIRS>
 __global__ __launch_bounds__(THR) void post_bigfftp_kernel(PostArgs a) {
     constexpr int H = 4 * THR * B, N = 2 * H, M = 2 * N;
+    // 32768 outputs per chunk (decimation 2 of 8-bit records, round 5): the item's samples do not fit the LDS beside nothing (266 KB);
+    // they go through the output buffer for the lowpass, as in post_bigfft_kernel, and the even samples are written at once
+    constexpr bool ZL = (size_t) (M + M / 64) * 8 <= 160 * 1024;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ cd ptot[SDRT_OUT_MAXMODES][THR / 64];
     cd *X = (cd *) smem;                                        // [H + H/16]
@@ -785,7 +788,8 @@ __global__ __launch_bounds__(THR) void post_bigfftp_kernel(PostArgs a) {
             const int n = tid + THR * b + k * (H / 4);
             const double a0 = angle_of(2 * n), a1 = angle_of(2 * n + 1);
             x[b][k] = mk(a0, a1);
-            ev[b][k] = x[b][k];                                 // (64 registers through the transforms: no round trip through memory)
+            if constexpr (ZL) ev[b][k] = x[b][k];               // (64 registers through the transforms: no round trip through memory)
+            else { out[4 * n] = a0; out[4 * n + 2] = a1; }
         }
     fft_group<THR, B, false>(x, X, tw, tid, [&](int o, cd v) { X[xq(o)] = v; });
     __syncthreads();
@@ -801,6 +805,12 @@ __global__ __launch_bounds__(THR) void post_bigfftp_kernel(PostArgs a) {
                          fma(c.x, Z.im, fma(c.y, Z.re, fma(c.w, Zm.re, -(c.z * Zm.im)))));
         }
     __syncthreads();
+    if constexpr (!ZL) {
+        fft_group<THR, B, true>(x, X, tw, tid, [&](int o, cd v) { out[4 * o + 1] = v.re; out[4 * o + 3] = v.im; });
+        __syncthreads();
+        workgroup_lowpass<false, THR, THR / 64>(a, out, ptot);
+        return;
+    }
     // The item's M output samples for the lowpass live in LDS, over the transform image (whose last reads are done when the last
     // pass stores: fft_workgroup).  Round 4: they went through the output buffer before (8-byte stores 32 bytes apart, thread runs
     // read back twice and written once, 512 bytes apart between lanes): 1.67 GB per 2^26 samples against 0.81 GB algorithmic.
@@ -831,6 +841,7 @@ bool post_bigfft_supported(const PostArgs &a) {
         const int on = sdrt_diag_int("post_wg4096", 1);
         return on != 0;
     }
+    if (a.m == 32768) return a.fftp_tw && a.fftp_ab;                                     // (the packed form only)
     return (!a.pairs || (a.fftp_tw && a.fftp_ab)) && (a.m == 8192 || a.m == 16384);      // (pair products: the packed form only)
 }
 
@@ -854,7 +865,7 @@ static hipError_t launch_post_bigfftp_b(const PostArgs &a, hipStream_t s) {
     // the transform image [H + H/16] complex, then (over it) the M = 4 H output samples, one pad element per 64 (B: in units of 1024 points)
     const size_t img = (size_t) (1024 * B + 64 * B) * 16, seq = (size_t) (4096 * B + 64 * B) * 8;
     constexpr int BT = B * 256 / THR;                     // points per thread / 4
-    const size_t lds = img > seq ? img : seq;
+    const size_t lds = seq > 160 * 1024 ? img : (img > seq ? img : seq);       // (32768 outputs per chunk: the transform image alone)
     static thread_local int done_dev = -1;
     int dev = 0;
     (void) hipGetDevice(&dev);
@@ -872,6 +883,7 @@ hipError_t launch_post_bigfft(const PostArgs &a, hipStream_t s) {
         switch (a.m) {
             case 4096: return a.pairs ? launch_post_bigfftp_b<1, true>(a, s) : launch_post_bigfftp_b<1, false>(a, s);
             case 8192: return a.pairs ? launch_post_bigfftp_b<2, true>(a, s) : launch_post_bigfftp_b<2, false>(a, s);
+            case 32768: return a.pairs ? launch_post_bigfftp_b<8, true, 512>(a, s) : launch_post_bigfftp_b<8, false, 512>(a, s);
             case 16384: {
                 const int thr = sdrt_diag_int("post_thr", 512);
                 if (thr == 256) return a.pairs ? launch_post_bigfftp_b<4, true>(a, s) : launch_post_bigfftp_b<4, false>(a, s);

@@ -46,25 +46,31 @@ namespace {
 template <int DT> struct SqEnc;        // slices per component, what each slice XORs with, what they leave out of the value
 template <> struct SqEnc<SDRT_S16> { static constexpr unsigned xlo = 0x80808080u, xhi = 0u; static constexpr double off = 128.0; };
 template <> struct SqEnc<SDRT_U16> { static constexpr unsigned xlo = 0x80808080u, xhi = 0x80808080u; static constexpr double off = 32896.0; };
+// 8-bit records (round 5): ONE slice -- the record's own bytes (the unsigned ones made signed by the XOR)
+template <> struct SqEnc<SDRT_S8> { static constexpr unsigned xlo = 0u, xhi = 0u; static constexpr double off = 0.0; };
+template <> struct SqEnc<SDRT_U8> { static constexpr unsigned xlo = 0u, xhi = 0x80808080u; static constexpr double off = 128.0; };
 
-constexpr int SQ_S = SDRT_I8_DIGITS, SQ_LC = SDRT_SQ_LC, SQ_KS = SQ_LC / 32, SQ_MAXCOL = 128, SQ_WV = 4, SQ_TPW = 2, SQ_MAXT = SQ_WV * SQ_TPW;
+// (a wave works on TWO tiles at a time; the reference's chunk of 131072 bytes is 8 tiles of 16-bit records -- one such pair per
+// wave -- or 16 tiles of 8-bit records: two pairs per wave, one after the other through the aggregate and the local phase)
+constexpr int SQ_S = SDRT_I8_DIGITS, SQ_LC = SDRT_SQ_LC, SQ_KS = SQ_LC / 32, SQ_WV = 4, SQ_TPW = 2;
+__host__ __device__ constexpr int sq_max_tiles(int bytes_per_component) { return bytes_per_component == 1 ? 16 : 8; }
 
 struct SqLds {          // byte offsets
     int agg, master, tf, tg, cf, cg, f0, gu, psi, samp, cst, share, total;
 };
-__host__ __device__ inline SqLds sq_lds(int ncp, int nout) {
+__host__ __device__ inline SqLds sq_lds(int ncp, int nout, int maxt) {
     const int q = SQ_LC / nout;
     SqLds l;
     int p = 0;
     l.agg = p; p += 2 * SQ_S * SQ_KS * 64 * 16;
     l.master = p; p += SDRT_SQ_MASTER_BYTES(q, SQ_S, ncp);
-    l.tf = p; p += SQ_MAXT * 8 * 16;                  // the tiles' totals ...
-    l.tg = p; p += SQ_MAXT * 8 * 16;
-    l.cf = p; p += (SQ_MAXT + 1) * 8 * 16;              // ... and what enters each tile from the left / from the right
-    l.cg = p; p += (SQ_MAXT + 1) * 8 * 16;
+    l.tf = p; p += maxt * 8 * 16;                     // the tiles' totals ...
+    l.tg = p; p += maxt * 8 * 16;
+    l.cf = p; p += (maxt + 1) * 8 * 16;                 // ... and what enters each tile from the left / from the right
+    l.cg = p; p += (maxt + 1) * 8 * 16;
     l.f0 = p; p += 8 * 16;
     l.gu = p; p += 8 * 16;
-    l.psi = p; p += SQ_MAXCOL * 16;                   // exp(i theta 256 c)
+    l.psi = p; p += maxt * 16 * 16;                   // exp(i theta 256 c)
     l.samp = p; p += SQ_LC * 16;                      // exp(i theta j), j < 256
     l.cst = p; p += 4 * 13 * 16;                      // per mode: mu^(1, 2, 4, 8, 16), tailF[mode][0..3], tailFc[mode][0..3]
     l.share = p; p += nout * 8 * 16;                  // the states' shares per output
@@ -107,8 +113,11 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
     constexpr int TUNITS = 16 * SQ_LC * 4 / SDRT_SQ_TOUCH, NTOUCH = SQ_TPW * TUNITS / 64, TPS = (NTOUCH + NRT - 1) / NRT;
     static_assert(NRT % 2 == 0 && KS == 8 && SQ_TPW == 2, "the local phase walks row tiles in pairs, k-steps in quarters, two tiles per wave");
     typedef typename Enc<DT>::raw raw_t;
+    // 8-bit records: one byte slice, 16 bytes of a column per lane and k-step, two pairs of tiles per wave
+    constexpr bool B8 = Enc<DT>::size == 1;
+    constexpr int NP = B8 ? 2 : 1, TT = SQ_TPW * NP, RW = B8 ? 4 : 8, SB = 2 * Enc<DT>::size, MAXT = sq_max_tiles(Enc<DT>::size);
     extern __shared__ __align__(16) unsigned char smem[];
-    const SqLds lo = sq_lds(NCP, NOUT);
+    const SqLds lo = sq_lds(NCP, NOUT, MAXT);
     const v4i *aggL = (const v4i *) (smem + lo.agg);
     const v4i *masterL = (const v4i *) (smem + lo.master);
     cd *TFL = (cd *) (smem + lo.tf), *TGL = (cd *) (smem + lo.tg);
@@ -149,7 +158,8 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
     // a.stagger the workgroups of an XCD start a.stagger x (position in the XCD) sleeps of 64 cycles apart and stay apart
     if (a.stagger > 0)
         for (int i = (int) (blockIdx.x >> 3) * a.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(1);
-    const double cagg = a.comb_agg * 256.0, cloc = a.comb_loc * 256.0;       // accumulator index a holds level a + 1
+    // (two slices: accumulator index a holds level a + 1 -- digit a x high slice, digit a + 1 x low slice; one slice: level a)
+    const double cagg = a.comb_agg * (B8 ? 1.0 : 256.0), cloc = a.comb_loc * (B8 ? 1.0 : 256.0);
     const double off = SqEnc<DT>::off;
     // (this thread's edge coefficients, the phasors of its two edge samples and the powers that carry a tile's entry states to its
     // columns are the same for every chunk -- and are fetched / formed again in every chunk: 32 registers held through the local phase
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
     // before (the byte slices are dead there), so that they travel during its last row tile's vector work and this chunk's E.
     // E: the chunk's first and last 28 records; A1: the wave's two tiles, 16 columns each (lane (g, nb): 32 bytes of column nb per k-step)
     raw_t e_raw[2][2] = {{0, 0}, {0, 0}};
-    uint32_t cur[SQ_TPW][KS][8];
+    uint32_t cur[TT][KS][RW];
     auto ask_for = [&](const unsigned char *chunk_raw) {
         if (e_l <= SDRT_EDGE) {
 #pragma unroll
@@ -172,20 +182,19 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
             }
         }
 #pragma unroll
-        for (int j = 0; j < SQ_TPW; ++j)
+        for (int j = 0; j < TT; ++j) {
+            // (a tile the chunk does not have reads the wave's first tile again: its sums are never used, and a branch around each load
+            // made every load wait for the one before -- 80 k cycles for the 32 of a chunk of 8-bit records)
+            const int tl = wave + SQ_WV * j < ntiles ? wave + SQ_WV * j : 0;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (wave + SQ_WV * j < ntiles) load_words<32>(chunk_raw + ((size_t) ((wave + SQ_WV * j) * 16 + (lane0 & 15)) * SQ_LC + 32 * ks + 8 * (lane0 >> 4)) * 4, cur[j][ks]);
-                else {
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) cur[j][ks][w] = 0;
-                }
-            }
+            for (int ks = 0; ks < KS; ++ks)
+                load_words<RW * 4>(chunk_raw + ((size_t) (tl * 16 + (lane0 & 15)) * SQ_LC + 32 * ks + 8 * (lane0 >> 4)) * SB, cur[j][ks]);
+        }
     };
-    ask_for((const unsigned char *) a.raw + first * (size_t) n * 4);
+    ask_for((const unsigned char *) a.raw + first * (size_t) n * SB);
 
     for (size_t chunk = first; chunk < a.n_chunks; chunk += wpr) {
-        const unsigned char *chunk_raw = (const unsigned char *) a.raw + chunk * (size_t) n * 4;
+        const unsigned char *chunk_raw = (const unsigned char *) a.raw + chunk * (size_t) n * SB;
         // (the lane's coordinates made opaque per chunk: everything addressed through them is then computed where it is used.  Hoisted
         // out of this loop -- sixteen load addresses, the LDS addresses of every phase -- those values outlive the whole iteration, the
         // allocator spills them, and every reload waits for all memory traffic in flight, one load address at a time)
@@ -200,7 +209,6 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
 #define SQ_STAMP(i) do { } while (0)
 #endif
         SQ_STAMP(0);
-        const bool have0 = wave < ntiles, have1 = wave + SQ_WV < ntiles;
         // ---- E: this thread's two edge coefficients (its records: ask_for)
         cd e_head = mk(0.0, 0.0), e_tailc = mk(0.0, 0.0);
         if (e_l <= SDRT_EDGE) {
@@ -234,30 +242,44 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
         }
         SQ_STAMP(1);
         // ---- A1: byte slices (kept for A2), the aggregates of both tiles from ONE read of every A fragment, the scans over a tile's columns
-        v4i bhi[SQ_TPW][KS], blo[SQ_TPW][KS];
+        v4i bhi[TT][KS], blo[B8 ? 1 : TT][KS];
         // lane (g, nb): mode g of column nb of tile j: the causal state at the column's start, the anticausal one at the start of the
         // next column, per real stream -- first as if the tile's neighbours were zero (A1), then with the tile's carries (A2)
-        cd Fl[SQ_TPW][2], Gl[SQ_TPW][2];
+        cd Fl[TT][2], Gl[TT][2];
         {
-            const unsigned sel_lo = swap ? 0x07050301u : 0x06040200u, sel_hi = swap ? 0x06040200u : 0x07050301u;
+            if constexpr (B8) {
 #pragma unroll
-            for (int j = 0; j < SQ_TPW; ++j)
+                for (int j = 0; j < TT; ++j)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        blo[j][ks][w] = (int) (__builtin_amdgcn_perm(cur[j][ks][2 * w + 1], cur[j][ks][2 * w], sel_lo) ^ SqEnc<DT>::xlo);
-                        bhi[j][ks][w] = (int) (__builtin_amdgcn_perm(cur[j][ks][2 * w + 1], cur[j][ks][2 * w], sel_hi) ^ SqEnc<DT>::xhi);
-                    }
+                        for (int w = 0; w < 4; ++w) bhi[j][ks][w] = (int) (cur[j][ks][w] ^ SqEnc<DT>::xhi);
+            } else {
+                const unsigned sel_lo = swap ? 0x07050301u : 0x06040200u, sel_hi = swap ? 0x06040200u : 0x07050301u;
+#pragma unroll
+                for (int j = 0; j < TT; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            blo[j][ks][w] = (int) (__builtin_amdgcn_perm(cur[j][ks][2 * w + 1], cur[j][ks][2 * w], sel_lo) ^ SqEnc<DT>::xlo);
+                            bhi[j][ks][w] = (int) (__builtin_amdgcn_perm(cur[j][ks][2 * w + 1], cur[j][ks][2 * w], sel_hi) ^ SqEnc<DT>::xhi);
+                        }
+            }
             // (each slice ONE value in four consecutive accumulation registers from here on: only matrix instructions read them.  Left
             // to the allocator the slices sat there anyway, word by word, and were copied out in front of every matrix instruction
             // that takes one: 150 of the 590 vector instructions of a row tile)
 #pragma unroll
-            for (int j = 0; j < SQ_TPW; ++j)
+            for (int j = 0; j < TT; ++j)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(bhi[j][ks]), "+a"(blo[j][ks]));
+                for (int ks = 0; ks < KS; ++ks) {
+                    if constexpr (B8) asm volatile("" : "+a"(bhi[j][ks]));
+                    else asm volatile("" : "+a"(bhi[j][ks]), "+a"(blo[j][ks]));
+                }
         }
-        if (have0) {
+        static_for<0, NP>([&](auto pc) {
+        constexpr int JB = SQ_TPW * decltype(pc)::value;          // this pair's tiles: wave + 4 (JB + j)
+        if (wave + SQ_WV * JB < ntiles) {
             v4i Aq[2][2 * S], acc[SQ_TPW][S];
             auto load_agg = [&](auto stc) {
                 constexpr int st = decltype(stc)::value, rt = st >> 2, kq = st & 3;
@@ -283,8 +305,8 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
                     for (int d = 0; d < S; ++d)
 #pragma unroll
                         for (int j = 0; j < SQ_TPW; ++j) {
-                            acc[j][d] = SQ_MFMA(Aq[st & 1][ksl * S + d], bhi[j][2 * kq + ksl], acc[j][d]);                     // digit d x high slice: level d + 1
-                            if (d >= 1) acc[j][d - 1] = SQ_MFMA(Aq[st & 1][ksl * S + d], blo[j][2 * kq + ksl], acc[j][d - 1]);    // x low slice: level d
+                            acc[j][d] = SQ_MFMA(Aq[st & 1][ksl * S + d], bhi[JB + j][2 * kq + ksl], acc[j][d]);                     // digit d x high slice: level d + 1
+                            if constexpr (!B8) if (d >= 1) acc[j][d - 1] = SQ_MFMA(Aq[st & 1][ksl * S + d], blo[B8 ? 0 : JB + j][2 * kq + ksl], acc[j][d - 1]);    // x low slice: level d
                         }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (kq == 3) {
@@ -292,8 +314,8 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
                     const cd m1 = cstG[0], m2 = cstG[1], m4 = cstG[2], m8 = cstG[3];
 #pragma unroll
                     for (int j = 0; j < SQ_TPW; ++j) {
-                        const int tile = wave + SQ_WV * j, col = tile * 16 + nb;
-                        if (tile >= ntiles) { if constexpr (rt == 0) Fl[j][0] = Fl[j][1] = mk(0.0, 0.0); else Gl[j][0] = Gl[j][1] = mk(0.0, 0.0); }
+                        const int tile = wave + SQ_WV * (JB + j), col = tile * 16 + nb;
+                        if (tile >= ntiles) { if constexpr (rt == 0) Fl[JB + j][0] = Fl[JB + j][1] = mk(0.0, 0.0); else Gl[JB + j][0] = Gl[JB + j][1] = mk(0.0, 0.0); }
                         else {
                             const cd ps = psiL[col];
                             double val[4];
@@ -315,8 +337,8 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
                                 x0 = cfma(m4, dpp_row<0x114>(x0), x0); x1 = cfma(m4, dpp_row<0x114>(x1), x1);
                                 x0 = cfma(m8, dpp_row<0x118>(x0), x0); x1 = cfma(m8, dpp_row<0x118>(x1), x1);
                                 if (nb == 15) { TFL[tile * 8 + g * 2] = x0; TFL[tile * 8 + g * 2 + 1] = x1; }
-                                Fl[j][0] = dpp_row<0x111>(x0);           // exclusive: the state at the column's own start
-                                Fl[j][1] = dpp_row<0x111>(x1);
+                                Fl[JB + j][0] = dpp_row<0x111>(x0);           // exclusive: the state at the column's own start
+                                Fl[JB + j][1] = dpp_row<0x111>(x1);
                             } else {
                                 // anticausal: G(c) = B_c + mu G(c + 1), from zero beyond the tile
                                 x0 = cfma(m1, dpp_row<0x101>(x0), x0); x1 = cfma(m1, dpp_row<0x101>(x1), x1);
@@ -324,14 +346,19 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
                                 x0 = cfma(m4, dpp_row<0x104>(x0), x0); x1 = cfma(m4, dpp_row<0x104>(x1), x1);
                                 x0 = cfma(m8, dpp_row<0x108>(x0), x0); x1 = cfma(m8, dpp_row<0x108>(x1), x1);
                                 if (nb == 0) { TGL[tile * 8 + g * 2] = x0; TGL[tile * 8 + g * 2 + 1] = x1; }
-                                Gl[j][0] = dpp_row<0x101>(x0);           // the state at the start of the NEXT column
-                                Gl[j][1] = dpp_row<0x101>(x1);
+                                Gl[JB + j][0] = dpp_row<0x101>(x0);           // the state at the start of the NEXT column
+                                Gl[JB + j][1] = dpp_row<0x101>(x1);
                             }
                         }
                     }
                 }
             });
         }
+        else {
+#pragma unroll
+            for (int j = 0; j < SQ_TPW; ++j) Fl[JB + j][0] = Fl[JB + j][1] = Gl[JB + j][0] = Gl[JB + j][1] = mk(0.0, 0.0);
+        }
+        });
         SQ_STAMP(2);
         __syncthreads();
         SQ_STAMP(3);
@@ -362,17 +389,20 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
         __syncthreads();
         SQ_STAMP(5);
         // ---- A2: the local part of every output of both tiles' columns, the states' shares, ybias, store ------------------------------------
-        if (have0) {
+        static_for<0, NP>([&](auto pc) {
+        constexpr int JB = SQ_TPW * decltype(pc)::value;
+        const bool have1 = wave + SQ_WV * (JB + 1) < ntiles;
+        if (wave + SQ_WV * JB < ntiles) {
             // the columns' true states: the tile-local value + the tile's carry through nb / 15 - nb columns (mode g)
             {
                 const cd pfc = mu_pow(cstL + g * 13, nb), pgc = mu_pow(cstL + g * 13, 15 - nb);
 #pragma unroll
                 for (int j = 0; j < SQ_TPW; ++j) {
-                    const int tcl = wave + SQ_WV * j < ntiles ? wave + SQ_WV * j : wave;
+                    const int tcl = wave + SQ_WV * (JB + j) < ntiles ? wave + SQ_WV * (JB + j) : 0;
 #pragma unroll
                     for (int st = 0; st < 2; ++st) {
-                        Fl[j][st] = cfma(pfc, CFL[tcl * 8 + g * 2 + st], Fl[j][st]);
-                        Gl[j][st] = cfma(pgc, CGL[tcl * 8 + g * 2 + st], Gl[j][st]);
+                        Fl[JB + j][st] = cfma(pfc, CFL[tcl * 8 + g * 2 + st], Fl[JB + j][st]);
+                        Gl[JB + j][st] = cfma(pgc, CGL[tcl * 8 + g * 2 + st], Gl[JB + j][st]);
                     }
                 }
             }
@@ -387,7 +417,7 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
             // (one word of every SDRT_SQ_TOUCH bytes of this wave's tiles of the NEXT chunk, spread over the row tiles: the next
             // iteration's loads find at least part of it on the way)
             const bool more = chunk + wpr < a.n_chunks;
-            const unsigned char *nx = chunk_raw + (more ? wpr * (size_t) n * 4 : 0);
+            const unsigned char *nx = chunk_raw + (more ? wpr * (size_t) n * SB : 0);
             unsigned tv = 0;
 
             v4i Aq[2][2 * S], accA[SQ_TPW][S], accB[SQ_TPW][S];
@@ -411,7 +441,7 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) smp[h] = sampL[(rt * 8 + 2 * g + h) << QS];
 #pragma unroll
-                for (int j = 0; j < SQ_TPW; ++j) psj[j] = psiL[(wave + SQ_WV * j < ntiles ? wave + SQ_WV * j : wave) * 16 + nb];
+                for (int j = 0; j < SQ_TPW; ++j) psj[j] = psiL[(wave + SQ_WV * (JB + j) < ntiles ? wave + SQ_WV * (JB + j) : 0) * 16 + nb];
             };
             auto epi_recombine = [&](const v4i (&pv)[SQ_TPW][S]) {
 #pragma unroll
@@ -453,8 +483,8 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             // outputs k0 + k (wanted by the lower half of the wave) and k0 + k + 4 (by the upper half)
-                            const double lo_ = fma(pf[k].re, Fl[j][c].re, fma(-pf[k].im, Fl[j][c].im, fma(pg[k].re, Gl[j][c].re, -(pg[k].im * Gl[j][c].im))));
-                            const double hi_ = fma(pf[2 + k].re, Fl[j][c].re, fma(-pf[2 + k].im, Fl[j][c].im, fma(pg[2 + k].re, Gl[j][c].re, -(pg[2 + k].im * Gl[j][c].im))));
+                            const double lo_ = fma(pf[k].re, Fl[JB + j][c].re, fma(-pf[k].im, Fl[JB + j][c].im, fma(pg[k].re, Gl[JB + j][c].re, -(pg[k].im * Gl[JB + j][c].im))));
+                            const double hi_ = fma(pf[2 + k].re, Fl[JB + j][c].re, fma(-pf[2 + k].im, Fl[JB + j][c].im, fma(pg[2 + k].re, Gl[JB + j][c].re, -(pg[2 + k].im * Gl[JB + j][c].im))));
                             const double sw = sq_swap32_add(lo_, hi_);
                             if constexpr (k0 == 0) r1[j][k][c] = sw;
                             else {
@@ -469,7 +499,7 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
             auto load_yb = [&](const int rt) {
 #pragma unroll
                 for (int j = 0; j < SQ_TPW; ++j) {
-                    const int tcl = wave + SQ_WV * j < ntiles ? wave + SQ_WV * j : wave;
+                    const int tcl = wave + SQ_WV * (JB + j) < ntiles ? wave + SQ_WV * (JB + j) : 0;
                     const cd *p = yb + (size_t) (tcl * 16 + nb) * NOUT + rt * 8 + 2 * g;
                     ybv[j][0] = p[0];
                     ybv[j][1] = p[1];
@@ -483,8 +513,8 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
                         y2[j][h].re = (y2[j][h].re + ybv[j][h].re) + 0.0;           // -0.0 -> +0.0 (angle(-0) would be pi)
                         y2[j][h].im = (y2[j][h].im + ybv[j][h].im) + 0.0;
                     }
-                    if (wave + SQ_WV * j < ntiles) {
-                        const int col = (wave + SQ_WV * j) * 16 + nb, k0 = col * NOUT + rt * 8 + 2 * g;
+                    if (wave + SQ_WV * (JB + j) < ntiles) {
+                        const int col = (wave + SQ_WV * (JB + j)) * 16 + nb, k0 = col * NOUT + rt * 8 + 2 * g;
                         if constexpr (PAIR) {
                             // FM without a debug buffer: the product the discriminator takes the angle of (demodulation.py:25-32)
                             *(double2 *) (yd + (size_t) k0) = make_double2(y2[j][0].re * y2[j][1].re + y2[j][0].im * y2[j][1].im, y2[j][0].im * y2[j][1].re - y2[j][0].re * y2[j][1].im);
@@ -518,9 +548,11 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
 #pragma unroll
                         for (int t = 0; t < TPS; ++t) {
                             const int ti = rt * TPS + t;                                  // touch ti covers units 64 ti .. 64 ti + 63 of the wave's TUNITS per tile
-                            const bool ok = a.touch && ti < NTOUCH && (ti * 64 < TUNITS || have1);
-                            const int u = ok ? ti * 64 + lane : 0;
-                            tv ^= *(const unsigned *) (nx + (size_t) (wave * 16 * SQ_LC * 4) + (size_t) (u / TUNITS) * (SQ_WV * 16 * SQ_LC * 4) + (size_t) (u % TUNITS) * SDRT_SQ_TOUCH);
+                            const bool ok = !B8 && a.touch && ti < NTOUCH && (ti * 64 < TUNITS || have1);
+                            const int u = ti * 64 + lane;
+                            // (not touching: the chunk's first word -- in bounds for every encoding and chunk size)
+                            const size_t at = ok ? (size_t) (wave * 16 * SQ_LC * 4) + (size_t) (u / TUNITS) * (SQ_WV * 16 * SQ_LC * 4) + (size_t) (u % TUNITS) * SDRT_SQ_TOUCH : 0;
+                            tv ^= *(const unsigned *) (nx + at);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -530,8 +562,8 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
                         for (int d = 0; d < S; ++d)
 #pragma unroll
                             for (int j = 0; j < SQ_TPW; ++j) {
-                                ac[j][d] = SQ_MFMA(Aq[kq & 1][ksl * S + d], bhi[j][2 * kq + ksl], ac[j][d]);
-                                if (d >= 1) ac[j][d - 1] = SQ_MFMA(Aq[kq & 1][ksl * S + d], blo[j][2 * kq + ksl], ac[j][d - 1]);
+                                ac[j][d] = SQ_MFMA(Aq[kq & 1][ksl * S + d], bhi[JB + j][2 * kq + ksl], ac[j][d]);
+                                if constexpr (!B8) if (d >= 1) ac[j][d - 1] = SQ_MFMA(Aq[kq & 1][ksl * S + d], blo[B8 ? 0 : JB + j][2 * kq + ksl], ac[j][d - 1]);
                             }
                     if constexpr (EPI) {
                         if constexpr (kq == 0) epi_recombine(pv);
@@ -556,7 +588,8 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
             SQ_STAMP(7);
             load_yb(NRT - 1);
             __builtin_amdgcn_sched_barrier(0);
-            ask_for(nx);                                   // (behind ybias: the last row tile's store waits for that, not for these; the last chunk asks for itself again)
+            // (behind ybias: the last row tile's store waits for that, not for these; the last chunk asks for itself again)
+            if constexpr (JB + SQ_TPW == TT) ask_for(nx);
             __builtin_amdgcn_sched_barrier(0);
             epi_recombine_loads(NRT - 1);
             epi_recombine(accB);
@@ -566,7 +599,12 @@ __global__ __launch_bounds__(64 * SQ_WV, 1) void chain_sq_kernel(const SqArgs a)
             epi_modes(std::integral_constant<int, 2>{});
             epi_store(NRT - 1);
             touched ^= tv;
+        } else if constexpr (JB + SQ_TPW == TT) {
+            // (a wave without this pair, in a chunk shorter than the reference's, asks here: on BOTH paths, so that the registers of the
+            // records are not held through the local phase for the sake of the path that does not write them)
+            ask_for(chunk_raw + (chunk + wpr < a.n_chunks ? wpr * (size_t) n * SB : 0));
         }
+        });
         // (no barrier here: what the next chunk writes before its first barrier -- F0 / Gu in E, the tile totals in A1 -- was read by
         // wave 0 before this chunk's second barrier; the carries it writes in P2 come after a barrier every wave reaches only behind
         // its reads of them here)
@@ -581,7 +619,7 @@ hipError_t launch_sq_q(const SqArgs &a, int q, dim3 grid, hipStream_t s) {
     auto go = [&](auto qc, auto pc) -> hipError_t {
         constexpr int QS = decltype(qc)::value, qq = 1 << QS, NCP = 2 * qq >= 16 ? 1 : 16 / (2 * qq);
         constexpr bool PAIR = decltype(pc)::value;
-        const size_t lds = (size_t) sq_lds(NCP, SQ_LC / qq).total;
+        const size_t lds = (size_t) sq_lds(NCP, SQ_LC / qq, sq_max_tiles(Enc<DT>::size)).total;
         static thread_local int done_dev = -1;
         int dev = 0;
         (void) hipGetDevice(&dev);
@@ -611,7 +649,9 @@ bool chain_sq_supported(int q, int dt, int n) {
     // 389 - 413 GS/s there against 457 here, profiles/r05_experiments.txt section 9)
     const char *e = sdrt_diag("sq");
     const int maxq = e && atoi(e) == 8 ? 8 : 16;
-    return (q == 2 || q == 4 || q == 8 || q == 16) && q <= maxq && (dt == SDRT_S16 || dt == SDRT_U16) && n % (16 * SQ_LC) == 0 && nc >= 16 && nc <= SQ_MAXCOL;
+    const bool two = dt == SDRT_S16 || dt == SDRT_U16, one = dt == SDRT_S8 || dt == SDRT_U8;
+    if (one && sdrt_diag_int("sq8", 1) == 0) return false;                  // (SDRTERM_DIAG=sq8=0: 8-bit records on the forms they had before round 5)
+    return (q == 2 || q == 4 || q == 8 || q == 16) && q <= maxq && (two || one) && n % (16 * SQ_LC) == 0 && nc >= 16 && nc <= 16 * sq_max_tiles(one ? 1 : 2);
 }
 
 hipError_t launch_chain_sq(const SqArgs &a, int q, int dt, int n_cus, hipStream_t s) {
@@ -623,5 +663,7 @@ hipError_t launch_chain_sq(const SqArgs &a, int q, int dt, int n_cus, hipStream_
     const dim3 grid((unsigned) (wpr * (size_t) a.rows));
     if (dt == SDRT_S16) return launch_sq_q<SDRT_S16>(a, q, grid, s);
     if (dt == SDRT_U16) return launch_sq_q<SDRT_U16>(a, q, grid, s);
+    if (dt == SDRT_S8) return launch_sq_q<SDRT_S8>(a, q, grid, s);
+    if (dt == SDRT_U8) return launch_sq_q<SDRT_U8>(a, q, grid, s);
     return hipErrorInvalidValue;
 }

@@ -334,7 +334,7 @@ def test_pair_products_between_the_stages_equal_the_sample_path(code, q, rows, m
     # (decimation 4 .. 16: several passes of the wide kernel over the chunk, each finishing whole pairs; 16-bit records at decimation
     # 4 .. 16: the one-pass kernel, whose lanes hold both outputs of a pair)
     eng = Engine(fs, q, 'fm', code, row_freqs=freqs, apply_shift=True, omega_out=5000 if q >= 32 else 8000 * (32 // q))
-    assert eng.stage_a == ('sq' if code in 'hH' and q <= 16 else 'i8w')
+    assert eng.stage_a == ('sq' if code in 'hHbB' and q <= 16 else 'i8w')
     a = eng.process(raw)
     b, _y = eng.process_debug(raw)
     err = np.abs(a - b).max()
@@ -707,21 +707,23 @@ def test_a_stream_that_starts_silent_under_correct_iq_comes_out_as_exact_zeros(c
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n,q,mode,rows', [(8192, 2, 'fm', 1), (4096, 16, 'am', 2), (8192, 4, 'fm', 3), (12288, 8, 'am', 1), (16384, 2, 'fm', 2), (20480, 16, 'am', 1),
-                                            (28672, 4, 'am', 2), (16384, 16, 'fm', 1)])
-def test_one_pass_kernel_on_other_chunk_sizes(n, q, mode, rows, monkeypatch):
+@pytest.mark.parametrize('code,n,q,mode,rows', [('h', 8192, 2, 'fm', 1), ('h', 4096, 16, 'am', 2), ('h', 8192, 4, 'fm', 3), ('h', 12288, 8, 'am', 1), ('h', 16384, 2, 'fm', 2),
+                                                 ('h', 20480, 16, 'am', 1), ('H', 28672, 4, 'am', 2), ('h', 16384, 16, 'fm', 1),
+                                                 ('B', 65536, 2, 'fm', 1), ('b', 65536, 4, 'fm', 2), ('B', 65536, 8, 'am', 3), ('B', 36864, 16, 'am', 1), ('b', 20480, 8, 'am', 2),
+                                                 ('B', 32768, 2, 'fm', 1), ('b', 4096, 16, 'am', 1), ('B', 49152, 4, 'am', 1)])
+def test_one_pass_kernel_on_other_chunk_sizes(code, n, q, mode, rows, monkeypatch):
     """chain_sq_kernel gives each of its four waves the tiles w and w + 4 of a chunk (16 columns of 256 samples each): the reference's
-    16-bit chunk has eight (32768 samples, read_file.py:51), the C ABI takes any multiple of 4096 samples up to that (from 8192 at
-    decimation 2 and 4) -- one to seven
+    16-bit chunk has eight (32768 samples, read_file.py:51), its 8-bit chunk sixteen (65536 samples: two pairs of tiles per wave, one
+    after the other), the C ABI takes any multiple of 4096 samples up to that (from 8192 at decimation 2 and 4) -- one to fifteen
     tiles: waves without a tile, waves with one, an odd count.  Against oracle/chain.c (dsp_processor.py:140-149), several rows, with
     the chunk's bits independent of the batch it arrives in.  (FM where the chunk's output count is a power of two: the resampler.)"""
     from sdrterm_amd.engine import Engine
     from tests.golden import prng
     monkeypatch.delenv('SDRTERM_STAGE_A', raising=False)
-    code, fs, nch = 'h', 1024000, 9
+    fs, nch = 1024000, 9
     freqs = [15700.0, -203300.0, 100100.0][:rows]
     omega = 100000 if q == 2 else (60000 if q == 4 else (30000 if q == 8 else 15000))
-    raw = prng.raw_bytes(code, n * nch, seed=900 + n // 4096 + q, amp=8000)
+    raw = prng.raw_bytes(code, n * nch, seed=900 + n // 4096 + q, amp=100 if code in 'bB' else 8000)
     eng = Engine(fs, q, mode, code, n_samples=n, row_freqs=freqs, apply_shift=True, omega_out=omega)
     assert eng.stage_a == 'sq'
     out, y = eng.process_debug(raw)
@@ -818,7 +820,7 @@ def test_small_decimations_in_passes_of_the_wide_kernel(code, q, mode, rows, for
     per pass (8 / 4 / 2 passes over the chunk, tables and local planes per pass: api.hip WidePass).  Against oracle/chain.c (the
     reference's chain, dsp_processor.py:140-149) on several rows, FM and AM, odd batch sizes; the bits of a chunk must not depend on
     the batch it arrives in; and the fp64 kernel forced on the same input must agree to the usual 1e-9 of the decimated peak.
-    Round 5, form 'one-pass': 16-bit records at decimation 2 .. 16 take chain_sq_kernel instead (kernels_sq.hip: all 256 / q outputs
+    Round 5, form 'one-pass': 8- and 16-bit records at decimation 2 .. 16 take chain_sq_kernel instead (kernels_sq.hip: all 256 / q outputs
     of a column from ONE read of the input, the local operator as windows of one master sequence) -- the same checks; 'passes'
     keeps the older forms under test (SDRTERM_DIAG=sq=0: they still serve 8-bit records and are what a context falls back to)."""
     from sdrterm_amd.engine import Engine
@@ -828,8 +830,6 @@ def test_small_decimations_in_passes_of_the_wide_kernel(code, q, mode, rows, for
         _diag(monkeypatch, sq=0)
         if q == 2:
             pytest.skip('decimation 2 without the one-pass kernel is the per-sample kernel (test_every_instantiation_of_the_per_sample_kernel)')
-    elif code in 'bB':
-        pytest.skip('8-bit records keep the passes of the wide kernel')
     fs, n, nch = 1024000, samples_per_chunk(code), 7
     freqs = [15700.0, -203300.0, 100100.0][:rows]
     omega = 60000 if q == 4 else (30000 if q == 8 else 15000)

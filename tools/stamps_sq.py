@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: phase lengths of one steady-state chunk of chain_sq_kernel from in-kernel s_memtime stamps (GPU box).
-   tools/stamps_sq.py [decimation] [chunks] [waves per workgroup of the build]; needs a library built with EXTRA=-DSDRT_STAMPS
+   tools/stamps_sq.py [decimation] [chunks] [waves per workgroup of the build] [encoding h / B]; needs a library built with EXTRA=-DSDRT_STAMPS
    (make -C sdrterm_amd/csrc OUT=../libsdrterm_hip_exp.so OBJ=_obj_exp EXTRA=-DSDRT_STAMPS; SDRTERM_HIP_LIB= that file)."""
 import ctypes as C
 import sys, os
@@ -15,9 +15,10 @@ def main():
     q = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     n_chunks = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
     wv = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-    eng = Engine(256_000_000, q, 'fm', 'h', row_freqs=[15000], omega_out=12500)
+    code = sys.argv[4] if len(sys.argv) > 4 else 'h'          # 'B': uint8 records (65536-sample chunks, two pairs of tiles per wave: the stamps are the last pair's)
+    eng = Engine(256_000_000, q, 'fm', code, row_freqs=[15000], omega_out=12500)
     assert eng.stage_a == 'sq', eng.stage_a
-    one = np.frombuffer(prng.raw_bytes('h', eng.n * 64, 3, 8000), dtype=np.uint8)
+    one = np.frombuffer(prng.raw_bytes(code, eng.n * 64, 3, 100 if code in 'bB' else 8000), dtype=np.uint8)
     d_raw = nat.DeviceBuffer(n_chunks * eng.chunk_bytes)
     for i in range(0, n_chunks, 64):
         nat.check(nat.lib().sdrt_memcpy_h2d(d_raw.ptr + i * eng.chunk_bytes, one.ctypes.data, min(64, n_chunks - i) * eng.chunk_bytes))
