@@ -69,6 +69,8 @@ WORKLOADS = {
     'fm4': (4, 1, 4096, 'weak', 'h', 256_000_000, False, None),
     'fm2': (2, 1, 2048, 'weak', 'h', 256_000_000, False, None),          # decimation 2, the CLI's default (src/sdrterm.py:80)
     'fm16b': (16, 1, 8192, 'weak', 'B', 256_000_000, False, None),       # the same as uint8 records (65536-sample chunks)
+    'fm8b': (8, 1, 4096, 'weak', 'B', 256_000_000, False, None),
+    'fm4b': (4, 1, 2048, 'weak', 'B', 256_000_000, False, None),
     'fm2b': (2, 1, 1024, 'weak', 'B', 256_000_000, False, None),
     'simo8': (32, 8, 4096, 'strong', 'h', 256_000_000, True, ('fm', 'am', 'fm', 'am', 'fm', 'am', 'am', 'fm')),
     'simo64': (32, 64, 512, 'strong', 'h', 256_000_000, False, None),
@@ -78,9 +80,10 @@ METRIC = {'fm64': 'input MSamples/s IQ->FM demod, dec=64', 'fm64f': 'input MSamp
           'fm64b': 'input MSamples/s IQ->FM demod, uint8 IQ, dec=64',
           'fm16': 'input MSamples/s IQ->FM demod, dec=16', 'fm8': 'input MSamples/s IQ->FM demod, dec=8', 'fm4': 'input MSamples/s IQ->FM demod, dec=4', 'fm2': 'input MSamples/s IQ->FM demod, dec=2',
           'fm16b': 'input MSamples/s IQ->FM demod, uint8 IQ, dec=16', 'fm2b': 'input MSamples/s IQ->FM demod, uint8 IQ, dec=2',
+          'fm8b': 'input MSamples/s IQ->FM demod, uint8 IQ, dec=8', 'fm4b': 'input MSamples/s IQ->FM demod, uint8 IQ, dec=4',
           'simo8': 'input MSamples/s 8-VFO --simo FM+AM mixed, --correct-iq, dec=32',
           'simo64': 'input MSamples/s 64-VFO --simo FM, dec=32', 'f32x256': 'input MSamples/s 256-VFO --simo FM, float32 IQ, dec=64'}
-CONFIG_NO = {'fm64': 1, 'fm64f': 1, 'fm64b': 1, 'fm16': 1, 'fm8': 1, 'fm4': 1, 'fm2': 1, 'fm16b': 1, 'fm2b': 1, 'simo8': 2, 'simo64': 3, 'f32x256': 4}
+CONFIG_NO = {'fm64': 1, 'fm64f': 1, 'fm64b': 1, 'fm16': 1, 'fm8': 1, 'fm4': 1, 'fm2': 1, 'fm16b': 1, 'fm8b': 1, 'fm4b': 1, 'fm2b': 1, 'simo8': 2, 'simo64': 3, 'f32x256': 4}
 ITEM = {'h': 2, 'f': 4, 'B': 1}
 NP_DTYPE = {'h': 'int16', 'f': 'float32', 'B': 'uint8'}
 ENC_NAME = {'h': 'int16', 'f': 'float32', 'B': 'uint8'}
