@@ -1,4 +1,4 @@
-// chain_sq_kernel: unpack .. decimate for decimation 2, 4, 8, 16 of 16-bit records in ONE pass over the input, on the int8 matrix
+// chain_sq_kernel: unpack .. decimate for decimation 2, 4, 8, 16 of 8- and 16-bit records in ONE pass over the input, on the int8 matrix
 // cores (src/sdrterm.py:80 makes 2 the CLI's default; scipy.signal.decimate at src/dsp/dsp_processor.py:147).
 //
 // What the other forms do there: the wide kernel walks the chunk 2 .. 8 times (eight outputs of every 256-sample column per pass,
@@ -12,7 +12,8 @@
 //   fp64 afterwards) -- A fragments are read from LDS at 16-byte aligned offsets of it (q < 8: 16 / 2q copies shifted by 2 q bytes),
 //   whatever the number of outputs: 40 KB at decimation 2 where row planes would take 640 KB;
 // * the column aggregates (two 16-row tiles, as in the wide kernel) are computed ONCE per column, scanned over the chunk's columns
-//   (wave scans, 128 columns), and every output adds its share of its column's two states.
+//   (a DPP row scan per 16-column tile, the tiles' totals chained by eight lanes), and every output adds its share of its column's
+//   two states.
 // Arithmetic: exact integer slicing (x = 256 hi + lo' + offset), S = 5 balanced base-256 digits of the weights, int32 sums, one fp64
 // recombination per value -- as kernels_i8w.hip; the constant the slices leave out and the normalisation
 // bias come back through ybias, calibrated with this kernel's own response to a zero / a unit chunk (api.hip: setup_sq).
@@ -28,7 +29,9 @@
 //               A2 per row tile (8 outputs x 2 parts of every column of both tiles) 72 + 72 matrix instructions; between their
 //                  quarters the vector work of the PREVIOUS row tile: recombination and rotation, what the lane's mode adds to
 //                  all eight outputs of its column (reduce-scattered over the four lane groups by permlane swaps: every lane ends
-//                  with the four modes' sum for its own two outputs), ybias, pair product, store                 | barrier
+//                  with the four modes' sum for its own two outputs), ybias, pair product, store; the next chunk's records
+//                  asked for behind the last matrix instruction                                       (no third barrier)
+//   (8-bit records: one byte slice, 16 tiles per chunk: A1 and A2 twice per chunk, for the wave's tiles w, w + 4 and w + 8, w + 12)
 // LDS reads of A fragments are issued a quarter (two k-steps, ten fragments) ahead of the matrix instructions that take them --
 // written one fragment before its use the compiler waited for every single read (lgkmcnt(0) forty times per row tile: 4700 cycles
 // per row tile and tile against 1152 of matrix work, profiles/r05_experiments.txt section 7).  What is left per row tile of both
