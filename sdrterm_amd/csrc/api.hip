@@ -145,6 +145,7 @@ struct sdrt_ctx {
     bool f32c = false;                // float32 records in the reference's complex64 arithmetic (sdrt_config.faithful_f32, kernels_f32c.hip)
     F32cArgs f32c_args;               //   coefficient tables
     double *d_shift_tab = nullptr;    //   [rows][n][2] the host's shift table
+    double *d_shift_tab_t = nullptr;  //   the same as [rows / 64][n][64][2] where rows % 64 == 0 (f32c_fused_kernel)
     float *d_f32c_work = nullptr;     //   the extended sequences of a batch (grow-only)
     size_t f32c_cap = 0;
     int iq_gs = 0;                    // samples per group of the IQ prefix tables
@@ -823,6 +824,18 @@ int sdrt_create(const sdrt_config *cfg, sdrt_ctx **out) {
         memcpy(fa.sos, cfg->f32_sos, sizeof(fa.sos));
         memcpy(fa.zi, cfg->f32_zi, sizeof(fa.zi));
         if (c->nco) rc = upload(&c->d_shift_tab, cfg->shift_table, (size_t) c->rows * n * 2 * sizeof(double));
+        if (rc == SDRT_OK && c->nco && c->rows % 64 == 0) {
+            // lane = row for the kernel that recomputes the shifted samples: 64 rows' entries of one time step side by side
+            std::vector<double> t((size_t) c->rows * n * 2);
+            const double *src = cfg->shift_table;
+            for (int r = 0; r < c->rows; ++r)
+                for (int k = 0; k < n; ++k) {
+                    const size_t o = (((size_t) (r / 64) * n + k) * 64 + (r % 64)) * 2, i = ((size_t) r * n + k) * 2;
+                    t[o] = src[i];
+                    t[o + 1] = src[i + 1];
+                }
+            rc = upload(&c->d_shift_tab_t, t.data(), t.size() * sizeof(double));
+        }
     }
     if (rc == SDRT_OK && !f32c) {
         // sdrt_config.stage_a; the environment variable overrides it (diagnostics: auto / i8 / f64, and i8t = the
@@ -949,6 +962,7 @@ void sdrt_destroy(sdrt_ctx *c) {
     (void) hipFree(c->d_cond_list);
     (void) hipFree(c->d_cond_count);
     (void) hipFree(c->d_shift_tab);
+    (void) hipFree(c->d_shift_tab_t);
     (void) hipFree(c->d_f32c_work);
     for (auto &sl : c->hs) {
         (void) hipFree(sl.d_raw);
@@ -1136,6 +1150,7 @@ int enqueue_chain(sdrt_ctx *c, const void *raw_dev, size_t n_chunks, double *ybu
         F32cArgs fa = c->f32c_args;
         fa.raw = raw_dev;
         fa.shift = c->nco ? c->d_shift_tab : nullptr;
+        fa.shift_t = c->nco ? c->d_shift_tab_t : nullptr;
         fa.work = c->d_f32c_work;
         fa.ydec = ybuf;
         fa.n_chunks = n_chunks;

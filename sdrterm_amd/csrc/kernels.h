@@ -211,6 +211,7 @@ hipError_t launch_chain_sq(const SqArgs &a, int q, int dt, int n_cus, hipStream_
 struct F32cArgs {
     const void *raw;            // [n_chunks][n][2] float32 records
     const double *shift;        // [rows][n][2] the shift table exactly as the reference builds it with numpy (or NULL: no shift)
+    const double *shift_t;      // the same table as [rows / 64][n][64][2] where rows % 64 == 0 (f32c_fused_kernel), else NULL
     float *work;                // [groups of 64 items][n + 54][64][2] complex64: odd-extended shifted samples, filtered in place
     double *ydec;               // [row][chunk][m][2]
     size_t n_chunks;            // chunks in the batch = row stride of ydec

@@ -227,6 +227,119 @@ __global__ __launch_bounds__(64) void f32c_seq_kernel(const F32cArgs a) {
     for (; t >= 0; --t) emit(t, cascade(c, w[(size_t) t * 64], z0, z1));
 }
 
+
+// ---- the many-row layouts (rows a multiple of 64) WITHOUT the sequences in memory (round 5) -------------
+// The two kernels above move 32 bytes per row-sample (the complex64 sequence written by the preparation pass, read and written by
+// the forward pass, read by the backward pass) and were bound by exactly that.  Here a wave is (chunk, group of 64 rows), lane = row:
+//   * a shifted sample is recomputed where it is needed from the chunk's record (one address for the whole wave) and the shift table
+//     TRANSPOSED to [row group][k][lane] (F32cArgs.shift_t: 1 KiB per wave and time step, coalesced; the waves in flight walk the
+//     table at about the same k and blockIdx % 8 = XCD sees one row group when there are four, so the table comes from L2 / MALL);
+//   * the forward pass keeps nothing but the cascade's state every kB steps (64 bytes per lane: 4 bytes per row-sample at kB = 16);
+//   * the backward pass walks the blocks from the last to the first: the forward recurrence again from the block's checkpoint (the
+//     same operations on the same values: the same bits), its kB outputs in registers, then the backward recurrence over them.
+// Three recurrences instead of two and two shifted-sample computations instead of one, for 8 bytes per row-sample instead of 32.
+constexpr int kB = 16;
+static_assert(kB >= 16, "a group's checkpoints (8 values per kB steps) live in its share of the work buffer (one value per step)");
+
+template <bool EDGE>
+__device__ __forceinline__ f2 fused_sample(const uint32_t *cr, const double2 *tab, int e, int n, int swap, f2 x0, f2 xe) {
+    int k = e - kEdge;
+    if constexpr (EDGE) {
+        if (e < kEdge) k = kEdge - e;
+        else if (e >= kEdge + n) k = 2 * n + kEdge - 2 - e;
+    }
+    const float re = f32_record(cr + 2 * (size_t) k, swap), im = f32_record(cr + 2 * (size_t) k + 1, swap);
+    const double2 b = tab[(size_t) k * 64];
+    const double ar = (double) re, ai = (double) im;
+    const double pi = ai * b.y, pr = ai * b.x;
+    f2 v;
+    v.x = (float) fma(ar, b.x, -pi);
+    v.y = (float) fma(ar, b.y, pr);
+    if constexpr (EDGE) {
+        if (e < kEdge) v = 2.0f * x0 - v;
+        else if (e >= kEdge + n) v = 2.0f * xe - v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void f32c_fused_kernel(const F32cArgs a) {
+    const size_t g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int n = a.n, N = n + 2 * kEdge, nblk = (N + kB - 1) / kB, RQ = a.rows / 64;
+    const size_t chunk = g / RQ;
+    const int rg = (int) (g - chunk * RQ);
+    const uint32_t *cr = (const uint32_t *) a.raw + chunk * (size_t) n * 2;
+    const double2 *tab = (const double2 *) a.shift_t + (size_t) rg * n * 64 + lane;
+    f2 *ck = (f2 *) a.work + g * (size_t) N * 64 + lane;
+    const int swap = a.swap;
+    Sos c;
+#pragma unroll
+    for (int s = 0; s < kNS; ++s) {
+        c.b0[s] = a.sos[s][0]; c.b1[s] = a.sos[s][1]; c.b2[s] = a.sos[s][2]; c.a1[s] = a.sos[s][4]; c.a2[s] = a.sos[s][5];
+    }
+    const f2 zero = {0.0f, 0.0f};
+    const f2 x0 = fused_sample<false>(cr, tab, kEdge, n, swap, zero, zero), xe = fused_sample<false>(cr, tab, kEdge + n - 1, n, swap, zero, zero);
+    // a block of kB extended samples: the ones inside the chunk without the extension's cases
+    auto block = [&](int e0, f2 (&v)[kB]) {
+        if (e0 >= kEdge && e0 + kB <= kEdge + n) {
+#pragma unroll
+            for (int u = 0; u < kB; ++u) v[u] = fused_sample<false>(cr, tab, e0 + u, n, swap, x0, xe);
+        } else {
+#pragma unroll
+            for (int u = 0; u < kB; ++u) v[u] = e0 + u < N ? fused_sample<true>(cr, tab, e0 + u, n, swap, x0, xe) : zero;
+        }
+    };
+    f2 z0[kNS], z1[kNS];
+    {
+        const f2 e0v = 2.0f * x0 - fused_sample<false>(cr, tab, 2 * kEdge, n, swap, zero, zero);      // ext[0] = 2 x[0] - x[27]
+#pragma unroll
+        for (int s = 0; s < kNS; ++s) { z0[s] = a.zi[s][0] * e0v; z1[s] = a.zi[s][1] * e0v; }
+    }
+    f2 last = zero;
+    for (int blk = 0; blk < nblk; ++blk) {
+        f2 *p = ck + (size_t) blk * (2 * kNS * 64);
+#pragma unroll
+        for (int s = 0; s < kNS; ++s) { p[s * 64] = z0[s]; p[(kNS + s) * 64] = z1[s]; }
+        const int e0 = blk * kB;
+        f2 v[kB];
+        block(e0, v);
+#pragma unroll
+        for (int u = 0; u < kB; ++u)
+            if (e0 + u < N) last = cascade(c, v[u], z0, z1);
+    }
+    // backward: zi * y[-1]; ext index 27 + k q is output k ([27:-27][::q])
+    const int row = rg * 64 + lane;
+    double *yo = a.ydec + ((size_t) row * a.n_chunks + chunk) * (size_t) a.m * 2;
+    f2 y0[kNS], y1[kNS];
+#pragma unroll
+    for (int s = 0; s < kNS; ++s) { y0[s] = a.zi[s][0] * last; y1[s] = a.zi[s][1] * last; }
+    const int qm = a.q - 1, qs = __builtin_ctz(a.q);          // q is a power of two (sdrt_create)
+    for (int blk = nblk - 1; blk >= 0; --blk) {
+        const f2 *p = ck + (size_t) blk * (2 * kNS * 64);
+#pragma unroll
+        for (int s = 0; s < kNS; ++s) { z0[s] = p[s * 64]; z1[s] = p[(kNS + s) * 64]; }
+        const int e0 = blk * kB;
+        f2 v[kB];
+        block(e0, v);
+#pragma unroll
+        for (int u = 0; u < kB; ++u)
+            if (e0 + u < N) v[u] = cascade(c, v[u], z0, z1);
+#pragma unroll
+        for (int u = kB - 1; u >= 0; --u) {
+            const int e = e0 + u, k = e - kEdge;
+            if (e < N) {
+                const f2 r = cascade(c, v[u], y0, y1);
+                if (k >= 0 && k < n && (k & qm) == 0) {
+                    double2 o;
+                    o.x = (double) r.x;
+                    o.y = (double) r.y;
+                    *(double2 *) (yo + 2 * (size_t) (k >> qs)) = o;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 size_t f32c_work_bytes(int n, int rows, size_t n_chunks) {
@@ -239,6 +352,10 @@ hipError_t launch_f32c(const F32cArgs &a, hipStream_t s) {
     if (!groups) return hipSuccess;
     const size_t tiles = (size_t) (a.n + 2 * kEdge + 63) / 64;
     if (groups * tiles > 0x7fffffffull) return hipErrorInvalidValue;
+    if (a.shift_t && a.rows % 64 == 0 && sdrt_diag_int("f32c_fused", 1) != 0) {
+        hipLaunchKernelGGL(f32c_fused_kernel, dim3((unsigned) groups), dim3(64), 0, s, a);
+        return hipGetLastError();
+    }
     if (a.shift && a.rows % 64 == 0) {
         const size_t blocks = (size_t) (a.rows / 64) * tiles * ((a.n_chunks + kCPB - 1) / kCPB);
         hipLaunchKernelGGL(f32c_prep_rows_kernel, dim3((unsigned) blocks), dim3(256), 0, s, a);

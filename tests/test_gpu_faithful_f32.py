@@ -59,9 +59,13 @@ def test_big_endian_float32_records(golden):
 _ROWS63 = ','.join(str((i - 31) * 7000 + 500) for i in range(63))          # 63 csv rows + the centre = 64: a whole lane group per chunk
 
 
+_ROWS127 = ','.join(str((i - 63) * 3500 + 250) for i in range(127))       # two lane groups per chunk (the kernel without sequences in memory)
+
+
 @pytest.mark.parametrize('rows_csv,nch,q,mode', [('-200000,-150000,-100000,50000', 30, 64, 'fm'), (None, 70, 32, 'am'),
-                                                  ('-200000,150000', 5, 4, 'fm'), ('100000', 3, 2, 'am'), (_ROWS63, 19, 64, 'fm')],
-                         ids=['5rows-30', '1row-70', '3rows-q4', '2rows-q2', '64rows-19'])
+                                                  ('-200000,150000', 5, 4, 'fm'), ('100000', 3, 2, 'am'), (_ROWS63, 19, 64, 'fm'),
+                                                  (_ROWS127, 5, 32, 'am'), (_ROWS63, 3, 2, 'fm')],
+                         ids=['5rows-30', '1row-70', '3rows-q4', '2rows-q2', '64rows-19', '128rows-5', '64rows-q2'])
 def test_many_sequences_against_the_faithful_oracle(rows_csv, nch, q, mode):
     """More (chunk, row) sequences than one wave holds (groups of 64 lanes, the last one partly filled), against oracle/chain.c's
     complex64 restatement (itself pinned bit for bit to the reference's vectors): decimated samples identical, outputs 1e-6; the
