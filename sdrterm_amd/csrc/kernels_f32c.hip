@@ -262,7 +262,11 @@ __device__ __forceinline__ f2 fused_sample(const uint32_t *cr, const double2 *ta
     return v;
 }
 
-__global__ __launch_bounds__(64) void f32c_fused_kernel(const F32cArgs a) {
+// CK = false: the forward outputs go to the work buffer instead ([t][lane], 8 bytes per row-sample written and read back) and the
+// backward pass reads them: two recurrences instead of three for 16 bytes per row-sample instead of 8 -- packed fp32 instructions
+// issue at half the rate the peak figures assume on this chip, so the checkpointed form is bound by its third recurrence.
+template <bool CK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void f32c_fused_kernel(const F32cArgs a) {
     const size_t g = blockIdx.x;
     const int lane = threadIdx.x;
     const int n = a.n, N = n + 2 * kEdge, nblk = (N + kB - 1) / kB, RQ = a.rows / 64;
@@ -297,15 +301,30 @@ __global__ __launch_bounds__(64) void f32c_fused_kernel(const F32cArgs a) {
     }
     f2 last = zero;
     for (int blk = 0; blk < nblk; ++blk) {
-        f2 *p = ck + (size_t) blk * (2 * kNS * 64);
+        if constexpr (CK) {
+            f2 *p = ck + (size_t) blk * (2 * kNS * 64);
 #pragma unroll
-        for (int s = 0; s < kNS; ++s) { p[s * 64] = z0[s]; p[(kNS + s) * 64] = z1[s]; }
+            for (int s = 0; s < kNS; ++s) { p[s * 64] = z0[s]; p[(kNS + s) * 64] = z1[s]; }
+        }
         const int e0 = blk * kB;
         f2 v[kB];
         block(e0, v);
+        if (e0 + kB <= N) {                     // (one straight line of kB cascades: the sections of neighbouring steps overlap)
 #pragma unroll
-        for (int u = 0; u < kB; ++u)
-            if (e0 + u < N) last = cascade(c, v[u], z0, z1);
+            for (int u = 0; u < kB; ++u) v[u] = cascade(c, v[u], z0, z1);
+            last = v[kB - 1];
+            if constexpr (!CK) {
+#pragma unroll
+                for (int u = 0; u < kB; ++u) ck[(size_t) (e0 + u) * 64] = v[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kB; ++u)
+                if (e0 + u < N) {
+                    last = cascade(c, v[u], z0, z1);
+                    if constexpr (!CK) ck[(size_t) (e0 + u) * 64] = last;
+                }
+        }
     }
     // backward: zi * y[-1]; ext index 27 + k q is output k ([27:-27][::q])
     const int row = rg * 64 + lane;
@@ -315,26 +334,42 @@ __global__ __launch_bounds__(64) void f32c_fused_kernel(const F32cArgs a) {
     for (int s = 0; s < kNS; ++s) { y0[s] = a.zi[s][0] * last; y1[s] = a.zi[s][1] * last; }
     const int qm = a.q - 1, qs = __builtin_ctz(a.q);          // q is a power of two (sdrt_create)
     for (int blk = nblk - 1; blk >= 0; --blk) {
-        const f2 *p = ck + (size_t) blk * (2 * kNS * 64);
-#pragma unroll
-        for (int s = 0; s < kNS; ++s) { z0[s] = p[s * 64]; z1[s] = p[(kNS + s) * 64]; }
         const int e0 = blk * kB;
         f2 v[kB];
-        block(e0, v);
+        if constexpr (CK) {
+            const f2 *p = ck + (size_t) blk * (2 * kNS * 64);
 #pragma unroll
-        for (int u = 0; u < kB; ++u)
-            if (e0 + u < N) v[u] = cascade(c, v[u], z0, z1);
+            for (int s = 0; s < kNS; ++s) { z0[s] = p[s * 64]; z1[s] = p[(kNS + s) * 64]; }
+            block(e0, v);
+        } else {
 #pragma unroll
-        for (int u = kB - 1; u >= 0; --u) {
-            const int e = e0 + u, k = e - kEdge;
-            if (e < N) {
-                const f2 r = cascade(c, v[u], y0, y1);
-                if (k >= 0 && k < n && (k & qm) == 0) {
-                    double2 o;
-                    o.x = (double) r.x;
-                    o.y = (double) r.y;
-                    *(double2 *) (yo + 2 * (size_t) (k >> qs)) = o;
-                }
+            for (int u = 0; u < kB; ++u) v[u] = e0 + u < N ? ck[(size_t) (e0 + u) * 64] : zero;
+        }
+        if (e0 + kB <= N) {
+            if constexpr (CK) {
+#pragma unroll
+                for (int u = 0; u < kB; ++u) v[u] = cascade(c, v[u], z0, z1);
+            }
+#pragma unroll
+            for (int u = kB - 1; u >= 0; --u) v[u] = cascade(c, v[u], y0, y1);
+        } else {
+            if constexpr (CK) {
+#pragma unroll
+                for (int u = 0; u < kB; ++u)
+                    if (e0 + u < N) v[u] = cascade(c, v[u], z0, z1);
+            }
+#pragma unroll
+            for (int u = kB - 1; u >= 0; --u)
+                if (e0 + u < N) v[u] = cascade(c, v[u], y0, y1);
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+            const int k = e0 + u - kEdge;
+            if (k >= 0 && k < n && (k & qm) == 0) {
+                double2 o;
+                o.x = (double) v[u].x;
+                o.y = (double) v[u].y;
+                *(double2 *) (yo + 2 * (size_t) (k >> qs)) = o;
             }
         }
     }
@@ -352,8 +387,10 @@ hipError_t launch_f32c(const F32cArgs &a, hipStream_t s) {
     if (!groups) return hipSuccess;
     const size_t tiles = (size_t) (a.n + 2 * kEdge + 63) / 64;
     if (groups * tiles > 0x7fffffffull) return hipErrorInvalidValue;
-    if (a.shift_t && a.rows % 64 == 0 && sdrt_diag_int("f32c_fused", 1) != 0) {
-        hipLaunchKernelGGL(f32c_fused_kernel, dim3((unsigned) groups), dim3(64), 0, s, a);
+    const int fused = sdrt_diag_int("f32c_fused", 2);          // 0: the two kernels with the sequences in memory, 1: checkpoints, 2: forward outputs stored
+    if (a.shift_t && a.rows % 64 == 0 && fused != 0) {
+        if (fused == 1) hipLaunchKernelGGL(f32c_fused_kernel<true>, dim3((unsigned) groups), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(f32c_fused_kernel<false>, dim3((unsigned) groups), dim3(64), 0, s, a);
         return hipGetLastError();
     }
     if (a.shift && a.rows % 64 == 0) {
