@@ -49,7 +49,7 @@ for k, cs in sorted(acc.items()):
         if 'SQ_VALU_MFMA_COEXEC_CYCLES' in cs and 'SQ_VALU_MFMA_BUSY_CYCLES' in cs and big(cs['SQ_VALU_MFMA_BUSY_CYCLES']) > 0:
             e['mfma_valu_coexec'] = round(big(cs['SQ_VALU_MFMA_COEXEC_CYCLES']) / big(cs['SQ_VALU_MFMA_BUSY_CYCLES']), 4)
     rec[e['kernel']] = e
-chain = next((v for k, v in rec.items() if k.startswith('chain')), None) or rec.get('f32c_seq_kernel')
+chain = next((v for k, v in rec.items() if k.startswith('chain')), None) or rec.get('f32c_fused_kernel') or rec.get('f32c_seq_kernel')
 if chain:
     defaults = {'fm64': 131072, 'fm64_iq': 131072, 'fm64f': 131072, 'fm64b': 65536, 'fm64b_iq': 65536, 'fm16': 16384, 'fm2': 2048, 'simo8': 4096, 'simo64': 512, 'f32x256': 128, 'fm64f_faithful': 131072, 'f32x256_faithful': 1024}
     wl = os.environ.get('BENCH_WORKLOAD', 'fm64')
