@@ -582,8 +582,8 @@ def main():
         # (tools/pmc.sh) is quoted under "from_profile", with the file it comes from and the commit it was taken at; traffic is per
         # launch and scales with the chunks of a launch, so a run with another --chunks quotes it scaled (and says so)
         pmc_file, pmc = committed_record(args.workload, correct_iq, faithful)
-        if eng.stage_a == 'f32c' and rows % 64 == 0:
-            KERNEL_OF['f32c'] = 'f32c_fused_kernel'            # the many-row form (kernels_f32c.hip)
+        if eng.stage_a == 'f32c':
+            KERNEL_OF['f32c'] = 'f32c_fused_kernel'            # kernels_f32c.hip: one kernel, no preparation pass
         pmc_ok = bool(pmc) and pmc.get('kernel', '') in KERNEL_OF[eng.stage_a] and pmc.get('chunks_per_step_per_gpu')
         from_profile = None
         if pmc_ok:
@@ -617,8 +617,8 @@ def main():
                                         'unit': 'Top/s (packed fp32 multiply / add, unfused)',
                                         'frac': round(ops / (k_avg_ms * 1e-3) / 1e12 / peak, 4) if k_avg_ms else None},
                         kernel_traffic_model=('f32c_fused_kernel (rows % 64 == 0): 8 B complex64 per row-sample written by the forward pass and read by the backward pass; '
-                                              'the shifted samples recomputed from the records and the transposed shift table (L2 / MALL)') if rows % 64 == 0 else
-                                             '8 B complex64 per row-sample: written by the preparation pass, read and written by the forward pass, read by the backward pass (+ 16 B of shift table per row-sample)')
+                                              'the shifted samples computed from the records and the transposed shift table (L2 / MALL) as the forward pass goes') if rows % 64 == 0 else
+                                             'f32c_fused_kernel, a lane reading its own records: 8 B per row-sample of records read (whole 128-byte lines per lane), 8 B of complex64 written by the forward pass and read by the backward pass')
         elif rows == 1 or not i8['int8_pops']:
             roof = dict(hbm, **i8)
         else:

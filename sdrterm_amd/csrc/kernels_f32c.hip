@@ -242,19 +242,24 @@ constexpr int kB = 16;
 static_assert(kB >= 16, "a group's checkpoints (8 values per kB steps) live in its share of the work buffer (one value per step)");
 
 template <bool EDGE>
-__device__ __forceinline__ f2 fused_sample(const uint32_t *cr, const double2 *tab, int e, int n, int swap, f2 x0, f2 xe) {
+__device__ __forceinline__ f2 fused_sample(const uint32_t *cr, const double2 *tab, const int ts, int e, int n, int swap, f2 x0, f2 xe) {
     int k = e - kEdge;
     if constexpr (EDGE) {
         if (e < kEdge) k = kEdge - e;
         else if (e >= kEdge + n) k = 2 * n + kEdge - 2 - e;
     }
     const float re = f32_record(cr + 2 * (size_t) k, swap), im = f32_record(cr + 2 * (size_t) k + 1, swap);
-    const double2 b = tab[(size_t) k * 64];
-    const double ar = (double) re, ai = (double) im;
-    const double pi = ai * b.y, pr = ai * b.x;
     f2 v;
-    v.x = (float) fma(ar, b.x, -pi);
-    v.y = (float) fma(ar, b.y, pr);
+    if (tab) {
+        const double2 b = tab[(size_t) k * ts];
+        const double ar = (double) re, ai = (double) im;
+        const double pi = ai * b.y, pr = ai * b.x;
+        v.x = (float) fma(ar, b.x, -pi);
+        v.y = (float) fma(ar, b.y, pr);
+    } else {
+        v.x = re;
+        v.y = im;
+    }
     if constexpr (EDGE) {
         if (e < kEdge) v = 2.0f * x0 - v;
         else if (e >= kEdge + n) v = 2.0f * xe - v;
@@ -265,15 +270,32 @@ __device__ __forceinline__ f2 fused_sample(const uint32_t *cr, const double2 *ta
 // CK = false: the forward outputs go to the work buffer instead ([t][lane], 8 bytes per row-sample written and read back) and the
 // backward pass reads them: two recurrences instead of three for 16 bytes per row-sample instead of 8 -- packed fp32 instructions
 // issue at half the rate the peak figures assume on this chip, so the checkpointed form is bound by its third recurrence.
-template <bool CK>
+// GEN = true: any number of rows (and none: no shift) -- a lane's item is (chunk, row) = divmod(g 64 + lane, rows) as in the two
+// kernels above, its records and its row of the [rows][n] table read through its own pointers: 8 / 16 bytes per lane and step,
+// but whole 128-byte lines per lane over 16 / 8 steps, every byte of them used.
+template <bool CK, bool GEN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void f32c_fused_kernel(const F32cArgs a) {
     const size_t g = blockIdx.x;
     const int lane = threadIdx.x;
     const int n = a.n, N = n + 2 * kEdge, nblk = (N + kB - 1) / kB, RQ = a.rows / 64;
-    const size_t chunk = g / RQ;
-    const int rg = (int) (g - chunk * RQ);
+    size_t chunk;
+    int row;
+    bool live = true;
+    const double2 *tab;
+    if constexpr (GEN) {
+        const size_t items = a.n_chunks * (size_t) a.rows, it = g * 64 + lane;
+        live = it < items;
+        chunk = live ? it / a.rows : 0;                 // (a lane past the last item walks item 0 and stores nothing)
+        row = live ? (int) (it - chunk * a.rows) : 0;
+        tab = a.shift ? (const double2 *) a.shift + (size_t) row * n : nullptr;
+    } else {
+        chunk = g / RQ;
+        const int rg = (int) (g - chunk * RQ);
+        row = rg * 64 + lane;
+        tab = (const double2 *) a.shift_t + (size_t) rg * n * 64 + lane;
+    }
+    const int ts = GEN ? 1 : 64;
     const uint32_t *cr = (const uint32_t *) a.raw + chunk * (size_t) n * 2;
-    const double2 *tab = (const double2 *) a.shift_t + (size_t) rg * n * 64 + lane;
     f2 *ck = (f2 *) a.work + g * (size_t) N * 64 + lane;
     const int swap = a.swap;
     Sos c;
@@ -282,20 +304,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         c.b0[s] = a.sos[s][0]; c.b1[s] = a.sos[s][1]; c.b2[s] = a.sos[s][2]; c.a1[s] = a.sos[s][4]; c.a2[s] = a.sos[s][5];
     }
     const f2 zero = {0.0f, 0.0f};
-    const f2 x0 = fused_sample<false>(cr, tab, kEdge, n, swap, zero, zero), xe = fused_sample<false>(cr, tab, kEdge + n - 1, n, swap, zero, zero);
+    const f2 x0 = fused_sample<false>(cr, tab, ts, kEdge, n, swap, zero, zero), xe = fused_sample<false>(cr, tab, ts, kEdge + n - 1, n, swap, zero, zero);
     // a block of kB extended samples: the ones inside the chunk without the extension's cases
     auto block = [&](int e0, f2 (&v)[kB]) {
         if (e0 >= kEdge && e0 + kB <= kEdge + n) {
 #pragma unroll
-            for (int u = 0; u < kB; ++u) v[u] = fused_sample<false>(cr, tab, e0 + u, n, swap, x0, xe);
+            for (int u = 0; u < kB; ++u) v[u] = fused_sample<false>(cr, tab, ts, e0 + u, n, swap, x0, xe);
         } else {
 #pragma unroll
-            for (int u = 0; u < kB; ++u) v[u] = e0 + u < N ? fused_sample<true>(cr, tab, e0 + u, n, swap, x0, xe) : zero;
+            for (int u = 0; u < kB; ++u) v[u] = e0 + u < N ? fused_sample<true>(cr, tab, ts, e0 + u, n, swap, x0, xe) : zero;
         }
     };
     f2 z0[kNS], z1[kNS];
     {
-        const f2 e0v = 2.0f * x0 - fused_sample<false>(cr, tab, 2 * kEdge, n, swap, zero, zero);      // ext[0] = 2 x[0] - x[27]
+        const f2 e0v = 2.0f * x0 - fused_sample<false>(cr, tab, ts, 2 * kEdge, n, swap, zero, zero);      // ext[0] = 2 x[0] - x[27]
 #pragma unroll
         for (int s = 0; s < kNS; ++s) { z0[s] = a.zi[s][0] * e0v; z1[s] = a.zi[s][1] * e0v; }
     }
@@ -327,7 +349,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
     }
     // backward: zi * y[-1]; ext index 27 + k q is output k ([27:-27][::q])
-    const int row = rg * 64 + lane;
     double *yo = a.ydec + ((size_t) row * a.n_chunks + chunk) * (size_t) a.m * 2;
     f2 y0[kNS], y1[kNS];
 #pragma unroll
@@ -365,7 +386,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
         for (int u = 0; u < kB; ++u) {
             const int k = e0 + u - kEdge;
-            if (k >= 0 && k < n && (k & qm) == 0) {
+            if (k >= 0 && k < n && (k & qm) == 0 && live) {
                 double2 o;
                 o.x = (double) v[u].x;
                 o.y = (double) v[u].y;
@@ -389,8 +410,12 @@ hipError_t launch_f32c(const F32cArgs &a, hipStream_t s) {
     if (groups * tiles > 0x7fffffffull) return hipErrorInvalidValue;
     const int fused = sdrt_diag_int("f32c_fused", 2);          // 0: the two kernels with the sequences in memory, 1: checkpoints, 2: forward outputs stored
     if (a.shift_t && a.rows % 64 == 0 && fused != 0) {
-        if (fused == 1) hipLaunchKernelGGL(f32c_fused_kernel<true>, dim3((unsigned) groups), dim3(64), 0, s, a);
-        else hipLaunchKernelGGL(f32c_fused_kernel<false>, dim3((unsigned) groups), dim3(64), 0, s, a);
+        if (fused == 1) hipLaunchKernelGGL((f32c_fused_kernel<true, false>), dim3((unsigned) groups), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((f32c_fused_kernel<false, false>), dim3((unsigned) groups), dim3(64), 0, s, a);
+        return hipGetLastError();
+    }
+    if (fused != 0 && sdrt_diag_int("f32c_fused_any", 1) != 0) {          // every other row count, and no shift at all
+        hipLaunchKernelGGL((f32c_fused_kernel<false, true>), dim3((unsigned) groups), dim3(64), 0, s, a);
         return hipGetLastError();
     }
     if (a.shift && a.rows % 64 == 0) {
