@@ -12,8 +12,10 @@
 // componentwise (the coefficients' imaginary parts are zero).  The recurrence is sequential in time: one (chunk, row) sequence
 // per LANE, 64 sequences per wave, re / im as the two halves of packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32).
 //
-//   f32c_prep_kernel   records -> shifted complex64 samples, odd-extended, transposed to [group][t][lane] (coalesced for the next)
-//   f32c_seq_kernel    forward pass in place, backward pass, every q-th sample out as complex128 for the demodulation stage
+//   f32c_fused_kernel  (default) forward pass straight from the records and the shift table, its outputs stored [group][t][lane];
+//                      backward pass over them, every q-th sample out as complex128 for the demodulation stage
+//   f32c_prep_kernel   (SDRTERM_DIAG=f32c_fused=0) records -> shifted complex64 samples, odd-extended, transposed to [group][t][lane]
+//   f32c_seq_kernel    (the same switch) forward pass in place over those, backward pass
 //
 // Everything after the decimator is float64 in the reference as well (the numba kernels' signatures are complex128,
 // demodulation.py:25,41): the demodulation stage is the one every other encoding uses.
