@@ -21,6 +21,7 @@
 // demodulation.py:25,41): the demodulation stage is the one every other encoding uses.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -243,7 +244,9 @@ __global__ __launch_bounds__(64) void f32c_seq_kernel(const F32cArgs a) {
 constexpr int kB = 16;
 static_assert(kB >= 16, "a group's checkpoints (8 values per kB steps) live in its share of the work buffer (one value per step)");
 
-template <bool EDGE>
+// (TAB: 1 the table is there, 0 it is not, decided once per block by the caller: a test per sample kept a block's loads from being
+// issued together -- 303 branches instead of 196 in the many-row form, 20.5 -> 26 ms)
+template <bool EDGE, int TAB>
 __device__ __forceinline__ f2 fused_sample(const uint32_t *cr, const double2 *tab, const int ts, int e, int n, int swap, f2 x0, f2 xe) {
     int k = e - kEdge;
     if constexpr (EDGE) {
@@ -252,7 +255,7 @@ __device__ __forceinline__ f2 fused_sample(const uint32_t *cr, const double2 *ta
     }
     const float re = f32_record(cr + 2 * (size_t) k, swap), im = f32_record(cr + 2 * (size_t) k + 1, swap);
     f2 v;
-    if (tab) {
+    if constexpr (TAB != 0) {
         const double2 b = tab[(size_t) k * ts];
         const double ar = (double) re, ai = (double) im;
         const double pi = ai * b.y, pr = ai * b.x;
@@ -306,20 +309,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         c.b0[s] = a.sos[s][0]; c.b1[s] = a.sos[s][1]; c.b2[s] = a.sos[s][2]; c.a1[s] = a.sos[s][4]; c.a2[s] = a.sos[s][5];
     }
     const f2 zero = {0.0f, 0.0f};
-    const f2 x0 = fused_sample<false>(cr, tab, ts, kEdge, n, swap, zero, zero), xe = fused_sample<false>(cr, tab, ts, kEdge + n - 1, n, swap, zero, zero);
+    auto sample = [&](int e) {
+        if constexpr (GEN) {                    // (tab: uniform, from a kernel argument)
+            return tab ? fused_sample<false, 1>(cr, tab, ts, e, n, swap, zero, zero) : fused_sample<false, 0>(cr, tab, ts, e, n, swap, zero, zero);
+        } else
+            return fused_sample<false, 1>(cr, tab, ts, e, n, swap, zero, zero);
+    };
+    const f2 x0 = sample(kEdge), xe = sample(kEdge + n - 1);
     // a block of kB extended samples: the ones inside the chunk without the extension's cases
-    auto block = [&](int e0, f2 (&v)[kB]) {
+    auto block_of = [&](auto with_tab, int e0, f2 (&v)[kB]) {
+        constexpr int TAB = decltype(with_tab)::value;
         if (e0 >= kEdge && e0 + kB <= kEdge + n) {
 #pragma unroll
-            for (int u = 0; u < kB; ++u) v[u] = fused_sample<false>(cr, tab, ts, e0 + u, n, swap, x0, xe);
+            for (int u = 0; u < kB; ++u) v[u] = fused_sample<false, TAB>(cr, tab, ts, e0 + u, n, swap, x0, xe);
         } else {
 #pragma unroll
-            for (int u = 0; u < kB; ++u) v[u] = e0 + u < N ? fused_sample<true>(cr, tab, ts, e0 + u, n, swap, x0, xe) : zero;
+            for (int u = 0; u < kB; ++u) v[u] = e0 + u < N ? fused_sample<true, TAB>(cr, tab, ts, e0 + u, n, swap, x0, xe) : zero;
+        }
+    };
+    auto block = [&](int e0, f2 (&v)[kB]) {
+        if constexpr (GEN) {
+            if (tab) block_of(std::integral_constant<int, 1>{}, e0, v);
+            else block_of(std::integral_constant<int, 0>{}, e0, v);
+        } else if (e0 >= kEdge && e0 + kB <= kEdge + n) {           // (spelled out: through block_of the compiler schedules this form 15 % slower)
+#pragma unroll
+            for (int u = 0; u < kB; ++u) v[u] = fused_sample<false, 1>(cr, tab, ts, e0 + u, n, swap, x0, xe);
+        } else {
+#pragma unroll
+            for (int u = 0; u < kB; ++u) v[u] = e0 + u < N ? fused_sample<true, 1>(cr, tab, ts, e0 + u, n, swap, x0, xe) : zero;
         }
     };
     f2 z0[kNS], z1[kNS];
     {
-        const f2 e0v = 2.0f * x0 - fused_sample<false>(cr, tab, ts, 2 * kEdge, n, swap, zero, zero);      // ext[0] = 2 x[0] - x[27]
+        const f2 e0v = 2.0f * x0 - sample(2 * kEdge);      // ext[0] = 2 x[0] - x[27]
 #pragma unroll
         for (int s = 0; s < kNS; ++s) { z0[s] = a.zi[s][0] * e0v; z1[s] = a.zi[s][1] * e0v; }
     }
